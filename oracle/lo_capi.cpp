@@ -1,0 +1,88 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  C entry points for ctypes (tests/, bench.py cpu_baseline, smoke()).
+// Never linked into or loaded by the product library (loro_amd/csrc).
+#include <thread>
+#include <atomic>
+#include <cstdlib>
+#include "lo_doc.hpp"
+
+using namespace lo;
+
+struct DocResult {
+  int32_t status = 0;
+  std::string json, vv, err;
+  uint64_t pending = 0;
+};
+struct Batch {
+  std::vector<DocResult> res;
+};
+
+static void run_one(const uint8_t* data, const uint64_t* blob_off, uint32_t b0, uint32_t b1, DocResult& r) {
+  try {
+    Doc d;
+    for (uint32_t b = b0; b < b1; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    r.json = d.to_json();
+    r.vv = d.vv_bytes();
+    r.pending = d.pending_atoms();
+    r.status = d.unsupported ? ST_UNSUPPORTED : ST_OK;
+  } catch (const DecodeErr& e) {
+    r.status = e.st;
+    r.err = e.what;
+    r.json.clear();
+    r.vv.clear();
+  } catch (const std::exception& e) {
+    r.status = ST_INTERNAL;
+    r.err = e.what();
+  }
+}
+
+extern "C" {
+
+// data: all blobs back to back; blob_off[n_blobs+1]; doc_blob[n_docs+1] = first blob index of each doc
+void* lo_batch_run(const uint8_t* data, const uint64_t* blob_off, const uint32_t* doc_blob, uint32_t n_docs, int n_threads) {
+  Batch* b = new Batch();
+  b->res.resize(n_docs);
+  if (n_threads < 1) n_threads = 1;
+  std::atomic<uint32_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      uint32_t i = next.fetch_add(1);
+      if (i >= n_docs) return;
+      run_one(data, blob_off, doc_blob[i], doc_blob[i + 1], b->res[i]);
+    }
+  };
+  if (n_threads == 1) worker();
+  else {
+    std::vector<std::thread> ts;
+    for (int t = 0; t < n_threads; t++) ts.emplace_back(worker);
+    for (auto& t : ts) t.join();
+  }
+  return b;
+}
+int32_t lo_batch_status(void* h, uint32_t i) { return ((Batch*)h)->res[i].status; }
+uint64_t lo_batch_pending(void* h, uint32_t i) { return ((Batch*)h)->res[i].pending; }
+const char* lo_batch_json(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*)h)->res[i]; *len = r.json.size(); return r.json.data(); }
+const char* lo_batch_vv(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*)h)->res[i]; *len = r.vv.size(); return r.vv.data(); }
+const char* lo_batch_err(void* h, uint32_t i) { return ((Batch*)h)->res[i].err.c_str(); }
+void lo_batch_free(void* h) { delete (Batch*)h; }
+
+uint32_t lo_xxh32(const uint8_t* p, uint64_t n, uint32_t seed) { return xxh32(p, (size_t)n, seed); }
+
+// visible element ids of the root sequence container `name` (kind 1 List / 2 Text) after importing the blobs.
+// Returns the count, writes up to cap (peer, counter) pairs.  Generator helper for tests.
+int64_t lo_visible_ids(const uint8_t* data, const uint64_t* blob_off, uint32_t n_blobs, const char* name, int kind,
+                       uint64_t* peers, int32_t* counters, uint64_t cap) {
+  try {
+    Doc d;
+    for (uint32_t b = 0; b < n_blobs; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    ContainerID cid;
+    cid.root = true;
+    cid.kind = (uint8_t)kind;
+    cid.name = name;
+    std::vector<ID> ids = d.visible_ids(cid);
+    for (size_t i = 0; i < ids.size() && i < cap; i++) { peers[i] = ids[i].peer; counters[i] = ids[i].counter; }
+    return (int64_t)ids.size();
+  } catch (...) {
+    return -1;
+  }
+}
+}

@@ -1,0 +1,525 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lo_codec.hpp header).
+// CPU restatement of LoroDoc::import → OpLog/DAG → diff_calc replay → state → canonical JSON + VV.
+//
+// Restates (reference file:line, relative to /root/reference/crates/loro-internal/src):
+//   import filtering by receiver VV / slice         oplog/change_store.rs:329-352
+//   sort by lamport, apply, pending                  encoding/fast_snapshot.rs:398, encoding/outdated_encode_reordered.rs:40-83,
+//                                                    oplog/pending_changes.rs:12-36, encoding.rs:266-293
+//   lamport from deps                                oplog/loro_dag.rs:1179-1187
+//   trim known prefix                                oplog.rs:367-382
+//   change/op slicing                                change.rs (Sliceable), container/list/list_op.rs:251-277,426-433
+//   version vectors at a change's deps               oplog/loro_dag.rs:1083-1154,1192-1207
+//   causal iteration (node-at-a-time Kahn order)     dag/iter.rs:199-386, oplog.rs:591-669
+//   replay of a sequence container from empty        diff_calc.rs:445-485 (replay_container_ops_from_empty),
+//                                                    :1301-1338 (build_full_crdt_tracker), :993-1137 (apply_crdt_op_to_tracker)
+//   Map LWW                                          diff_calc.rs:515-538, delta/map_delta.rs:20-46, state/map_state.rs:240-292,438-449
+//   deep value / JSON                                state.rs:1294-1329, loro-common/src/value.rs:719-738
+//   VersionVector encode                             version.rs:962-964
+// The final state of a document is the same for every import order (CRDT convergence), so the oracle
+// materialises it the way the reference itself rebuilds a container whenever an import is concurrent
+// (diff_calc.rs:1615-1643): replay the container's ops from the empty version in a causal order and
+// read the elements active at the final version.
+#pragma once
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <charconv>
+#include "lo_codec.hpp"
+#include "lo_tracker.hpp"
+
+namespace lo {
+
+// ---------------------------------------------------------------- canonical JSON
+inline void json_escape(const std::string& s, std::string& out) {
+  static const char* hex = "0123456789abcdef";
+  out.push_back('"');
+  for (unsigned char c : s) {
+    switch (c) {
+      case '"': out += "\\\""; break;
+      case '\\': out += "\\\\"; break;
+      case '\b': out += "\\b"; break;
+      case '\f': out += "\\f"; break;
+      case '\n': out += "\\n"; break;
+      case '\r': out += "\\r"; break;
+      case '\t': out += "\\t"; break;
+      default:
+        if (c < 0x20) { out += "\\u00"; out.push_back(hex[c >> 4]); out.push_back(hex[c & 15]); }
+        else out.push_back((char)c);
+    }
+  }
+  out.push_back('"');
+}
+// serde_json / ryu "pretty" float formatting
+inline void json_f64(double v, std::string& out) {
+  if (!std::isfinite(v)) { out += "null"; return; }
+  if (v == 0) { out += std::signbit(v) ? "-0.0" : "0.0"; return; }
+  char buf[64];
+  auto res = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
+  std::string sci(buf, res.ptr);  // d[.ddd]e[+-]XX shortest round-trip
+  bool neg = sci[0] == '-';
+  size_t p = neg ? 1 : 0;
+  size_t e = sci.find('e');
+  std::string digits;
+  for (size_t i = p; i < e; i++) if (sci[i] != '.') digits.push_back(sci[i]);
+  int exp10 = atoi(sci.c_str() + e + 1);
+  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+  int len = (int)digits.size();
+  int k = exp10 - (len - 1);  // value = digits * 10^k
+  int kk = len + k;
+  if (neg) out.push_back('-');
+  if (0 <= k && kk <= 16) {
+    out += digits; out.append((size_t)k, '0'); out += ".0";
+  } else if (0 < kk && kk <= 16) {
+    out.append(digits, 0, (size_t)kk); out.push_back('.'); out.append(digits, (size_t)kk, std::string::npos);
+  } else if (-5 < kk && kk <= 0) {
+    out += "0."; out.append((size_t)(-kk), '0'); out += digits;
+  } else {
+    out.push_back(digits[0]);
+    if (len > 1) { out.push_back('.'); out.append(digits, 1, std::string::npos); }
+    out.push_back('e');
+    out += std::to_string(kk - 1);
+  }
+}
+
+struct Doc;
+inline void json_value(const Doc& d, const Value& v, std::string& out, int depth);
+
+// ---------------------------------------------------------------- document
+struct StyleRec { PeerID peer; Counter cnt; uint32_t end; };
+
+struct SeqState {
+  Tracker tr;
+  std::vector<uint32_t> cps;      // text: unicode scalars; 0xFFFFFFFF = style anchor
+  std::vector<Value> values;      // list
+  std::vector<StyleRec> styles;
+};
+struct MapEntry { Lamport lamp; PeerID peer; bool has; Value v; };
+
+struct Doc {
+  std::map<PeerID, std::vector<Change>> changes;  // per peer: counter-contiguous from the first imported change
+  VV vv;
+  std::vector<Change> pending;
+  std::vector<ContainerID> containers;
+  std::map<ContainerID, uint32_t> container_idx;
+  bool unsupported = false;   // met a container kind outside Map/List/Text
+  bool materialized = false;
+  std::map<uint32_t, std::unique_ptr<SeqState>> seqs;
+  std::map<uint32_t, std::map<std::string, MapEntry>> maps;
+  std::set<uint32_t> touched;  // containers that received at least one applied op
+
+  uint32_t reg(const ContainerID& c) {
+    auto it = container_idx.find(c);
+    if (it != container_idx.end()) return it->second;
+    uint32_t i = (uint32_t)containers.size();
+    containers.push_back(c);
+    container_idx[c] = i;
+    if (c.kind > CK_TEXT) unsupported = true;
+    return i;
+  }
+
+  // ---- op / change slicing (Sliceable impls)
+  static Op slice_op(const Op& o, int32_t from, int32_t to) {
+    Op r = o;
+    r.counter = o.counter + from;
+    r.len = to - from;
+    switch (o.kind) {
+      case OP_TEXT_INSERT:
+        r.cps.assign(o.cps.begin() + from, o.cps.begin() + to);
+        r.prop = o.prop + from;
+        break;
+      case OP_LIST_INSERT:
+        r.values.assign(o.values.begin() + from, o.values.begin() + to);
+        r.prop = o.prop + from;
+        break;
+      case OP_SEQ_DELETE: {
+        // DeleteSpanWithId::slice (list_op.rs:251-277) + DeleteSpan::slice (:426-433)
+        int64_t L = o.del_signed_len < 0 ? -o.del_signed_len : o.del_signed_len;
+        if (o.del_signed_len > 0) {
+          r.del_id_start.counter = o.del_id_start.counter + from;
+          r.del_signed_len = to - from;
+          // pos unchanged
+        } else {
+          r.del_id_start.counter = o.del_id_start.counter + (Counter)(L - to);
+          r.prop = o.prop - from;
+          r.del_signed_len = from - to;
+        }
+        break;
+      }
+      default: break;  // len-1 ops
+    }
+    return r;
+  }
+  static Change slice_change(const Change& c, int32_t from) {  // keep [from, len)
+    Change r;
+    r.id = ID{c.id.peer, c.id.counter + from};
+    r.lamport = c.lamport + (Lamport)from;
+    r.len = c.len - from;
+    r.cids = c.cids;
+    r.deps = from > 0 ? std::vector<ID>{ID{c.id.peer, c.id.counter + from - 1}} : c.deps;
+    Counter cut = c.id.counter + from;
+    for (const Op& o : c.ops) {
+      if (o.counter + o.len <= cut) continue;
+      if (o.counter >= cut) r.ops.push_back(o);
+      else r.ops.push_back(slice_op(o, cut - o.counter, o.len));
+    }
+    return r;
+  }
+
+  const Change* find_change(ID id) const {
+    auto it = changes.find(id.peer);
+    if (it == changes.end()) return nullptr;
+    const auto& v = it->second;
+    size_t lo_ = 0, hi = v.size();
+    while (lo_ < hi) {
+      size_t mid = (lo_ + hi) / 2;
+      if (v[mid].ctr_end() <= id.counter) lo_ = mid + 1; else hi = mid;
+    }
+    if (lo_ < v.size() && v[lo_].id.counter <= id.counter) return &v[lo_];
+    return nullptr;
+  }
+  bool has_id(ID id) const {
+    auto it = vv.find(id.peer);
+    return it != vv.end() && id.counter < it->second && find_change(id) != nullptr;
+  }
+  // returns false if some dep is missing (loro_dag.rs:1179-1187)
+  bool lamport_from_deps(const std::vector<ID>& deps, Lamport& out) const {
+    Lamport l = 0;
+    for (const ID& d : deps) {
+      const Change* c = find_change(d);
+      if (!c) return false;
+      Lamport x = c->lamport + (Lamport)(d.counter - c->id.counter);
+      l = std::max(l, x + 1);
+    }
+    out = l;
+    return true;
+  }
+  Counter vv_get(PeerID p) const {
+    auto it = vv.find(p);
+    return it == vv.end() ? 0 : it->second;
+  }
+  // try to apply one decoded change (outdated_encode_reordered.rs:48-75); returns 0 applied/skipped, 1 pending
+  int try_apply(Change& ch) {
+    if (ch.ctr_end() <= vv_get(ch.id.peer)) return 0;  // skip included changes
+    Lamport l;
+    if (!lamport_from_deps(ch.deps, l)) return 1;
+    Counter end = vv_get(ch.id.peer);
+    if (ch.id.counter > end) return 1;  // counter gap: cannot be produced by a valid exporter; parked
+    ch.lamport = l;
+    Change c2 = ch.id.counter < end ? slice_change(ch, end - ch.id.counter) : std::move(ch);
+    for (Op& o : c2.ops) o.container = reg(c2.cids[o.container]);
+    c2.cids.clear();
+    vv[c2.id.peer] = c2.ctr_end();
+    changes[c2.id.peer].push_back(std::move(c2));
+    return 0;
+  }
+  void import(const uint8_t* blob, size_t len) {
+    std::vector<Change> decoded;
+    decode_updates_blob(blob, len, decoded);
+    materialized = false;
+    // receiver-VV filter happens per change in try_apply (drop / slice); application order = lamport order
+    std::stable_sort(decoded.begin(), decoded.end(), [](const Change& a, const Change& b) { return a.lamport < b.lamport; });
+    for (auto& c : decoded)
+      if (try_apply(c)) pending.push_back(std::move(c));
+    // pending retry until no progress (pending_changes.rs)
+    bool progress = true;
+    while (progress && !pending.empty()) {
+      progress = false;
+      std::vector<Change> still;
+      for (auto& c : pending) {
+        if (try_apply(c)) still.push_back(std::move(c)); else progress = true;
+      }
+      pending.swap(still);
+    }
+  }
+  uint64_t pending_atoms() const {
+    uint64_t n = 0;
+    for (auto& c : pending) {
+      Counter end = vv_get(c.id.peer);
+      if (c.ctr_end() > end) n += (uint64_t)(c.ctr_end() - std::max(end, c.id.counter));
+    }
+    return n;
+  }
+
+  // ---- DAG nodes: runs of one peer's changes linked only by self-dependency (loro_dag.rs:995-1019)
+  struct Node { PeerID peer; size_t first, last; std::vector<ID> deps; std::vector<size_t> succ; int indeg = 0; };
+
+  void materialize() {
+    if (materialized) return;
+    seqs.clear();
+    maps.clear();
+    touched.clear();
+    // nodes
+    std::vector<Node> nodes;
+    std::map<std::pair<PeerID, Counter>, size_t> node_of_change;  // change start → node
+    for (auto& kv : changes) {
+      auto& v = kv.second;
+      for (size_t i = 0; i < v.size(); i++) {
+        bool cont = i > 0 && v[i].deps.size() == 1 && v[i].deps[0].peer == kv.first &&
+                    v[i].deps[0].counter == v[i].id.counter - 1;
+        if (cont) nodes.back().last = i;
+        else { Node n; n.peer = kv.first; n.first = n.last = i; n.deps = v[i].deps; nodes.push_back(n); }
+        node_of_change[{kv.first, v[i].id.counter}] = nodes.size() - 1;
+      }
+    }
+    for (size_t ni = 0; ni < nodes.size(); ni++) {
+      std::set<size_t> dn;
+      for (const ID& d : nodes[ni].deps) {
+        const Change* dc = find_change(d);
+        dn.insert(node_of_change[{dc->id.peer, dc->id.counter}]);
+      }
+      for (size_t x : dn) { nodes[x].succ.push_back(ni); nodes[ni].indeg++; }
+    }
+    std::vector<size_t> order, stack;
+    for (size_t ni = nodes.size(); ni-- > 0;) if (nodes[ni].indeg == 0) stack.push_back(ni);
+    while (!stack.empty()) {
+      size_t n = stack.back();
+      stack.pop_back();
+      order.push_back(n);
+      for (size_t s : nodes[n].succ) if (--nodes[s].indeg == 0) stack.push_back(s);
+    }
+    if (order.size() != nodes.size()) fail(ST_INTERNAL, "cycle in DAG");
+    // replay; vv_head[n] = version seen by the first op of node n (loro_dag.rs:1083-1154)
+    std::vector<VV> vv_head(nodes.size());
+    for (size_t ni : order) {
+      Node& n = nodes[ni];
+      auto& v = changes[n.peer];
+      {
+        VV& out = vv_head[ni];
+        for (const ID& d : n.deps) {
+          const Change* dc = find_change(d);
+          const VV& sub = vv_head[node_of_change[{dc->id.peer, dc->id.counter}]];
+          for (auto& kv : sub) Tracker::bump(out, kv.first, kv.second);
+          Tracker::bump(out, d.peer, d.counter + 1);
+        }
+      }
+      VV cur = vv_head[ni];
+      for (size_t ci = n.first; ci <= n.last; ci++) {
+        const Change& ch = v[ci];
+        std::set<uint32_t> visited;
+        for (const Op& op : ch.ops) {
+          touched.insert(op.container);
+          const ContainerID& cid = containers[op.container];
+          if (cid.kind == CK_MAP) {
+            if (op.kind != OP_MAP_SET && op.kind != OP_MAP_DELETE) continue;
+            Lamport lamp = ch.lamport + (Lamport)(op.counter - ch.id.counter);
+            auto& m = maps[op.container];
+            auto it = m.find(op.key);
+            // keep old iff old > new by (lamport, peer) (diff_calc.rs:532-537, map_delta.rs:26-32)
+            if (it != m.end() && (it->second.lamp > lamp || (it->second.lamp == lamp && it->second.peer > ch.id.peer))) continue;
+            MapEntry e{lamp, ch.id.peer, op.kind == OP_MAP_SET, op.kind == OP_MAP_SET ? op.value : Value()};
+            m[op.key] = std::move(e);
+            continue;
+          }
+          if (cid.kind != CK_TEXT && cid.kind != CK_LIST) continue;
+          auto& sp = seqs[op.container];
+          if (!sp) sp.reset(new SeqState());
+          SeqState& st = *sp;
+          if (!visited.count(op.container)) {
+            VV at = cur;
+            Tracker::bump(at, ch.id.peer, op.counter);  // diff_calc.rs:480-481
+            st.tr.checkout(at);
+            visited.insert(op.container);
+          }
+          ID op_id{ch.id.peer, op.counter};
+          switch (op.kind) {
+            case OP_TEXT_INSERT: {
+              uint32_t start = (uint32_t)st.cps.size();
+              st.cps.insert(st.cps.end(), op.cps.begin(), op.cps.end());
+              st.tr.insert(op_id, op.prop, (int32_t)op.cps.size(), start);
+              break;
+            }
+            case OP_LIST_INSERT: {
+              uint32_t start = (uint32_t)st.values.size();
+              st.values.insert(st.values.end(), op.values.begin(), op.values.end());
+              st.tr.insert(op_id, op.prop, (int32_t)op.values.size(), start);
+              break;
+            }
+            case OP_SEQ_DELETE: {
+              int64_t sl = op.del_signed_len;
+              int64_t L = sl < 0 ? -sl : sl;
+              int64_t start = sl > 0 ? op.prop : (int64_t)op.prop + 1 + sl;  // DeleteSpan::start (list_op.rs:303-309)
+              st.tr.del(op_id, op.del_id_start, start, (int32_t)L, sl < 0);
+              break;
+            }
+            case OP_STYLE_START: {
+              uint32_t start = (uint32_t)st.cps.size();
+              st.cps.push_back(0xFFFFFFFFu);
+              st.styles.push_back(StyleRec{ch.id.peer, op.counter, op.style_end});
+              st.tr.insert(op_id, op.prop, 1, start);
+              break;
+            }
+            case OP_STYLE_END: {
+              // diff_calc.rs:1105-1132
+              int64_t end_pos = -1;
+              for (size_t k = st.styles.size(); k-- > 0;)
+                if (st.styles[k].peer == ch.id.peer && st.styles[k].cnt == op.counter - 1) { end_pos = st.styles[k].end; break; }
+              if (end_pos < 0) {
+                const Change* sc = find_change(ID{ch.id.peer, op.counter - 1});
+                if (sc)
+                  for (const Op& so : sc->ops)
+                    if (so.counter == op.counter - 1 && so.kind == OP_STYLE_START) end_pos = so.style_end;
+                if (end_pos < 0) fail(ST_DATA_CORRUPTION, "style end without start");
+              }
+              uint32_t start = (uint32_t)st.cps.size();
+              st.cps.push_back(0xFFFFFFFFu);
+              int64_t pos = std::min<int64_t>(end_pos + 1, st.tr.active_len());
+              st.tr.insert(op_id, pos, 1, start);
+              break;
+            }
+            default: break;
+          }
+        }
+        Tracker::bump(cur, ch.id.peer, ch.ctr_end());
+      }
+    }
+    for (auto& kv : seqs) kv.second->tr.checkout(vv);
+    materialized = true;
+  }
+
+  // ---- deep value as canonical JSON (state.rs:1294-1329; keys sorted bytewise)
+  void container_json(uint32_t idx, std::string& out, int depth) const {
+    if (depth > 200) { out += "null"; return; }
+    const ContainerID& cid = containers[idx];
+    if (cid.kind == CK_TEXT) {
+      std::string s;
+      auto it = seqs.find(idx);
+      if (it != seqs.end())
+        for (Span* sp = it->second->tr.head; sp; sp = sp->next)
+          if (sp->active())
+            for (int32_t k = 0; k < sp->len; k++) {
+              uint32_t cp = it->second->cps[sp->content + (uint32_t)k];
+              if (cp != 0xFFFFFFFFu) cp_to_utf8(cp, s);
+            }
+      json_escape(s, out);
+    } else if (cid.kind == CK_LIST) {
+      out.push_back('[');
+      bool first = true;
+      auto it = seqs.find(idx);
+      if (it != seqs.end())
+        for (Span* sp = it->second->tr.head; sp; sp = sp->next)
+          if (sp->active())
+            for (int32_t k = 0; k < sp->len; k++) {
+              if (!first) out.push_back(',');
+              first = false;
+              json_value(*this, it->second->values[sp->content + (uint32_t)k], out, depth + 1);
+            }
+      out.push_back(']');
+    } else if (cid.kind == CK_MAP) {
+      out.push_back('{');
+      bool first = true;
+      auto it = maps.find(idx);
+      if (it != maps.end())
+        for (auto& kv : it->second) {  // std::map<std::string,..> iterates bytewise-sorted
+          if (!kv.second.has) continue;
+          if (!first) out.push_back(',');
+          first = false;
+          json_escape(kv.first, out);
+          out.push_back(':');
+          json_value(*this, kv.second.v, out, depth + 1);
+        }
+      out.push_back('}');
+    } else {
+      out += "null";
+    }
+  }
+  std::string to_json() {
+    materialize();
+    std::map<std::string, uint32_t> roots;
+    for (uint32_t i = 0; i < containers.size(); i++) {
+      if (!containers[i].root || !touched.count(i)) continue;
+      if (roots.count(containers[i].name)) fail(ST_UNSUPPORTED, "two root containers share a name");
+      roots[containers[i].name] = i;
+    }
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : roots) {
+      if (!first) out.push_back(',');
+      first = false;
+      json_escape(kv.first, out);
+      out.push_back(':');
+      container_json(kv.second, out, 0);
+    }
+    out.push_back('}');
+    return out;
+  }
+  std::string vv_bytes() const {  // postcard map, entries sorted by peer
+    std::string out;
+    auto uleb = [&](uint64_t v) {
+      do { uint8_t b = v & 0x7f; v >>= 7; if (v) b |= 0x80; out.push_back((char)b); } while (v);
+    };
+    uleb(vv.size());
+    for (auto& kv : vv) {
+      uleb(kv.first);
+      int64_t c = kv.second;
+      uleb((uint64_t)((c << 1) ^ (c >> 63)));
+    }
+    return out;
+  }
+  // visible element ids of a sequence container (test helper for local-edit generators)
+  std::vector<ID> visible_ids(const ContainerID& cid) {
+    materialize();
+    std::vector<ID> out;
+    auto ci = container_idx.find(cid);
+    if (ci == container_idx.end()) return out;
+    auto it = seqs.find(ci->second);
+    if (it == seqs.end()) return out;
+    for (Span* sp = it->second->tr.head; sp; sp = sp->next)
+      if (sp->active())
+        for (int32_t k = 0; k < sp->len; k++) out.push_back(ID{sp->id.peer, sp->id.counter + k});
+    return out;
+  }
+};
+
+inline void json_value(const Doc& d, const Value& v, std::string& out, int depth) {
+  switch (v.kind) {
+    case V_NULL: out += "null"; break;
+    case V_BOOL: out += v.b ? "true" : "false"; break;
+    case V_I64: out += std::to_string(v.i); break;
+    case V_F64: json_f64(v.f, out); break;
+    case V_STR: json_escape(v.s, out); break;
+    case V_BIN: {
+      out.push_back('[');
+      for (size_t i = 0; i < v.s.size(); i++) { if (i) out.push_back(','); out += std::to_string((unsigned)(uint8_t)v.s[i]); }
+      out.push_back(']');
+      break;
+    }
+    case V_LIST: {
+      out.push_back('[');
+      for (size_t i = 0; i < v.list.size(); i++) { if (i) out.push_back(','); json_value(d, v.list[i], out, depth + 1); }
+      out.push_back(']');
+      break;
+    }
+    case V_MAP: {
+      std::vector<const std::pair<std::string, Value>*> es;
+      for (auto& e : v.map) es.push_back(&e);
+      std::stable_sort(es.begin(), es.end(), [](auto a, auto b) { return a->first < b->first; });
+      out.push_back('{');
+      bool first = true;
+      for (size_t i = 0; i < es.size(); i++) {
+        if (i + 1 < es.size() && es[i + 1]->first == es[i]->first) continue;  // last write wins on duplicate keys
+        if (!first) out.push_back(',');
+        first = false;
+        json_escape(es[i]->first, out);
+        out.push_back(':');
+        json_value(d, es[i]->second, out, depth + 1);
+      }
+      out.push_back('}');
+      break;
+    }
+    case V_CONTAINER: {
+      auto it = d.container_idx.find(v.cid);
+      if (it == d.container_idx.end()) {
+        // child container that never received an op: empty value of its kind (state.rs:1550-1616)
+        if (v.cid.kind == CK_TEXT) out += "\"\"";
+        else if (v.cid.kind == CK_MAP) out += "{}";
+        else if (v.cid.kind == CK_LIST) out += "[]";
+        else out += "null";
+      } else d.container_json(it->second, out, depth + 1);
+      break;
+    }
+  }
+}
+
+}  // namespace lo
