@@ -1,0 +1,90 @@
+/* loro_merge.h — C ABI of the MI355X batched CRDT merge engine.
+ *
+ * Drop-in boundary for Loro's import → diff_calc → state path.  The reference has no FFI on this path
+ * (SURVEY.md §8b); the boundary therefore sits at the byte interface the Rust host already owns:
+ *
+ *   input   exactly what `LoroDoc::export(ExportMode::Updates{..})` produces and `LoroDoc::import()` consumes
+ *           (crates/loro/src/lib.rs:710,1306; crates/loro-internal/src/encoding.rs:334-373,399-405;
+ *           docs/encoding.md §2,§6-10).  The blobs of one document are imported in order, like
+ *           `LoroDoc::import_batch` (crates/loro-internal/src/loro.rs:1432-1523), into an empty document.
+ *   output  what `doc.get_deep_value().to_json_value()` (crates/loro/src/lib.rs:937,
+ *           crates/loro-internal/src/state.rs:1294-1329) and `doc.oplog_vv().encode()`
+ *           (crates/loro/src/lib.rs:887, crates/loro-internal/src/version.rs:962-964) produce:
+ *           canonical JSON (UTF-8, object keys sorted bytewise, no whitespace) and a postcard map
+ *           peer→exclusive counter with entries sorted by peer.
+ *
+ * Errors are per document and mirror LoroError (crates/loro-common/src/error.rs): a bad document never
+ * fails the batch (reference import is per-document atomic, loro.rs:780-838).  Changes whose dependencies
+ * are missing are not errors: they are reported as pending (ImportStatus.pending, encoding.rs:227-231) and
+ * excluded from state and version vector.
+ *
+ * Threading: a context is single-caller; several contexts may be used concurrently.
+ * Ownership: inputs are borrowed for the duration of the call; outputs belong to the context and stay
+ * valid until the next lm_merge_batch / lm_run / lm_destroy on it.
+ */
+#ifndef LORO_MERGE_H
+#define LORO_MERGE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  LM_OK = 0,
+  LM_DECODE_ERROR = 1,       /* LoroError::DecodeError */
+  LM_CHECKSUM_MISMATCH = 2,  /* LoroError::DecodeChecksumMismatchError */
+  LM_DATA_CORRUPTION = 3,    /* LoroError::DecodeDataCorruptionError */
+  LM_UNSUPPORTED = 4,        /* container kind / value shape / size outside the device path's scope */
+  LM_INTERNAL = 5
+};
+
+typedef struct lm_ctx lm_ctx;
+
+typedef struct lm_doc_in {
+  const uint8_t* const* blobs; /* n_blobs update blobs (EncodeMode::FastUpdates), imported in order */
+  const size_t* blob_lens;
+  size_t n_blobs;
+} lm_doc_in;
+
+typedef struct lm_doc_out {
+  int32_t status;       /* LM_* */
+  const uint8_t* json;  /* canonical deep-value JSON (not NUL terminated) */
+  size_t json_len;
+  const uint8_t* vv;    /* postcard VersionVector, entries sorted by peer */
+  size_t vv_len;
+  uint64_t pending_ops; /* atoms parked because a dependency is missing */
+} lm_doc_out;
+
+/* Create a context on HIP device `device` (>= 0).  Returns NULL when no usable MI355X-class device or the
+ * HIP runtime is missing — there is no CPU fallback. */
+lm_ctx* lm_create(int device);
+void lm_destroy(lm_ctx* ctx);
+const char* lm_last_error(lm_ctx* ctx);
+
+/* One-shot: stage + run + fetch.  Returns 0 on success (per-document results in outs[i].status). */
+int lm_merge_batch(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs, lm_doc_out* outs);
+
+/* Split form, for callers that keep batches resident in HBM (and for benchmarking the device path):
+ * lm_stage packs the blobs and uploads them, lm_run executes the device pipeline on the staged batch
+ * (may be repeated), lm_fetch copies the rendered states back and fills outs[0..n_docs). */
+int lm_stage(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs);
+int lm_run(lm_ctx* ctx);
+int lm_fetch(lm_ctx* ctx, lm_doc_out* outs);
+
+/* Introspection for bench.py: byte counts of the last run and per-kernel HIP-event timings. */
+typedef struct lm_run_stats {
+  uint64_t n_docs, n_blobs;
+  uint64_t in_bytes;   /* Σ blob lengths */
+  uint64_t out_bytes;  /* Σ json_len + Σ vv_len */
+  uint64_t device_bytes_allocated;
+  uint32_t n_kernels;
+} lm_run_stats;
+int lm_get_stats(lm_ctx* ctx, lm_run_stats* out);
+int lm_set_profiling(lm_ctx* ctx, int enabled);               /* record hipEvents around every stage of lm_run */
+int lm_kernel_time(lm_ctx* ctx, uint32_t i, const char** name, double* ms); /* i < n_kernels, after lm_run */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

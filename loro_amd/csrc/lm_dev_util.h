@@ -1,0 +1,241 @@
+// Device helpers: bounded byte readers, varints, serde_columnar cursors, xxHash32.
+// Wire grammar: /root/reference/docs/encoding.md §1, §8.1; docs/encoding-xxhash32.md.
+#pragma once
+#include "lm_wave.h"
+#include "lm_types.h"
+
+namespace lm {
+
+struct Rd {                 // bounded reader over global memory; `bad` latches on any overrun
+  const uint8_t* p;
+  const uint8_t* end;
+  bool bad;
+};
+LM_DEV Rd rd_make(const uint8_t* p, uint64_t n) { Rd r; r.p = p; r.end = p + n; r.bad = false; return r; }
+LM_DEV uint64_t rd_left(const Rd& r) { return (uint64_t)(r.end - r.p); }
+LM_DEV uint32_t rd_u8(Rd& r) {
+  if (r.p >= r.end) { r.bad = true; return 0; }
+  return *r.p++;
+}
+LM_DEV uint64_t rd_uleb(Rd& r) {
+  uint64_t v = 0;
+  for (int i = 0; i < 10; i++) {
+    uint32_t b = rd_u8(r);
+    v |= (uint64_t)(b & 0x7f) << (7 * i);
+    if (!(b & 0x80)) return v;
+  }
+  r.bad = true;
+  return v;
+}
+LM_DEV int64_t rd_zigzag(Rd& r) {
+  uint64_t v = rd_uleb(r);
+  return (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+}
+// i128 zigzag varint (DeltaRle deltas); values beyond i64 are flagged bad
+LM_DEV int64_t rd_zigzag128(Rd& r) {
+  uint64_t lo = 0, hi = 0;
+  for (int i = 0; i < 19; i++) {
+    uint32_t b = rd_u8(r);
+    uint64_t part = b & 0x7f;
+    int sh = 7 * i;
+    if (sh < 64) { lo |= part << sh; if (sh > 57) hi |= part >> (64 - sh); }
+    else hi |= part << (sh - 64);
+    if (!(b & 0x80)) {
+      // value = (hi:lo); zigzag decode needs it to fit in 65 bits
+      if (hi > 1) { r.bad = true; return 0; }
+      uint64_t mag = (lo >> 1) | (hi << 63);
+      return (int64_t)mag ^ -(int64_t)(lo & 1);
+    }
+  }
+  r.bad = true;
+  return 0;
+}
+LM_DEV int64_t rd_sleb(Rd& r) {
+  int64_t result = 0;
+  int shift = 0;
+  uint32_t b;
+  do {
+    b = rd_u8(r);
+    if (shift < 64) result |= (int64_t)((uint64_t)(b & 0x7f) << shift);
+    shift += 7;
+    if (shift > 70) { r.bad = true; return 0; }
+  } while ((b & 0x80) && !r.bad);
+  if (shift < 64 && (b & 0x40)) result |= -((int64_t)1 << shift);
+  return result;
+}
+LM_DEV void rd_skip(Rd& r, uint64_t n) {
+  if (n > rd_left(r)) { r.bad = true; r.p = r.end; return; }
+  r.p += n;
+}
+// uleb length + bytes → sub-reader
+LM_DEV Rd rd_bytes(Rd& r) {
+  uint64_t n = rd_uleb(r);
+  if (n > rd_left(r)) { r.bad = true; n = rd_left(r); }
+  Rd s = rd_make(r.p, n);
+  s.bad = r.bad;
+  r.p += n;
+  return s;
+}
+
+// AnyRle cursor: segments {zigzag k; k>0: one value ×k | k<0: |k| literals}
+struct RleCur {
+  Rd r;
+  int64_t rem;
+  bool run;
+  int64_t val;   // run value, or running sum for delta columns
+  int64_t runv;  // run delta for delta columns
+};
+LM_DEV RleCur rle_make(Rd r) { RleCur c; c.r = r; c.rem = 0; c.run = false; c.val = 0; c.runv = 0; return c; }
+LM_DEV bool rle_head(RleCur& c) {  // start next segment; false at end / error
+  if (c.r.p >= c.r.end) { c.r.bad = true; return false; }
+  int64_t k = rd_zigzag(c.r);
+  if (k == 0) { c.r.bad = true; return false; }
+  c.run = k > 0;
+  c.rem = k > 0 ? k : -k;
+  return true;
+}
+LM_DEV uint64_t rle_next_uvar(RleCur& c) {
+  if (c.rem == 0) { if (!rle_head(c)) return 0; if (c.run) c.val = (int64_t)rd_uleb(c.r); }
+  c.rem--;
+  return c.run ? (uint64_t)c.val : rd_uleb(c.r);
+}
+LM_DEV uint32_t rle_next_u8(RleCur& c) {
+  if (c.rem == 0) { if (!rle_head(c)) return 0; if (c.run) c.val = (int64_t)rd_u8(c.r); }
+  c.rem--;
+  return c.run ? (uint32_t)c.val : rd_u8(c.r);
+}
+LM_DEV int64_t rle_next_delta(RleCur& c) {  // DeltaRle: running sum of i128 deltas
+  if (c.rem == 0) { if (!rle_head(c)) return c.val; if (c.run) c.runv = rd_zigzag128(c.r); }
+  c.rem--;
+  c.val += c.run ? c.runv : rd_zigzag128(c.r);
+  return c.val;
+}
+// number of values in a whole AnyRle payload whose literals are single bytes (Rle<u8>)
+LM_DEV uint64_t rle_count_u8(Rd r) {
+  uint64_t n = 0;
+  while (r.p < r.end && !r.bad) {
+    int64_t k = rd_zigzag(r);
+    if (k == 0) { r.bad = true; break; }
+    if (k > 0) { (void)rd_u8(r); n += (uint64_t)k; }
+    else { rd_skip(r, (uint64_t)(-k)); n += (uint64_t)(-k); }
+    if (n > (1u << 30)) { r.bad = true; break; }
+  }
+  return r.bad ? ~0ull : n;
+}
+// number of values in an AnyRle payload with varint values (uleb or zigzag128 share the skip rule)
+LM_DEV uint64_t rle_count_var(Rd r) {
+  uint64_t n = 0;
+  while (r.p < r.end && !r.bad) {
+    int64_t k = rd_zigzag(r);
+    if (k == 0) { r.bad = true; break; }
+    uint64_t m = k > 0 ? 1 : (uint64_t)(-k);
+    for (uint64_t i = 0; i < m && !r.bad; i++) {
+      for (int j = 0; j < 19; j++) { uint32_t b = rd_u8(r); if (!(b & 0x80)) break; }
+    }
+    n += k > 0 ? (uint64_t)k : (uint64_t)(-k);
+    if (n > (1u << 30)) { r.bad = true; break; }
+  }
+  return r.bad ? ~0ull : n;
+}
+
+// BoolRle cursor: alternating run lengths, first run is FALSE
+struct BoolCur { Rd r; uint64_t rem; bool cur; bool started; };
+LM_DEV BoolCur bool_make(Rd r) { BoolCur c; c.r = r; c.rem = 0; c.cur = true; c.started = false; return c; }
+LM_DEV bool bool_next(BoolCur& c) {
+  int guard = 0;
+  while (c.rem == 0) {
+    c.cur = !c.cur;
+    c.rem = rd_uleb(c.r);
+    if (c.r.bad || ++guard > 4) { c.r.bad = true; return false; }
+  }
+  c.rem--;
+  return c.cur;
+}
+
+// DeltaOfDelta cursor (docs/encoding.md:713-726)
+struct DodCur { const uint8_t* p; uint64_t nbits, pos; int64_t prev, delta; bool has_first, first_taken, bad; uint32_t last_used; };
+LM_DEV uint64_t dod_bits(DodCur& c, int n) {
+  if (c.pos + (uint64_t)n > c.nbits) { c.bad = true; return 0; }
+  uint64_t v = 0;
+  for (int i = 0; i < n; i++) {
+    v = (v << 1) | ((c.p[c.pos >> 3] >> (7 - (c.pos & 7))) & 1);
+    c.pos++;
+  }
+  return v;
+}
+LM_DEV DodCur dod_make(Rd& r) {  // consumes the head (Option<i64> + last-used byte); bitstream follows at r.p
+  DodCur c;
+  c.bad = false; c.pos = 0; c.delta = 0; c.prev = 0; c.first_taken = false;
+  uint32_t tag = rd_u8(r);
+  c.has_first = tag == 1;
+  if (tag > 1) c.bad = true;
+  if (c.has_first) c.prev = rd_zigzag(r);
+  c.last_used = rd_u8(r);
+  c.p = r.p;
+  c.nbits = rd_left(r) * 8;
+  if (r.bad) c.bad = true;
+  return c;
+}
+LM_DEV int64_t dod_next(DodCur& c) {
+  if (!c.has_first) { c.bad = true; return 0; }
+  if (!c.first_taken) { c.first_taken = true; return c.prev; }
+  int64_t dd;
+  if (dod_bits(c, 1) == 0) dd = 0;
+  else if (dod_bits(c, 1) == 0) dd = (int64_t)dod_bits(c, 7) - 63;
+  else if (dod_bits(c, 1) == 0) dd = (int64_t)dod_bits(c, 9) - 255;
+  else if (dod_bits(c, 1) == 0) dd = (int64_t)dod_bits(c, 12) - 2047;
+  else if (dod_bits(c, 1) == 0) dd = (int64_t)dod_bits(c, 21) - 1048575;
+  else dd = (int64_t)dod_bits(c, 64);
+  c.delta += dd;
+  c.prev += c.delta;
+  return c.prev;
+}
+// after taking `n` values: validate the used-bits byte and advance the byte reader past the stream
+LM_DEV void dod_finish(DodCur& c, Rd& r, uint64_t n) {
+  if (!c.has_first) { if (n != 0 || c.last_used != 0) r.bad = true; return; }
+  if (n == 0) { r.bad = true; return; }
+  if (n == 1) { if (c.last_used != 0) r.bad = true; }
+  else { uint32_t e = (uint32_t)(c.pos % 8 ? c.pos % 8 : 8); if (c.last_used != e) r.bad = true; }
+  if (c.bad) r.bad = true;
+  rd_skip(r, (c.pos + 7) / 8);
+}
+
+LM_DEV uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+LM_DEV uint32_t ld32le(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+// xxHash32, one lane (docs/encoding-xxhash32.md).  `p` must be 4-byte aligned.
+LM_DEV uint32_t xxh32_lane(const uint8_t* p, uint64_t len, uint32_t seed) {
+  const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, P4 = 0x27D4EB2Fu, P5 = 0x165667B1u;
+  const uint8_t* end = p + len;
+  uint32_t h;
+  if (len >= 16) {
+    uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+    const uint8_t* limit = end - 16;
+    const uint32_t* w = (const uint32_t*)p;
+    do {
+      uint32_t a = w[0], b = w[1], c = w[2], d = w[3];
+      v1 = rotl32(v1 + a * P2, 13) * P1;
+      v2 = rotl32(v2 + b * P2, 13) * P1;
+      v3 = rotl32(v3 + c * P2, 13) * P1;
+      v4 = rotl32(v4 + d * P2, 13) * P1;
+      w += 4;
+    } while ((const uint8_t*)w <= limit);
+    p = (const uint8_t*)w;
+    h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+  } else {
+    h = seed + P5;
+  }
+  h += (uint32_t)len;
+  while (p + 4 <= end) { h = rotl32(h + ld32le(p) * P3, 17) * P4; p += 4; }
+  while (p < end) { h = rotl32(h + (*p) * P5, 11) * P1; p++; }
+  h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+  return h;
+}
+
+// packed element id helpers
+LM_DEV uint32_t pid_make(uint32_t peer, uint32_t ctr) { return (peer << 24) | ctr; }
+LM_DEV uint32_t pid_peer(uint32_t pid) { return pid >> 24; }
+LM_DEV uint32_t pid_ctr(uint32_t pid) { return pid & 0xFFFFFFu; }
+
+}  // namespace lm

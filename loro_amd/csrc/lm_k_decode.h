@@ -1,0 +1,536 @@
+// Decode stage: envelope + checksum, change-block framing, columnar op tables.
+// Follows the reference decoder (paths relative to /root/reference/crates/loro-internal/src):
+//   parse_header_and_body / checksum   encoding.rs:302-373
+//   decode_updates                      encoding/fast_snapshot.rs:372-400
+//   EncodedBlock                        oplog/change_store/block_encode.rs:94-119
+//   decode_changes_header               oplog/change_store/block_meta_encode.rs:90-242
+//   EncodedOp columns + row walk        oplog/change_store/block_encode.rs:417-445,651-704
+//   decode_op / delete start ids        encoding/outdated_encode_reordered.rs:215-476,480-489
+//   value payloads                      encoding/value.rs:342-459,608-859 (docs/encoding.md §10)
+#pragma once
+#include "lm_dev_util.h"
+
+namespace lm {
+
+struct Dev {  // device pointers of one batch (passed by value to every kernel)
+  // inputs
+  const uint8_t* data;
+  const uint64_t* blob_off;   // [n_blobs] 16-byte aligned start of each blob
+  const uint32_t* blob_len;   // [n_blobs] exact byte length
+  const uint32_t* doc_blob;   // [n_docs+1] first blob of each doc
+  uint32_t n_blobs, n_docs;
+  // per blob
+  int32_t* blob_status;
+  uint32_t* blob_nblk;
+  uint32_t* blob_blk0;
+  uint32_t* blob_doc;
+  // per block
+  uint32_t n_blocks;
+  BlockDesc* blk;
+  uint32_t* bcnt;   // [n_blocks+1][BCN] counts, then exclusive offsets in boff
+  uint32_t* boff;
+  // rows
+  ChangeRow* chg;
+  uint32_t* dep_peer;
+  uint32_t* dep_ctr;
+  OpRow* op;
+  uint64_t* op_val;
+  uint32_t* op_blk;
+  uint64_t* key_off;
+  uint32_t* key_len;
+  uint32_t* cid_raw;   // 4 words per raw cid: kind|root<<8, peer local idx, key idx / counter, block
+  uint32_t* cid_map;   // raw cid row → doc container idx
+  uint64_t* peer_raw;  // per block peer tables
+  uint32_t* peer_map;  // raw peer row → doc peer idx
+  // per doc
+  DocMeta* doc;
+  uint64_t* peer_uniq;   // [praw0 + i], i < n_peers, ascending
+  uint32_t* peer_end;    // applied (exclusive) counter end == final VV
+  uint32_t* peer_ext;    // contiguous covered end
+  uint32_t* elem_base;   // first element slot of the peer inside the doc's element range
+  uint32_t* peer_chg0;   // range of the peer's changes in chg_sorted
+  uint32_t* peer_chg1;
+  ContRow* cont;         // [cid0 + i], i < n_cont
+  // dag
+  uint32_t* chg_sorted;  // [chg0 + i] → global change row
+  uint32_t* chg_lamport; // per global change row
+  uint32_t* chg_skip;    // atoms to skip at the start of a change (already known prefix)
+  uint32_t* chg_flag;    // 1 = applied
+  uint32_t* node_first;  // [chg0 + n] indices into chg_sorted (doc-relative)
+  uint32_t* node_last;
+  uint32_t* node_order;  // replay order (doc-relative node ids)
+  uint32_t* vvh;         // [vvh0 + node*P + p]
+  // elements
+  uint32_t* cp;          // text: unicode scalar (0xFFFFFFFF = style anchor) | list: value offset rel. to the doc's first byte
+  uint32_t* loc;         // element → leaf
+  // tracker pools
+  uint32_t* it_id; uint32_t* it_ol; uint32_t* it_or; uint32_t* it_st;
+  uint32_t* lf_n; uint32_t* lf_next; uint32_t* lf_grp;
+  uint32_t* gp_leaf; uint32_t* gp_act; uint32_t* gp_n;
+  uint32_t* rt_grp; uint32_t* rt_act;
+  uint32_t* cont_root0;  // per doc container: root array start (doc-relative) / length
+  uint32_t* cont_nroot;
+  unsigned long long* vis;  // per doc scratch for the Fugue sibling scan
+  // map LWW
+  unsigned long long* ht_key;   // per doc open-addressing table
+  unsigned long long* ht_best;
+  uint64_t* ht0;                // per doc first slot; ht_cap per doc
+  uint32_t* ht_cap;
+  // outputs
+  uint8_t* out;          // JSON bytes
+  uint64_t* out_off;     // per doc offset (n_docs+1)
+  uint8_t* vv_out;
+  uint64_t* vv_off;
+};
+static constexpr int BCN = 8;  // counters per block: chg, dep, op, key, cid, peer, mapop, atoms
+enum { BC_CHG = 0, BC_DEP, BC_OP, BC_KEY, BC_CID, BC_PEER, BC_MAPOP, BC_ATOMS };
+static constexpr uint32_t VIS_CAP = 1024;
+
+// -------------------------------------------------------------------------------------------------
+// K1: one lane per blob — envelope, xxh32, block count.
+LM_KERNEL void k_frame_count(Dev d) {
+  uint32_t b = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (b >= d.n_blobs) return;
+  const uint8_t* p = d.data + d.blob_off[b];  // blob starts are 16-byte aligned by the host packer
+  uint64_t len = d.blob_len[b];
+  int32_t st = ST_OK;
+  uint32_t nblk = 0;
+  if (len < 22) st = ST_DECODE_ERROR;
+  else if (!(p[0] == 'l' && p[1] == 'o' && p[2] == 'r' && p[3] == 'o')) st = ST_DECODE_ERROR;
+  else {
+    uint32_t mode = ((uint32_t)p[20] << 8) | p[21];
+    if (mode == 3) st = ST_UNSUPPORTED;        // FastSnapshot: outside the hot-path scope
+    else if (mode != 4) st = ST_DECODE_ERROR;
+    else {
+      uint32_t expect = ld32le(p + 16);
+      if (xxh32_lane(p + 20, len - 20, 0x4f524f4cu) != expect) st = ST_CHECKSUM_MISMATCH;
+      else {
+        Rd r = rd_make(p + 22, len - 22);
+        while (r.p < r.end && !r.bad) {
+          uint64_t bl = rd_uleb(r);
+          if (bl == 0 || bl > rd_left(r)) { r.bad = true; break; }
+          r.p += bl;
+          nblk++;
+        }
+        if (r.bad) { st = ST_DECODE_ERROR; nblk = 0; }
+      }
+    }
+  }
+  d.blob_status[b] = st;
+  d.blob_nblk[b] = nblk;
+}
+
+// K2: one lane per blob — write a BlockDesc per block (postcard struct head + section extents).
+LM_KERNEL void k_frame_fill(Dev d) {
+  uint32_t b = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (b >= d.n_blobs) return;
+  if (d.blob_status[b] != ST_OK) return;
+  uint64_t base = d.blob_off[b];
+  const uint8_t* p = d.data + base;
+  uint64_t len = d.blob_len[b];
+  Rd r = rd_make(p + 22, len - 22);
+  uint32_t bi = d.blob_blk0[b];
+  uint32_t nblk = d.blob_nblk[b];
+  for (uint32_t k = 0; k < nblk; k++, bi++) {
+    uint64_t bl = rd_uleb(r);
+    Rd q = rd_make(r.p, bl);
+    BlockDesc bd;
+    bd.base = (uint64_t)(r.p - d.data);
+    bd.blob = b;
+    bd.doc = d.blob_doc[b];
+    uint64_t cs = rd_uleb(q), cl = rd_uleb(q), ls = rd_uleb(q), ll = rd_uleb(q), nc = rd_uleb(q);
+    bd.status = ST_OK;
+    if (cs > 0x7fffffffull || cl > 0x7fffffffull || ls > 0xffffffffull || ll > 0xffffffffull || nc > 0x7fffffffull || nc == 0)
+      bd.status = ST_DECODE_ERROR;
+    if (cs + cl > MAX_COUNTER) bd.status = bd.status ? bd.status : ST_UNSUPPORTED;
+    bd.counter_start = (uint32_t)cs; bd.counter_len = (uint32_t)cl;
+    bd.lamport_start = (uint32_t)ls; bd.lamport_len = (uint32_t)ll; bd.n_changes = (uint32_t)nc;
+    for (int s = 0; s < (int)SEC_N; s++) {
+      Rd sec = rd_bytes(q);
+      bd.sec_rel[s] = (uint32_t)(sec.p - r.p);
+      bd.sec_len[s] = (uint32_t)rd_left(sec);
+    }
+    if (q.bad) bd.status = ST_DECODE_ERROR;
+    d.blk[bi] = bd;
+    r.p += bl;
+  }
+}
+
+LM_DEV Rd blk_sec(const Dev& d, const BlockDesc& bd, int s) {
+  return rd_make(d.data + bd.base + bd.sec_rel[s], bd.sec_len[s]);
+}
+
+// K3: one lane per block — count the rows each table will receive.
+LM_KERNEL void k_block_count(Dev d) {
+  uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (bi >= d.n_blocks) return;
+  BlockDesc bd = d.blk[bi];
+  uint32_t* c = d.bcnt + (uint64_t)bi * BCN;
+  for (int i = 0; i < BCN; i++) c[i] = 0;
+  if (bd.status != ST_OK) return;
+  uint32_t N = bd.n_changes;
+  bool bad = false;
+  // header: peers, N-1 lens, BoolRle[N], AnyRle[N] dep counts
+  Rd h = blk_sec(d, bd, SEC_HEADER);
+  uint64_t np = rd_uleb(h);
+  if (np == 0 || np > rd_left(h) / 8 || np > MAX_PEERS) bad = true;
+  uint64_t ndep = 0;
+  if (!bad) {
+    rd_skip(h, np * 8);
+    for (uint32_t i = 0; i + 1 < N && !h.bad; i++) (void)rd_uleb(h);
+    BoolCur bc = bool_make(h);
+    for (uint32_t i = 0; i < N && !bc.r.bad; i++) if (bool_next(bc)) ndep++;
+    if (bc.rem != 0) bc.r.bad = true;
+    RleCur dc = rle_make(bc.r);
+    for (uint32_t i = 0; i < N && !dc.r.bad; i++) ndep += rle_next_uvar(dc);
+    if (dc.rem != 0) dc.r.bad = true;
+    if (dc.r.bad || ndep > (1u << 28)) bad = true;
+  }
+  // ops: count rows through the value_type column (raw-byte literals)
+  uint64_t nops = 0, nmap = 0;
+  {
+    Rd o = blk_sec(d, bd, SEC_OPS);
+    uint64_t outer = rd_uleb(o), ncols = rd_uleb(o);
+    if (outer != 1 || ncols != 4) bad = true;
+    Rd c0 = rd_bytes(o); (void)c0;
+    Rd c1 = rd_bytes(o); (void)c1;
+    Rd c2 = rd_bytes(o);
+    if (o.bad) bad = true;
+    if (!bad) { nops = rle_count_u8(c2); if (nops == ~0ull) bad = true; }
+  }
+  uint64_t nkeys = 0;
+  {
+    Rd k = blk_sec(d, bd, SEC_KEYS);
+    while (k.p < k.end && !k.bad) { uint64_t l = rd_uleb(k); rd_skip(k, l); nkeys++; }
+    if (k.bad) bad = true;
+  }
+  uint64_t ncid = 0;
+  {
+    Rd k = blk_sec(d, bd, SEC_CIDS);
+    if (k.p < k.end) ncid = rd_uleb(k);
+    if (k.bad || ncid > (1u << 20)) bad = true;
+  }
+  if (bad) { d.blk[bi].status = ST_DECODE_ERROR; return; }
+  (void)nmap;
+  c[BC_CHG] = N;
+  c[BC_DEP] = (uint32_t)ndep;
+  c[BC_OP] = (uint32_t)nops;
+  c[BC_KEY] = (uint32_t)nkeys;
+  c[BC_CID] = (uint32_t)ncid;
+  c[BC_PEER] = (uint32_t)np;
+  c[BC_MAPOP] = (uint32_t)nops;   // upper bound on map ops (refined per doc by the LWW kernel's table size)
+  c[BC_ATOMS] = bd.counter_len;
+}
+
+// skip one nested LoroValue (docs/encoding.md §10.1); iterative with an explicit frame stack.
+// `unsupported` is raised for shapes the device emitter does not render yet (maps, child containers, f64).
+LM_DEV void skip_loro_value(Rd& r, bool& unsupported) {
+  uint32_t f_cnt[16];
+  uint32_t f_map = 0;  // bit i: frame i is a map (each item is preceded by a key index)
+  int sp = 0;
+  uint32_t cnt = 1;
+  bool in_map = false;
+  for (uint32_t guard = 0; guard < (1u << 28); guard++) {
+    while (cnt == 0) {
+      if (sp == 0) return;
+      sp--;
+      cnt = f_cnt[sp];
+      in_map = (f_map >> sp) & 1;
+    }
+    if (r.bad) return;
+    cnt--;
+    if (in_map) (void)rd_uleb(r);
+    uint32_t tag = rd_u8(r);
+    switch (tag) {
+      case 0: case 1: case 2: break;
+      case 3: (void)rd_sleb(r); break;
+      case 4: rd_skip(r, 8); unsupported = true; break;
+      case 5: case 6: { uint64_t l = rd_uleb(r); rd_skip(r, l); break; }
+      case 7: case 8: {
+        uint64_t n = rd_uleb(r);
+        if (n > (1u << 28) || sp >= 16) { r.bad = true; return; }
+        f_cnt[sp] = cnt;
+        f_map = (f_map & ~(1u << sp)) | ((in_map ? 1u : 0u) << sp);
+        sp++;
+        cnt = (uint32_t)n;
+        in_map = tag == 8;
+        if (tag == 8) unsupported = true;
+        break;
+      }
+      case 9: (void)rd_u8(r); unsupported = true; break;
+      default: r.bad = true; return;
+    }
+  }
+  r.bad = true;
+}
+
+// K4: one lane per block — full decode into the row tables (block-local indices; K6 remaps them).
+LM_KERNEL void k_block_decode(Dev d) {
+  uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (bi >= d.n_blocks) return;
+  BlockDesc bd = d.blk[bi];
+  if (bd.status != ST_OK) return;
+  const uint32_t* off = d.boff + (uint64_t)bi * BCN;
+  const uint32_t* cnt = d.bcnt + (uint64_t)bi * BCN;
+  uint32_t N = bd.n_changes;
+  uint32_t chg0 = off[BC_CHG], dep0 = off[BC_DEP], op0 = off[BC_OP], key0 = off[BC_KEY], cid0 = off[BC_CID], peer0 = off[BC_PEER];
+  uint32_t n_peers = cnt[BC_PEER], n_ops = cnt[BC_OP], n_keys = cnt[BC_KEY], n_cids = cnt[BC_CID];
+  int32_t st = ST_OK;
+  bool unsupported = false;
+  // ---- header
+  Rd h = blk_sec(d, bd, SEC_HEADER);
+  (void)rd_uleb(h);
+  for (uint32_t i = 0; i < n_peers; i++) {
+    uint64_t v = 0;
+    for (int k = 0; k < 8; k++) v |= (uint64_t)rd_u8(h) << (8 * k);
+    d.peer_raw[peer0 + i] = v;
+  }
+  {
+    // change lens → counters
+    uint64_t known = 0;
+    uint32_t ctr = bd.counter_start;
+    for (uint32_t i = 0; i < N; i++) {
+      uint64_t l;
+      if (i + 1 < N) { l = rd_uleb(h); known += l; if (known > bd.counter_len) { st = ST_DECODE_ERROR; l = 0; } }
+      else l = bd.counter_len - (known > bd.counter_len ? bd.counter_len : known);
+      ChangeRow c;
+      c.peer = 0; c.ctr = ctr; c.len = (uint32_t)l; c.dep0 = 0; c.n_dep = 0; c.op0 = 0; c.n_op = 0; c.blk = bi;
+      d.chg[chg0 + i] = c;
+      ctr += (uint32_t)l;
+    }
+    // dep_on_self BoolRle[N]  (kept in op0 until the op rows are assigned)
+    BoolCur bc = bool_make(h);
+    for (uint32_t i = 0; i < N; i++) d.chg[chg0 + i].op0 = bool_next(bc) ? 1u : 0u;
+    if (bc.rem != 0) bc.r.bad = true;
+    // other dep counts AnyRle<usize>[N]
+    RleCur dc = rle_make(bc.r);
+    uint32_t dcur = dep0;
+    for (uint32_t i = 0; i < N; i++) {
+      uint64_t others = rle_next_uvar(dc);
+      ChangeRow c = d.chg[chg0 + i];
+      uint32_t ds = c.op0;
+      if (dcur + ds + others > dep0 + cnt[BC_DEP]) { st = ST_DECODE_ERROR; others = 0; ds = 0; }
+      c.dep0 = dcur;
+      c.n_dep = ds + (uint32_t)others;
+      if (ds) {
+        if (c.ctr == 0) st = ST_DECODE_ERROR;
+        d.dep_peer[dcur] = 0;
+        d.dep_ctr[dcur] = c.ctr ? c.ctr - 1 : 0;
+      }
+      dcur += c.n_dep;
+      d.chg[chg0 + i] = c;
+    }
+    if (dc.rem != 0) dc.r.bad = true;
+    if (dcur - dep0 != cnt[BC_DEP]) st = ST_DECODE_ERROR;
+    // dep peer idx AnyRle<u32>[D]
+    RleCur pc = rle_make(dc.r);
+    uint64_t D = 0;
+    for (uint32_t i = 0; i < N; i++) {
+      ChangeRow c = d.chg[chg0 + i];
+      for (uint32_t k = c.dep0 + c.op0; k < c.dep0 + c.n_dep; k++) {
+        uint64_t pi = rle_next_uvar(pc);
+        if (pi >= n_peers) { st = ST_DECODE_ERROR; pi = 0; }
+        d.dep_peer[k] = (uint32_t)pi;
+        D++;
+      }
+    }
+    if (pc.rem != 0) pc.r.bad = true;
+    // dep counters DeltaOfDelta[D]
+    Rd hr = pc.r;
+    DodCur dd = dod_make(hr);
+    for (uint32_t i = 0; i < N && D; i++) {
+      ChangeRow c = d.chg[chg0 + i];
+      for (uint32_t k = c.dep0 + c.op0; k < c.dep0 + c.n_dep; k++) {
+        int64_t v = dod_next(dd);
+        if (v < 0 || v >= (int64_t)MAX_COUNTER) { st = st ? st : ST_DECODE_ERROR; v = 0; }
+        d.dep_ctr[k] = (uint32_t)v;
+      }
+    }
+    dod_finish(dd, hr, D);
+    // wire lamports (DeltaOfDelta[N-1]) are validated for shape only: lamports are recomputed from deps on
+    // import (outdated_encode_reordered.rs:61-62)
+    DodCur ld = dod_make(hr);
+    for (uint32_t i = 0; i + 1 < N; i++) (void)dod_next(ld);
+    dod_finish(ld, hr, N - 1);
+    if (h.bad || bc.r.bad || dc.r.bad || pc.r.bad || hr.bad) st = st ? st : ST_DECODE_ERROR;
+    for (uint32_t i = 0; i < N; i++) d.chg[chg0 + i].op0 = 0;
+  }
+  // ---- change_meta: timestamps + message lengths, shape only (block_encode.rs:563-571)
+  {
+    Rd m = blk_sec(d, bd, SEC_META);
+    DodCur td = dod_make(m);
+    for (uint32_t i = 0; i < N; i++) (void)dod_next(td);
+    dod_finish(td, m, N);
+    RleCur mc = rle_make(m);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < N; i++) tot += rle_next_uvar(mc);
+    if (mc.r.bad || tot > rd_left(mc.r)) st = st ? st : ST_DATA_CORRUPTION;
+  }
+  // ---- keys
+  {
+    Rd k = blk_sec(d, bd, SEC_KEYS);
+    for (uint32_t i = 0; i < n_keys; i++) {
+      uint64_t l = rd_uleb(k);
+      d.key_off[key0 + i] = (uint64_t)(k.p - d.data);
+      d.key_len[key0 + i] = (uint32_t)l;
+      rd_skip(k, l);
+    }
+    if (k.bad) st = st ? st : ST_DECODE_ERROR;
+  }
+  // ---- cids (arena.rs:39-105)
+  {
+    Rd k = blk_sec(d, bd, SEC_CIDS);
+    if (n_cids) (void)rd_uleb(k);
+    for (uint32_t i = 0; i < n_cids; i++) {
+      uint64_t fields = rd_uleb(k);
+      uint32_t is_root = rd_u8(k), kind = rd_u8(k);
+      uint64_t pidx = rd_uleb(k);
+      int64_t koc = rd_zigzag(k);
+      if (fields != 4) st = st ? st : ST_DECODE_ERROR;
+      uint32_t* w = d.cid_raw + (uint64_t)(cid0 + i) * 4;
+      if (is_root) { if (koc < 0 || (uint64_t)koc >= n_keys) { st = st ? st : ST_DATA_CORRUPTION; koc = 0; } }
+      else { if (pidx >= n_peers) { st = st ? st : ST_DATA_CORRUPTION; pidx = 0; } if (koc < 0 || koc >= (int64_t)MAX_COUNTER) { st = st ? st : ST_UNSUPPORTED; koc = 0; } }
+      w[0] = kind | (is_root ? 0x100u : 0u);
+      w[1] = (uint32_t)pidx;
+      w[2] = (uint32_t)koc;
+      w[3] = bi;
+      if (kind > CK_TEXT) unsupported = true;
+    }
+    if (k.bad) st = st ? st : ST_DECODE_ERROR;
+  }
+  // ---- op rows
+  {
+    Rd o = blk_sec(d, bd, SEC_OPS);
+    (void)rd_uleb(o); (void)rd_uleb(o);
+    RleCur c_cont = rle_make(rd_bytes(o));
+    RleCur c_prop = rle_make(rd_bytes(o));
+    RleCur c_vt = rle_make(rd_bytes(o));
+    RleCur c_len = rle_make(rd_bytes(o));
+    Rd dsec = blk_sec(d, bd, SEC_DEL);
+    bool has_del = dsec.p < dsec.end;
+    RleCur d_peer = rle_make(dsec), d_ctr = rle_make(dsec), d_len = rle_make(dsec);
+    if (has_del) {
+      uint64_t outer = rd_uleb(dsec), ncols = rd_uleb(dsec);
+      if (outer != 1 || ncols != 3) st = st ? st : ST_DECODE_ERROR;
+      d_peer = rle_make(rd_bytes(dsec));
+      d_ctr = rle_make(rd_bytes(dsec));
+      d_len = rle_make(rd_bytes(dsec));
+    }
+    Rd v = blk_sec(d, bd, SEC_VALUES);
+    uint64_t counter = bd.counter_start;
+    uint32_t change_index = 0;
+    uint64_t next_boundary = N > 1 ? d.chg[chg0 + 1].ctr : (uint64_t)bd.counter_start + bd.counter_len;
+    d.chg[chg0].op0 = op0;
+    for (uint32_t row = 0; row < n_ops; row++) {
+      int64_t ci = rle_next_delta(c_cont);
+      int64_t prop = rle_next_delta(c_prop);
+      uint32_t vt = rle_next_u8(c_vt) & 0x7f;
+      uint64_t len = rle_next_uvar(c_len);
+      if (ci < 0 || (uint64_t)ci >= n_cids) { st = st ? st : ST_DATA_CORRUPTION; ci = 0; }
+      if (prop < INT32_MIN || prop > INT32_MAX) { st = st ? st : ST_DECODE_ERROR; prop = 0; }
+      uint32_t ckind = n_cids ? (d.cid_raw[(uint64_t)(cid0 + (uint32_t)ci) * 4] & 0xff) : 0xff;
+      OpRow r;
+      r.cidx_kind = (uint32_t)ci;  // block-local until K6
+      r.prop = (int32_t)prop;
+      r.len = (uint32_t)len;
+      r.ctr = (uint32_t)counter;
+      r.a0 = 0; r.a1 = 0; r.a2 = 0;
+      r.chg = chg0 + change_index;
+      uint64_t val_at = (uint64_t)(v.p - d.data);
+      uint32_t kind = OK_OTHER;
+      uint32_t mark_len = 0;
+      bool is_list_value = false;
+      // value payload (docs/encoding.md §10)
+      switch (vt) {
+        case 0: case 1: case 2: case 8: case 9: break;
+        case 3: (void)rd_sleb(v); break;
+        case 4: rd_skip(v, 8); break;
+        case 5: case 6: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
+        case 7: (void)rd_uleb(v); break;
+        case 10: (void)rd_sleb(v); break;
+        case 11: {
+          // peek the top-level tag to know whether it is a list (List insert) before skipping
+          is_list_value = v.p < v.end && *v.p == 7;
+          if (is_list_value) {
+            Rd t = v;
+            (void)rd_u8(t);
+            r.a0 = (uint32_t)rd_uleb(t);
+          }
+          skip_loro_value(v, unsupported);
+          break;
+        }
+        case 12: {
+          (void)rd_u8(v);
+          mark_len = (uint32_t)rd_uleb(v);
+          uint64_t key_idx = rd_uleb(v);
+          if (key_idx >= n_keys) st = st ? st : ST_DATA_CORRUPTION;
+          bool u = false;
+          skip_loro_value(v, u);
+          break;
+        }
+        case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
+        case 14: (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v); break;
+        case 15: { (void)rd_uleb(v); (void)rd_uleb(v); bool u = false; skip_loro_value(v, u); break; }
+        case 16: {
+          (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v);
+          uint32_t isn = rd_u8(v);
+          if (!isn) { (void)rd_uleb(v); (void)rd_uleb(v); }
+          break;
+        }
+        default: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
+      }
+      // decode_op mapping (outdated_encode_reordered.rs:215-476)
+      bool take_del = false;
+      if (ckind == CK_TEXT) {
+        if (vt == 5) kind = OK_TEXT_INS;
+        else if (vt == 9) { kind = OK_DEL; take_del = true; }
+        else if (vt == 12) { kind = OK_STYLE_START; r.a0 = mark_len; }
+        else if (vt == 0) kind = OK_STYLE_END;
+        else st = st ? st : ST_DATA_CORRUPTION;
+      } else if (ckind == CK_MAP) {
+        if (prop < 0 || (uint64_t)prop >= n_keys) st = st ? st : ST_DATA_CORRUPTION;
+        if (vt == 8) kind = OK_MAP_DEL;
+        else if (vt == 11) kind = OK_MAP_SET;
+        else st = st ? st : ST_DATA_CORRUPTION;
+      } else if (ckind == CK_LIST) {
+        if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else st = st ? st : ST_DATA_CORRUPTION; }
+        else if (vt == 9) { kind = OK_DEL; take_del = true; }
+        else st = st ? st : ST_DATA_CORRUPTION;
+      } else if (ckind == CK_MOVABLE) {
+        if (vt == 9) take_del = true;
+      }
+      if (take_del) {
+        if (!has_del) st = st ? st : ST_DATA_CORRUPTION;
+        else {
+          int64_t dp = rle_next_delta(d_peer), dctr = rle_next_delta(d_ctr), dl = rle_next_delta(d_len);
+          if (dp < 0 || (uint64_t)dp >= n_peers) { st = st ? st : ST_DATA_CORRUPTION; dp = 0; }
+          if (dl == 0 || dl > (int64_t)MAX_COUNTER || dl < -(int64_t)MAX_COUNTER) { st = st ? st : ST_DATA_CORRUPTION; dl = 1; }
+          if (dctr < 0 || dctr >= (int64_t)MAX_COUNTER) { st = st ? st : ST_DATA_CORRUPTION; dctr = 0; }
+          r.a0 = (uint32_t)dp; r.a1 = (uint32_t)dctr; r.a2 = (int32_t)dl;
+          if (d_peer.r.bad || d_ctr.r.bad || d_len.r.bad) st = st ? st : ST_DATA_CORRUPTION;
+        }
+      }
+      r.cidx_kind |= kind << 16;
+      d.op[op0 + row] = r;
+      d.op_val[op0 + row] = val_at;
+      d.op_blk[op0 + row] = bi;
+      counter += len;
+      if (counter > MAX_COUNTER) { st = st ? st : ST_UNSUPPORTED; counter = MAX_COUNTER; }
+      if (change_index >= N) { st = st ? st : ST_DATA_CORRUPTION; change_index = N - 1; }
+      d.chg[chg0 + change_index].n_op++;
+      if (counter >= next_boundary && change_index + 1 < N) {
+        change_index++;
+        d.chg[chg0 + change_index].op0 = op0 + row + 1;
+        next_boundary = change_index + 1 < N ? d.chg[chg0 + change_index + 1].ctr : (uint64_t)bd.counter_start + bd.counter_len;
+      }
+    }
+    // changes that received no rows still need a valid op0
+    for (uint32_t i = 1; i < N; i++) if (d.chg[chg0 + i].n_op == 0) d.chg[chg0 + i].op0 = op0 + n_ops;
+    if (c_cont.r.bad || c_prop.r.bad || c_vt.r.bad || c_len.r.bad || v.bad) st = st ? st : ST_DECODE_ERROR;
+    if (counter != (uint64_t)bd.counter_start + bd.counter_len) st = st ? st : ST_DATA_CORRUPTION;
+  }
+  if (st == ST_OK && unsupported) st = ST_UNSUPPORTED;
+  d.blk[bi].status = st;
+}
+
+}  // namespace lm

@@ -1,0 +1,372 @@
+// LWW map resolve and state emission: canonical JSON of get_deep_value() + postcard VersionVector.
+// Reference semantics (paths relative to /root/reference/crates):
+//   Map LWW winner = max (lamport, peer)      loro-internal/src/diff_calc.rs:515-538, delta/map_delta.rs:20-46
+//   deletes hide the key                      loro-internal/src/state/map_state.rs:438-449
+//   deep value of roots                       loro-internal/src/state.rs:1294-1329
+//   JSON rendering                            loro-common/src/value.rs:719-738 (serde_json, keys sorted)
+//   VersionVector::encode                     loro-internal/src/version.rs:962-964 (entries sorted by peer here)
+#pragma once
+#include "lm_k_integrate.h"
+
+namespace lm {
+
+static constexpr unsigned long long HT_EMPTY = ~0ull;
+
+LM_DEV uint64_t fnv1a(const uint8_t* p, uint32_t n, uint64_t h) {
+  for (uint32_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+LM_DEV bool bytes_eq(const uint8_t* a, const uint8_t* b, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) if (a[i] != b[i]) return false;
+  return true;
+}
+// bytewise string order (what serde_json::Value / BTreeMap<String,_> uses)
+LM_DEV int bytes_cmp(const uint8_t* a, uint32_t na, const uint8_t* b, uint32_t nb) {
+  uint32_t n = na < nb ? na : nb;
+  for (uint32_t i = 0; i < n; i++) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  return na < nb ? -1 : (na > nb ? 1 : 0);
+}
+
+// K10: one lane per op row — running LWW maximum per (container, key) in the doc's hash table.
+LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
+  uint32_t t = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (t >= n_ops) return;
+  OpRow r = d.op[t];
+  uint32_t kind = (r.cidx_kind >> 16) & 0xff;
+  if (kind != OK_MAP_SET && kind != OK_MAP_DEL) return;
+  if (!d.chg_flag[r.chg]) return;
+  uint32_t blk = d.op_blk[t];
+  uint32_t doc = d.blk[blk].doc;
+  const DocMeta& m = d.doc[doc];
+  if (status_fatal(m.status)) return;
+  const ChangeRow& ch = d.chg[r.chg];
+  if (r.ctr < ch.ctr + d.chg_skip[r.chg]) return;  // already-known prefix of a sliced change
+  uint32_t cap = d.ht_cap[doc];
+  if (cap == 0) { d.doc[doc].status = ST_INTERNAL; return; }
+  uint32_t cidx = r.cidx_kind & 0xffff;
+  uint32_t krow = d.boff[(uint64_t)blk * BCN + BC_KEY] + (uint32_t)r.prop;
+  const uint8_t* ks = d.data + d.key_off[krow];
+  uint32_t kl = d.key_len[krow];
+  uint64_t h = fnv1a(ks, kl, 0xcbf29ce484222325ull ^ cidx);
+  unsigned long long mine = ((unsigned long long)cidx << 32) | krow;
+  unsigned long long* keys = d.ht_key + d.ht0[doc];
+  unsigned long long* best = d.ht_best + d.ht0[doc];
+  uint32_t slot = (uint32_t)h & (cap - 1);
+  for (uint32_t probe = 0; probe < cap; probe++, slot = (slot + 1) & (cap - 1)) {
+    unsigned long long cur = keys[slot];
+    if (cur == HT_EMPTY) {
+      cur = lmw::atomic_cas64(&keys[slot], HT_EMPTY, mine);
+      if (cur == HT_EMPTY) cur = mine;
+    }
+    bool same = cur == mine;
+    if (!same && (uint32_t)(cur >> 32) == cidx) {
+      uint32_t orow = (uint32_t)cur;
+      same = d.key_len[orow] == kl && bytes_eq(d.data + d.key_off[orow], ks, kl);
+    }
+    if (same) {
+      uint32_t lam = d.chg_lamport[r.chg] + (r.ctr - ch.ctr);
+      uint32_t rel = t - m.op0;
+      if (rel >= (1u << 24)) { d.doc[doc].status = ST_UNSUPPORTED; return; }
+      unsigned long long v = ((unsigned long long)lam << 32) | ((unsigned long long)ch.peer << 24) | rel;
+      lmw::atomic_max64(&best[slot], v + 1);  // +1 so that 0 stays "no write"
+      d.cont[m.cid0 + cidx].touched = 1;
+      return;
+    }
+  }
+  d.doc[doc].status = ST_INTERNAL;
+}
+
+// ------------------------------------------------------------------------------------------------ sink
+struct Sink {
+  uint8_t* out;       // nullptr in the sizing pass
+  uint64_t pos;       // wave-uniform
+};
+LM_DEV void sink_byte(Sink& s, uint8_t b) {
+  if (s.out && lmw::lane() == 0) s.out[s.pos] = b;
+  s.pos++;
+}
+LM_DEV void sink_lit(Sink& s, const char* lit, uint32_t n) {
+  if (s.out && lmw::lane() == 0) for (uint32_t i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)lit[i];
+  s.pos += n;
+}
+// each lane contributes `n` (<= 8) bytes packed little-endian in `bytes`; lanes are concatenated in lane order
+LM_DEV void sink_lanes(Sink& s, uint64_t bytes, uint32_t n) {
+  uint32_t inc = lmw::scan_incl_add(n);
+  uint32_t tot = lmw::bcast(inc, 63);
+  if (s.out) {
+    uint64_t at = s.pos + inc - n;
+    for (uint32_t i = 0; i < n; i++) s.out[at + i] = (uint8_t)(bytes >> (8 * i));
+  }
+  s.pos += tot;
+}
+LM_DEV char hexd(uint32_t v) { return (char)(v < 10 ? '0' + v : 'a' + (v - 10)); }
+// JSON escape of one byte of a UTF-8 string (bytes >= 0x80 pass through)
+LM_DEV void esc_byte(uint32_t c, uint64_t& bytes, uint32_t& n) {
+  if (c == '"') { bytes = (uint64_t)'\\' | ((uint64_t)'"' << 8); n = 2; }
+  else if (c == '\\') { bytes = (uint64_t)'\\' | ((uint64_t)'\\' << 8); n = 2; }
+  else if (c >= 0x20) { bytes = c; n = 1; }
+  else {
+    char e = 0;
+    if (c == 8) e = 'b'; else if (c == 12) e = 'f'; else if (c == 10) e = 'n'; else if (c == 13) e = 'r'; else if (c == 9) e = 't';
+    if (e) { bytes = (uint64_t)'\\' | ((uint64_t)e << 8); n = 2; }
+    else {
+      bytes = (uint64_t)'\\' | ((uint64_t)'u' << 8) | ((uint64_t)'0' << 16) | ((uint64_t)'0' << 24) |
+              ((uint64_t)hexd(c >> 4) << 32) | ((uint64_t)hexd(c & 15) << 40);
+      n = 6;
+    }
+  }
+}
+LM_DEV void sink_escaped(Sink& s, const uint8_t* p, uint32_t len) {  // without the quotes
+  int lane = lmw::lane();
+  for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+    uint32_t i = c0 + (uint32_t)lane;
+    uint64_t bytes = 0;
+    uint32_t n = 0;
+    if (i < len) esc_byte(p[i], bytes, n);
+    sink_lanes(s, bytes, n);
+  }
+}
+LM_DEV void sink_string(Sink& s, const uint8_t* p, uint32_t len) {
+  sink_byte(s, '"');
+  sink_escaped(s, p, len);
+  sink_byte(s, '"');
+}
+LM_DEV void sink_i64(Sink& s, int64_t v) {
+  char buf[24];
+  int n = 0;
+  uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+  do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (v < 0) buf[n++] = '-';
+  if (s.out && lmw::lane() == 0) for (int i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)buf[n - 1 - i];
+  s.pos += (uint32_t)n;
+}
+// one unicode scalar of a Text container → escaped UTF-8 (anchors contribute nothing)
+LM_DEV void cp_bytes(uint32_t cp, uint64_t& bytes, uint32_t& n) {
+  if (cp == 0xFFFFFFFFu) { n = 0; bytes = 0; return; }
+  if (cp < 0x80) { esc_byte(cp, bytes, n); return; }
+  if (cp < 0x800) { bytes = (0xC0 | (cp >> 6)) | ((uint64_t)(0x80 | (cp & 0x3F)) << 8); n = 2; }
+  else if (cp < 0x10000) {
+    bytes = (0xE0 | (cp >> 12)) | ((uint64_t)(0x80 | ((cp >> 6) & 0x3F)) << 8) | ((uint64_t)(0x80 | (cp & 0x3F)) << 16);
+    n = 3;
+  } else {
+    bytes = (0xF0 | (cp >> 18)) | ((uint64_t)(0x80 | ((cp >> 12) & 0x3F)) << 8) | ((uint64_t)(0x80 | ((cp >> 6) & 0x3F)) << 16) |
+            ((uint64_t)(0x80 | (cp & 0x3F)) << 24);
+    n = 4;
+  }
+}
+
+// render one nested LoroValue at `r` (wave-uniform parse; lists only — maps/containers/f64 were rejected at decode)
+LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err) {
+  uint32_t f_cnt[16];
+  uint32_t f_first = 0;
+  int sp = 0;
+  uint32_t cnt = 1;
+  bool in_list = false, first = true;
+  for (uint32_t guard = 0; guard < (1u << 28); guard++) {
+    while (cnt == 0) {
+      if (sp == 0) return;
+      sink_byte(s, ']');
+      sp--;
+      cnt = f_cnt[sp] & 0x7fffffffu;
+      in_list = (f_cnt[sp] >> 31) != 0;
+      first = false;
+      (void)f_first;
+    }
+    if (r.bad) { err = ST_DATA_CORRUPTION; return; }
+    cnt--;
+    if (in_list && !first) sink_byte(s, ',');
+    first = false;
+    uint32_t tag = rd_u8(r);
+    switch (tag) {
+      case 0: sink_lit(s, "null", 4); break;
+      case 1: sink_lit(s, "true", 4); break;
+      case 2: sink_lit(s, "false", 5); break;
+      case 3: sink_i64(s, rd_sleb(r)); break;
+      case 5: { uint64_t l = rd_uleb(r); if (l > rd_left(r)) { err = ST_DATA_CORRUPTION; return; } sink_string(s, r.p, (uint32_t)l); rd_skip(r, l); break; }
+      case 6: {  // binary → array of ints
+        uint64_t l = rd_uleb(r);
+        if (l > rd_left(r)) { err = ST_DATA_CORRUPTION; return; }
+        sink_byte(s, '[');
+        for (uint64_t i = 0; i < l; i++) { if (i) sink_byte(s, ','); sink_i64(s, r.p[i]); }
+        sink_byte(s, ']');
+        rd_skip(r, l);
+        break;
+      }
+      case 7: {
+        uint64_t n = rd_uleb(r);
+        if (sp >= 16 || n > (1u << 28)) { err = ST_UNSUPPORTED; return; }
+        sink_byte(s, '[');
+        f_cnt[sp++] = cnt | (in_list ? 0x80000000u : 0u);
+        cnt = (uint32_t)n;
+        in_list = true;
+        first = true;
+        break;
+      }
+      default: err = ST_UNSUPPORTED; return;
+    }
+  }
+}
+
+// K11: one wave per doc — JSON of the deep value (mode 0: size only, mode 1: write) and the VV bytes.
+LM_KERNEL void k_emit(Dev d, uint32_t* ht_list, int mode) {
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  LM_SHARED(uint32_t, s_order, MAX_CONTAINERS);
+  DocMeta m = d.doc[doc];
+  if (status_fatal(m.status)) { if (lane == 0 && mode == 0) { d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; } return; }
+  int32_t err = 0;
+  // ---- root containers that received an applied op, ordered bytewise by name
+  uint32_t C = m.n_cont;
+  bool mine = false;
+  ContRow my;
+  my.name_off = 0; my.name_len = 0; my.kind_root = 0; my.touched = 0;
+  if ((uint32_t)lane < C) { my = d.cont[m.cid0 + lane]; mine = (my.kind_root & 0x100) && my.touched; }
+  uint32_t n_roots = (uint32_t)lmw::popc64(lmw::ballot(mine));
+  {
+    uint32_t rank = 0;
+    bool dup = false;
+    for (uint32_t j = 0; j < C; j++) {
+      const ContRow o = d.cont[m.cid0 + j];
+      if (!((o.kind_root & 0x100) && o.touched)) continue;
+      if (mine && j != (uint32_t)lane) {
+        int c = bytes_cmp(d.data + o.name_off, o.name_len, d.data + my.name_off, my.name_len);
+        if (c < 0) rank++;
+        if (c == 0) dup = true;
+      }
+    }
+    if (lmw::any(mine && dup)) err = ST_UNSUPPORTED;  // two roots share a name (state.rs:1352-1392 picks by registration order)
+    if (mine && !dup) s_order[rank] = (uint32_t)lane;
+  }
+  lmw::block_sync();
+  uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
+  uint64_t doc_data0 = d.blob_off[d.doc_blob[doc]];
+  Sink s;
+  s.out = mode ? d.out + d.out_off[doc] : nullptr;
+  s.pos = 0;
+  sink_byte(s, '{');
+  for (uint32_t oi = 0; oi < n_roots && !err; oi++) {
+    uint32_t cidx = s_order[oi];
+    const ContRow c = d.cont[m.cid0 + cidx];
+    uint32_t kind = c.kind_root & 0xff;
+    if (oi) sink_byte(s, ',');
+    sink_string(s, d.data + c.name_off, c.name_len);
+    sink_byte(s, ':');
+    if (kind == CK_TEXT || kind == CK_LIST) {
+      if (kind == CK_TEXT) sink_byte(s, '"'); else sink_byte(s, '[');
+      bool first_item = true;
+      uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
+      for (uint32_t ri = 0; ri < nr && !err; ri++) {
+        uint32_t G = d.rt_grp[m.grp0 + r0 + ri];
+        uint32_t gn = d.gp_n[m.grp0 + G];
+        for (uint32_t gs = 0; gs < gn && !err; gs++) {
+          uint32_t L = d.gp_leaf[(uint64_t)(m.grp0 + G) * 64 + gs];
+          uint32_t n = d.lf_n[m.leaf0 + L];
+          bool in = (uint32_t)lane < n;
+          uint32_t id = in ? d.it_id[(uint64_t)(m.leaf0 + L) * 64 + lane] : NONE;
+          uint32_t st = in ? d.it_st[(uint64_t)(m.leaf0 + L) * 64 + lane] : ST_EVER;
+          bool vis = in && !(st & ST_EVER);
+          uint32_t payload = vis ? d.cp[elem0 + d.elem_base[m.praw0 + pid_peer(id)] + pid_ctr(id)] : 0;
+          if (kind == CK_TEXT) {
+            uint64_t bytes = 0;
+            uint32_t nb = 0;
+            if (vis) cp_bytes(payload, bytes, nb);
+            sink_lanes(s, bytes, nb);
+          } else {
+            uint64_t vm = lmw::ballot(vis);
+            while (vm && !err) {
+              int l0 = lmw::ffs64(vm);
+              vm &= vm - 1;
+              uint32_t off = lmw::bcast(payload, l0);
+              if (!first_item) sink_byte(s, ',');
+              first_item = false;
+              // bounded by the end of the doc's last blob
+              uint64_t doc_end = d.blob_off[d.doc_blob[doc + 1] - 1] + d.blob_len[d.doc_blob[doc + 1] - 1];
+              Rd r = rd_make(d.data + doc_data0 + off, doc_end - (doc_data0 + off));
+              sink_value(s, r, err);
+            }
+          }
+        }
+      }
+      if (kind == CK_TEXT) sink_byte(s, '"'); else sink_byte(s, ']');
+    } else if (kind == CK_MAP) {
+      // collect this container's winning SET entries, rank them by key, emit in order
+      uint32_t cap = d.ht_cap[doc];
+      const unsigned long long* keys = d.ht_key + d.ht0[doc];
+      const unsigned long long* best = d.ht_best + d.ht0[doc];
+      uint32_t* list = ht_list + d.ht0[doc];
+      uint32_t K = 0;
+      for (uint32_t c0 = 0; c0 < cap; c0 += 64) {
+        uint32_t sl = c0 + (uint32_t)lane;
+        bool live = false;
+        if (sl < cap) {
+          unsigned long long k = keys[sl], b = best[sl];
+          if (k != HT_EMPTY && (uint32_t)(k >> 32) == cidx && b != 0) {
+            uint32_t row = m.op0 + (uint32_t)((b - 1) & 0xffffffu);
+            live = ((d.op[row].cidx_kind >> 16) & 0xff) == OK_MAP_SET;
+          }
+        }
+        uint64_t lm_ = lmw::ballot(live);
+        if (live) list[K + (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1))] = sl;
+        K += (uint32_t)lmw::popc64(lm_);
+      }
+      lmw::block_sync();
+      // rank sort into the upper half of the list scratch (cap entries are available: K <= cap/2)
+      uint32_t* sorted = list + cap / 2;
+      for (uint32_t e = (uint32_t)lane; e < K; e += 64) {
+        uint32_t krow = (uint32_t)keys[list[e]];
+        const uint8_t* ka = d.data + d.key_off[krow];
+        uint32_t la = d.key_len[krow];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < K; j++) {
+          if (j == e) continue;
+          uint32_t kj = (uint32_t)keys[list[j]];
+          if (bytes_cmp(d.data + d.key_off[kj], d.key_len[kj], ka, la) < 0) rank++;
+        }
+        sorted[rank] = list[e];
+      }
+      lmw::block_sync();
+      sink_byte(s, '{');
+      for (uint32_t e = 0; e < K && !err; e++) {
+        uint32_t sl = sorted[e];
+        uint32_t krow = (uint32_t)keys[sl];
+        uint32_t row = m.op0 + (uint32_t)((best[sl] - 1) & 0xffffffu);
+        if (e) sink_byte(s, ',');
+        sink_string(s, d.data + d.key_off[krow], d.key_len[krow]);
+        sink_byte(s, ':');
+        const BlockDesc& bd = d.blk[d.op_blk[row]];
+        const uint8_t* lim = d.data + bd.base + bd.sec_rel[SEC_VALUES] + bd.sec_len[SEC_VALUES];
+        const uint8_t* p = d.data + d.op_val[row];
+        Rd r = rd_make(p, (uint64_t)(lim - p));
+        sink_value(s, r, err);
+      }
+      sink_byte(s, '}');
+    } else {
+      sink_lit(s, "null", 4);
+    }
+  }
+  sink_byte(s, '}');
+  // ---- VersionVector: postcard map, entries sorted by peer, only peers with applied ops
+  uint32_t vvn = 0;
+  {
+    uint32_t P = m.n_peers;
+    uint8_t* vo = mode ? d.vv_out + d.vv_off[doc] : nullptr;
+    uint32_t cntp = 0;
+    for (uint32_t p = 0; p < P; p++) if (d.peer_end[m.praw0 + p] > 0) cntp++;
+    auto put_uleb = [&](uint64_t v) {
+      do { uint8_t b = v & 0x7f; v >>= 7; if (v) b |= 0x80; if (vo && lane == 0) vo[vvn] = b; vvn++; } while (v);
+    };
+    put_uleb(cntp);
+    for (uint32_t p = 0; p < P; p++) {
+      uint32_t e = d.peer_end[m.praw0 + p];
+      if (e == 0) continue;
+      put_uleb(d.peer_uniq[m.praw0 + p]);
+      put_uleb((uint64_t)e << 1);  // zigzag of a non-negative i32
+    }
+  }
+  if (lane == 0) {
+    if (err) { d.doc[doc].status = err; d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; }
+    else if (mode == 0) { d.doc[doc].out_len = (uint32_t)s.pos; d.doc[doc].vv_len = vvn; }
+  }
+}
+
+}  // namespace lm

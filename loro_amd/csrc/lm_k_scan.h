@@ -1,0 +1,52 @@
+// Exclusive prefix sums over interleaved u32 counters (rows × ncomp) — table offsets of the decode stage.
+#pragma once
+#include "lm_wave.h"
+
+namespace lm {
+
+static constexpr int SCAN_TILE = 256;
+
+// phase 1: per-tile exclusive scan; out[row] = exclusive-in-tile, tile_sum[tile] = tile total
+LM_KERNEL void k_scan_tile(const uint32_t* in, uint32_t* out, uint32_t* tile_sum, uint32_t n, uint32_t ncomp) {
+  LM_SHARED(uint32_t, s_w, 4);
+  uint32_t tile = (uint32_t)lmw::bid();
+  uint32_t row = tile * SCAN_TILE + (uint32_t)lmw::tid();
+  int lane = lmw::lane(), w = lmw::wave_in_block();
+  for (uint32_t c = 0; c < ncomp; c++) {
+    uint32_t v = row < n ? in[(uint64_t)row * ncomp + c] : 0;
+    uint32_t inc = lmw::scan_incl_add(v);
+    if (lane == 63) s_w[w] = inc;
+    lmw::block_sync();
+    uint32_t base = 0;
+    for (int k = 0; k < w; k++) base += s_w[k];
+    if (row < n) out[(uint64_t)row * ncomp + c] = base + inc - v;
+    if (lmw::tid() == SCAN_TILE - 1) tile_sum[(uint64_t)tile * ncomp + c] = base + inc;
+    lmw::block_sync();
+  }
+}
+// phase 2: one wave scans the tile sums in place (exclusive)
+LM_KERNEL void k_scan_sums(uint32_t* tile_sum, uint32_t n_tiles, uint32_t ncomp, uint32_t* totals) {
+  int lane = lmw::lane();
+  for (uint32_t c = 0; c < ncomp; c++) {
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 64) {
+      uint32_t t = t0 + (uint32_t)lane;
+      uint32_t v = t < n_tiles ? tile_sum[(uint64_t)t * ncomp + c] : 0;
+      uint32_t inc = lmw::scan_incl_add(v);
+      if (t < n_tiles) tile_sum[(uint64_t)t * ncomp + c] = run + inc - v;
+      run += lmw::bcast(inc, 63);
+    }
+    if (lane == 0) totals[c] = run;
+  }
+}
+// phase 3: add tile bases; row n receives the totals
+LM_KERNEL void k_scan_add(uint32_t* out, const uint32_t* tile_sum, const uint32_t* totals, uint32_t n, uint32_t ncomp) {
+  uint32_t tile = (uint32_t)lmw::bid();
+  uint32_t row = tile * SCAN_TILE + (uint32_t)lmw::tid();
+  for (uint32_t c = 0; c < ncomp; c++) {
+    if (row < n) out[(uint64_t)row * ncomp + c] += tile_sum[(uint64_t)tile * ncomp + c];
+    if (row == n) out[(uint64_t)row * ncomp + c] = totals[c];
+  }
+}
+
+}  // namespace lm

@@ -1,0 +1,340 @@
+// Host orchestration of the batched merge: staging, table sizing, kernel sequence, result fetch.
+// Mirrors the reference's import flow at batch granularity (crates/loro-internal/src/loro.rs:568-649,
+// 720-851: parse → decode changes → apply to oplog → diff_calc → state) with every stage on the device.
+//
+// The including translation unit provides the backend:
+//   lmbe::dalloc/dfree/dmemset/h2d/d2h/sync/halloc/hfree, lmbe::tic()/toc(name) and the macro
+//   LM_LAUNCH(kernel, grid, block, args...).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "lm_k_scan.h"
+#include "lm_k_emit.h"
+
+namespace lm {
+
+struct DBuf {  // grow-only device buffer
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) lmbe::dfree(p);
+    size_t want = n + n / 8 + 256;
+    p = lmbe::dalloc(want);
+    if (!p) throw std::runtime_error("device allocation failed");
+    cap = want;
+  }
+  void release() { if (p) lmbe::dfree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() { return (T*)p; }
+};
+
+struct DocResult {
+  int32_t status;
+  uint64_t json_off, json_len, vv_off, vv_len, pending;
+};
+
+struct KernelTime { std::string name; double ms; };
+
+struct Engine {
+  // staged input
+  uint32_t n_docs = 0, n_blobs = 0;
+  uint64_t data_bytes = 0, in_bytes = 0;
+  std::vector<uint64_t> h_blob_off;
+  std::vector<uint32_t> h_blob_len, h_doc_blob, h_blob_doc;
+  DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc;
+  // work buffers
+  DBuf b_blob_status, b_blob_nblk, b_blob_blk0, b_tile, b_tot;
+  DBuf b_blk, b_bcnt, b_boff;
+  DBuf b_chg, b_dep_peer, b_dep_ctr, b_op, b_op_val, b_op_blk, b_key_off, b_key_len, b_cid_raw, b_cid_map, b_peer_raw, b_peer_map;
+  DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
+  DBuf b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
+  DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
+  DBuf b_cp, b_loc;
+  DBuf b_it_id, b_it_ol, b_it_or, b_it_st, b_lf_n, b_lf_next, b_lf_grp, b_gp_leaf, b_gp_act, b_gp_n, b_rt_grp, b_rt_act;
+  DBuf b_cont_root0, b_cont_nroot, b_vis;
+  DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list;
+  DBuf b_out, b_out_off, b_vv_out, b_vv_off;
+  // results
+  std::vector<DocMeta> h_doc;
+  std::vector<DocResult> results;
+  std::vector<uint8_t> h_out, h_vv;
+  std::vector<uint64_t> h_out_off, h_vv_off;
+  uint64_t out_bytes = 0, vv_bytes = 0;
+  bool ran = false, fetched = false;
+  std::vector<KernelTime> times;
+  bool profiling = false;
+  std::string last_error;
+  uint64_t device_bytes = 0;
+
+  ~Engine() { release_all(); }
+  void release_all() {
+    DBuf* all[] = {&b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
+                   &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
+                   &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_elem_base,
+                   &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
+                   &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it_id,
+                   &b_it_ol, &b_it_or, &b_it_st, &b_lf_n, &b_lf_next, &b_lf_grp, &b_gp_leaf, &b_gp_act, &b_gp_n, &b_rt_grp, &b_rt_act,
+                   &b_cont_root0, &b_cont_nroot, &b_vis, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_out, &b_out_off,
+                   &b_vv_out, &b_vv_off};
+    for (DBuf* b : all) b->release();
+  }
+
+  // ---- stage: pack the blobs (16-byte aligned starts) and upload
+  struct DocIn { const uint8_t* const* blobs; const size_t* lens; size_t n; };
+  void stage(const DocIn* docs, size_t nd) {
+    n_docs = (uint32_t)nd;
+    h_doc_blob.assign(nd + 1, 0);
+    size_t nb = 0;
+    for (size_t i = 0; i < nd; i++) { h_doc_blob[i] = (uint32_t)nb; nb += docs[i].n; }
+    h_doc_blob[nd] = (uint32_t)nb;
+    n_blobs = (uint32_t)nb;
+    h_blob_off.assign(nb + 1, 0);
+    h_blob_len.assign(nb, 0);
+    h_blob_doc.assign(nb, 0);
+    uint64_t off = 0;
+    in_bytes = 0;
+    size_t b = 0;
+    for (size_t i = 0; i < nd; i++)
+      for (size_t k = 0; k < docs[i].n; k++, b++) {
+        if (docs[i].lens[k] > 0xfffffff0ull) throw std::runtime_error("blob larger than 4 GiB");
+        h_blob_off[b] = off;
+        h_blob_len[b] = (uint32_t)docs[i].lens[k];
+        h_blob_doc[b] = (uint32_t)i;
+        in_bytes += docs[i].lens[k];
+        off += (docs[i].lens[k] + 15) & ~(uint64_t)15;
+      }
+    h_blob_off[nb] = off;
+    data_bytes = off + 64;
+    uint8_t* host = (uint8_t*)lmbe::halloc(data_bytes);
+    if (!host) throw std::runtime_error("host staging allocation failed");
+    memset(host, 0, data_bytes);
+    b = 0;
+    for (size_t i = 0; i < nd; i++)
+      for (size_t k = 0; k < docs[i].n; k++, b++) memcpy(host + h_blob_off[b], docs[i].blobs[k], docs[i].lens[k]);
+    b_data.ensure(data_bytes);
+    lmbe::h2d(b_data.p, host, data_bytes);
+    lmbe::hfree(host);
+    b_blob_off.ensure((nb + 1) * 8); lmbe::h2d(b_blob_off.p, h_blob_off.data(), (nb + 1) * 8);
+    b_blob_len.ensure(nb * 4 + 4); if (nb) lmbe::h2d(b_blob_len.p, h_blob_len.data(), nb * 4);
+    b_doc_blob.ensure((nd + 1) * 4); lmbe::h2d(b_doc_blob.p, h_doc_blob.data(), (nd + 1) * 4);
+    b_blob_doc.ensure(nb * 4 + 4); if (nb) lmbe::h2d(b_blob_doc.p, h_blob_doc.data(), nb * 4);
+    lmbe::sync();
+    ran = fetched = false;
+  }
+
+  void scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t ncomp) {
+    uint32_t tiles = (n + 1 + SCAN_TILE - 1) / SCAN_TILE;
+    b_tile.ensure((size_t)tiles * ncomp * 4 + 64);
+    b_tot.ensure(64 * 4);
+    LM_LAUNCH(k_scan_tile, tiles, SCAN_TILE, in, out, b_tile.as<uint32_t>(), n, ncomp);
+    LM_LAUNCH(k_scan_sums, 1, 64, b_tile.as<uint32_t>(), tiles, ncomp, b_tot.as<uint32_t>());
+    LM_LAUNCH(k_scan_add, tiles, SCAN_TILE, out, b_tile.as<uint32_t>(), b_tot.as<uint32_t>(), n, ncomp);
+  }
+
+  static uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+  // ---- run: the device pipeline over the staged batch
+  void run() {
+    times.clear();
+    Dev d;
+    memset(&d, 0, sizeof d);
+    d.data = b_data.as<uint8_t>();
+    d.blob_off = b_blob_off.as<uint64_t>();
+    d.blob_len = b_blob_len.as<uint32_t>();
+    d.doc_blob = b_doc_blob.as<uint32_t>();
+    d.n_blobs = n_blobs;
+    d.n_docs = n_docs;
+    results.assign(n_docs, DocResult{0, 0, 0, 0, 0, 0});
+    if (n_docs == 0) { ran = true; return; }
+    // 1. envelope / checksum / block count
+    b_blob_status.ensure((size_t)n_blobs * 4 + 4);
+    b_blob_nblk.ensure((size_t)(n_blobs + 1) * 4);
+    b_blob_blk0.ensure((size_t)(n_blobs + 1) * 4);
+    d.blob_status = b_blob_status.as<int32_t>();
+    d.blob_nblk = b_blob_nblk.as<uint32_t>();
+    d.blob_blk0 = b_blob_blk0.as<uint32_t>();
+    d.blob_doc = b_blob_doc.as<uint32_t>();
+    lmbe::tic();
+    if (n_blobs) LM_LAUNCH(k_frame_count, cdiv(n_blobs, 64), 64, d);
+    lmbe::toc("k_frame_count", times, profiling);
+    scan(d.blob_nblk, d.blob_blk0, n_blobs, 1);
+    uint32_t NB = 0;
+    lmbe::d2h(&NB, d.blob_blk0 + n_blobs, 4);
+    d.n_blocks = NB;
+    // 2. block descriptors + row counts
+    b_blk.ensure((size_t)(NB + 1) * sizeof(BlockDesc));
+    b_bcnt.ensure((size_t)(NB + 1) * BCN * 4);
+    b_boff.ensure((size_t)(NB + 1) * BCN * 4);
+    d.blk = b_blk.as<BlockDesc>();
+    d.bcnt = b_bcnt.as<uint32_t>();
+    d.boff = b_boff.as<uint32_t>();
+    lmbe::tic();
+    if (n_blobs) LM_LAUNCH(k_frame_fill, cdiv(n_blobs, 64), 64, d);
+    if (NB) LM_LAUNCH(k_block_count, cdiv(NB, 64), 64, d);
+    lmbe::toc("k_frame_fill+k_block_count", times, profiling);
+    scan(d.bcnt, d.boff, NB, BCN);
+    uint32_t tot[BCN];
+    lmbe::d2h(tot, d.boff + (uint64_t)NB * BCN, sizeof tot);
+    uint32_t NC = tot[BC_CHG], ND = tot[BC_DEP], NO = tot[BC_OP], NK = tot[BC_KEY], NCID = tot[BC_CID], NP = tot[BC_PEER];
+    // 3. row tables
+    b_chg.ensure((size_t)(NC + 1) * sizeof(ChangeRow));
+    b_dep_peer.ensure((size_t)(ND + 1) * 4); b_dep_ctr.ensure((size_t)(ND + 1) * 4);
+    b_op.ensure((size_t)(NO + 1) * sizeof(OpRow)); b_op_val.ensure((size_t)(NO + 1) * 8); b_op_blk.ensure((size_t)(NO + 1) * 4);
+    b_key_off.ensure((size_t)(NK + 1) * 8); b_key_len.ensure((size_t)(NK + 1) * 4);
+    b_cid_raw.ensure((size_t)(NCID + 1) * 16); b_cid_map.ensure((size_t)(NCID + 1) * 4);
+    b_peer_raw.ensure((size_t)(NP + 1) * 8); b_peer_map.ensure((size_t)(NP + 1) * 4);
+    b_doc.ensure((size_t)n_docs * sizeof(DocMeta));
+    b_peer_uniq.ensure((size_t)(NP + 1) * 8);
+    for (DBuf* b : {&b_peer_end, &b_peer_ext, &b_elem_base, &b_peer_chg0, &b_peer_chg1}) b->ensure((size_t)(NP + 1) * 4);
+    b_cont.ensure((size_t)(NCID + 1) * sizeof(ContRow));
+    for (DBuf* b : {&b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first, &b_node_last, &b_node_order, &b_chg_node,
+                    &b_node_done, &b_node_lam})
+      b->ensure((size_t)(NC + 1) * 4);
+    b_blk_sorted.ensure((size_t)(NB + 1) * 4);
+    b_cont_root0.ensure((size_t)(NCID + 1) * 4); b_cont_nroot.ensure((size_t)(NCID + 1) * 4);
+    d.chg = b_chg.as<ChangeRow>(); d.dep_peer = b_dep_peer.as<uint32_t>(); d.dep_ctr = b_dep_ctr.as<uint32_t>();
+    d.op = b_op.as<OpRow>(); d.op_val = b_op_val.as<uint64_t>(); d.op_blk = b_op_blk.as<uint32_t>();
+    d.key_off = b_key_off.as<uint64_t>(); d.key_len = b_key_len.as<uint32_t>();
+    d.cid_raw = b_cid_raw.as<uint32_t>(); d.cid_map = b_cid_map.as<uint32_t>();
+    d.peer_raw = b_peer_raw.as<uint64_t>(); d.peer_map = b_peer_map.as<uint32_t>();
+    d.doc = b_doc.as<DocMeta>(); d.peer_uniq = b_peer_uniq.as<uint64_t>();
+    d.peer_end = b_peer_end.as<uint32_t>(); d.peer_ext = b_peer_ext.as<uint32_t>(); d.elem_base = b_elem_base.as<uint32_t>();
+    d.peer_chg0 = b_peer_chg0.as<uint32_t>(); d.peer_chg1 = b_peer_chg1.as<uint32_t>();
+    d.cont = b_cont.as<ContRow>();
+    d.chg_sorted = b_chg_sorted.as<uint32_t>(); d.chg_lamport = b_chg_lamport.as<uint32_t>();
+    d.chg_skip = b_chg_skip.as<uint32_t>(); d.chg_flag = b_chg_flag.as<uint32_t>();
+    d.node_first = b_node_first.as<uint32_t>(); d.node_last = b_node_last.as<uint32_t>(); d.node_order = b_node_order.as<uint32_t>();
+    d.cont_root0 = b_cont_root0.as<uint32_t>(); d.cont_nroot = b_cont_nroot.as<uint32_t>();
+    DevDag g;
+    g.blk_sorted = b_blk_sorted.as<uint32_t>(); g.chg_node = b_chg_node.as<uint32_t>();
+    g.node_done = b_node_done.as<uint32_t>(); g.node_lam = b_node_lam.as<uint32_t>();
+    lmbe::dmemset(b_chg_flag.p, 0, (size_t)(NC + 1) * 4);
+    lmbe::dmemset(b_chg_skip.p, 0, (size_t)(NC + 1) * 4);
+    lmbe::dmemset(b_chg_lamport.p, 0, (size_t)(NC + 1) * 4);
+    lmbe::tic();
+    if (NB) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
+    lmbe::toc("k_block_decode", times, profiling);
+    lmbe::tic();
+    LM_LAUNCH(k_doc_ranges, cdiv(n_docs, 64), 64, d);
+    LM_LAUNCH(k_doc_tables, n_docs, 64, d);
+    uint32_t nmax = NO > NC ? NO : NC;
+    if (nmax) LM_LAUNCH(k_remap, cdiv(nmax, 256), 256, d, NO, NC);
+    lmbe::toc("k_doc_tables+k_remap", times, profiling);
+    lmbe::tic();
+    LM_LAUNCH(k_dag_a, n_docs, 64, d, g);
+    lmbe::toc("k_dag_a", times, profiling);
+    // 4. per-doc pool sizing on the host (one small round trip)
+    h_doc.resize(n_docs);
+    lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+    uint64_t elem = 0, leaves = 0, grps = 0, vvh = 0, ht = 0;
+    std::vector<uint64_t> h_ht0(n_docs);
+    std::vector<uint32_t> h_ht_cap(n_docs);
+    for (uint32_t i = 0; i < n_docs; i++) {
+      DocMeta& m = h_doc[i];
+      bool ok = m.status == ST_OK;
+      m.elem0_lo = (uint32_t)elem; m.elem0_hi = (uint32_t)(elem >> 32);
+      uint32_t lc = ok ? m.atoms / 32 + 2 * m.n_cont + 4 : 0;
+      uint32_t gc = ok ? lc / 32 + 2 * m.n_cont + 4 : 0;
+      if (leaves + lc > 0xfffffff0ull || grps + gc > 0xfffffff0ull) throw std::runtime_error("batch too large for 32-bit pool indices");
+      m.leaf0 = (uint32_t)leaves; m.leaf_cap = lc;
+      m.grp0 = (uint32_t)grps; m.grp_cap = gc;
+      m.vvh0_lo = (uint32_t)vvh; m.vvh0_hi = (uint32_t)(vvh >> 32);
+      if (ok) { elem += m.atoms; leaves += lc; grps += gc; vvh += (uint64_t)m.n_nodes * m.n_peers; }
+      // map table: 2× the doc's op rows rounded to a power of two when the doc has a map container (DocMeta.pad = #map op rows, from k_dag_a)
+      uint32_t cap = 0;
+      if (ok && m.pad) { cap = 64; while (cap < 2 * m.pad) cap <<= 1; }
+      h_ht0[i] = ht; h_ht_cap[i] = cap;
+      ht += cap;
+    }
+    lmbe::h2d(d.doc, h_doc.data(), (size_t)n_docs * sizeof(DocMeta));
+    b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
+    b_it_id.ensure((leaves + 1) * 64 * 4); b_it_ol.ensure((leaves + 1) * 64 * 4); b_it_or.ensure((leaves + 1) * 64 * 4); b_it_st.ensure((leaves + 1) * 64 * 4);
+    b_lf_n.ensure((leaves + 1) * 4); b_lf_next.ensure((leaves + 1) * 4); b_lf_grp.ensure((leaves + 1) * 4);
+    b_gp_leaf.ensure((grps + 1) * 64 * 4); b_gp_act.ensure((grps + 1) * 64 * 4); b_gp_n.ensure((grps + 1) * 4);
+    b_rt_grp.ensure((grps + 1) * 4); b_rt_act.ensure((grps + 1) * 4);
+    b_vvh.ensure((vvh + 1) * 4);
+    b_vis.ensure((size_t)n_docs * VIS_CAP * 8);
+    b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 4);
+    b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4);
+    lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
+    lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
+    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>();
+    d.it_id = b_it_id.as<uint32_t>(); d.it_ol = b_it_ol.as<uint32_t>(); d.it_or = b_it_or.as<uint32_t>(); d.it_st = b_it_st.as<uint32_t>();
+    d.lf_n = b_lf_n.as<uint32_t>(); d.lf_next = b_lf_next.as<uint32_t>(); d.lf_grp = b_lf_grp.as<uint32_t>();
+    d.gp_leaf = b_gp_leaf.as<uint32_t>(); d.gp_act = b_gp_act.as<uint32_t>(); d.gp_n = b_gp_n.as<uint32_t>();
+    d.rt_grp = b_rt_grp.as<uint32_t>(); d.rt_act = b_rt_act.as<uint32_t>();
+    d.vvh = b_vvh.as<uint32_t>();
+    d.vis = b_vis.as<unsigned long long>();
+    d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>();
+    d.ht0 = b_ht0.as<uint64_t>(); d.ht_cap = b_ht_cap.as<uint32_t>();
+    lmbe::dmemset(b_loc.p, 0xff, (elem + 1) * 4);
+    lmbe::dmemset(b_cp.p, 0xff, (elem + 1) * 4);
+    if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
+    lmbe::dmemset(b_cont_root0.p, 0, (size_t)(NCID + 1) * 4);
+    lmbe::dmemset(b_cont_nroot.p, 0, (size_t)(NCID + 1) * 4);
+    // 5. causal order, element payloads, LWW, integrate
+    lmbe::tic();
+    LM_LAUNCH(k_dag_b, n_docs, 64, d, g);
+    lmbe::toc("k_dag_b", times, profiling);
+    lmbe::tic();
+    if (NO) LM_LAUNCH(k_elem_fill, cdiv(NO, 256), 256, d, NO);
+    lmbe::toc("k_elem_fill", times, profiling);
+    lmbe::tic();
+    if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
+    lmbe::toc("k_map_lww", times, profiling);
+    lmbe::tic();
+    LM_LAUNCH(k_integrate, n_docs, 64, d, g);
+    lmbe::toc("k_integrate", times, profiling);
+    // 6. emit: size pass, offsets, write pass
+    lmbe::tic();
+    LM_LAUNCH(k_emit, n_docs, 64, d, b_ht_list.as<uint32_t>(), 0);
+    lmbe::toc("k_emit(size)", times, profiling);
+    lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+    h_out_off.assign(n_docs + 1, 0);
+    h_vv_off.assign(n_docs + 1, 0);
+    for (uint32_t i = 0; i < n_docs; i++) {
+      bool ok = h_doc[i].status == ST_OK;
+      h_out_off[i + 1] = h_out_off[i] + (ok ? h_doc[i].out_len : 0);
+      h_vv_off[i + 1] = h_vv_off[i] + (ok ? h_doc[i].vv_len : 0);
+    }
+    out_bytes = h_out_off[n_docs];
+    vv_bytes = h_vv_off[n_docs];
+    b_out.ensure(out_bytes + 64); b_vv_out.ensure(vv_bytes + 64);
+    b_out_off.ensure((size_t)(n_docs + 1) * 8); b_vv_off.ensure((size_t)(n_docs + 1) * 8);
+    lmbe::h2d(b_out_off.p, h_out_off.data(), (size_t)(n_docs + 1) * 8);
+    lmbe::h2d(b_vv_off.p, h_vv_off.data(), (size_t)(n_docs + 1) * 8);
+    d.out = b_out.as<uint8_t>(); d.out_off = b_out_off.as<uint64_t>();
+    d.vv_out = b_vv_out.as<uint8_t>(); d.vv_off = b_vv_off.as<uint64_t>();
+    lmbe::tic();
+    LM_LAUNCH(k_emit, n_docs, 64, d, b_ht_list.as<uint32_t>(), 1);
+    lmbe::toc("k_emit(write)", times, profiling);
+    lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+    lmbe::sync();
+    for (uint32_t i = 0; i < n_docs; i++) {
+      DocResult& r = results[i];
+      r.status = h_doc[i].status;
+      bool ok = r.status == ST_OK;
+      r.json_off = h_out_off[i]; r.json_len = ok ? h_doc[i].out_len : 0;
+      r.vv_off = h_vv_off[i]; r.vv_len = ok ? h_doc[i].vv_len : 0;
+      r.pending = ok ? (((uint64_t)h_doc[i].pending_hi << 32) | h_doc[i].pending_lo) : 0;
+    }
+    ran = true;
+    fetched = false;
+  }
+
+  // ---- fetch: copy the rendered states back to the host
+  void fetch() {
+    if (!ran) throw std::runtime_error("lm_fetch before lm_run");
+    h_out.resize(out_bytes + 1);
+    h_vv.resize(vv_bytes + 1);
+    if (out_bytes) lmbe::d2h(h_out.data(), b_out.p, out_bytes);
+    if (vv_bytes) lmbe::d2h(h_vv.data(), b_vv_out.p, vv_bytes);
+    lmbe::sync();
+    fetched = true;
+  }
+};
+
+}  // namespace lm

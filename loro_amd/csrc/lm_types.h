@@ -1,0 +1,98 @@
+// Device-side tables of the batched merge engine (HBM layout).  See DESIGN.md §"Data layout in HBM".
+#pragma once
+#include <cstdint>
+
+namespace lm {
+
+static constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// per-doc status codes == LM_* in include/loro_merge.h
+enum : int32_t {
+  ST_OK = 0,
+  ST_DECODE_ERROR = 1,
+  ST_CHECKSUM_MISMATCH = 2,
+  ST_DATA_CORRUPTION = 3,
+  ST_UNSUPPORTED = 4,
+  ST_INTERNAL = 5,
+};
+
+enum : uint32_t { SEC_HEADER = 0, SEC_META, SEC_CIDS, SEC_KEYS, SEC_POS, SEC_OPS, SEC_DEL, SEC_VALUES, SEC_N };
+
+// container kinds on the wire (loro-common/src/lib.rs:748-793)
+enum : uint32_t { CK_MAP = 0, CK_LIST = 1, CK_TEXT = 2, CK_TREE = 3, CK_MOVABLE = 4, CK_COUNTER = 5 };
+
+// decoded op kinds (outdated_encode_reordered.rs:215-476 mapping)
+enum : uint32_t {
+  OK_OTHER = 0, OK_TEXT_INS = 1, OK_DEL = 2, OK_STYLE_START = 3, OK_STYLE_END = 4, OK_LIST_INS = 5, OK_MAP_SET = 6, OK_MAP_DEL = 7
+};
+
+// limits of the packed element id (peer_idx:8 | counter:24)
+static constexpr uint32_t MAX_PEERS = 256;
+static constexpr uint32_t MAX_COUNTER = 1u << 24;
+static constexpr uint32_t MAX_CONTAINERS = 64;
+
+struct BlockDesc {           // one per change block; owned by one lane during decode
+  uint64_t base;             // absolute byte offset of the block in `data`
+  uint32_t blob, doc;
+  uint32_t sec_rel[SEC_N], sec_len[SEC_N];
+  uint32_t counter_start, counter_len, lamport_start, lamport_len, n_changes;
+  int32_t status;
+};
+// per-block row counts; scanned component-wise to get table offsets
+struct BlockCounts { uint32_t n_chg, n_dep, n_op, n_key, n_cid, n_peer; };
+static constexpr int BC_N = 6;
+
+struct OpRow {               // 32 B, read with scalar loads by the integrate kernel
+  uint32_t cidx_kind;        // container idx (low 16) | op kind (bits 16-23) | flags (bits 24-31)
+  int32_t prop;              // position / key idx
+  uint32_t len;              // atom length
+  uint32_t ctr;              // absolute counter of the first atom
+  uint32_t a0, a1;           // delete: target peer idx, target counter | style start: mark len | list insert: #items
+  int32_t a2;                // delete: signed len
+  uint32_t chg;              // global change row
+};
+
+struct ChangeRow {           // 32 B
+  uint32_t peer;             // block-local 0 → doc peer idx after remap
+  uint32_t ctr, len;
+  uint32_t dep0, n_dep;      // global dep rows
+  uint32_t op0, n_op;        // global op rows
+  uint32_t blk;
+};
+
+struct ContRow {             // doc-level container
+  uint64_t name_off;         // root: absolute offset of the name bytes
+  uint32_t name_len;
+  uint32_t kind_root;        // kind | is_root<<8
+  uint32_t peer, counter;    // normal containers
+  uint32_t touched;          // received at least one applied op
+  uint32_t pad;
+};
+
+struct DocMeta {             // per document, filled progressively
+  int32_t status;
+  uint32_t blk0, n_blk;      // block range
+  uint32_t chg0, n_chg;      // change rows
+  uint32_t op0, n_op;
+  uint32_t dep0, n_dep;
+  uint32_t key0, n_key;
+  uint32_t cid0, n_cid;      // raw (per-block) cid rows
+  uint32_t praw0, n_praw;    // raw (per-block) peer rows
+  uint32_t n_peers;          // unique peers (sorted ascending by PeerID)
+  uint32_t n_cont;           // unique containers
+  uint32_t atoms;            // Σ counter_len over blocks (upper bound on elements)
+  uint32_t n_valid_chg;      // applied changes (sorted order array length)
+  uint32_t n_nodes;
+  uint32_t pending_lo, pending_hi;  // pending atoms (u64 split)
+  uint32_t elem0_lo, elem0_hi;      // first element slot of this doc (u64 split)
+  uint32_t leaf0, leaf_cap;  // leaf pool
+  uint32_t grp0, grp_cap;    // group pool (also root capacity)
+  uint32_t node0;            // node rows
+  uint32_t vvh0_lo, vvh0_hi; // vv_head rows (n_nodes × n_peers)
+  uint32_t out_len;          // JSON bytes
+  uint32_t vv_len;           // VV bytes
+  uint32_t n_seq;            // sequence containers
+  uint32_t pad;
+};
+
+}  // namespace lm

@@ -1,0 +1,245 @@
+// Wave-level programming layer for the merge kernels.
+//
+// Product build (hipcc, gfx950): thin inline wrappers over the CDNA4 wave64 builtins.
+// Test build (g++, -DLM_EMU, used ONLY by tests/emu): every lane of a workgroup runs as a cooperative
+// fiber and the cross-lane primitives rendezvous through a per-wave mailbox, so the very same kernel
+// source can be exercised on a machine without a GPU.  The emulation is a debugging harness for the
+// kernels' logic; it is never compiled into, nor reachable from, the shipped library.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+#ifndef LM_EMU
+#include <hip/hip_runtime.h>
+#define LM_DEV __device__ __forceinline__
+#define LM_DEV_NOINLINE __device__ __noinline__
+#define LM_KERNEL extern "C" __global__
+#define LM_SHARED(type, name, n) __shared__ type name[n]
+
+namespace lmw {
+static constexpr int WAVE = 64;
+LM_DEV int tid() { return (int)threadIdx.x; }
+LM_DEV int bid() { return (int)blockIdx.x; }
+LM_DEV int bdim() { return (int)blockDim.x; }
+LM_DEV int lane() { return (int)(threadIdx.x & 63); }
+LM_DEV int wave_in_block() { return (int)(threadIdx.x >> 6); }
+LM_DEV void block_sync() { __syncthreads(); }
+LM_DEV uint64_t ballot(bool p) { return __ballot(p); }
+LM_DEV uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+LM_DEV uint64_t shfl64(uint64_t v, int src) {
+  uint32_t lo = shfl((uint32_t)v, src), hi = shfl((uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+LM_DEV uint32_t shfl_up(uint32_t v, int d) { return (uint32_t)__shfl_up((int)v, d, 64); }
+LM_DEV uint32_t shfl_xor(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+// value of `v` in lane `src`; src must be wave-uniform
+LM_DEV uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+LM_DEV uint32_t first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+LM_DEV uint32_t atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+LM_DEV uint32_t atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+LM_DEV uint64_t atomic_max64(unsigned long long* p, uint64_t v) { return atomicMax(p, (unsigned long long)v); }
+LM_DEV uint64_t atomic_cas64(unsigned long long* p, uint64_t cmp, uint64_t v) {
+  return atomicCAS(p, (unsigned long long)cmp, (unsigned long long)v);
+}
+LM_DEV int popc64(uint64_t m) { return __popcll(m); }
+LM_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }  // -1 if empty
+}  // namespace lmw
+
+#else  // ------------------------------------------------------------------ LM_EMU (tests only)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <functional>
+#include <ucontext.h>
+#define LM_DEV inline
+#define LM_DEV_NOINLINE inline
+#define LM_KERNEL inline
+#define LM_SHARED(type, name, n) static type name[n]
+
+namespace lmw {
+static constexpr int WAVE = 64;
+struct EmuFiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  int tid = 0;
+};
+struct EmuWave {
+  uint64_t box[2][64];
+  int arrived = 0;
+  int live = 0;
+  uint64_t gen = 0;
+};
+struct EmuBlock {
+  std::vector<EmuFiber> fibers;
+  std::vector<EmuWave> waves;
+  ucontext_t sched;
+  int cur = 0, bid = 0, bdim = 0;
+  int blk_arrived = 0, blk_live = 0;
+  uint64_t blk_gen = 0;
+  uint64_t progress = 0;
+  std::function<void()> body;
+};
+inline EmuBlock*& emu_cur() {
+  static thread_local EmuBlock* b = nullptr;
+  return b;
+}
+inline void emu_yield() {
+  EmuBlock* b = emu_cur();
+  swapcontext(&b->fibers[b->cur].ctx, &b->sched);
+}
+inline void emu_trampoline() {
+  EmuBlock* b = emu_cur();
+  b->body();
+  EmuFiber& f = b->fibers[b->cur];
+  f.done = true;
+  EmuWave& w = b->waves[f.tid >> 6];
+  w.live--;
+  b->blk_live--;
+  b->progress++;
+  if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; w.gen++; }
+  if (b->blk_live > 0 && b->blk_arrived == b->blk_live) { b->blk_arrived = 0; b->blk_gen++; }
+  swapcontext(&f.ctx, &b->sched);
+}
+// run one workgroup of `bdim` threads
+inline void emu_run_block(int bid, int bdim, std::function<void()> body) {
+  static const size_t STACK = 256 * 1024;
+  EmuBlock blk;
+  blk.bid = bid;
+  blk.bdim = bdim;
+  blk.body = body;
+  blk.fibers.resize(bdim);
+  blk.waves.resize((bdim + 63) / 64);
+  blk.blk_live = bdim;
+  EmuBlock* prev = emu_cur();
+  emu_cur() = &blk;
+  for (int t = 0; t < bdim; t++) {
+    EmuFiber& f = blk.fibers[t];
+    f.tid = t;
+    f.stack = (char*)malloc(STACK);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = STACK;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())emu_trampoline, 0);
+    blk.waves[t >> 6].live++;
+  }
+  int remaining = bdim;
+  uint64_t last_progress = ~0ull;
+  while (remaining > 0) {
+    if (blk.progress == last_progress) {
+      fprintf(stderr, "lm emu: deadlock — lanes blocked at different collectives (non-uniform control flow)\n");
+      abort();
+    }
+    last_progress = blk.progress;
+    remaining = 0;
+    for (int t = 0; t < bdim; t++) {
+      if (blk.fibers[t].done) continue;
+      blk.cur = t;
+      swapcontext(&blk.sched, &blk.fibers[t].ctx);
+      if (!blk.fibers[t].done) remaining++;
+    }
+  }
+  for (auto& f : blk.fibers) free(f.stack);
+  emu_cur() = prev;
+}
+template <class F>
+inline void emu_launch(int grid, int block, F&& body) {
+  for (int b = 0; b < grid; b++) emu_run_block(b, block, body);
+}
+
+inline int tid() { return emu_cur()->fibers[emu_cur()->cur].tid; }
+inline int bid() { return emu_cur()->bid; }
+inline int bdim() { return emu_cur()->bdim; }
+inline int lane() { return tid() & 63; }
+inline int wave_in_block() { return tid() >> 6; }
+inline void block_sync() {
+  EmuBlock* b = emu_cur();
+  uint64_t g = b->blk_gen;
+  b->blk_arrived++;
+  b->progress++;
+  if (b->blk_arrived == b->blk_live) { b->blk_arrived = 0; b->blk_gen++; return; }
+  while (b->blk_gen == g) emu_yield();
+}
+// all live lanes of the wave publish `v`; returns pointer to the 64 published values (dead lanes = 0)
+inline const uint64_t* emu_exchange(uint64_t v) {
+  EmuBlock* b = emu_cur();
+  int t = tid();
+  EmuWave& w = b->waves[t >> 6];
+  uint64_t g = w.gen;
+  uint64_t* box = w.box[g & 1];
+  if (w.arrived == 0) memset(box, 0, sizeof(uint64_t) * 64);
+  box[t & 63] = v;
+  w.arrived++;
+  b->progress++;
+  if (w.arrived == w.live) { w.arrived = 0; w.gen++; return box; }
+  while (w.gen == g) emu_yield();
+  return box;
+}
+inline uint64_t ballot(bool p) {
+  const uint64_t* x = emu_exchange(p ? 1 : 0);
+  uint64_t m = 0;
+  for (int i = 0; i < 64; i++) if (x[i]) m |= 1ull << i;
+  return m;
+}
+inline uint64_t shfl64(uint64_t v, int src) {
+  // src may differ per lane: publish value, then read after the rendezvous
+  const uint64_t* x = emu_exchange(v);
+  return x[src & 63];
+}
+inline uint32_t shfl(uint32_t v, int src) { return (uint32_t)shfl64(v, src); }
+inline uint32_t shfl_up(uint32_t v, int d) {
+  int l = lane();
+  const uint64_t* x = emu_exchange(v);
+  return l >= d ? (uint32_t)x[l - d] : v;
+}
+inline uint32_t shfl_xor(uint32_t v, int m) {
+  int l = lane();
+  const uint64_t* x = emu_exchange(v);
+  return (uint32_t)x[(l ^ m) & 63];
+}
+inline uint32_t bcast(uint32_t v, int src) { return shfl(v, src); }
+inline uint32_t first(uint32_t v) {
+  // value of the lowest live lane: publish (v | 1<<32) so dead lanes (0) are distinguishable
+  const uint64_t* x = emu_exchange((uint64_t)v | (1ull << 32));
+  for (int i = 0; i < 64; i++) if (x[i] >> 32) return (uint32_t)x[i];
+  return v;
+}
+inline uint32_t atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+inline uint32_t atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+inline uint64_t atomic_max64(unsigned long long* p, uint64_t v) { uint64_t o = *p; if (v > o) *p = v; return o; }
+inline uint64_t atomic_cas64(unsigned long long* p, uint64_t cmp, uint64_t v) { uint64_t o = *p; if (o == cmp) *p = v; return o; }
+inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
+}  // namespace lmw
+#endif
+
+namespace lmw {
+// ---- derived wave collectives (same source for both builds); all lanes must participate
+LM_DEV uint32_t scan_incl_add(uint32_t v) {
+  int l = lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = shfl_up(v, d);
+    if (l >= d) v += t;
+  }
+  return v;
+}
+LM_DEV uint32_t reduce_add(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+LM_DEV uint32_t reduce_max(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { uint32_t t = shfl_xor(v, m); v = t > v ? t : v; }
+  return v;
+}
+LM_DEV uint32_t reduce_min(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { uint32_t t = shfl_xor(v, m); v = t < v ? t : v; }
+  return v;
+}
+LM_DEV bool any(bool p) { return ballot(p) != 0; }
+}  // namespace lmw

@@ -1,0 +1,122 @@
+"""ctypes view of the C ABI in include/loro_merge.h, shared by the product binding (loro_amd) and the
+kernel-logic test harness (tests/emu).  `prefix` selects the exported symbol family."""
+import ctypes
+
+
+class DocIn(ctypes.Structure):
+    _fields_ = [("blobs", ctypes.POINTER(ctypes.c_char_p)), ("blob_lens", ctypes.POINTER(ctypes.c_size_t)), ("n_blobs", ctypes.c_size_t)]
+
+
+class DocOut(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("json", ctypes.c_void_p), ("json_len", ctypes.c_size_t), ("vv", ctypes.c_void_p),
+                ("vv_len", ctypes.c_size_t), ("pending_ops", ctypes.c_uint64)]
+
+
+class RunStats(ctypes.Structure):
+    _fields_ = [("n_docs", ctypes.c_uint64), ("n_blobs", ctypes.c_uint64), ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64),
+                ("device_bytes_allocated", ctypes.c_uint64), ("n_kernels", ctypes.c_uint32)]
+
+
+SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time"]
+
+
+class Binding:
+    def __init__(self, so_path, prefix):
+        self.lib = ctypes.CDLL(so_path)
+        g = lambda n: getattr(self.lib, prefix + n)
+        self.create = g("create"); self.create.restype = ctypes.c_void_p; self.create.argtypes = [ctypes.c_int]
+        self.destroy = g("destroy"); self.destroy.argtypes = [ctypes.c_void_p]
+        self.last_error = g("last_error"); self.last_error.restype = ctypes.c_char_p; self.last_error.argtypes = [ctypes.c_void_p]
+        self.merge_batch = g("merge_batch"); self.merge_batch.restype = ctypes.c_int
+        self.merge_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocIn), ctypes.c_size_t, ctypes.POINTER(DocOut)]
+        self.stage = g("stage"); self.stage.restype = ctypes.c_int
+        self.stage.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocIn), ctypes.c_size_t]
+        self.run = g("run"); self.run.restype = ctypes.c_int; self.run.argtypes = [ctypes.c_void_p]
+        self.fetch = g("fetch"); self.fetch.restype = ctypes.c_int; self.fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocOut)]
+        self.get_stats = g("get_stats"); self.get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(RunStats)]
+        self.set_profiling = g("set_profiling"); self.set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.kernel_time = g("kernel_time"); self.kernel_time.restype = ctypes.c_int
+        self.kernel_time.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double)]
+
+
+class Context:
+    """Thin object wrapper: stage/run/fetch over lists of lists of bytes."""
+
+    def __init__(self, binding, device=0):
+        self.b = binding
+        self.h = binding.create(device)
+        if not self.h:
+            raise RuntimeError("lm_create failed: no usable HIP device (there is no CPU fallback)")
+        self.n = 0
+
+    def close(self):
+        if self.h:
+            self.b.destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @staticmethod
+    def _pack(docs):
+        n = len(docs)
+        arr = (DocIn * max(n, 1))()
+        keep = []
+        for i, blobs in enumerate(docs):
+            blobs = [bytes(x) for x in blobs]
+            ptrs = (ctypes.c_char_p * max(len(blobs), 1))(*blobs)
+            lens = (ctypes.c_size_t * max(len(blobs), 1))(*[len(x) for x in blobs])
+            keep.append((blobs, ptrs, lens))
+            arr[i].blobs = ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_char_p))
+            arr[i].blob_lens = lens
+            arr[i].n_blobs = len(blobs)
+        return arr, keep
+
+    def stage(self, docs):
+        arr, keep = self._pack(docs)
+        self.n = len(docs)
+        if self.b.stage(self.h, arr, self.n) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        del keep  # the engine copied the blobs into its staging buffer
+
+    def run(self):
+        if self.b.run(self.h) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+
+    def fetch(self):
+        outs = (DocOut * max(self.n, 1))()
+        if self.b.fetch(self.h, outs) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        res = []
+        for i in range(self.n):
+            o = outs[i]
+            js = ctypes.string_at(o.json, o.json_len) if o.json_len else b""
+            vv = ctypes.string_at(o.vv, o.vv_len) if o.vv_len else b""
+            res.append((o.status, js, vv, o.pending_ops))
+        return res
+
+    def merge_batch(self, docs):
+        self.stage(docs)
+        self.run()
+        return self.fetch()
+
+    def set_profiling(self, on=True):
+        self.b.set_profiling(self.h, 1 if on else 0)
+
+    def stats(self):
+        s = RunStats()
+        self.b.get_stats(self.h, ctypes.byref(s))
+        return s
+
+    def kernel_times(self):
+        s = self.stats()
+        out = []
+        name = ctypes.c_char_p()
+        ms = ctypes.c_double()
+        for i in range(s.n_kernels):
+            if self.b.kernel_time(self.h, i, ctypes.byref(name), ctypes.byref(ms)) == 0:
+                out.append((name.value.decode(), ms.value))
+        return out

@@ -1,0 +1,38 @@
+// TEST HARNESS ONLY — compiles the device kernels for the host with every lane as a cooperative fiber
+// (lm_wave.h, LM_EMU) so the kernels' logic can be checked against the oracle on a machine without a GPU.
+// It is built and loaded exclusively by tests/ (never by loro_amd/, bench.py or the C-ABI product library),
+// and its exports carry the lmemu_ prefix so it cannot be mistaken for libloromerge.so.
+#define LM_EMU 1
+#include <chrono>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../loro_amd/csrc/lm_wave.h"
+
+namespace lmbe {
+static uint64_t g_alloc = 0;
+static std::chrono::steady_clock::time_point g_t0;
+inline bool init(int) { return true; }
+inline void* dalloc(size_t n) { g_alloc += n; return malloc(n ? n : 1); }
+inline void dfree(void* p) { free(p); }
+inline void dmemset(void* p, int v, size_t n) { memset(p, v, n); }
+inline void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
+inline void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
+inline void sync() {}
+inline void* halloc(size_t n) { return malloc(n ? n : 1); }
+inline void hfree(void* p) { free(p); }
+inline uint64_t allocated_bytes() { return g_alloc; }
+inline void tic() { g_t0 = std::chrono::steady_clock::now(); }
+template <class V>
+inline void toc(const char* name, V& times, bool profiling) {
+  if (!profiling) return;
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0).count();
+  times.push_back({name, ms});
+}
+}  // namespace lmbe
+
+#define LM_LAUNCH(kern, grid, block, ...) lmw::emu_launch((int)(grid), (int)(block), [&]() { lm::kern(__VA_ARGS__); })
+#define LM_API(name) lmemu_##name
+
+#include "../../loro_amd/csrc/lm_capi_impl.h"
