@@ -76,7 +76,7 @@ LM_KERNEL void k_doc_tables(Dev d) {
       lmw::block_sync();
     }
   }
-  if (too_many) { if (lane == 0) d.doc[doc].status = ST_UNSUPPORTED; return; }
+  if (too_many) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
   lmw::block_sync();
   for (uint32_t e = (uint32_t)lane; e < P; e += 64) {
     uint64_t v = s_peers[e];
@@ -313,7 +313,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
       if (p < P) d.elem_base[m.praw0 + p] = run + inc - e;
       run += lmw::bcast(inc, 63);
     }
-    if (run > m.atoms && lane == 0) d.doc[doc].status = ST_INTERNAL;
+    if (run > m.atoms && lane == 0) LM_SETERR(d.doc[doc].status, ST_INTERNAL);
   }
   // ---- 5. DAG nodes: maximal runs linked only by a dependency on the peer's previous op
   uint32_t n_nodes = 0;
@@ -388,7 +388,7 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
       n_done += (uint32_t)lmw::popc64(rm);
     }
     lmw::block_sync();
-    if (n_done == batch0) { if (lane == 0) d.doc[doc].status = ST_INTERNAL; return; }  // cycle: malformed deps
+    if (n_done == batch0) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }  // cycle: malformed deps
     // finish the batch: lamport + vv at the head, lamports of every change of the node
     for (uint32_t bi = batch0; bi < n_done; bi++) {
       uint32_t n = d.node_order[m.chg0 + bi];
@@ -477,7 +477,7 @@ LM_KERNEL void k_elem_fill(Dev d, uint32_t n_ops) {
       if (v.bad) bad = true;
     }
   }
-  if (bad) d.doc[doc].status = ST_DATA_CORRUPTION;
+  if (bad) LM_SETERR(d.doc[doc].status, ST_DATA_CORRUPTION);
 }
 
 }  // namespace lm

@@ -42,7 +42,7 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
   const ChangeRow& ch = d.chg[r.chg];
   if (r.ctr < ch.ctr + d.chg_skip[r.chg]) return;  // already-known prefix of a sliced change
   uint32_t cap = d.ht_cap[doc];
-  if (cap == 0) { d.doc[doc].status = ST_INTERNAL; return; }
+  if (cap == 0) { LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }
   uint32_t cidx = r.cidx_kind & 0xffff;
   uint32_t krow = d.boff[(uint64_t)blk * BCN + BC_KEY] + (uint32_t)r.prop;
   const uint8_t* ks = d.data + d.key_off[krow];
@@ -66,14 +66,14 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
     if (same) {
       uint32_t lam = d.chg_lamport[r.chg] + (r.ctr - ch.ctr);
       uint32_t rel = t - m.op0;
-      if (rel >= (1u << 24)) { d.doc[doc].status = ST_UNSUPPORTED; return; }
+      if (rel >= (1u << 24)) { LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
       unsigned long long v = ((unsigned long long)lam << 32) | ((unsigned long long)ch.peer << 24) | rel;
       lmw::atomic_max64(&best[slot], v + 1);  // +1 so that 0 stays "no write"
       d.cont[m.cid0 + cidx].touched = 1;
       return;
     }
   }
-  d.doc[doc].status = ST_INTERNAL;
+  LM_SETERR(d.doc[doc].status, ST_INTERNAL);
 }
 
 // ------------------------------------------------------------------------------------------------ sink

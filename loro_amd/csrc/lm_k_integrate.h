@@ -38,6 +38,7 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
 LM_DEV uint32_t tr_g(const Tr& t, uint32_t pid) { return t.ebase[pid_peer(pid)] + pid_ctr(pid); }
 
 LM_DEV uint32_t tr_root_find(const Tr& t, uint32_t G) {
+  lmw::wave_sync();  // lane-0 stores of the previous step must land before any lane reloads (emulation rendezvous)
   int lane = lmw::lane();
   for (uint32_t c = 0; c < t.n_root; c += 64) {
     uint32_t i = c + (uint32_t)lane;
@@ -47,6 +48,7 @@ LM_DEV uint32_t tr_root_find(const Tr& t, uint32_t G) {
   return NONE;
 }
 LM_DEV uint32_t tr_grp_slot(const Tr& t, uint32_t G, uint32_t L) {
+  lmw::wave_sync();  // lane-0 stores of the previous step must land before any lane reloads (emulation rendezvous)
   int lane = lmw::lane();
   uint64_t m = lmw::ballot((uint32_t)lane < t.gp_n[G] && t.gp_leaf[G * 64 + lane] == L);
   return m ? (uint32_t)lmw::ffs64(m) : NONE;
@@ -57,7 +59,12 @@ LM_DEV void tr_add_active(Tr& t, uint32_t L, int32_t delta) {
   uint32_t G = t.lf_grp[L];
   uint32_t s = tr_grp_slot(t, G, L);
   uint32_t ri = tr_root_find(t, G);
-  if (s == NONE || ri == NONE) { t.err = ST_INTERNAL; return; }
+  if (s == NONE || ri == NONE) {
+#ifdef LM_EMU_TRACE
+    if (lane == 0) fprintf(stderr, "add_active L=%u G=%u s=%u ri=%u n_leaf=%u n_grp=%u n_root=%u gp_n=%u\n", L, G, s, ri, t.n_leaf, t.n_grp, t.n_root, G < t.n_grp ? t.gp_n[G] : 999);
+    if (lane == 0 && G < t.n_grp) { for (uint32_t q = 0; q < t.gp_n[G]; q++) fprintf(stderr, " [%u]=%u", q, t.gp_leaf[G * 64 + q]); fprintf(stderr, "\n"); }
+#endif
+    LM_SETERR(t.err, ST_INTERNAL); return; }
   if (lane == 0) {
     t.gp_act[G * 64 + s] += (uint32_t)delta;
     t.rt_act[ri] += (uint32_t)delta;
@@ -68,7 +75,7 @@ LM_DEV void tr_add_active(Tr& t, uint32_t L, int32_t delta) {
 // insert (grp G, act) into the root array right after position `after`
 LM_DEV void tr_root_insert(Tr& t, uint32_t after, uint32_t G, uint32_t act) {
   int lane = lmw::lane();
-  if (t.n_root >= t.root_cap) { t.err = ST_INTERNAL; return; }
+  if (t.n_root >= t.root_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
   // shift [after+1, n_root) right by one, processed from the tail in 64-entry chunks
   uint32_t lo = after + 1;
   for (uint32_t hi = t.n_root; hi > lo;) {
@@ -77,7 +84,9 @@ LM_DEV void tr_root_insert(Tr& t, uint32_t after, uint32_t G, uint32_t act) {
     uint32_t a = 0, b = 0;
     bool in = i < hi;
     if (in) { a = t.rt_grp[i]; b = t.rt_act[i]; }
+    lmw::wave_sync();
     if (in) { t.rt_grp[i + 1] = a; t.rt_act[i + 1] = b; }
+    lmw::wave_sync();
     hi = c0;
   }
   if (lane == 0) { t.rt_grp[lo] = G; t.rt_act[lo] = act; }
@@ -89,16 +98,22 @@ LM_DEV void tr_group_insert(Tr& t, uint32_t L, uint32_t NL, uint32_t act) {
   uint32_t G = t.lf_grp[L];
   uint32_t n = t.gp_n[G];
   uint32_t s = tr_grp_slot(t, G, L);
-  if (s == NONE) { t.err = ST_INTERNAL; return; }
+  if (s == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
   uint32_t lf = (uint32_t)lane < n ? t.gp_leaf[G * 64 + lane] : NONE;
   uint32_t ac = (uint32_t)lane < n ? t.gp_act[G * 64 + lane] : 0;
+  lmw::wave_sync();
   if (n < 64) {
     if ((uint32_t)lane > s && (uint32_t)lane < n) { t.gp_leaf[G * 64 + lane + 1] = lf; t.gp_act[G * 64 + lane + 1] = ac; }
-    if (lane == 0) { t.gp_leaf[G * 64 + s + 1] = NL; t.gp_act[G * 64 + s + 1] = act; t.gp_n[G] = n + 1; t.lf_grp[NL] = G; }
+    uint32_t ri = tr_root_find(t, G);
+    if (ri == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    if (lane == 0) {
+      t.gp_leaf[G * 64 + s + 1] = NL; t.gp_act[G * 64 + s + 1] = act; t.gp_n[G] = n + 1; t.lf_grp[NL] = G;
+      t.rt_act[ri] += act;
+    }
     return;
   }
   // split the full group: 65 entries → 33 stay, 32 move to a new group
-  if (t.n_grp >= t.grp_cap) { t.err = ST_INTERNAL; return; }
+  if (t.n_grp >= t.grp_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
   uint32_t NG = t.n_grp++;
   // logical sequence q ∈ [0,65): q<=s → old[q]; q==s+1 → new; q>s+1 → old[q-1]
   uint32_t keep = 33;
@@ -123,13 +138,14 @@ LM_DEV void tr_group_insert(Tr& t, uint32_t L, uint32_t NL, uint32_t act) {
   uint32_t a_old = lmw::reduce_add((uint32_t)lane < keep ? t.gp_act[G * 64 + lane] : 0);
   uint32_t a_new = lmw::reduce_add(lane < 32 ? t.gp_act[NG * 64 + lane] : 0);
   uint32_t ri = tr_root_find(t, G);
-  if (ri == NONE) { t.err = ST_INTERNAL; return; }
+  if (ri == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
   if (lane == 0) t.rt_act[ri] = a_old;
   tr_root_insert(t, ri, NG, a_new);
 }
 
 struct LeafRegs { uint32_t n, id, ol, orr, st; };
 LM_DEV LeafRegs tr_leaf_load(const Tr& t, uint32_t L) {
+  lmw::wave_sync();  // lane-0 stores of the previous step must land before any lane reloads (emulation rendezvous)
   int lane = lmw::lane();
   LeafRegs r;
   r.n = t.lf_n[L];
@@ -143,6 +159,7 @@ LM_DEV LeafRegs tr_leaf_load(const Tr& t, uint32_t L) {
 
 // k-th active element (k >= 1, k <= tot_active) → (leaf, slot)
 LM_DEV void tr_find_kth(const Tr& t, uint32_t k, uint32_t& leaf, uint32_t& slot) {
+  lmw::wave_sync();  // lane-0 stores of the previous step must land before any lane reloads (emulation rendezvous)
   int lane = lmw::lane();
   uint32_t G = NONE;
   for (uint32_t c = 0; c < t.n_root; c += 64) {
@@ -182,10 +199,11 @@ LM_DEV void tr_find_kth(const Tr& t, uint32_t k, uint32_t& leaf, uint32_t& slot)
 
 // position comparison of two elements (by packed id): -1 a before b, 0 same, +1 a after b
 LM_DEV int tr_cmp_pos(Tr& t, uint32_t a, uint32_t b) {
+  lmw::wave_sync();  // lane-0 stores of the previous step must land before any lane reloads (emulation rendezvous)
   int lane = lmw::lane();
   if (a == b) return 0;
   uint32_t la = t.loc[tr_g(t, a)], lb = t.loc[tr_g(t, b)];
-  if (la >= t.n_leaf || lb >= t.n_leaf) { t.err = ST_INTERNAL; return 0; }
+  if (la >= t.n_leaf || lb >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); return 0; }
   if (la == lb) {
     uint32_t id = (uint32_t)lane < t.lf_n[la] ? t.it_id[la * 64 + lane] : NONE;
     int sa = lmw::ffs64(lmw::ballot(id == a)), sb = lmw::ffs64(lmw::ballot(id == b));
@@ -200,6 +218,7 @@ LM_DEV int tr_cmp_pos(Tr& t, uint32_t a, uint32_t b) {
 // visited id runs of the sibling scan (crdt_rope.rs:161,177-181)
 struct Vis { uint32_t n; uint32_t lo, hi; bool open; };
 LM_DEV bool vis_contains(const Tr& t, const Vis& v, uint32_t pid) {
+  lmw::wave_sync();  // lane-0 stores of the previous step must land before any lane reloads (emulation rendezvous)
   int lane = lmw::lane();
   if (pid == NONE) return false;
   if (v.open && pid >= v.lo && pid <= v.hi) return true;
@@ -214,7 +233,7 @@ LM_DEV bool vis_contains(const Tr& t, const Vis& v, uint32_t pid) {
 LM_DEV void vis_add(Tr& t, Vis& v, uint32_t pid) {
   if (v.open && pid == v.hi + 1 && pid_peer(pid) == pid_peer(v.hi)) { v.hi = pid; return; }
   if (v.open) {
-    if (v.n >= VIS_CAP) { t.err = ST_UNSUPPORTED; return; }
+    if (v.n >= VIS_CAP) { LM_SETERR(t.err, ST_UNSUPPORTED); return; }
     if (lmw::lane() == 0) t.vis[v.n] = ((unsigned long long)v.lo << 32) | v.hi;
     v.n++;
   }
@@ -267,7 +286,7 @@ LM_DEV void tr_place_run(Tr& t, uint32_t L, uint32_t ins, uint32_t pid0, uint32_
       ins += piece;
     } else {
       // even split into two leaves (total <= 128)
-      if (t.n_leaf >= t.leaf_cap) { t.err = ST_INTERNAL; return; }
+      if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
       uint32_t NL = t.n_leaf++;
       uint32_t left = (total + 1) / 2, right = total - left;
       uint32_t na_l = tr_write_items(t, L, 0, left, R, ins, piece, pid0 + done, 0, p_ol, orr, false);
@@ -294,7 +313,15 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   else {
     uint32_t slot;
     tr_find_kth(t, pos, L, slot);
-    if (L == NONE) { t.err = ST_INTERNAL; return; }
+    if (L == NONE) {
+#ifdef LM_EMU_TRACE
+      if (lane == 0) {
+        uint32_t rs = 0; for (uint32_t q = 0; q < t.n_root; q++) rs += t.rt_act[q];
+        fprintf(stderr, "find_kth pos=%u tot=%u rootsum=%u n_root=%u n_grp=%u n_leaf=%u pid0=%x len=%u\n", pos, t.tot_active, rs, t.n_root, t.n_grp, t.n_leaf, pid0, len);
+        for (uint32_t q = 0; q < t.n_root; q++) { uint32_t G = t.rt_grp[q], gs = 0; for (uint32_t z = 0; z < t.gp_n[G]; z++) gs += t.gp_act[G * 64 + z]; fprintf(stderr, " root[%u] G=%u act=%u gsum=%u gn=%u\n", q, G, t.rt_act[q], gs, t.gp_n[G]); }
+      }
+#endif
+      LM_SETERR(t.err, ST_INTERNAL); return; }
     ins = slot + 1;
   }
   LeafRegs R = tr_leaf_load(t, L);
@@ -350,11 +377,11 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
           uint32_t opr = NONE;
           if (o_or != NONE) {
             uint32_t xl = t.loc[tr_g(t, o_or)];
-            if (xl >= t.n_leaf) { t.err = ST_INTERNAL; break; }
+            if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
             uint32_t xid = (uint32_t)lane < t.lf_n[xl] ? t.it_id[xl * 64 + lane] : NONE;
             uint32_t xol = (uint32_t)lane < t.lf_n[xl] ? t.it_ol[xl * 64 + lane] : NONE;
             uint64_t xm = lmw::ballot(xid == o_or);
-            if (!xm) { t.err = ST_INTERNAL; break; }
+            if (!xm) { LM_SETERR(t.err, ST_INTERNAL); break; }
             if (lmw::bcast(xol, lmw::ffs64(xm)) == origin_left) opr = o_or;
           }
           int c;
@@ -380,6 +407,7 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   int lane = lmw::lane();
   uint32_t eb = t.ebase[peer];
   for (uint32_t cb = c0; cb < c1 && !t.err; cb += 64) {
+    lmw::wave_sync();
     uint32_t c = cb + (uint32_t)lane;
     bool valid = c < c1;
     uint32_t lf = valid ? t.loc[eb + c] : NONE;
@@ -442,6 +470,32 @@ LM_DEV void tr_move_ops(Tr& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
   }
 }
 
+#ifdef LM_EMU_CHECK
+// debug-only (emulation): verify cached active counts against the leaves
+inline bool tr_check(Tr& t, const char* what, uint32_t row) {
+  bool ok = true;
+  if (lmw::lane() == 0) {
+    uint32_t tot = 0;
+    for (uint32_t q = 0; q < t.n_root && ok; q++) {
+      uint32_t G = t.rt_grp[q], gs = 0;
+      for (uint32_t z = 0; z < t.gp_n[G]; z++) {
+        uint32_t L = t.gp_leaf[G * 64 + z], a = 0;
+        for (uint32_t i = 0; i < t.lf_n[L]; i++) a += st_active(t.it_st[L * 64 + i]) ? 1 : 0;
+        if (a != t.gp_act[G * 64 + z] || t.lf_grp[L] != G) { fprintf(stderr, "CHECK %s row=%u: leaf %u (grp %u slot %u) act=%u cached=%u lf_grp=%u n=%u\n", what, row, L, G, z, a, t.gp_act[G * 64 + z], t.lf_grp[L], t.lf_n[L]); ok = false; break; }
+        gs += a;
+      }
+      if (ok && gs != t.rt_act[q]) { fprintf(stderr, "CHECK %s row=%u: grp %u sum=%u cached=%u\n", what, row, G, gs, t.rt_act[q]); ok = false; }
+      tot += gs;
+    }
+    if (ok && tot != t.tot_active) { fprintf(stderr, "CHECK %s row=%u: tot=%u cached=%u\n", what, row, tot, t.tot_active); ok = false; }
+  }
+  return lmw::any(!ok) ? false : true;
+}
+#define TR_CHECK(what, row) do { if (!t.err && !tr_check(t, what, row)) t.err = ST_INTERNAL; } while (0)
+#else
+#define TR_CHECK(what, row) do {} while (0)
+#endif
+
 // K9: one wave per document — replay every sequence container from the empty version.
 LM_KERNEL void k_integrate(Dev d, DevDag g) {
   uint32_t doc = (uint32_t)lmw::bid();
@@ -472,7 +526,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g) {
     uint32_t ckind = kr & 0xff;
     if (ckind != CK_TEXT && ckind != CK_LIST) continue;
     // fresh tree: one empty leaf in one group
-    if (t.n_leaf >= t.leaf_cap || t.n_grp >= t.grp_cap || root_used >= m.grp_cap) { t.err = ST_INTERNAL; break; }
+    if (t.n_leaf >= t.leaf_cap || t.n_grp >= t.grp_cap || root_used >= m.grp_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     t.rt_grp = d.rt_grp + m.grp0 + root_used;
     t.rt_act = d.rt_act + m.grp0 + root_used;
     t.root_cap = m.grp_cap - root_used;
@@ -517,12 +571,14 @@ LM_KERNEL void k_integrate(Dev d, DevDag g) {
           }
           if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
             tr_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), r.len - a);
+            TR_CHECK("insert", row);
           } else if (kind == OK_DEL) {
             uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
             uint32_t t0, t1;
             if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + Ln; }
             else { t0 = r.a1; t1 = r.a1 + (Ln - a); }
             tr_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
+            TR_CHECK("delete", row);
           } else if (kind == OK_STYLE_START) {
             tr_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
           } else if (kind == OK_STYLE_END) {
@@ -533,7 +589,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g) {
               if (((pr.cidx_kind >> 16) & 0xff) == OK_STYLE_START && pr.ctr + 1 == r.ctr && (pr.cidx_kind & 0xffff) == cidx)
                 end_pos = (uint32_t)pr.prop + pr.a0;
             }
-            if (end_pos == NONE) { t.err = ST_UNSUPPORTED; break; }
+            if (end_pos == NONE) { LM_SETERR(t.err, ST_UNSUPPORTED); break; }
             uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
             tr_insert(t, pos, pid_make(node_peer, r.ctr), 1);
           }

@@ -43,6 +43,10 @@ LM_DEV uint64_t atomic_cas64(unsigned long long* p, uint64_t cmp, uint64_t v) {
 }
 LM_DEV int popc64(uint64_t m) { return __popcll(m); }
 LM_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }  // -1 if empty
+// Separates a "every lane loads" phase from a "every lane stores" phase over the same addresses.  A wave
+// executes each instruction for all lanes at once, so this is only a scheduling fence here; the fiber
+// emulation needs a real rendezvous.
+LM_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 }  // namespace lmw
 
 #else  // ------------------------------------------------------------------ LM_EMU (tests only)
@@ -212,7 +216,14 @@ inline uint64_t atomic_max64(unsigned long long* p, uint64_t v) { uint64_t o = *
 inline uint64_t atomic_cas64(unsigned long long* p, uint64_t cmp, uint64_t v) { uint64_t o = *p; if (o == cmp) *p = v; return o; }
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
+inline void wave_sync() { (void)emu_exchange(0); }
 }  // namespace lmw
+#endif
+
+#if defined(LM_EMU) && defined(LM_EMU_TRACE)
+#define LM_SETERR(lhs, code) do { if (lmw::lane() == 0) fprintf(stderr, "lm emu: " #lhs " = " #code " at %s:%d\n", __FILE__, __LINE__); (lhs) = (code); } while (0)
+#else
+#define LM_SETERR(lhs, code) do { (lhs) = (code); } while (0)
 #endif
 
 namespace lmw {

@@ -1,6 +1,6 @@
 """Kernel-logic harness: the HIP kernels compiled for the host (tests/emu/lm_emu.cpp).  Tests only."""
 import os, subprocess
-from _cabi import Binding, Context
+from loro_amd._cabi import Binding, Context
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _B = None
@@ -14,7 +14,7 @@ def binding():
         csrc = os.path.join(os.path.dirname(_HERE), "loro_amd", "csrc")
         newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith(".h")])
         if not os.path.exists(so) or os.path.getmtime(so) < newest:
-            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DLM_EMU_TRACE", "-o", so, src])
         _B = Binding(so, "lmemu_")
     return _B
 

@@ -1,0 +1,79 @@
+"""Random multi-peer editing sessions → update blobs (used by CPU and GPU parity tests)."""
+import random
+import _oracle
+from loro_amd import wire
+
+ALPHA = "abcdefghijklmnopqrstuvwxyz ABCDEFGH\n\"\\\t" + "äßλ中😀"
+
+
+def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15, max_ins=6, commit_prob=0.4,
+                   peer_base=None, styles=False):
+    """Returns (list of blobs in a random delivery order, replicas).  Replicas edit concurrently and sync
+    pairwise; after a sync the receiver's visible sequences are refreshed from the oracle."""
+    rng = random.Random(seed)
+    base = peer_base if peer_base is not None else rng.randrange(1, 1 << 40)
+    reps = [wire.Replica(base + i * rng.randrange(1, 1000) + i) for i in range(n_peers)]
+    peers = {r.peer for r in reps}
+    assert len(peers) == n_peers
+
+    def refresh(r):
+        blob = r.export()
+        for cid in list(r.seq.keys()) + [wire.root_cid("text", wire.KIND_TEXT), wire.root_cid("list", wire.KIND_LIST)]:
+            if (cid.kind == wire.KIND_TEXT and "text" in kinds) or (cid.kind == wire.KIND_LIST and "list" in kinds):
+                r.set_visible(cid.name, cid.kind, _oracle.visible_ids([blob], cid.name, cid.kind))
+
+    for _ in range(n_steps):
+        r = rng.choice(reps)
+        kind = rng.choice(kinds)
+        if kind == "text":
+            ids = r.seq.setdefault(wire.root_cid("text", wire.KIND_TEXT), [])
+            if ids and rng.random() < 0.35:
+                pos = rng.randrange(len(ids))
+                n = min(len(ids) - pos, rng.randint(1, 4))
+                r.text_delete("text", pos, n)
+            elif styles and len(ids) >= 2 and rng.random() < 0.1:
+                s = rng.randrange(len(ids) - 1)
+                e = rng.randrange(s + 1, len(ids))
+                r.text_mark("text", s, e, "bold", True)
+            else:
+                pos = rng.randint(0, len(ids))
+                s = "".join(rng.choice(ALPHA) for _ in range(rng.randint(1, max_ins)))
+                r.text_insert("text", pos, s)
+        elif kind == "list":
+            ids = r.seq.setdefault(wire.root_cid("list", wire.KIND_LIST), [])
+            if ids and rng.random() < 0.3:
+                pos = rng.randrange(len(ids))
+                r.list_delete("list", pos, min(len(ids) - pos, rng.randint(1, 3)))
+            else:
+                vals = [rng.choice([None, True, False, rng.randint(-10**12, 10**12), "s%d" % rng.randint(0, 99), b"\x00\x01\xff",
+                                    [1, "x", [None]]]) for _ in range(rng.randint(1, 3))]
+                r.list_insert("list", rng.randint(0, len(ids)), vals)
+        else:
+            key = "k%d" % rng.randint(0, 7)
+            if rng.random() < 0.2:
+                r.map_delete("map", key)
+            else:
+                r.map_set("map", key, rng.choice([None, True, rng.randint(-5, 5), "v\"%d" % rng.randint(0, 9), [1, 2, "z"]]))
+        if rng.random() < commit_prob:
+            r.commit()
+        if rng.random() < sync_prob and n_peers > 1:
+            a, b = rng.sample(reps, 2)
+            a.commit(); b.commit()
+            if a.merge_from(b):
+                refresh(a)
+    for r in reps:
+        r.commit()
+    return reps
+
+
+def blobs_of(reps, rng=None, split=False):
+    """Each replica exports only its OWN changes (as a relay would hold them); order optionally shuffled."""
+    out = []
+    for r in reps:
+        own = wire.Replica(r.peer)
+        own.changes = {r.peer: r.changes.get(r.peer, [])}
+        if own.changes[r.peer]:
+            out.append(own.export())
+    if rng:
+        rng.shuffle(out)
+    return out
