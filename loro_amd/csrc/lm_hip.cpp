@@ -69,6 +69,12 @@ inline void check_launch(const char* name) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, lmbe::g_stream, __VA_ARGS__); \
     lmbe::check_launch(#kern);                                                                     \
   } while (0)
+#define LM_LAUNCH_DYN(kern, grid, block, shmem, ...)                                               \
+  do {                                                                                             \
+    LM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shmem))); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (shmem), lmbe::g_stream, __VA_ARGS__); \
+    lmbe::check_launch(#kern);                                                                     \
+  } while (0)
 #define LM_API(name) lm_##name
 
 #include "lm_capi_impl.h"

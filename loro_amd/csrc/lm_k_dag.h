@@ -345,18 +345,22 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     g.node_done[m.chg0 + n] = 0;
   }
   // number of Map op rows (sizes the doc's LWW hash table)
-  uint32_t n_map = 0;
+  uint32_t n_map = 0, n_el = 0;
   for (uint32_t i = (uint32_t)lane; i < m.n_op; i += 64) {
-    uint32_t k = (d.op[m.op0 + i].cidx_kind >> 16) & 0xff;
+    const OpRow& r = d.op[m.op0 + i];
+    uint32_t k = (r.cidx_kind >> 16) & 0xff;
     n_map += (k == OK_MAP_SET || k == OK_MAP_DEL) ? 1u : 0u;
+    n_el += (k == OK_TEXT_INS || k == OK_LIST_INS || k == OK_STYLE_START || k == OK_STYLE_END) ? r.len : 0u;
   }
   n_map = lmw::reduce_add(n_map);
+  n_el = lmw::reduce_add(n_el);
   if (lane == 0) {
     d.doc[doc].n_valid_chg = n_valid;
     d.doc[doc].n_nodes = n_nodes;
     d.doc[doc].pending_lo = pending;
     d.doc[doc].pending_hi = 0;
-    d.doc[doc].pad = n_map;
+    d.doc[doc].n_mapop = n_map;
+    d.doc[doc].n_elems = n_el;
   }
 }
 

@@ -65,10 +65,8 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* loc;         // element → leaf
   // tracker pools
   uint32_t* it_id; uint32_t* it_ol; uint32_t* it_or; uint32_t* it_st;
-  uint32_t* lf_n; uint32_t* lf_next; uint32_t* lf_grp;
-  uint32_t* gp_leaf; uint32_t* gp_act; uint32_t* gp_n;
-  uint32_t* rt_grp; uint32_t* rt_act;
-  uint32_t* cont_root0;  // per doc container: root array start (doc-relative) / length
+  uint32_t* dir_out;     // [leaf0 + i] flushed leaf directories (entry = leaf | n<<18 | act<<25)
+  uint32_t* cont_root0;  // per doc container: first directory entry (doc-relative) / number of entries
   uint32_t* cont_nroot;
   unsigned long long* vis;  // per doc scratch for the Fugue sibling scan
   // map LWW

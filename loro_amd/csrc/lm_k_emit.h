@@ -256,11 +256,9 @@ LM_KERNEL void k_emit(Dev d, uint32_t* ht_list, int mode) {
       bool first_item = true;
       uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
       for (uint32_t ri = 0; ri < nr && !err; ri++) {
-        uint32_t G = d.rt_grp[m.grp0 + r0 + ri];
-        uint32_t gn = d.gp_n[m.grp0 + G];
-        for (uint32_t gs = 0; gs < gn && !err; gs++) {
-          uint32_t L = d.gp_leaf[(uint64_t)(m.grp0 + G) * 64 + gs];
-          uint32_t n = d.lf_n[m.leaf0 + L];
+        {
+          uint32_t de = d.dir_out[m.leaf0 + r0 + ri];
+          uint32_t L = de_leaf(de), n = de_n(de);
           bool in = (uint32_t)lane < n;
           uint32_t id = in ? d.it_id[(uint64_t)(m.leaf0 + L) * 64 + lane] : NONE;
           uint32_t st = in ? d.it_st[(uint64_t)(m.leaf0 + L) * 64 + lane] : ST_EVER;

@@ -53,7 +53,7 @@ struct Engine {
   DBuf b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
   DBuf b_cp, b_loc;
-  DBuf b_it_id, b_it_ol, b_it_or, b_it_st, b_lf_n, b_lf_next, b_lf_grp, b_gp_leaf, b_gp_act, b_gp_n, b_rt_grp, b_rt_act;
+  DBuf b_it_id, b_it_ol, b_it_or, b_it_st, b_dir_out;
   DBuf b_cont_root0, b_cont_nroot, b_vis;
   DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list;
   DBuf b_out, b_out_off, b_vv_out, b_vv_off;
@@ -76,7 +76,7 @@ struct Engine {
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it_id,
-                   &b_it_ol, &b_it_or, &b_it_st, &b_lf_n, &b_lf_next, &b_lf_grp, &b_gp_leaf, &b_gp_act, &b_gp_n, &b_rt_grp, &b_rt_act,
+                   &b_it_ol, &b_it_or, &b_it_st, &b_dir_out,
                    &b_cont_root0, &b_cont_nroot, &b_vis, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
@@ -229,32 +229,33 @@ struct Engine {
     // 4. per-doc pool sizing on the host (one small round trip)
     h_doc.resize(n_docs);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
-    uint64_t elem = 0, leaves = 0, grps = 0, vvh = 0, ht = 0;
+    uint64_t elem = 0, leaves = 0, vvh = 0, ht = 0;
+    uint32_t dir_cap = 64;
+    static const uint32_t DIR_CAP_MAX = 36000;  // (36000 + 2·MAX_PEERS)·4 B stays inside the 160 KiB LDS of a CU
     std::vector<uint64_t> h_ht0(n_docs);
     std::vector<uint32_t> h_ht_cap(n_docs);
     for (uint32_t i = 0; i < n_docs; i++) {
       DocMeta& m = h_doc[i];
       bool ok = m.status == ST_OK;
       m.elem0_lo = (uint32_t)elem; m.elem0_hi = (uint32_t)(elem >> 32);
-      uint32_t lc = ok ? m.atoms / 32 + 2 * m.n_cont + 4 : 0;
-      uint32_t gc = ok ? lc / 32 + 2 * m.n_cont + 4 : 0;
-      if (leaves + lc > 0xfffffff0ull || grps + gc > 0xfffffff0ull) throw std::runtime_error("batch too large for 32-bit pool indices");
+      // every split leaves both halves with >= 32 elements; each container starts with one (possibly small) leaf
+      uint32_t lc = ok ? m.n_elems / 32 + 2 * m.n_cont + 2 : 0;
+      if (leaves + lc > 0xfffffff0ull) throw std::runtime_error("batch too large for 32-bit pool indices");
       m.leaf0 = (uint32_t)leaves; m.leaf_cap = lc;
-      m.grp0 = (uint32_t)grps; m.grp_cap = gc;
       m.vvh0_lo = (uint32_t)vvh; m.vvh0_hi = (uint32_t)(vvh >> 32);
-      if (ok) { elem += m.atoms; leaves += lc; grps += gc; vvh += (uint64_t)m.n_nodes * m.n_peers; }
-      // map table: 2× the doc's op rows rounded to a power of two when the doc has a map container (DocMeta.pad = #map op rows, from k_dag_a)
+      if (ok) { elem += m.atoms; leaves += lc; vvh += (uint64_t)m.n_nodes * m.n_peers; }
+      if (lc > dir_cap) dir_cap = lc;
+      // LWW table: 2× the doc's Map op rows rounded up to a power of two
       uint32_t cap = 0;
-      if (ok && m.pad) { cap = 64; while (cap < 2 * m.pad) cap <<= 1; }
+      if (ok && m.n_mapop) { cap = 64; while (cap < 2 * m.n_mapop) cap <<= 1; }
       h_ht0[i] = ht; h_ht_cap[i] = cap;
       ht += cap;
     }
+    if (dir_cap > DIR_CAP_MAX) dir_cap = DIR_CAP_MAX;  // larger documents are reported LM_UNSUPPORTED by k_integrate
     lmbe::h2d(d.doc, h_doc.data(), (size_t)n_docs * sizeof(DocMeta));
     b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
     b_it_id.ensure((leaves + 1) * 64 * 4); b_it_ol.ensure((leaves + 1) * 64 * 4); b_it_or.ensure((leaves + 1) * 64 * 4); b_it_st.ensure((leaves + 1) * 64 * 4);
-    b_lf_n.ensure((leaves + 1) * 4); b_lf_next.ensure((leaves + 1) * 4); b_lf_grp.ensure((leaves + 1) * 4);
-    b_gp_leaf.ensure((grps + 1) * 64 * 4); b_gp_act.ensure((grps + 1) * 64 * 4); b_gp_n.ensure((grps + 1) * 4);
-    b_rt_grp.ensure((grps + 1) * 4); b_rt_act.ensure((grps + 1) * 4);
+    b_dir_out.ensure((leaves + 1) * 4);
     b_vvh.ensure((vvh + 1) * 4);
     b_vis.ensure((size_t)n_docs * VIS_CAP * 8);
     b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 4);
@@ -263,9 +264,7 @@ struct Engine {
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
     d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>();
     d.it_id = b_it_id.as<uint32_t>(); d.it_ol = b_it_ol.as<uint32_t>(); d.it_or = b_it_or.as<uint32_t>(); d.it_st = b_it_st.as<uint32_t>();
-    d.lf_n = b_lf_n.as<uint32_t>(); d.lf_next = b_lf_next.as<uint32_t>(); d.lf_grp = b_lf_grp.as<uint32_t>();
-    d.gp_leaf = b_gp_leaf.as<uint32_t>(); d.gp_act = b_gp_act.as<uint32_t>(); d.gp_n = b_gp_n.as<uint32_t>();
-    d.rt_grp = b_rt_grp.as<uint32_t>(); d.rt_act = b_rt_act.as<uint32_t>();
+    d.dir_out = b_dir_out.as<uint32_t>();
     d.vvh = b_vvh.as<uint32_t>();
     d.vis = b_vis.as<unsigned long long>();
     d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>();
@@ -286,7 +285,7 @@ struct Engine {
     if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
     lmbe::toc("k_map_lww", times, profiling);
     lmbe::tic();
-    LM_LAUNCH(k_integrate, n_docs, 64, d, g);
+    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 2 * MAX_PEERS) * 4, d, g, dir_cap);
     lmbe::toc("k_integrate", times, profiling);
     // 6. emit: size pass, offsets, write pass
     lmbe::tic();

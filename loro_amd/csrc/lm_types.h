@@ -85,14 +85,13 @@ struct DocMeta {             // per document, filled progressively
   uint32_t n_nodes;
   uint32_t pending_lo, pending_hi;  // pending atoms (u64 split)
   uint32_t elem0_lo, elem0_hi;      // first element slot of this doc (u64 split)
-  uint32_t leaf0, leaf_cap;  // leaf pool
-  uint32_t grp0, grp_cap;    // group pool (also root capacity)
+  uint32_t leaf0, leaf_cap;  // leaf pool (also the capacity of the flushed leaf directory)
+  uint32_t n_elems, n_mapop; // Σ len of insert-type op rows (element upper bound); number of Map op rows
   uint32_t node0;            // node rows
   uint32_t vvh0_lo, vvh0_hi; // vv_head rows (n_nodes × n_peers)
   uint32_t out_len;          // JSON bytes
   uint32_t vv_len;           // VV bytes
-  uint32_t n_seq;            // sequence containers
-  uint32_t pad;
+  uint32_t pad0, pad1;
 };
 
 }  // namespace lm

@@ -15,6 +15,7 @@
 #define LM_DEV_NOINLINE __device__ __noinline__
 #define LM_KERNEL extern "C" __global__
 #define LM_SHARED(type, name, n) __shared__ type name[n]
+#define LM_DYN_SHARED(type, name) extern __shared__ type name[]
 
 namespace lmw {
 static constexpr int WAVE = 64;
@@ -60,6 +61,7 @@ LM_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 #define LM_DEV_NOINLINE inline
 #define LM_KERNEL inline
 #define LM_SHARED(type, name, n) static type name[n]
+#define LM_DYN_SHARED(type, name) type* name = (type*)lmw::emu_dyn_shared()
 
 namespace lmw {
 static constexpr int WAVE = 64;
@@ -148,8 +150,11 @@ inline void emu_run_block(int bid, int bdim, std::function<void()> body) {
   for (auto& f : blk.fibers) free(f.stack);
   emu_cur() = prev;
 }
+inline std::vector<uint64_t>& emu_dyn_buf() { static std::vector<uint64_t> v; return v; }
+inline void* emu_dyn_shared() { return emu_dyn_buf().data(); }
 template <class F>
-inline void emu_launch(int grid, int block, F&& body) {
+inline void emu_launch(int grid, int block, size_t dyn_shared_bytes, F&& body) {
+  emu_dyn_buf().assign(dyn_shared_bytes / 8 + 2, 0);
   for (int b = 0; b < grid; b++) emu_run_block(b, block, body);
 }
 

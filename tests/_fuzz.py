@@ -12,9 +12,13 @@ def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15,
     pairwise; after a sync the receiver's visible sequences are refreshed from the oracle."""
     rng = random.Random(seed)
     base = peer_base if peer_base is not None else rng.randrange(1, 1 << 40)
-    reps = [wire.Replica(base + i * rng.randrange(1, 1000) + i) for i in range(n_peers)]
-    peers = {r.peer for r in reps}
-    assert len(peers) == n_peers
+    ids = []
+    for i in range(n_peers):
+        p = base + rng.randrange(0, 1000)
+        while p in ids:
+            p += 1
+        ids.append(p)
+    reps = [wire.Replica(p) for p in ids]
 
     def refresh(r):
         blob = r.export()
