@@ -34,7 +34,6 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   uint32_t *it_id, *it_ol, *it_or, *it_st;   // HBM leaves: [leaf*64 + slot]
   uint32_t* loc;                  // doc element → leaf
   const uint32_t* ebase;          // LDS: element base per peer
-  unsigned long long* vis;        // HBM scratch runs for the sibling scan
   uint32_t* dir;                  // LDS leaf directory in document order
   uint32_t n_dir, dir_cap, CH;    // CH: entries owned by one lane in the chunked scans (odd → conflict-free)
   uint32_t n_leaf, leaf_cap;
@@ -135,31 +134,6 @@ LM_DEV int tr_cmp_pos(Tr& t, uint32_t a, uint32_t b) {
   }
   uint32_t pa = dir_find_leaf(t, la), pb = dir_find_leaf(t, lb);
   return pa < pb ? -1 : 1;
-}
-
-// visited id runs of the sibling scan (crdt_rope.rs:161,177-181)
-struct Vis { uint32_t n; uint32_t lo, hi; bool open; };
-LM_DEV bool vis_contains(const Tr& t, const Vis& v, uint32_t pid) {
-  int lane = lmw::lane();
-  if (pid == NONE) return false;
-  if (v.open && pid >= v.lo && pid <= v.hi) return true;
-  lmw::wave_sync();
-  for (uint32_t c = 0; c < v.n; c += 64) {
-    uint32_t i = c + (uint32_t)lane;
-    bool hit = false;
-    if (i < v.n) { unsigned long long e = t.vis[i]; uint32_t lo = (uint32_t)(e >> 32), hi = (uint32_t)e; hit = pid >= lo && pid <= hi; }
-    if (lmw::any(hit)) return true;
-  }
-  return false;
-}
-LM_DEV void vis_add(Tr& t, Vis& v, uint32_t pid) {
-  if (v.open && pid == v.hi + 1 && pid_peer(pid) == pid_peer(v.hi)) { v.hi = pid; return; }
-  if (v.open) {
-    if (v.n >= VIS_CAP) { LM_SETERR(t.err, ST_UNSUPPORTED); return; }
-    if (lmw::lane() == 0) t.vis[v.n] = ((unsigned long long)v.lo << 32) | v.hi;
-    v.n++;
-  }
-  v.open = true; v.lo = pid; v.hi = pid;
 }
 
 // write `cnt` consecutive items of the logical sequence Q into leaf `dst` starting at Q index q0.
@@ -275,55 +249,95 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   }
   uint32_t ins_p = p, ins_idx = ins;
   if (between) {
+    // Sibling scan over the future elements between the cursor and origin_right (crdt_rope.rs:156-237).
+    // Only run HEADS need the sequential rule: an element whose origin_left is the element physically right
+    // before it is a continuation of a visited run — it can neither break the scan nor be a sibling — so a
+    // whole run is skipped with one ballot.  "visited" (crdt_rope.rs:161,177-181) is the set of in-between
+    // elements already passed, i.e. membership is a position test against [cursor, current).
     bool parent_right = origin_right != NONE && r_ol == origin_left;
     bool scanning = false;
-    Vis v; v.n = 0; v.open = false; v.lo = v.hi = 0;
     uint32_t cp = p, ci = ins;
     LeafRegs C = R;
     uint32_t my_peer = pid_peer(pid0);
-    for (uint32_t guard = 0; guard < (1u << 26) && !t.err; guard++) {
-      if (ci >= C.n) {
-        if (cp + 1 >= t.n_dir) break;
-        cp++; ci = 0;
-        uint32_t e = t.dir[cp];
-        C = tr_leaf_load(t, de_leaf(e), de_n(e));
-        continue;
-      }
-      if (origin_right != NONE && cp == r_p && ci == r_slot) break;
-      uint32_t o_id = lmw::bcast(C.id, (int)ci), o_ol = lmw::bcast(C.ol, (int)ci), o_or = lmw::bcast(C.orr, (int)ci);
-      if (o_ol != origin_left && !vis_contains(t, v, o_ol)) break;
-      vis_add(t, v, o_id);
-      if (o_ol == origin_left) {
-        if (o_or == origin_right) {
-          if (pid_peer(o_id) > my_peer) break;
-          scanning = false;
-        } else {
-          uint32_t opr = NONE;
-          if (o_or != NONE) {
+    uint32_t carry_id = NONE;   // id of the element physically before slot 0 of the current leaf (within the scan)
+    bool stop = false;
+    for (uint32_t guard = 0; guard <= t.n_dir && !t.err && !stop; guard++) {
+      uint32_t limit = (origin_right != NONE && cp == r_p) ? r_slot : C.n;
+      uint32_t prev_id = lmw::shfl_up(C.id, 1);
+      if (lane == 0) prev_id = carry_id;
+      bool inr = (uint32_t)lane >= ci && (uint32_t)lane < limit;
+      bool is_head = inr && (C.ol != prev_id || (cp == p && (uint32_t)lane == ins));
+      uint64_t hm = lmw::ballot(is_head);
+      while (hm && !stop && !t.err) {
+        int h = lmw::ffs64(hm);
+        hm &= hm - 1;
+        // continuation elements in [ci, h) extend the visited runs
+        if (!scanning && (uint32_t)h > ci) { ins_p = cp; ins_idx = (uint32_t)h; }
+        uint32_t o_id = lmw::bcast(C.id, h), o_ol = lmw::bcast(C.ol, h), o_or = lmw::bcast(C.orr, h);
+        if (o_ol != origin_left) {
+          // is o_ol one of the in-between elements already visited?  (position in [cursor, (cp,h)))
+          bool visited = false;
+          if (o_ol != NONE) {
             lmw::wave_sync();
-            uint32_t xl = t.loc[tr_g(t, o_or)];
-            if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
-            uint32_t xp = dir_find_leaf(t, xl);
-            if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
-            uint32_t xn = de_n(t.dir[xp]);
-            uint32_t xid = (uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE;
-            uint32_t xol = (uint32_t)lane < xn ? t.it_ol[xl * 64 + lane] : NONE;
-            uint64_t xm = lmw::ballot(xid == o_or);
-            if (!xm) { LM_SETERR(t.err, ST_INTERNAL); break; }
-            if (lmw::bcast(xol, lmw::ffs64(xm)) == origin_left) opr = o_or;
+            uint32_t xl = t.loc[tr_g(t, o_ol)];
+            if (xl < t.n_leaf) {
+              uint32_t xp = dir_find_leaf(t, xl);
+              if (xp != NONE && xp >= p && xp <= cp) {
+                if (xp > p && xp < cp) visited = true;
+                else {
+                  uint32_t xn = de_n(t.dir[xp]);
+                  uint32_t xid = xp == cp ? C.id : ((uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE);
+                  uint64_t xm = lmw::ballot((uint32_t)lane < xn && xid == o_ol);
+                  if (xm) {
+                    uint32_t xs = (uint32_t)lmw::ffs64(xm);
+                    visited = (xp != p || xs >= ins) && (xp != cp || xs < (uint32_t)h);
+                  }
+                }
+              }
+            }
           }
-          int c;
-          if (opr != NONE && parent_right) c = tr_cmp_pos(t, opr, origin_right);
-          else if (opr != NONE) c = -1;
-          else if (parent_right) c = 1;
-          else c = 0;
-          if (c < 0) scanning = true;
-          else if (c == 0 && pid_peer(o_id) > my_peer) break;
-          else scanning = false;
+          if (!visited) { stop = true; break; }
+        } else {
+          if (o_or == origin_right) {
+            if (pid_peer(o_id) > my_peer) { stop = true; break; }
+            scanning = false;
+          } else {
+            uint32_t opr = NONE;
+            if (o_or != NONE) {
+              lmw::wave_sync();
+              uint32_t xl = t.loc[tr_g(t, o_or)];
+              if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
+              uint32_t xp = dir_find_leaf(t, xl);
+              if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
+              uint32_t xn = de_n(t.dir[xp]);
+              uint32_t xid = (uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE;
+              uint32_t xol = (uint32_t)lane < xn ? t.it_ol[xl * 64 + lane] : NONE;
+              uint64_t xm = lmw::ballot(xid == o_or);
+              if (!xm) { LM_SETERR(t.err, ST_INTERNAL); break; }
+              if (lmw::bcast(xol, lmw::ffs64(xm)) == origin_left) opr = o_or;
+            }
+            int c;
+            if (opr != NONE && parent_right) c = tr_cmp_pos(t, opr, origin_right);
+            else if (opr != NONE) c = -1;
+            else if (parent_right) c = 1;
+            else c = 0;
+            if (c < 0) scanning = true;
+            else if (c == 0 && pid_peer(o_id) > my_peer) { stop = true; break; }
+            else scanning = false;
+          }
         }
+        if (!scanning) { ins_p = cp; ins_idx = (uint32_t)h + 1; }
+        ci = (uint32_t)h + 1;
       }
-      if (!scanning) { ins_p = cp; ins_idx = ci + 1; }
-      ci++;
+      if (stop || t.err) break;
+      // trailing continuation elements of this leaf
+      if (!scanning && limit > ci) { ins_p = cp; ins_idx = limit; }
+      if (origin_right != NONE && cp == r_p) break;   // reached origin_right
+      if (cp + 1 >= t.n_dir) break;
+      carry_id = C.n ? lmw::bcast(C.id, (int)(C.n - 1)) : carry_id;
+      cp++; ci = 0;
+      uint32_t e = t.dir[cp];
+      C = tr_leaf_load(t, de_leaf(e), de_n(e));
     }
   }
   tr_place_run(t, ins_p, ins_idx, pid0, len, origin_left, origin_right, R, ins_p == p);
@@ -446,7 +460,6 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
   t.it_or = d.it_or + (uint64_t)m.leaf0 * 64; t.it_st = d.it_st + (uint64_t)m.leaf0 * 64;
   t.loc = d.loc + elem0;
   t.ebase = s_ebase;
-  t.vis = d.vis + (uint64_t)doc * VIS_CAP;
   t.dir = s_dir;
   t.dir_cap = dir_cap;
   t.leaf_cap = m.leaf_cap;
