@@ -63,6 +63,13 @@ int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   s->n_kernels = (uint32_t)x->eng.times.size();
   return 0;
 }
+// LM_PROF builds only: sum over documents of the 16 cycle-accounting slots of k_integrate
+int LM_API(prof_sum)(void* c, uint64_t* out16) {
+  auto* x = (lm_ctx_impl*)c;
+  for (int i = 0; i < 16; i++) out16[i] = 0;
+  for (size_t k = 0; k < x->eng.h_prof.size(); k++) out16[k % 16] += x->eng.h_prof[k];
+  return x->eng.h_prof.empty() ? -1 : 0;
+}
 int LM_API(set_profiling)(void* c, int en) { ((lm_ctx_impl*)c)->eng.profiling = en != 0; return 0; }
 int LM_API(kernel_time)(void* c, uint32_t i, const char** name, double* ms) {
   auto* x = (lm_ctx_impl*)c;

@@ -68,12 +68,12 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* dir_out;     // [leaf0 + i] flushed leaf directories (entry = leaf | n<<18 | act<<25)
   uint32_t* cont_root0;  // per doc container: first directory entry (doc-relative) / number of entries
   uint32_t* cont_nroot;
-  unsigned long long* vis;  // per doc scratch for the Fugue sibling scan
   // map LWW
   unsigned long long* ht_key;   // per doc open-addressing table
   unsigned long long* ht_best;
   uint64_t* ht0;                // per doc first slot; ht_cap per doc
   uint32_t* ht_cap;
+  unsigned long long* prof;     // [doc*16 + slot] cycle accounting (LM_PROF builds)
   // outputs
   uint8_t* out;          // JSON bytes
   uint64_t* out_off;     // per doc offset (n_docs+1)

@@ -30,6 +30,18 @@ LM_DEV uint32_t de_leaf(uint32_t e) { return e & DIR_LEAF_MASK; }
 LM_DEV uint32_t de_n(uint32_t e) { return (e >> 18) & 0x7f; }
 LM_DEV uint32_t de_act(uint32_t e) { return e >> 25; }
 
+// optional cycle accounting (compile with -DLM_PROF): slots of the per-document profile record
+enum { PF_ROW = 0, PF_FIND, PF_LEAF, PF_ORIGHT, PF_BETWEEN, PF_PLACE, PF_DELETE, PF_CHECKOUT, PF_NINS, PF_NDEL, PF_NEXTRA, PF_NHEAD, PF_TOTAL, PF_N = 16 };
+#ifdef LM_PROF
+#define PROF_T0() uint64_t pf_t0_ = lmw::clock()
+#define PROF_ADD(t, slot) do { uint64_t pf_t1_ = lmw::clock(); (t).prof[slot] += pf_t1_ - pf_t0_; pf_t0_ = pf_t1_; } while (0)
+#define PROF_CNT(t, slot, v) do { (t).prof[slot] += (v); } while (0)
+#else
+#define PROF_T0() do {} while (0)
+#define PROF_ADD(t, slot) do {} while (0)
+#define PROF_CNT(t, slot, v) do {} while (0)
+#endif
+
 struct Tr {  // wave-uniform context of one (document, sequence container) replay
   uint32_t *it_id, *it_ol, *it_or, *it_st;   // HBM leaves: [leaf*64 + slot]
   uint32_t* loc;                  // doc element → leaf
@@ -39,6 +51,9 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   uint32_t n_leaf, leaf_cap;
   uint32_t tot_active;
   int32_t err;
+#ifdef LM_PROF
+  uint64_t prof[PF_N];
+#endif
 };
 
 LM_DEV uint32_t tr_g(const Tr& t, uint32_t pid) { return t.ebase[pid_peer(pid)] + pid_ctr(pid); }
@@ -202,6 +217,8 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
 // Fugue integrate of one insert run at active position `pos` (crdt_rope.rs:63-247)
 LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   int lane = lmw::lane();
+  PROF_T0();
+  PROF_CNT(t, PF_NINS, 1);
   uint32_t p, ins, origin_left = NONE;
   if (pos > t.tot_active) pos = t.tot_active;  // beyond the end: clamp (query "missing" case)
   if (pos == 0) { p = 0; ins = 0; }
@@ -212,6 +229,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     ins = k;  // rank inside the leaf, resolved to a slot below
   }
   lmw::wave_sync();
+  PROF_ADD(t, PF_FIND);
   uint32_t e0 = t.dir[p];
   LeafRegs R = tr_leaf_load(t, de_leaf(e0), de_n(e0));
   if (pos != 0) {
@@ -224,6 +242,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     origin_left = lmw::bcast(R.id, slot);
     ins = (uint32_t)slot + 1;
   }
+  PROF_ADD(t, PF_LEAF);
   // origin_right = first non-future element at/after the cursor; everything before it is "in between"
   uint32_t origin_right = NONE, r_ol = NONE, r_p = NONE, r_slot = 0;
   bool between = false;
@@ -245,8 +264,10 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       cp++; from = 0;
       uint32_t e = t.dir[cp];
       C = tr_leaf_load(t, de_leaf(e), de_n(e));
+      PROF_CNT(t, PF_NEXTRA, 1);
     }
   }
+  PROF_ADD(t, PF_ORIGHT);
   uint32_t ins_p = p, ins_idx = ins;
   if (between) {
     // Sibling scan over the future elements between the cursor and origin_right (crdt_rope.rs:156-237).
@@ -271,6 +292,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       while (hm && !stop && !t.err) {
         int h = lmw::ffs64(hm);
         hm &= hm - 1;
+        PROF_CNT(t, PF_NHEAD, 1);
         // continuation elements in [ci, h) extend the visited runs
         if (!scanning && (uint32_t)h > ci) { ins_p = cp; ins_idx = (uint32_t)h; }
         uint32_t o_id = lmw::bcast(C.id, h), o_ol = lmw::bcast(C.ol, h), o_or = lmw::bcast(C.orr, h);
@@ -340,7 +362,9 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       C = tr_leaf_load(t, de_leaf(e), de_n(e));
     }
   }
+  PROF_ADD(t, PF_BETWEEN);
   tr_place_run(t, ins_p, ins_idx, pid0, len, origin_left, origin_right, R, ins_p == p);
+  PROF_ADD(t, PF_PLACE);
 }
 
 // status update of the elements with ids [c0,c1) of `peer` (crdt_rope.rs:345-381 by id instead of by cursor)
@@ -465,6 +489,10 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
   t.leaf_cap = m.leaf_cap;
   t.n_leaf = 0;
   t.err = 0;
+#ifdef LM_PROF
+  for (int i = 0; i < PF_N; i++) t.prof[i] = 0;
+  uint64_t pf_begin = lmw::clock();
+#endif
   uint32_t dir_used = 0;  // directory entries already flushed to HBM by earlier containers of this doc
   if (m.leaf_cap > MAX_LEAVES_PER_DOC || m.leaf_cap > dir_cap) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
   for (uint32_t cidx = 0; cidx < m.n_cont && !t.err; cidx++) {
@@ -492,6 +520,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
         const ChangeRow ch = d.chg[crow];
         uint32_t skip_to = ch.ctr + d.chg_skip[crow];
         for (uint32_t row = ch.op0; row < ch.op0 + ch.n_op && !t.err; row++) {
+          PROF_T0();
           const OpRow r = d.op[row];
           if ((r.cidx_kind & 0xffff) != cidx) continue;
           if (r.ctr + r.len <= skip_to) continue;
@@ -509,7 +538,9 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
             lmw::block_sync();
             for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = vv[p];
             lmw::block_sync();
+            PROF_ADD(t, PF_CHECKOUT);
           }
+          PROF_ADD(t, PF_ROW);
           if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
             tr_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), r.len - a);
             TR_CHECK("insert", row);
@@ -519,6 +550,8 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
             if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + Ln; }
             else { t0 = r.a1; t1 = r.a1 + (Ln - a); }
             tr_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
+            PROF_ADD(t, PF_DELETE);
+            PROF_CNT(t, PF_NDEL, 1);
             TR_CHECK("delete", row);
           } else if (kind == OK_STYLE_START) {
             tr_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
@@ -553,6 +586,10 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
     lmw::block_sync();
   }
   if (t.err && lane == 0) d.doc[doc].status = t.err;
+#ifdef LM_PROF
+  t.prof[PF_TOTAL] = lmw::clock() - pf_begin;
+  if (lane == 0) for (int i = 0; i < PF_N; i++) d.prof[(uint64_t)doc * PF_N + i] = t.prof[i];
+#endif
 }
 
 }  // namespace lm

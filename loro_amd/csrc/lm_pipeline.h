@@ -54,9 +54,10 @@ struct Engine {
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
   DBuf b_cp, b_loc;
   DBuf b_it_id, b_it_ol, b_it_or, b_it_st, b_dir_out;
-  DBuf b_cont_root0, b_cont_nroot, b_vis;
+  DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list;
-  DBuf b_out, b_out_off, b_vv_out, b_vv_off;
+  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof;
+  std::vector<uint64_t> h_prof;
   // results
   std::vector<DocMeta> h_doc;
   std::vector<DocResult> results;
@@ -77,7 +78,7 @@ struct Engine {
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it_id,
                    &b_it_ol, &b_it_or, &b_it_st, &b_dir_out,
-                   &b_cont_root0, &b_cont_nroot, &b_vis, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_out, &b_out_off,
+                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
   }
@@ -257,7 +258,9 @@ struct Engine {
     b_it_id.ensure((leaves + 1) * 64 * 4); b_it_ol.ensure((leaves + 1) * 64 * 4); b_it_or.ensure((leaves + 1) * 64 * 4); b_it_st.ensure((leaves + 1) * 64 * 4);
     b_dir_out.ensure((leaves + 1) * 4);
     b_vvh.ensure((vvh + 1) * 4);
-    b_vis.ensure((size_t)n_docs * VIS_CAP * 8);
+    b_prof.ensure((size_t)n_docs * 16 * 8);
+    d.prof = b_prof.as<unsigned long long>();
+    lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
     b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 4);
     b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
@@ -266,7 +269,6 @@ struct Engine {
     d.it_id = b_it_id.as<uint32_t>(); d.it_ol = b_it_ol.as<uint32_t>(); d.it_or = b_it_or.as<uint32_t>(); d.it_st = b_it_st.as<uint32_t>();
     d.dir_out = b_dir_out.as<uint32_t>();
     d.vvh = b_vvh.as<uint32_t>();
-    d.vis = b_vis.as<unsigned long long>();
     d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>();
     d.ht0 = b_ht0.as<uint64_t>(); d.ht_cap = b_ht_cap.as<uint32_t>();
     lmbe::dmemset(b_loc.p, 0xff, (elem + 1) * 4);
@@ -311,6 +313,10 @@ struct Engine {
     LM_LAUNCH(k_emit, n_docs, 64, d, b_ht_list.as<uint32_t>(), 1);
     lmbe::toc("k_emit(write)", times, profiling);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+#ifdef LM_PROF
+    h_prof.resize((size_t)n_docs * 16);
+    lmbe::d2h(h_prof.data(), d.prof, (size_t)n_docs * 16 * 8);
+#endif
     lmbe::sync();
     for (uint32_t i = 0; i < n_docs; i++) {
       DocResult& r = results[i];
