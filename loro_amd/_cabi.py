@@ -17,7 +17,7 @@ class RunStats(ctypes.Structure):
                 ("device_bytes_allocated", ctypes.c_uint64), ("n_kernels", ctypes.c_uint32)]
 
 
-SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time"]
+SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest"]
 
 
 class Binding:
@@ -35,6 +35,7 @@ class Binding:
         self.fetch = g("fetch"); self.fetch.restype = ctypes.c_int; self.fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocOut)]
         self.get_stats = g("get_stats"); self.get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(RunStats)]
         self.set_profiling = g("set_profiling"); self.set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.selftest = g("selftest"); self.selftest.restype = ctypes.c_int; self.selftest.argtypes = [ctypes.c_void_p]
         self.kernel_time = g("kernel_time"); self.kernel_time.restype = ctypes.c_int
         self.kernel_time.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double)]
 

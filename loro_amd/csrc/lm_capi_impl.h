@@ -63,6 +63,13 @@ int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   s->n_kernels = (uint32_t)x->eng.times.size();
   return 0;
 }
+// returns the number of mismatches of the wave-primitive self test (0 = ok)
+int LM_API(selftest)(void* c) {
+  auto* x = (lm_ctx_impl*)c;
+  try {
+    return x->eng.selftest();
+  } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
 // LM_PROF builds only: sum over documents of the 16 cycle-accounting slots of k_integrate
 int LM_API(prof_sum)(void* c, uint64_t* out16) {
   auto* x = (lm_ctx_impl*)c;

@@ -64,7 +64,14 @@ LM_DEV uint32_t dir_find_kth(const Tr& t, uint32_t& k) {
   int lane = lmw::lane();
   lmw::wave_sync();
   uint32_t base = (uint32_t)lane * t.CH, sum = 0;
-  for (uint32_t j = 0; j < t.CH; j++) { uint32_t i = base + j; if (i < t.n_dir) sum += de_act(t.dir[i]); }
+  // independent LDS reads (address clamped instead of branching) so the loads pipeline
+  uint32_t last = t.n_dir - 1;
+#pragma unroll 8
+  for (uint32_t j = 0; j < t.CH; j++) {
+    uint32_t i = base + j;
+    uint32_t e = t.dir[i < last ? i : last];
+    sum += i <= last ? de_act(e) : 0u;
+  }
   uint32_t inc = lmw::scan_incl_add(sum);
   uint64_t m = lmw::ballot(inc >= k);
   if (!m) return NONE;
@@ -90,7 +97,13 @@ LM_DEV uint32_t dir_find_leaf(const Tr& t, uint32_t L) {
   int lane = lmw::lane();
   lmw::wave_sync();
   uint32_t base = (uint32_t)lane * t.CH, found = NONE;
-  for (uint32_t j = 0; j < t.CH; j++) { uint32_t i = base + j; if (i < t.n_dir && de_leaf(t.dir[i]) == L) found = i; }
+  uint32_t last = t.n_dir - 1;
+#pragma unroll 8
+  for (uint32_t j = 0; j < t.CH; j++) {
+    uint32_t i = base + j;
+    uint32_t e = t.dir[i < last ? i : last];
+    found = (i <= last && de_leaf(e) == L) ? i : found;
+  }
   uint64_t m = lmw::ballot(found != NONE);
   if (!m) return NONE;
   return lmw::bcast(found, lmw::ffs64(m));
@@ -115,6 +128,7 @@ LM_DEV void dir_insert_after(Tr& t, uint32_t p, uint32_t e) {
   }
   if (lane == 0) t.dir[lo] = e;
   t.n_dir++;
+  t.CH = ((t.n_dir + 63) / 64) | 1u;
   lmw::wave_sync();
 }
 
@@ -504,8 +518,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
     uint32_t L0 = t.n_leaf++;
     if (lane == 0) s_dir[0] = de_make(L0, 0, 0);
     t.n_dir = 1; t.tot_active = 0;
-    // chunk per lane for the directory scans: covers the leaves this container can still create, kept odd
-    t.CH = ((m.leaf_cap - L0 + 63) / 64) | 1u;
+    t.CH = 1;  // chunk per lane of the directory scans; grows with the directory, kept odd (bank-conflict free)
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
     lmw::block_sync();
     bool touched = false;

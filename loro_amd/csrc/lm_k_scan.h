@@ -49,4 +49,23 @@ LM_KERNEL void k_scan_add(uint32_t* out, const uint32_t* tile_sum, const uint32_
   }
 }
 
+// wave-primitive self test: DPP scan vs the bpermute formulation on pseudo-random lane values
+LM_KERNEL void k_selftest(uint32_t* out, uint32_t rounds) {
+  int lane = lmw::lane();
+  uint32_t bad = 0;
+  uint32_t x = 0x9E3779B9u * (uint32_t)(lane + 1) + (uint32_t)lmw::bid();
+  for (uint32_t r = 0; r < rounds; r++) {
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    uint32_t v = (r & 1) ? (x & 0xffff) : (x % 65u);
+    uint32_t a = lmw::scan_incl_add(v), b = lmw::scan_incl_add_shfl(v);
+    bad += a != b ? 1u : 0u;
+    uint64_t m = lmw::ballot((v & 1) != 0);
+    uint32_t c = (uint32_t)lmw::popc64(m & ((2ull << lane) - 1));
+    uint32_t dref = lmw::scan_incl_add_shfl(v & 1);
+    bad += c != dref ? 1u : 0u;
+  }
+  bad = lmw::reduce_add(bad);
+  if (lane == 0) out[lmw::bid()] = bad;
+}
+
 }  // namespace lm

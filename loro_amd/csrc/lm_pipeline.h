@@ -135,6 +135,18 @@ struct Engine {
     LM_LAUNCH(k_scan_add, tiles, SCAN_TILE, out, b_tile.as<uint32_t>(), b_tot.as<uint32_t>(), n, ncomp);
   }
 
+  int selftest() {
+    DBuf b;
+    b.ensure(64 * 4);
+    LM_LAUNCH(k_selftest, 64, 64, b.as<uint32_t>(), 200u);
+    uint32_t h[64];
+    lmbe::d2h(h, b.p, sizeof h);
+    b.release();
+    int bad = 0;
+    for (int i = 0; i < 64; i++) bad += (int)h[i];
+    return bad;
+  }
+
   static uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
   // ---- run: the device pipeline over the staged batch

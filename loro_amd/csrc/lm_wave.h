@@ -235,7 +235,8 @@ inline uint64_t clock() { return 0; }
 
 namespace lmw {
 // ---- derived wave collectives (same source for both builds); all lanes must participate
-LM_DEV uint32_t scan_incl_add(uint32_t v) {
+// reference formulation (bpermute based); kept for the self-test and the emulation build
+LM_DEV uint32_t scan_incl_add_shfl(uint32_t v) {
   int l = lane();
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -244,6 +245,24 @@ LM_DEV uint32_t scan_incl_add(uint32_t v) {
   }
   return v;
 }
+#ifndef LM_EMU
+// wave64 inclusive prefix sum on the DPP crossbar: row_shr 1/2/4/8 inside each 16-lane row, then
+// row_bcast:15 and row_bcast:31 to carry the row totals (six VALU ops instead of six LDS round trips).
+LM_DEV uint32_t scan_incl_add(uint32_t v) {
+  int l = lane();
+  int rl = l & 15;
+  uint32_t t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); if (rl >= 1) v += t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); if (rl >= 2) v += t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); if (rl >= 4) v += t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); if (rl >= 8) v += t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xf, 0xf, false); if ((l & 31) >= 16) v += t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xf, 0xf, false); if (l >= 32) v += t;
+  return v;
+}
+#else
+LM_DEV uint32_t scan_incl_add(uint32_t v) { return scan_incl_add_shfl(v); }
+#endif
 LM_DEV uint32_t reduce_add(uint32_t v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);

@@ -12,6 +12,7 @@ tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
 docs = [tpl.stamp(d) for d in range(n_docs)]
 names = ["row", "find", "leaf", "oright", "between", "place", "delete", "checkout", "n_ins", "n_del", "n_extra_leaf", "n_heads", "total"]
 with Context(b, 0) as e:
+    print("selftest mismatches:", b.selftest(e.h))
     e.stage(docs)
     e.run(); e.run()
     t = time.time(); e.run(); dt = time.time() - t

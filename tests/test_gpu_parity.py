@@ -57,3 +57,8 @@ def test_trace_shape_both_orders(engine):
         got = _same(engine, docs)
         for d in range(8):
             assert got[2 * d][1] == got[2 * d + 1][1] and got[2 * d][2] == got[2 * d + 1][2]
+
+
+def test_wave_primitives_selftest(engine):
+    # DPP prefix scan / ballot ranks against the bpermute formulation, on the device
+    assert engine.b.selftest(engine.h) == 0
