@@ -47,7 +47,9 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   uint32_t* loc;                  // doc element → leaf
   const uint32_t* ebase;          // LDS: element base per peer
   uint32_t* dir;                  // LDS leaf directory in document order
-  uint32_t n_dir, dir_cap, CH;    // CH: entries owned by one lane in the chunked scans (odd → conflict-free)
+  uint8_t* lchunk;                // LDS: leaf → chunk (= owning lane) of its directory entry
+  uint32_t n_dir, dir_cap, CH;    // lane c owns directory entries [c*CH, (c+1)*CH); CH is odd (bank-conflict free)
+  uint32_t my_sum;                // PER-LANE: Σ active counts of this lane's chunk, maintained incrementally
   uint32_t n_leaf, leaf_cap;
   uint32_t tot_active;
   int32_t err;
@@ -59,24 +61,20 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
 LM_DEV uint32_t tr_g(const Tr& t, uint32_t pid) { return t.ebase[pid_peer(pid)] + pid_ctr(pid); }
 
 // ---- directory primitives (LDS only)
+// The directory is an array of entries in document order.  Lane c owns the chunk [c*CH, (c+1)*CH) and keeps
+// the sum of its active counts in a register (my_sum), so locating the k-th active element is one DPP scan
+// over the 64 chunk sums plus one scan inside the owning chunk.
+LM_DEV uint32_t dir_chunk_of(const Tr& t, uint32_t p) { return t.lchunk[de_leaf(t.dir[p])]; }
+
 // k-th active element (1 <= k <= tot_active) → directory position; k becomes the rank inside that leaf
 LM_DEV uint32_t dir_find_kth(const Tr& t, uint32_t& k) {
   int lane = lmw::lane();
   lmw::wave_sync();
-  uint32_t base = (uint32_t)lane * t.CH, sum = 0;
-  // independent LDS reads (address clamped instead of branching) so the loads pipeline
-  uint32_t last = t.n_dir - 1;
-#pragma unroll 8
-  for (uint32_t j = 0; j < t.CH; j++) {
-    uint32_t i = base + j;
-    uint32_t e = t.dir[i < last ? i : last];
-    sum += i <= last ? de_act(e) : 0u;
-  }
-  uint32_t inc = lmw::scan_incl_add(sum);
+  uint32_t inc = lmw::scan_incl_add(t.my_sum);
   uint64_t m = lmw::ballot(inc >= k);
   if (!m) return NONE;
   int owner = lmw::ffs64(m);
-  k -= lmw::bcast(inc, owner) - lmw::bcast(sum, owner);
+  k -= lmw::bcast(inc, owner) - lmw::bcast(t.my_sum, owner);
   uint32_t cbase = (uint32_t)owner * t.CH;
   for (uint32_t j0 = 0; j0 < t.CH; j0 += 64) {
     uint32_t j = j0 + (uint32_t)lane, i = cbase + j;
@@ -92,32 +90,49 @@ LM_DEV uint32_t dir_find_kth(const Tr& t, uint32_t& k) {
   }
   return NONE;
 }
-// directory position of leaf L
+// directory position of leaf L (searches only the chunk that holds it)
 LM_DEV uint32_t dir_find_leaf(const Tr& t, uint32_t L) {
   int lane = lmw::lane();
   lmw::wave_sync();
-  uint32_t base = (uint32_t)lane * t.CH, found = NONE;
-  uint32_t last = t.n_dir - 1;
-#pragma unroll 8
-  for (uint32_t j = 0; j < t.CH; j++) {
-    uint32_t i = base + j;
-    uint32_t e = t.dir[i < last ? i : last];
-    found = (i <= last && de_leaf(e) == L) ? i : found;
+  uint32_t cbase = (uint32_t)t.lchunk[L] * t.CH;
+  for (uint32_t j0 = 0; j0 < t.CH; j0 += 64) {
+    uint32_t j = j0 + (uint32_t)lane, i = cbase + j;
+    bool hit = j < t.CH && i < t.n_dir && de_leaf(t.dir[i]) == L;
+    uint64_t m = lmw::ballot(hit);
+    if (m) return cbase + j0 + (uint32_t)lmw::ffs64(m);
   }
-  uint64_t m = lmw::ballot(found != NONE);
-  if (!m) return NONE;
-  return lmw::bcast(found, lmw::ffs64(m));
+  return NONE;
 }
-LM_DEV void dir_set(Tr& t, uint32_t p, uint32_t e) {
-  if (lmw::lane() == 0) t.dir[p] = e;
-}
-// insert entry e right after position p
-LM_DEV void dir_insert_after(Tr& t, uint32_t p, uint32_t e) {
+// replace the entry at position p (same leaf, new counts); `chunk` is the chunk of p
+LM_DEV void dir_update(Tr& t, uint32_t p, uint32_t chunk, uint32_t old_e, uint32_t new_e) {
   int lane = lmw::lane();
-  if (t.n_dir >= t.dir_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
-  uint32_t lo = p + 1;
-  for (uint32_t hi = t.n_dir; hi > lo;) {
-    uint32_t c0 = hi > lo + 64 ? hi - 64 : lo;
+  if (lane == 0) t.dir[p] = new_e;
+  if ((uint32_t)lane == chunk) t.my_sum += de_act(new_e) - de_act(old_e);
+  t.tot_active += de_act(new_e) - de_act(old_e);
+}
+// insert entry e right after position p (`chunk` = chunk of p)
+LM_DEV void dir_insert_after(Tr& t, uint32_t p, uint32_t chunk, uint32_t e) {
+  int lane = lmw::lane();
+  if (t.n_dir >= t.dir_cap || t.n_dir >= 64 * t.CH) { LM_SETERR(t.err, ST_INTERNAL); return; }
+  lmw::wave_sync();
+  uint32_t q = p + 1, n_old = t.n_dir;
+  uint32_t cq = q == (chunk + 1) * t.CH ? chunk + 1 : chunk;
+  // chunk bookkeeping: every chunk right of q gains the last entry of its left neighbour and loses its own last
+  {
+    uint32_t c = (uint32_t)lane;
+    uint32_t first = c * t.CH, lastp = first + t.CH - 1;
+    uint32_t gain = NONE, lose = NONE;
+    if (c == cq) gain = e;
+    else if (first > q && first <= n_old) gain = t.dir[first - 1];
+    if (lastp >= q && lastp < n_old) lose = t.dir[lastp];
+    if (c == cq && lastp < q) lose = NONE;
+    if (gain != NONE) { t.my_sum += de_act(gain); t.lchunk[de_leaf(gain)] = (uint8_t)c; }
+    if (lose != NONE) t.my_sum -= de_act(lose);
+  }
+  t.tot_active += de_act(e);
+  lmw::wave_sync();
+  for (uint32_t hi = n_old; hi > q;) {
+    uint32_t c0 = hi > q + 64 ? hi - 64 : q;
     uint32_t i = c0 + (uint32_t)lane;
     bool in = i < hi;
     uint32_t v = in ? t.dir[i] : 0;
@@ -126,9 +141,8 @@ LM_DEV void dir_insert_after(Tr& t, uint32_t p, uint32_t e) {
     lmw::wave_sync();
     hi = c0;
   }
-  if (lane == 0) t.dir[lo] = e;
+  if (lane == 0) t.dir[q] = e;
   t.n_dir++;
-  t.CH = ((t.n_dir + 63) / 64) | 1u;
   lmw::wave_sync();
 }
 
@@ -204,10 +218,11 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
     have_R = false;
     uint32_t total = n + piece;
     uint32_t p_ol = done == 0 ? ol0 : pid0 + done - 1;
+    uint32_t chunk = t.lchunk[L];
+    (void)old_act;
     if (total <= 64) {
       uint32_t na = tr_write_items(t, L, 0, total, R, ins, piece, pid0 + done, p_ol, orr, false, ins);
-      dir_set(t, p, de_make(L, total, na));
-      t.tot_active += na - old_act;
+      dir_update(t, p, chunk, e, de_make(L, total, na));
       ins += piece;
     } else {
       // even split into two leaves (total <= 128); both halves keep >= 32 elements
@@ -216,9 +231,8 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
       uint32_t left = (total + 1) / 2, right = total - left;
       uint32_t na_l = tr_write_items(t, L, 0, left, R, ins, piece, pid0 + done, p_ol, orr, false, ins < left ? ins : left);
       uint32_t na_r = tr_write_items(t, NL, left, right, R, ins, piece, pid0 + done, p_ol, orr, true, 0);
-      dir_set(t, p, de_make(L, left, na_l));
-      dir_insert_after(t, p, de_make(NL, right, na_r));
-      t.tot_active += na_l + na_r - old_act;
+      dir_update(t, p, chunk, e, de_make(L, left, na_l));
+      dir_insert_after(t, p, chunk, de_make(NL, right, na_r));
       uint32_t endq = ins + piece;  // Q index right after the piece
       if (endq <= left) ins = endq;
       else { p = p + 1; ins = endq - left; }
@@ -313,7 +327,11 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
         if (o_ol != origin_left) {
           // is o_ol one of the in-between elements already visited?  (position in [cursor, (cp,h)))
           bool visited = false;
-          if (o_ol != NONE) {
+          uint64_t here = lmw::ballot((uint32_t)lane < C.n && C.id == o_ol);
+          if (here) {
+            uint32_t xs = (uint32_t)lmw::ffs64(here);
+            visited = xs < (uint32_t)h && (cp != p || xs >= ins);
+          } else if (o_ol != NONE) {
             lmw::wave_sync();
             uint32_t xl = t.loc[tr_g(t, o_ol)];
             if (xl < t.n_leaf) {
@@ -415,11 +433,10 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
         t.it_st[Lf * 64 + lane] = st;
       }
       uint32_t new_act = (uint32_t)lmw::popc64(lmw::ballot(in && st_active(st)));
-      uint32_t old_act = de_act(e);
-      if (new_act != old_act) {
-        dir_set(t, p, de_make(Lf, n, new_act));
-        t.tot_active += new_act - old_act;
-      }
+#ifdef LM_EMU_CHECK
+      if (lane == 0 && getenv("LM_DBG")) fprintf(stderr, "  upd peer=%u [%u,%u) mode=%d leaf=%u p=%u chunk=%u act %u->%u CH=%u\n", peer, c0, c1, mode, Lf, p, (unsigned)t.lchunk[Lf], de_act(e), new_act, t.CH);
+#endif
+      if (new_act != de_act(e)) dir_update(t, p, t.lchunk[Lf], e, de_make(Lf, n, new_act));
     }
   }
 }
@@ -460,6 +477,7 @@ LM_DEV void tr_move_ops(Tr& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
 // debug-only (emulation): verify the directory against the leaves
 inline bool tr_check(Tr& t, const char* what, uint32_t row) {
   bool ok = true;
+  lmw::wave_sync();
   if (lmw::lane() == 0) {
     uint32_t tot = 0;
     for (uint32_t q = 0; q < t.n_dir && ok; q++) {
@@ -470,6 +488,21 @@ inline bool tr_check(Tr& t, const char* what, uint32_t row) {
     }
     if (ok && tot != t.tot_active) { fprintf(stderr, "CHECK %s row=%u: tot=%u cached=%u\n", what, row, tot, t.tot_active); ok = false; }
   }
+  {
+    uint32_t c = (uint32_t)lmw::lane(), sum = 0;
+    for (uint32_t j = 0; j < t.CH; j++) {
+      uint32_t i = c * t.CH + j;
+      if (i < t.n_dir) {
+        sum += de_act(t.dir[i]);
+        if (t.lchunk[de_leaf(t.dir[i])] != c) { fprintf(stderr, "CHECK %s row=%u: lchunk[leaf %u]=%u expected %u\n", what, row, de_leaf(t.dir[i]), t.lchunk[de_leaf(t.dir[i])], c); ok = false; }
+      }
+    }
+    if (sum != t.my_sum) {
+      fprintf(stderr, "CHECK %s row=%u: lane %u my_sum=%u expected %u (CH=%u n_dir=%u)\n", what, row, c, t.my_sum, sum, t.CH, t.n_dir); ok = false;
+      for (uint32_t q = 0; q < t.n_dir; q++) fprintf(stderr, " %u:%u/%u/%u", q, de_leaf(t.dir[q]), de_n(t.dir[q]), de_act(t.dir[q]));
+      fprintf(stderr, "\n");
+    }
+  }
   return lmw::any(!ok) ? false : true;
 }
 #define TR_CHECK(what, row) do { if (!t.err && !tr_check(t, what, row)) t.err = ST_INTERNAL; } while (0)
@@ -479,13 +512,14 @@ inline bool tr_check(Tr& t, const char* what, uint32_t row) {
 
 // K9: one wave per document — replay every sequence container from the empty version.
 // Dynamic LDS: [dir_cap] directory entries, then MAX_PEERS element bases, then MAX_PEERS tracker versions.
-LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
+LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   LM_DYN_SHARED(uint32_t, s_mem);
-  uint32_t* s_dir = s_mem;
-  uint32_t* s_ebase = s_mem + dir_cap;
-  uint32_t* s_cur = s_ebase + MAX_PEERS;
+  uint32_t* s_dir = s_mem;                       // [dir_cap]
+  uint32_t* s_ebase = s_mem + dir_cap;           // [pmax]
+  uint32_t* s_cur = s_ebase + pmax;              // [pmax]
+  uint8_t* s_lchunk = (uint8_t*)(s_cur + pmax);  // [dir_cap] bytes
   DocMeta m = d.doc[doc];
   if (status_fatal(m.status)) return;
   uint32_t P = m.n_peers;
@@ -499,6 +533,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
   t.loc = d.loc + elem0;
   t.ebase = s_ebase;
   t.dir = s_dir;
+  t.lchunk = s_lchunk;
   t.dir_cap = dir_cap;
   t.leaf_cap = m.leaf_cap;
   t.n_leaf = 0;
@@ -508,7 +543,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
   uint64_t pf_begin = lmw::clock();
 #endif
   uint32_t dir_used = 0;  // directory entries already flushed to HBM by earlier containers of this doc
-  if (m.leaf_cap > MAX_LEAVES_PER_DOC || m.leaf_cap > dir_cap) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
+  if (m.leaf_cap > MAX_LEAVES_PER_DOC || m.leaf_cap > dir_cap || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
   for (uint32_t cidx = 0; cidx < m.n_cont && !t.err; cidx++) {
     uint32_t kr = d.cont[m.cid0 + cidx].kind_root;
     uint32_t ckind = kr & 0xff;
@@ -516,9 +551,10 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap) {
     // fresh tracker: one empty leaf
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     uint32_t L0 = t.n_leaf++;
-    if (lane == 0) s_dir[0] = de_make(L0, 0, 0);
-    t.n_dir = 1; t.tot_active = 0;
-    t.CH = 1;  // chunk per lane of the directory scans; grows with the directory, kept odd (bank-conflict free)
+    if (lane == 0) { s_dir[0] = de_make(L0, 0, 0); s_lchunk[L0] = 0; }
+    t.n_dir = 1; t.tot_active = 0; t.my_sum = 0;
+    // chunk size: the leaves this container can still create spread over 64 lanes, kept odd
+    t.CH = ((m.leaf_cap - L0 + 63) / 64) | 1u;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
     lmw::block_sync();
     bool touched = false;

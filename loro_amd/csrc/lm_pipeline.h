@@ -243,7 +243,7 @@ struct Engine {
     h_doc.resize(n_docs);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
     uint64_t elem = 0, leaves = 0, vvh = 0, ht = 0;
-    uint32_t dir_cap = 64;
+    uint32_t dir_cap = 64, pmax = 2;
     static const uint32_t DIR_CAP_MAX = 36000;  // (36000 + 2·MAX_PEERS)·4 B stays inside the 160 KiB LDS of a CU
     std::vector<uint64_t> h_ht0(n_docs);
     std::vector<uint32_t> h_ht_cap(n_docs);
@@ -258,6 +258,7 @@ struct Engine {
       m.vvh0_lo = (uint32_t)vvh; m.vvh0_hi = (uint32_t)(vvh >> 32);
       if (ok) { elem += m.atoms; leaves += lc; vvh += (uint64_t)m.n_nodes * m.n_peers; }
       if (lc > dir_cap) dir_cap = lc;
+      if (ok && m.n_peers > pmax) pmax = m.n_peers;
       // LWW table: 2× the doc's Map op rows rounded up to a power of two
       uint32_t cap = 0;
       if (ok && m.n_mapop) { cap = 64; while (cap < 2 * m.n_mapop) cap <<= 1; }
@@ -299,7 +300,8 @@ struct Engine {
     if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
     lmbe::toc("k_map_lww", times, profiling);
     lmbe::tic();
-    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 2 * MAX_PEERS) * 4, d, g, dir_cap);
+    dir_cap = (dir_cap + 3) & ~3u;
+    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 2 * pmax) * 4 + dir_cap, d, g, dir_cap, pmax);
     lmbe::toc("k_integrate", times, profiling);
     // 6. emit: size pass, offsets, write pass
     lmbe::tic();
