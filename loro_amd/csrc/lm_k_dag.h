@@ -424,64 +424,80 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
   }
 }
 
-// K8: one lane per op row — element payload table (unicode scalars / list value offsets).
-LM_KERNEL void k_elem_fill(Dev d, uint32_t n_ops) {
-  uint32_t t = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
-  if (t >= n_ops) return;
-  OpRow r = d.op[t];
-  uint32_t kind = (r.cidx_kind >> 16) & 0xff;
-  if (kind != OK_TEXT_INS && kind != OK_LIST_INS && kind != OK_STYLE_START && kind != OK_STYLE_END) return;
-  if (!d.chg_flag[r.chg]) return;
-  uint32_t blk = d.op_blk[t];
-  uint32_t doc = d.blk[blk].doc;
+// K8: one wave per change block — element payload table (unicode scalars / list value offsets).
+// Strings are read 64 bytes per step with coalesced loads; scalar boundaries come from a ballot over the
+// UTF-8 lead bytes and each lead lane assembles its scalar from the following lanes.
+LM_KERNEL void k_elem_fill(Dev d) {
+  uint32_t bi = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  const BlockDesc& bd = d.blk[bi];
+  if (bd.status != ST_OK) return;
+  uint32_t doc = bd.doc;
   const DocMeta& m = d.doc[doc];
   if (status_fatal(m.status)) return;
-  uint32_t peer = d.chg[r.chg].peer;
-  uint64_t e0 = (((uint64_t)m.elem0_hi << 32) | m.elem0_lo) + d.elem_base[m.praw0 + peer] + r.ctr;
+  const uint32_t* off = d.boff + (uint64_t)bi * BCN;
+  uint32_t op0 = off[BC_OP], n_op = d.bcnt[(uint64_t)bi * BCN + BC_OP];
+  uint32_t chg0 = off[BC_CHG];
+  uint32_t peer = d.chg[chg0].peer;
+  uint64_t ebase = (((uint64_t)m.elem0_hi << 32) | m.elem0_lo) + d.elem_base[m.praw0 + peer];
+  uint32_t ext = d.peer_ext[m.praw0 + peer];
   uint64_t doc_data0 = d.blob_off[d.doc_blob[doc]];
-  if (r.ctr + r.len > d.peer_ext[m.praw0 + peer]) return;
-  if (kind == OK_STYLE_START || kind == OK_STYLE_END) { d.cp[e0] = 0xFFFFFFFFu; return; }
-  const uint8_t* p = d.data + d.op_val[t];
-  // the payload was bounds-checked by k_block_decode; re-read with the block's values section as the limit
-  const BlockDesc& bd = d.blk[blk];
   const uint8_t* lim = d.data + bd.base + bd.sec_rel[SEC_VALUES] + bd.sec_len[SEC_VALUES];
-  Rd v = rd_make(p, (uint64_t)(lim - p));
   bool bad = false;
-  if (kind == OK_TEXT_INS) {
-    uint64_t nbytes = rd_uleb(v);
-    const uint8_t* s = v.p;
-    uint64_t i = 0;
-    uint32_t n = 0;
-    while (i < nbytes) {
-      uint32_t c = s[i], cp, extra;
-      if (c < 0x80) { cp = c; extra = 0; }
-      else if ((c & 0xE0) == 0xC0) { cp = c & 0x1F; extra = 1; }
-      else if ((c & 0xF0) == 0xE0) { cp = c & 0x0F; extra = 2; }
-      else if ((c & 0xF8) == 0xF0) { cp = c & 0x07; extra = 3; }
-      else { bad = true; break; }
-      if (i + extra >= nbytes) { bad = true; break; }
-      for (uint32_t k = 1; k <= extra; k++) { uint32_t cc = s[i + k]; if ((cc & 0xC0) != 0x80) bad = true; cp = (cp << 6) | (cc & 0x3F); }
-      if (n < r.len) d.cp[e0 + n] = cp;
-      n++;
-      i += extra + 1;
-    }
-    if (n != r.len) bad = true;
-  } else {  // list insert: tag 7, count, then items
-    (void)rd_u8(v);
-    uint64_t cnt = rd_uleb(v);
-    if (cnt != r.len) bad = true;
-    for (uint32_t k = 0; k < r.len && !bad; k++) {
-      d.cp[e0 + k] = (uint32_t)((uint64_t)(v.p - d.data) - doc_data0);
-      bool u = false;
-      // skip one item
-      Rd before = v;
-      (void)before;
-      // reuse the frame-stack skipper through a single-item wrapper
-      skip_loro_value(v, u);
-      if (v.bad) bad = true;
+  for (uint32_t row = op0; row < op0 + n_op; row++) {
+    const OpRow r = d.op[row];
+    uint32_t kind = (r.cidx_kind >> 16) & 0xff;
+    if (kind != OK_TEXT_INS && kind != OK_LIST_INS && kind != OK_STYLE_START && kind != OK_STYLE_END) continue;
+    if (!d.chg_flag[r.chg]) continue;
+    if (r.ctr + r.len > ext) continue;
+    uint64_t e0 = ebase + r.ctr;
+    if (kind == OK_STYLE_START || kind == OK_STYLE_END) { if (lane == 0) d.cp[e0] = 0xFFFFFFFFu; continue; }
+    const uint8_t* p = d.data + d.op_val[row];
+    Rd v = rd_make(p, (uint64_t)(lim - p));
+    if (kind == OK_TEXT_INS) {
+      uint64_t nbytes = rd_uleb(v);
+      if (v.bad || nbytes > rd_left(v)) { bad = true; continue; }
+      const uint8_t* s = v.p;
+      uint32_t n = 0;  // scalars emitted so far
+      // a scalar spans at most 4 bytes: advance 61 bytes per step so a lead byte below lane 61 has its tail loaded
+      for (uint64_t c = 0; c < nbytes; c += 61) {
+        uint64_t i = c + (uint64_t)lane;
+        uint32_t b = i < nbytes ? s[i] : 0x80u;
+        bool last_chunk = c + 61 >= nbytes;
+        bool lead = i < nbytes && (b & 0xC0) != 0x80 && (last_chunk || lane < 61);
+        uint32_t b1 = lmw::shfl(b, (lane + 1) & 63), b2 = lmw::shfl(b, (lane + 2) & 63), b3 = lmw::shfl(b, (lane + 3) & 63);
+        uint64_t lm_ = lmw::ballot(lead);
+        uint32_t rank = (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1));
+        if (lead) {
+          uint32_t cpv, extra;
+          if (b < 0x80) { cpv = b; extra = 0; }
+          else if ((b & 0xE0) == 0xC0) { cpv = ((b & 0x1F) << 6) | (b1 & 0x3F); extra = 1; }
+          else if ((b & 0xF0) == 0xE0) { cpv = ((b & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F); extra = 2; }
+          else if ((b & 0xF8) == 0xF0) { cpv = ((b & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F); extra = 3; }
+          else { cpv = 0; extra = 0; bad = true; }
+          if (i + extra >= nbytes) bad = true;
+          if (extra >= 1 && (b1 & 0xC0) != 0x80) bad = true;
+          if (extra >= 2 && (b2 & 0xC0) != 0x80) bad = true;
+          if (extra >= 3 && (b3 & 0xC0) != 0x80) bad = true;
+          if ((uint32_t)lane + extra > 63) bad = true;  // cannot happen: leads above lane 60 only exist in the last chunk
+          if (n + rank < r.len) d.cp[e0 + n + rank] = cpv;
+        }
+        n += (uint32_t)lmw::popc64(lm_);
+      }
+      if (n != r.len) bad = true;
+    } else {  // list insert: tag 7, count, then items (walked by every lane; lane 0 stores)
+      (void)rd_u8(v);
+      uint64_t cnt = rd_uleb(v);
+      if (cnt != r.len) bad = true;
+      for (uint32_t k = 0; k < r.len && !bad; k++) {
+        if (lane == 0) d.cp[e0 + k] = (uint32_t)((uint64_t)(v.p - d.data) - doc_data0);
+        bool u = false;
+        skip_loro_value(v, u);
+        if (v.bad) bad = true;
+      }
     }
   }
-  if (bad) LM_SETERR(d.doc[doc].status, ST_DATA_CORRUPTION);
+  if (lmw::any(bad) && lane == 0) LM_SETERR(d.doc[doc].status, ST_DATA_CORRUPTION);
 }
 
 }  // namespace lm

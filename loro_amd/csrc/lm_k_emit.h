@@ -255,33 +255,50 @@ LM_KERNEL void k_emit(Dev d, uint32_t* ht_list, int mode) {
       if (kind == CK_TEXT) sink_byte(s, '"'); else sink_byte(s, '[');
       bool first_item = true;
       uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
-      for (uint32_t ri = 0; ri < nr && !err; ri++) {
-        {
-          uint32_t de = d.dir_out[m.leaf0 + r0 + ri];
+      // software pipeline over the leaves: (id,status) of leaf i+2 and the payload gather of leaf i+1 are in
+      // flight while leaf i is rendered, so the three dependent HBM round trips overlap
+      const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
+      uint32_t id1 = NONE, st1 = ST_EVER, id2 = NONE, st2 = ST_EVER, pay1 = 0;
+      bool vis1 = false;
+      auto load_leaf = [&](uint32_t ri, uint32_t& id, uint32_t& st) {
+        id = NONE; st = ST_EVER;
+        if (ri < nr) {
+          uint32_t de = dirp[ri];
           uint32_t L = de_leaf(de), n = de_n(de);
-          bool in = (uint32_t)lane < n;
-          uint32_t id = in ? d.it_id[(uint64_t)(m.leaf0 + L) * 64 + lane] : NONE;
-          uint32_t st = in ? d.it_st[(uint64_t)(m.leaf0 + L) * 64 + lane] : ST_EVER;
-          bool vis = in && !(st & ST_EVER);
-          uint32_t payload = vis ? d.cp[elem0 + d.elem_base[m.praw0 + pid_peer(id)] + pid_ctr(id)] : 0;
-          if (kind == CK_TEXT) {
-            uint64_t bytes = 0;
-            uint32_t nb = 0;
-            if (vis) cp_bytes(payload, bytes, nb);
-            sink_lanes(s, bytes, nb);
-          } else {
-            uint64_t vm = lmw::ballot(vis);
-            while (vm && !err) {
-              int l0 = lmw::ffs64(vm);
-              vm &= vm - 1;
-              uint32_t off = lmw::bcast(payload, l0);
-              if (!first_item) sink_byte(s, ',');
-              first_item = false;
-              // bounded by the end of the doc's last blob
-              uint64_t doc_end = d.blob_off[d.doc_blob[doc + 1] - 1] + d.blob_len[d.doc_blob[doc + 1] - 1];
-              Rd r = rd_make(d.data + doc_data0 + off, doc_end - (doc_data0 + off));
-              sink_value(s, r, err);
-            }
+          if ((uint32_t)lane < n) { id = d.it_id[(uint64_t)(m.leaf0 + L) * 64 + lane]; st = d.it_st[(uint64_t)(m.leaf0 + L) * 64 + lane]; }
+        }
+      };
+      auto gather = [&](uint32_t id, uint32_t st, bool& vis) -> uint32_t {
+        vis = id != NONE && !(st & ST_EVER);
+        return vis ? d.cp[elem0 + d.elem_base[m.praw0 + pid_peer(id)] + pid_ctr(id)] : 0u;
+      };
+      load_leaf(0, id1, st1);
+      load_leaf(1, id2, st2);
+      pay1 = gather(id1, st1, vis1);
+      for (uint32_t ri = 0; ri < nr && !err; ri++) {
+        bool vis = vis1;
+        uint32_t payload = pay1;
+        // advance the pipeline
+        id1 = id2; st1 = st2;
+        load_leaf(ri + 2, id2, st2);
+        pay1 = gather(id1, st1, vis1);
+        if (kind == CK_TEXT) {
+          uint64_t bytes = 0;
+          uint32_t nb = 0;
+          if (vis) cp_bytes(payload, bytes, nb);
+          sink_lanes(s, bytes, nb);
+        } else {
+          uint64_t vm = lmw::ballot(vis);
+          while (vm && !err) {
+            int l0 = lmw::ffs64(vm);
+            vm &= vm - 1;
+            uint32_t off = lmw::bcast(payload, l0);
+            if (!first_item) sink_byte(s, ',');
+            first_item = false;
+            // bounded by the end of the doc's last blob
+            uint64_t doc_end = d.blob_off[d.doc_blob[doc + 1] - 1] + d.blob_len[d.doc_blob[doc + 1] - 1];
+            Rd r = rd_make(d.data + doc_data0 + off, doc_end - (doc_data0 + off));
+            sink_value(s, r, err);
           }
         }
       }

@@ -294,7 +294,7 @@ struct Engine {
     LM_LAUNCH(k_dag_b, n_docs, 64, d, g);
     lmbe::toc("k_dag_b", times, profiling);
     lmbe::tic();
-    if (NO) LM_LAUNCH(k_elem_fill, cdiv(NO, 256), 256, d, NO);
+    if (NB) LM_LAUNCH(k_elem_fill, NB, 64, d);
     lmbe::toc("k_elem_fill", times, profiling);
     lmbe::tic();
     if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
