@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — merged docs/s of the batched CRDT merge engine on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the device hot path (envelope/xxh32 → columnar decode → DAG → Event-Graph-Walker
+integrate → LWW → JSON + VersionVector) over one batch of synthetic documents already resident in HBM.
+
+Workload at every N: BASELINE.json configs[1] — 10,000 documents × 100k-op automerge-paper-shaped text trace,
+2 concurrent peers (base [0,50k) by A; A and B both apply [50k,75k) concurrently), three update blobs per
+document — PER GPU (weak scaling: rank r owns its own 10k documents).  Documents shard with no data-path
+collective; the single exchange is one all-gather of the per-document merged-state summary per step.
+
+    python bench.py                       # N=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ≈6300 GB/s achievable
+
+
+def build_docs(n_docs, first_doc, n_base, n_branch, commit_every, seed):
+    from loro_amd import workload
+    tpl = workload.Cfg2Template(n_base, n_branch, seed=seed, commit_every=commit_every, fuse=True)
+    return tpl, [tpl.stamp(first_doc + d) for d in range(n_docs)]
+
+
+def cpu_baseline(docs, sample, threads):
+    """The CPU restatement of the reference algorithm (oracle/, kind "port") timed on this box's host cores on a
+    bounded sample of the same workload.  Reported next to the GPU number; never the thing measured above."""
+    import _oracle
+    sample_docs = docs[:sample]
+    packed = _oracle.pack(sample_docs)
+    _oracle.merge_batch(None, threads=threads, packed=_oracle.pack(sample_docs[: max(1, threads)]))  # warm
+    t = time.perf_counter()
+    res = _oracle.merge_batch(None, threads=threads, packed=packed)
+    dt = time.perf_counter() - t
+    t1 = time.perf_counter()
+    _oracle.merge_batch(None, threads=1, packed=_oracle.pack(sample_docs[: min(16, len(sample_docs))]))
+    dt1 = (time.perf_counter() - t1) / min(16, len(sample_docs))
+    assert all(r[0] == 0 for r in res)
+    return {
+        "value": round(len(sample_docs) / dt, 1), "unit": "docs/s", "cores": threads, "kind": "port",
+        "sample": f"{len(sample_docs)} of the benchmark documents (same blobs), oracle/liblorooracle.so with {threads} threads, "
+                  f"{dt:.1f} s wall; single thread {1.0 / dt1:.1f} docs/s",
+    }, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--docs", type=int, default=10000, help="documents per GPU (configs[1]: 10,000)")
+    ap.add_argument("--base-ops", type=int, default=50000)
+    ap.add_argument("--branch-ops", type=int, default=25000)
+    ap.add_argument("--commit-every", type=int, default=10)
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import loro_amd
+    from loro_amd import dist as lmdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the merge engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    tpl, docs = build_docs(args.docs, rank * args.docs, args.base_ops, args.branch_ops, args.commit_every, seed=0)
+    doc_ids = list(range(rank * args.docs, (rank + 1) * args.docs))
+    eng = loro_amd.MergeEngine(local_rank)
+    eng.stage(docs)                       # blobs → HBM (outside the timed region)
+
+    def step():
+        eng.run()                          # device pipeline; returns when the batch is merged
+        st, jl, vl, pe = eng.result_meta()
+        if world > 1:
+            local = np.stack([np.asarray(doc_ids, dtype=np.int64), st.astype(np.int64), pe.astype(np.int64),
+                              jl.astype(np.int64), vl.astype(np.int64), np.zeros(len(st), dtype=np.int64)], axis=1)
+            return lmdist.all_gather_summaries(local, device=dev)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- everything below is outside the timed region
+    st, jl, vl, pe = eng.result_meta()
+    assert int((st != 0).sum()) == 0, "documents failed on the device path"
+    stats = eng.stats()
+    # per-kernel durations from HIP events on the engine's own stream (2 extra profiled passes)
+    eng.set_profiling(True)
+    ktimes = {}
+    for _ in range(2):
+        eng.run()
+        for name, ms in eng.kernel_times():
+            ktimes.setdefault(name, []).append(ms)
+    eng.set_profiling(False)
+    kavg = {k: sum(v) / len(v) for k, v in ktimes.items()}
+    dom = max(kavg, key=kavg.get)
+    alg_bytes = float(stats.in_bytes + stats.out_bytes)  # Σ blob bytes in + JSON + VV bytes out
+    achieved = alg_bytes / (kavg[dom] * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_integrate.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = None
+    if rank == 0:
+        # parity spot check of what was just timed (oracle = checker only)
+        got = eng.fetch()
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            threads = os.cpu_count() or 1
+            cpu, want = cpu_baseline(docs, min(args.cpu_sample, len(docs)), threads)
+            assert got[: len(want)] == want, "device results differ from the CPU oracle"
+        n_total = args.docs * world
+        line = {
+            "metric": "merged docs/sec (batch of N docs x M remote ops)",
+            "value": round(n_total * args.steps / dt, 1),
+            "unit": "docs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: {args.docs} docs/GPU x {args.base_ops + 2 * args.branch_ops}-op automerge-paper-shaped text "
+                            f"trace, 2 concurrent peers, 3 FastUpdates blobs/doc ({tpl.n_runs} op runs, {tpl.n_changes} changes, "
+                            f"{sum(len(b) for b in docs[0])} blob bytes/doc)",
+                "docs_per_gpu": args.docs, "ops_per_doc": args.base_ops + 2 * args.branch_ops,
+                "sharding": f"doc-sharded x{world}, one all-gather of per-doc summaries per step" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(kavg[dom], 3),
+                "pipeline_achieved": round(alg_bytes / (dt / args.steps) / 1e9, 2),
+            },
+            "kernels_ms": {k: round(v, 3) for k, v in kavg.items()},
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

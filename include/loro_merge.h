@@ -72,6 +72,13 @@ int lm_stage(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs);
 int lm_run(lm_ctx* ctx);
 int lm_fetch(lm_ctx* ctx, lm_doc_out* outs);
 
+/* Per-document metadata of the last lm_run (arrays of n_docs entries, any may be NULL) without copying the
+ * rendered bytes back: what a sharded deployment all-gathers as the merged-state summary. */
+int lm_result_meta(lm_ctx* ctx, int32_t* status, uint64_t* json_len, uint64_t* vv_len, uint64_t* pending_ops);
+
+/* Wave-primitive self test on the device (DPP scan, ballot ranks); returns the number of mismatches. */
+int lm_selftest(lm_ctx* ctx);
+
 /* Introspection for bench.py: byte counts of the last run and per-kernel HIP-event timings. */
 typedef struct lm_run_stats {
   uint64_t n_docs, n_blobs;

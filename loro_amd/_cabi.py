@@ -17,7 +17,7 @@ class RunStats(ctypes.Structure):
                 ("device_bytes_allocated", ctypes.c_uint64), ("n_kernels", ctypes.c_uint32)]
 
 
-SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest"]
+SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta"]
 
 
 class Binding:
@@ -35,6 +35,8 @@ class Binding:
         self.fetch = g("fetch"); self.fetch.restype = ctypes.c_int; self.fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocOut)]
         self.get_stats = g("get_stats"); self.get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(RunStats)]
         self.set_profiling = g("set_profiling"); self.set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.result_meta = g("result_meta"); self.result_meta.restype = ctypes.c_int
+        self.result_meta.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.selftest = g("selftest"); self.selftest.restype = ctypes.c_int; self.selftest.argtypes = [ctypes.c_void_p]
         self.kernel_time = g("kernel_time"); self.kernel_time.restype = ctypes.c_int
         self.kernel_time.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double)]
@@ -98,6 +100,17 @@ class Context:
             vv = ctypes.string_at(o.vv, o.vv_len) if o.vv_len else b""
             res.append((o.status, js, vv, o.pending_ops))
         return res
+
+    def result_meta(self):
+        """(status i32[n], json_len u64[n], vv_len u64[n], pending u64[n]) of the last run, as numpy arrays."""
+        import numpy as np
+        st = np.zeros(self.n, dtype=np.int32)
+        jl = np.zeros(self.n, dtype=np.uint64)
+        vl = np.zeros(self.n, dtype=np.uint64)
+        pe = np.zeros(self.n, dtype=np.uint64)
+        if self.b.result_meta(self.h, st.ctypes.data, jl.ctypes.data, vl.ctypes.data, pe.ctypes.data) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        return st, jl, vl, pe
 
     def merge_batch(self, docs):
         self.stage(docs)

@@ -55,6 +55,19 @@ int LM_API(merge_batch)(void* c, const lm_doc_in_c* docs, size_t n, lm_doc_out_c
   if (rc) return rc;
   return LM_API(fetch)(c, outs);
 }
+// per-document result metadata of the last lm_run without copying the rendered bytes back
+int LM_API(result_meta)(void* c, int32_t* status, uint64_t* json_len, uint64_t* vv_len, uint64_t* pending) {
+  auto* x = (lm_ctx_impl*)c;
+  if (!x->eng.ran) { x->err = "lm_result_meta before lm_run"; return -1; }
+  for (uint32_t i = 0; i < x->eng.n_docs; i++) {
+    const lm::DocResult& r = x->eng.results[i];
+    if (status) status[i] = r.status;
+    if (json_len) json_len[i] = r.json_len;
+    if (vv_len) vv_len[i] = r.vv_len;
+    if (pending) pending[i] = r.pending;
+  }
+  return 0;
+}
 int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   auto* x = (lm_ctx_impl*)c;
   s->n_docs = x->eng.n_docs; s->n_blobs = x->eng.n_blobs; s->in_bytes = x->eng.in_bytes;

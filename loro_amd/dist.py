@@ -1,0 +1,44 @@
+"""Multi-GPU sharding of a document batch: documents are independent (no cross-document state in
+LoroDocInner, crates/loro-internal/src/lib.rs:142-172), so rank r owns documents d with d % world == r
+and runs the whole per-document pipeline locally.  The only exchange is ONE all-gather (RCCL over xGMI on
+ROCm; gloo in the CPU tests) of a fixed-size per-document summary so that every rank holds the merged-state
+table; the JSON itself stays with the owning rank."""
+from __future__ import annotations
+
+import zlib
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+SUMMARY_WORDS = 6  # doc index, status, pending ops, json length, vv length, crc32(json)
+
+
+def owned_docs(n_docs: int, rank: int, world: int) -> List[int]:
+    return list(range(rank, n_docs, world))
+
+
+def summarize(doc_ids: Sequence[int], results: Sequence[Tuple[int, bytes, bytes, int]]) -> np.ndarray:
+    out = np.zeros((len(doc_ids), SUMMARY_WORDS), dtype=np.int64)
+    for i, (d, (st, js, vv, pend)) in enumerate(zip(doc_ids, results)):
+        out[i] = (d, st, pend, len(js), len(vv), zlib.crc32(js))
+    return out
+
+
+def all_gather_summaries(local: np.ndarray, device=None):
+    """One collective: every rank contributes its [n_local, SUMMARY_WORDS] table (padded to the largest
+    shard) and receives the table of all documents, ordered by document index."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)            # tiny: shard sizes (part of the same exchange step)
+    n_max = int(max(int(s.item()) for s in sizes))
+    buf = torch.full((n_max, SUMMARY_WORDS), -1, dtype=torch.int64, device=device)
+    if local.shape[0]:
+        buf[: local.shape[0]] = torch.from_numpy(local).to(buf.device)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)             # THE all-gather of the merged-state summary
+    table = torch.cat([g[: int(s.item())] for g, s in zip(gathered, sizes)], dim=0).cpu().numpy()
+    return table[np.argsort(table[:, 0], kind="stable")]

@@ -1,0 +1,101 @@
+"""Hand-built edge cases shared by the CPU (kernel-logic harness) and GPU parity tests."""
+import random
+from loro_amd import wire, workload
+import _fuzz
+
+
+def edge_case_docs():
+    docs, names = [], []
+
+    def add(name, blobs):
+        names.append(name)
+        docs.append(list(blobs))
+
+    add("no blobs", [])
+    add("empty updates blob", [wire.encode_updates([])])
+    a = wire.Replica(1); a.text_insert("text", 0, "ab"); a.commit()
+    good = a.export()
+    bad = bytearray(good); bad[-1] ^= 1
+    add("checksum mismatch", [bytes(bad)])
+    add("bad magic", [b"lor0" + good[4:]])
+    add("truncated", [good[:10]])
+    add("snapshot mode", [wire.envelope(b"\x00" * 12, mode=3)])
+    add("good next to bad docs", [good])
+    # pending: second export without the first
+    a.text_insert("text", 2, "cd"); a.commit()
+    second = a.export({1: 2})
+    add("pending only", [second])
+    add("pending resolved later", [second, good])
+    add("duplicate blob", [good, good, second, second])
+    # overlapping exports of the same history with different change boundaries (sliced on import)
+    s = "abcdefghijklmnopqrstuvwxyz0123"
+    cid = wire.root_cid("text", wire.KIND_TEXT)
+    c1 = wire.Change(7, 0, 0, [], [wire.Op(cid, 0, "text_insert", pos=0, text=s[:20])])
+    c2 = wire.Change(7, 10, 10, [(7, 9)], [wire.Op(cid, 10, "text_insert", pos=10, text=s[10:])])
+    add("overlapping changes", [wire.encode_updates([[c1]]), wire.encode_updates([[c2]])])
+    add("overlapping changes reversed", [wire.encode_updates([[c2]]), wire.encode_updates([[c1]])])
+    # overlapping delete: forward and reversed delete spans sliced in the middle
+    base = wire.Change(3, 0, 0, [], [wire.Op(cid, 0, "text_insert", pos=0, text="0123456789")])
+    d_full = wire.Change(3, 10, 10, [(3, 9)], [wire.Op(cid, 10, "delete", pos=2, del_id=(3, 2), signed_len=4)])
+    d_tail = wire.Change(3, 12, 12, [(3, 11)], [wire.Op(cid, 12, "delete", pos=2, del_id=(3, 4), signed_len=2)])
+    add("sliced forward delete", [wire.encode_updates([[base]]), wire.encode_updates([[d_tail]]), wire.encode_updates([[d_full]])])
+    r_full = wire.Change(3, 10, 10, [(3, 9)], [wire.Op(cid, 10, "delete", pos=5, del_id=(3, 2), signed_len=-4)])
+    add("reversed delete", [wire.encode_updates([[base]]), wire.encode_updates([[r_full]])])
+    # long pastes (> 64, > 128 elements), multi-byte text crossing the 61-byte chunking of the payload kernel
+    p = wire.Replica(11)
+    p.text_insert("text", 0, "x" * 300); p.text_insert("text", 150, "é中😀λ" * 60); p.text_delete("text", 100, 250); p.commit()
+    q = wire.Replica(12); q.text_insert("text", 0, "z" * 129); q.commit()
+    add("long pastes", [p.export(), q.export()])
+    # many leaves: > 64 leaves so directory chunks span several lanes
+    big = wire.Replica(21)
+    rng = random.Random(5)
+    n = 0
+    for i in range(900):
+        pos = rng.randint(0, n)
+        big.text_insert("text", pos, "abcdefgh"[: 1 + i % 8]); n += 1 + i % 8
+        if i % 7 == 0 and n > 10:
+            dp = rng.randint(0, n - 5); big.text_delete("text", dp, 3); n -= 3
+        if i % 50 == 0:
+            big.commit()
+    big.commit()
+    add("many leaves", [big.export()])
+    # rich text anchors occupy positions but not the string
+    m = wire.Replica(31); m.text_insert("text", 0, "hello world"); m.text_mark("text", 0, 5, "bold", True); m.text_insert("text", 3, "XY"); m.commit()
+    add("style anchors", [m.export()])
+    # list values and map values of every renderable scalar kind
+    l = wire.Replica(41)
+    l.list_insert("list", 0, [None, True, False, 0, -1, 2 ** 62, -2 ** 63, "q\"uo\\te\n\t\x01é", b"\x00\xff", [], [1, [2, [3]]]])
+    l.list_delete("list", 1, 2)
+    l.map_set("map", "b", "x"); l.map_set("map", "a", [1, 2]); l.map_set("map", "", 7); l.map_delete("map", "b"); l.commit()
+    add("list and map values", [l.export()])
+    # concurrent map writers with equal lamports
+    w1 = wire.Replica(5); w1.map_set("map", "k", "from5"); w1.map_set("map", "gone", 1); w1.commit()
+    w2 = wire.Replica(9); w2.map_set("map", "k", "from9"); w2.map_delete("map", "gone"); w2.commit()
+    add("map tie break", [w1.export(), w2.export()])
+    # unsupported shapes must be flagged, not guessed
+    u = wire.Replica(51); u.map_set("map", "f", 1.5); u.commit()
+    add("f64 value", [u.export()])
+    u2 = wire.Replica(52); u2.map_set("map", "nested", {"a": 1}); u2.commit()
+    add("nested map value", [u2.export()])
+    return names, docs
+
+
+def fuzz_docs(n, base=0, steps=40, peers=None, **kw):
+    docs = []
+    for seed in range(base, base + n):
+        kinds = [("text",), ("text", "list"), ("text", "list", "map"), ("map",)][seed % 4]
+        reps = _fuzz.random_session(seed, n_peers=peers or (2 + seed % 3), n_steps=steps + seed % 50, kinds=kinds, **kw)
+        docs.append(_fuzz.blobs_of(reps, random.Random(seed)))
+    return docs
+
+
+def trace_docs(n_base, variants=((10, True), (10, False), (0, True)), n_docs=2, seed=2):
+    docs = []
+    for ce, fuse in variants:
+        tpl = workload.Cfg2Template(n_base, n_base // 2, seed=seed, commit_every=ce, fuse=fuse)
+        for d in range(n_docs):
+            s = tpl.stamp(d)
+            docs.append(s)
+            docs.append([s[0], s[2], s[1]])
+            docs.append([s[0], s[1]])
+    return docs

@@ -1,0 +1,47 @@
+"""N>1 path on CPU: document sharding + the single all-gather of per-document summaries, world_size 2, gloo.
+The merge itself is stood in by the oracle here (no GPU in this container); what is under test is
+loro_amd.dist — ownership, padding of uneven shards, ordering of the gathered table."""
+import os, socket
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _oracle, _cases
+from loro_amd import dist as lmdist
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_docs, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    docs = _cases.fuzz_docs(n_docs)
+    mine = lmdist.owned_docs(n_docs, rank, world)
+    res = _oracle.merge_batch([docs[d] for d in mine])
+    table = lmdist.all_gather_summaries(lmdist.summarize(mine, res))
+    np.save(os.path.join(out_dir, f"table{rank}.npy"), table)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_docs", [7, 10])
+def test_sharded_summary_all_gather(tmp_path, n_docs):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_docs, str(tmp_path)), nprocs=world, join=True)
+    docs = _cases.fuzz_docs(n_docs)
+    ref = lmdist.summarize(list(range(n_docs)), _oracle.merge_batch(docs))
+    for r in range(world):
+        t = np.load(os.path.join(str(tmp_path), f"table{r}.npy"))
+        assert t.shape == ref.shape and (t == ref).all(), f"rank {r} holds a different merged-state table"
+
+
+def test_ownership_partitions_documents():
+    for n, w in ((10, 2), (7, 4), (3, 8)):
+        owned = [lmdist.owned_docs(n, r, w) for r in range(w)]
+        assert sorted(d for o in owned for d in o) == list(range(n))
