@@ -45,8 +45,10 @@ def test_reference_fixture_blobs(engine):
     got = _same(engine, docs)
     assert got[0][1] == b'{"text":"Hello World!"}' and got[1][1] == got[0][1]
     # fixtures with containers outside the device scope must be flagged, not guessed
-    for name in ("updates.blob", "concurrent-base.ts.blob", "runtime-updates.ts.blob"):
+    for name in ("updates.blob", "runtime-updates.ts.blob"):   # Tree / MovableList / Counter containers inside
         assert engine.merge_batch([[b[name]]])[0][0] == 4
+    got = _same(engine, [[b["concurrent-base.ts.blob"]]])        # List + Text only: fully in scope
+    assert got[0][1] == b'{"list":["base"],"text":"x"}'
 
 
 def test_edge_cases(engine):
