@@ -1,0 +1,45 @@
+"""Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) runs of bench.py into the files committed here.
+
+  python profiles/extract_rocprof.py gpurun_out/prof_stats/r01_results.db gpurun_out/prof_fetch/r01_results.db \
+         gpurun_out/prof_write/r01_results.db r01
+
+The three databases come from three separate runs of the SAME command, as the HBM section of
+/opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass):
+  rocprofv3 --kernel-trace --stats -d ... -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  rocprofv3 --pmc FETCH_SIZE      -d ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  rocprofv3 --pmc WRITE_SIZE      -d ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction from the guide: FETCH_SIZE under-reports wide coalesced
+reads by 2x; the corrected figure doubles it (other access widths are uncalibrated — both figures are kept).
+"""
+import json, sqlite3, sys
+
+
+def main():
+    stats_db, fetch_db, write_db, tag = sys.argv[1:5]
+    out = {"tag": tag, "kernels": {}}
+    c = sqlite3.connect(stats_db)
+    rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    lines = ["| kernel | calls | total ms | avg ms | % |", "|---|---:|---:|---:|---:|"]
+    for name, calls, tot, avg, pct in rows:
+        out["kernels"][name] = {"calls": calls, "avg_ms": round(avg / 1e3, 4), "total_ms": round(tot / 1e3, 3), "pct": round(pct, 2)}
+        lines.append(f"| {name} | {calls} | {tot / 1e3:.3f} | {avg / 1e3:.4f} | {pct:.2f} |")
+    for db, cn in ((fetch_db, "FETCH_SIZE"), (write_db, "WRITE_SIZE")):
+        c = sqlite3.connect(db)
+        q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
+        for name, n, avg in c.execute(q, (cn,)):
+            out["kernels"].setdefault(name, {})[cn + "_KiB_per_launch"] = round(avg, 1)
+    k = out["kernels"].get("k_integrate", {})
+    if "FETCH_SIZE_KiB_per_launch" in k and "WRITE_SIZE_KiB_per_launch" in k:
+        raw = (k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024
+        cor = (2 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024
+        out["k_integrate_hbm_bytes_per_launch_raw"] = int(raw)
+        out["hbm_bytes_per_launch"] = int(cor)
+        out["note"] = "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 for k_integrate (gfx950 FETCH_SIZE correction); raw = uncorrected"
+    json.dump(out, open(f"profiles/{tag}_pmc_integrate.json", "w"), indent=1, sort_keys=True)
+    open(f"profiles/{tag}_kernel_stats.md", "w").write(
+        f"# rocprofv3 --kernel-trace --stats — bench.py --steps 3 --warmup 1 (configs[1], 10k docs, 1 MI355X)\n\n" + "\n".join(lines) + "\n")
+    print(json.dumps(out, indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
