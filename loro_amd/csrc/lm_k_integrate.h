@@ -94,7 +94,7 @@ LM_DEV uint32_t dir_find_kth(const Tr& t, uint32_t& k) {
 LM_DEV uint32_t dir_find_leaf(const Tr& t, uint32_t L) {
   int lane = lmw::lane();
   lmw::wave_sync();
-  uint32_t cbase = (uint32_t)t.lchunk[L] * t.CH;
+  uint32_t cbase = lmw::first((uint32_t)t.lchunk[L]) * t.CH;
   for (uint32_t j0 = 0; j0 < t.CH; j0 += 64) {
     uint32_t j = j0 + (uint32_t)lane, i = cbase + j;
     bool hit = j < t.CH && i < t.n_dir && de_leaf(t.dir[i]) == L;
@@ -171,7 +171,7 @@ LM_DEV int tr_cmp_pos(Tr& t, uint32_t a, uint32_t b) {
     uint32_t id = t.it_id[la * 64 + lane];
     uint32_t pa = dir_find_leaf(t, la);
     if (pa == NONE) { LM_SETERR(t.err, ST_INTERNAL); return 0; }
-    uint32_t n = de_n(t.dir[pa]);
+    uint32_t n = de_n(lmw::first(t.dir[pa]));
     int sa = lmw::ffs64(lmw::ballot((uint32_t)lane < n && id == a)), sb = lmw::ffs64(lmw::ballot((uint32_t)lane < n && id == b));
     return sa < sb ? -1 : 1;
   }
@@ -212,13 +212,13 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
   while (done < len && !t.err) {
     uint32_t piece = len - done > 64 ? 64 : len - done;
     lmw::wave_sync();
-    uint32_t e = t.dir[p];
+    uint32_t e = lmw::first(t.dir[p]);
     uint32_t L = de_leaf(e), n = de_n(e), old_act = de_act(e);
     if (!have_R) R = tr_leaf_load(t, L, n);
     have_R = false;
     uint32_t total = n + piece;
     uint32_t p_ol = done == 0 ? ol0 : pid0 + done - 1;
-    uint32_t chunk = t.lchunk[L];
+    uint32_t chunk = lmw::first((uint32_t)t.lchunk[L]);
     (void)old_act;
     if (total <= 64) {
       uint32_t na = tr_write_items(t, L, 0, total, R, ins, piece, pid0 + done, p_ol, orr, false, ins);
@@ -258,7 +258,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   }
   lmw::wave_sync();
   PROF_ADD(t, PF_FIND);
-  uint32_t e0 = t.dir[p];
+  uint32_t e0 = lmw::first(t.dir[p]);
   LeafRegs R = tr_leaf_load(t, de_leaf(e0), de_n(e0));
   if (pos != 0) {
     // slot of the k-th active element of this leaf; the cursor sits right after it
@@ -290,7 +290,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       if (C.n > from) between = true;
       if (cp + 1 >= t.n_dir) break;
       cp++; from = 0;
-      uint32_t e = t.dir[cp];
+      uint32_t e = lmw::first(t.dir[cp]);
       C = tr_leaf_load(t, de_leaf(e), de_n(e));
       PROF_CNT(t, PF_NEXTRA, 1);
     }
@@ -339,7 +339,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
               if (xp != NONE && xp >= p && xp <= cp) {
                 if (xp > p && xp < cp) visited = true;
                 else {
-                  uint32_t xn = de_n(t.dir[xp]);
+                  uint32_t xn = de_n(lmw::first(t.dir[xp]));
                   uint32_t xid = xp == cp ? C.id : ((uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE);
                   uint64_t xm = lmw::ballot((uint32_t)lane < xn && xid == o_ol);
                   if (xm) {
@@ -363,7 +363,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
               if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
               uint32_t xp = dir_find_leaf(t, xl);
               if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
-              uint32_t xn = de_n(t.dir[xp]);
+              uint32_t xn = de_n(lmw::first(t.dir[xp]));
               uint32_t xid = (uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE;
               uint32_t xol = (uint32_t)lane < xn ? t.it_ol[xl * 64 + lane] : NONE;
               uint64_t xm = lmw::ballot(xid == o_or);
@@ -390,7 +390,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       if (cp + 1 >= t.n_dir) break;
       carry_id = C.n ? lmw::bcast(C.id, (int)(C.n - 1)) : carry_id;
       cp++; ci = 0;
-      uint32_t e = t.dir[cp];
+      uint32_t e = lmw::first(t.dir[cp]);
       C = tr_leaf_load(t, de_leaf(e), de_n(e));
     }
   }
@@ -419,7 +419,7 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       pend &= ~lmw::ballot(lf == Lf);
       uint32_t p = dir_find_leaf(t, Lf);
       if (p == NONE) continue;  // leaf of another container of the same document (malformed target)
-      uint32_t e = t.dir[p];
+      uint32_t e = lmw::first(t.dir[p]);
       uint32_t n = de_n(e);
       bool in = (uint32_t)lane < n;
       uint32_t id = in ? t.it_id[Lf * 64 + lane] : NONE;
@@ -436,7 +436,7 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
 #ifdef LM_EMU_CHECK
       if (lane == 0 && getenv("LM_DBG")) fprintf(stderr, "  upd peer=%u [%u,%u) mode=%d leaf=%u p=%u chunk=%u act %u->%u CH=%u\n", peer, c0, c1, mode, Lf, p, (unsigned)t.lchunk[Lf], de_act(e), new_act, t.CH);
 #endif
-      if (new_act != de_act(e)) dir_update(t, p, t.lchunk[Lf], e, de_make(Lf, n, new_act));
+      if (new_act != de_act(e)) dir_update(t, p, lmw::first((uint32_t)t.lchunk[Lf]), e, de_make(Lf, n, new_act));
     }
   }
 }
@@ -512,7 +512,9 @@ inline bool tr_check(Tr& t, const char* what, uint32_t row) {
 
 // K9: one wave per document — replay every sequence container from the empty version.
 // Dynamic LDS: [dir_cap] directory entries, then MAX_PEERS element bases, then MAX_PEERS tracker versions.
-LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax) {
+LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                           const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                           const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   LM_DYN_SHARED(uint32_t, s_mem);
@@ -561,16 +563,16 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax) {
     for (uint32_t oi = 0; oi < m.n_nodes && !t.err; oi++) {
       uint32_t n = d.node_order[m.chg0 + oi];
       uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
-      const uint32_t* vv = d.vvh + vvh0 + (uint64_t)n * P;
-      uint32_t node_peer = d.chg[d.chg_sorted[m.chg0 + first]].peer;
+      const uint32_t* vv = vvh_ro + vvh0 + (uint64_t)n * P;
+      uint32_t node_peer = chg_ro[sorted_ro[m.chg0 + first]].peer;
       bool checked_out = false;
       for (uint32_t ci = first; ci <= last && !t.err; ci++) {
-        uint32_t crow = d.chg_sorted[m.chg0 + ci];
-        const ChangeRow ch = d.chg[crow];
-        uint32_t skip_to = ch.ctr + d.chg_skip[crow];
+        uint32_t crow = sorted_ro[m.chg0 + ci];
+        const ChangeRow ch = chg_ro[crow];
+        uint32_t skip_to = ch.ctr + skip_ro[crow];
         for (uint32_t row = ch.op0; row < ch.op0 + ch.n_op && !t.err; row++) {
           PROF_T0();
-          const OpRow r = d.op[row];
+          const OpRow r = op_ro[row];
           if ((r.cidx_kind & 0xffff) != cidx) continue;
           if (r.ctr + r.len <= skip_to) continue;
           uint32_t kind = (r.cidx_kind >> 16) & 0xff;
@@ -608,7 +610,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax) {
             // diff_calc.rs:1105-1119: the matching StyleStart is the op right before (same peer, counter-1)
             uint32_t end_pos = NONE;
             if (row > ch.op0) {
-              const OpRow pr = d.op[row - 1];
+              const OpRow pr = op_ro[row - 1];
               if (((pr.cidx_kind >> 16) & 0xff) == OK_STYLE_START && pr.ctr + 1 == r.ctr && (pr.cidx_kind & 0xffff) == cidx)
                 end_pos = (uint32_t)pr.prop + pr.a0;
             }

@@ -301,7 +301,8 @@ struct Engine {
     lmbe::toc("k_map_lww", times, profiling);
     lmbe::tic();
     dir_cap = (dir_cap + 3) & ~3u;
-    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 2 * pmax) * 4 + dir_cap, d, g, dir_cap, pmax);
+    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 2 * pmax) * 4 + dir_cap, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                  (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh);
     lmbe::toc("k_integrate", times, profiling);
     // 6. emit: size pass, offsets, write pass
     lmbe::tic();
