@@ -47,8 +47,8 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   uint32_t* loc;                  // doc element → leaf
   const uint32_t* ebase;          // LDS: element base per peer
   uint32_t* dir;                  // LDS leaf directory in document order
-  uint8_t* lchunk;                // LDS: leaf → chunk (= owning lane) of its directory entry
-  uint32_t n_dir, dir_cap, CH;    // lane c owns directory entries [c*CH, (c+1)*CH); CH is odd (bank-conflict free)
+  uint8_t* lchunk;                // HBM: leaf → chunk (= owning lane) of its directory entry (kept out of LDS for occupancy)
+  uint32_t n_dir, dir_cap, CH, inv_CH;    // lane c owns directory entries [c*CH, (c+1)*CH); CH is odd (bank-conflict free)
   uint32_t my_sum;                // PER-LANE: Σ active counts of this lane's chunk, maintained incrementally
   uint32_t n_leaf, leaf_cap;
   uint32_t tot_active;
@@ -64,7 +64,8 @@ LM_DEV uint32_t tr_g(const Tr& t, uint32_t pid) { return t.ebase[pid_peer(pid)] 
 // The directory is an array of entries in document order.  Lane c owns the chunk [c*CH, (c+1)*CH) and keeps
 // the sum of its active counts in a register (my_sum), so locating the k-th active element is one DPP scan
 // over the 64 chunk sums plus one scan inside the owning chunk.
-LM_DEV uint32_t dir_chunk_of(const Tr& t, uint32_t p) { return t.lchunk[de_leaf(t.dir[p])]; }
+// chunk of directory position p: floor(p / CH) through the precomputed reciprocal (p < 2^16·CH is far inside its exact range)
+LM_DEV uint32_t dir_chunk_at(const Tr& t, uint32_t p) { return (uint32_t)(((uint64_t)p * t.inv_CH) >> 32); }
 
 // k-th active element (1 <= k <= tot_active) → directory position; k becomes the rank inside that leaf
 LM_DEV uint32_t dir_find_kth(const Tr& t, uint32_t& k) {
@@ -91,10 +92,15 @@ LM_DEV uint32_t dir_find_kth(const Tr& t, uint32_t& k) {
   return NONE;
 }
 // directory position of leaf L (searches only the chunk that holds it)
+LM_DEV uint32_t dir_find_leaf_in(const Tr& t, uint32_t L, uint32_t chunk);
 LM_DEV uint32_t dir_find_leaf(const Tr& t, uint32_t L) {
+  lmw::wave_sync();
+  return dir_find_leaf_in(t, L, lmw::first((uint32_t)t.lchunk[L]));
+}
+LM_DEV uint32_t dir_find_leaf_in(const Tr& t, uint32_t L, uint32_t chunk) {
   int lane = lmw::lane();
   lmw::wave_sync();
-  uint32_t cbase = lmw::first((uint32_t)t.lchunk[L]) * t.CH;
+  uint32_t cbase = chunk * t.CH;
   for (uint32_t j0 = 0; j0 < t.CH; j0 += 64) {
     uint32_t j = j0 + (uint32_t)lane, i = cbase + j;
     bool hit = j < t.CH && i < t.n_dir && de_leaf(t.dir[i]) == L;
@@ -218,7 +224,7 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
     have_R = false;
     uint32_t total = n + piece;
     uint32_t p_ol = done == 0 ? ol0 : pid0 + done - 1;
-    uint32_t chunk = lmw::first((uint32_t)t.lchunk[L]);
+    uint32_t chunk = dir_chunk_at(t, p);
     (void)old_act;
     if (total <= 64) {
       uint32_t na = tr_write_items(t, L, 0, total, R, ins, piece, pid0 + done, p_ol, orr, false, ins);
@@ -417,13 +423,16 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       int l0 = lmw::ffs64(pend);
       uint32_t Lf = lmw::bcast(lf, l0);
       pend &= ~lmw::ballot(lf == Lf);
-      uint32_t p = dir_find_leaf(t, Lf);
+      // the leaf's chunk byte, ids and statuses are fetched together (one round trip); counts come from LDS
+      uint32_t cbyte = t.lchunk[Lf];
+      uint32_t id = t.it_id[Lf * 64 + lane];
+      uint32_t st = t.it_st[Lf * 64 + lane];
+      uint32_t p = dir_find_leaf_in(t, Lf, lmw::first(cbyte));
       if (p == NONE) continue;  // leaf of another container of the same document (malformed target)
       uint32_t e = lmw::first(t.dir[p]);
       uint32_t n = de_n(e);
       bool in = (uint32_t)lane < n;
-      uint32_t id = in ? t.it_id[Lf * 64 + lane] : NONE;
-      uint32_t st = in ? t.it_st[Lf * 64 + lane] : ST_FUT;
+      if (!in) { id = NONE; st = ST_FUT; }
       bool hit = in && id >= lo_pid && id <= hi_pid;
       if (hit) {
         if (mode == UPD_SET_FUT) st |= ST_FUT;
@@ -436,7 +445,7 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
 #ifdef LM_EMU_CHECK
       if (lane == 0 && getenv("LM_DBG")) fprintf(stderr, "  upd peer=%u [%u,%u) mode=%d leaf=%u p=%u chunk=%u act %u->%u CH=%u\n", peer, c0, c1, mode, Lf, p, (unsigned)t.lchunk[Lf], de_act(e), new_act, t.CH);
 #endif
-      if (new_act != de_act(e)) dir_update(t, p, lmw::first((uint32_t)t.lchunk[Lf]), e, de_make(Lf, n, new_act));
+      if (new_act != de_act(e)) dir_update(t, p, dir_chunk_at(t, p), e, de_make(Lf, n, new_act));
     }
   }
 }
@@ -521,7 +530,6 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   uint32_t* s_dir = s_mem;                       // [dir_cap]
   uint32_t* s_ebase = s_mem + dir_cap;           // [pmax]
   uint32_t* s_cur = s_ebase + pmax;              // [pmax]
-  uint8_t* s_lchunk = (uint8_t*)(s_cur + pmax);  // [dir_cap] bytes
   DocMeta m = d.doc[doc];
   if (status_fatal(m.status)) return;
   uint32_t P = m.n_peers;
@@ -535,7 +543,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   t.loc = d.loc + elem0;
   t.ebase = s_ebase;
   t.dir = s_dir;
-  t.lchunk = s_lchunk;
+  t.lchunk = d.lf_chunk + m.leaf0;
   t.dir_cap = dir_cap;
   t.leaf_cap = m.leaf_cap;
   t.n_leaf = 0;
@@ -553,10 +561,12 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
     // fresh tracker: one empty leaf
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     uint32_t L0 = t.n_leaf++;
-    if (lane == 0) { s_dir[0] = de_make(L0, 0, 0); s_lchunk[L0] = 0; }
+    if (lane == 0) { s_dir[0] = de_make(L0, 0, 0); t.lchunk[L0] = 0; }
     t.n_dir = 1; t.tot_active = 0; t.my_sum = 0;
     // chunk size: the leaves this container can still create spread over 64 lanes, kept odd
     t.CH = ((m.leaf_cap - L0 + 63) / 64) | 1u;
+    if (t.CH < 3) t.CH = 3;  // keeps the 32-bit reciprocal below representable
+    t.inv_CH = 0xFFFFFFFFu / t.CH + 1u;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
     lmw::block_sync();
     bool touched = false;

@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <stdexcept>
@@ -53,7 +54,7 @@ struct Engine {
   DBuf b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
   DBuf b_cp, b_loc;
-  DBuf b_it_id, b_it_ol, b_it_or, b_it_st, b_dir_out;
+  DBuf b_it_id, b_it_ol, b_it_or, b_it_st, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list;
   DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof;
@@ -77,7 +78,7 @@ struct Engine {
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it_id,
-                   &b_it_ol, &b_it_or, &b_it_st, &b_dir_out,
+                   &b_it_ol, &b_it_or, &b_it_st, &b_dir_out, &b_lf_chunk,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
@@ -270,6 +271,7 @@ struct Engine {
     b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
     b_it_id.ensure((leaves + 1) * 64 * 4); b_it_ol.ensure((leaves + 1) * 64 * 4); b_it_or.ensure((leaves + 1) * 64 * 4); b_it_st.ensure((leaves + 1) * 64 * 4);
     b_dir_out.ensure((leaves + 1) * 4);
+    b_lf_chunk.ensure(leaves + 64);
     b_vvh.ensure((vvh + 1) * 4);
     b_prof.ensure((size_t)n_docs * 16 * 8);
     d.prof = b_prof.as<unsigned long long>();
@@ -281,6 +283,7 @@ struct Engine {
     d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>();
     d.it_id = b_it_id.as<uint32_t>(); d.it_ol = b_it_ol.as<uint32_t>(); d.it_or = b_it_or.as<uint32_t>(); d.it_st = b_it_st.as<uint32_t>();
     d.dir_out = b_dir_out.as<uint32_t>();
+    d.lf_chunk = b_lf_chunk.as<uint8_t>();
     d.vvh = b_vvh.as<uint32_t>();
     d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>();
     d.ht0 = b_ht0.as<uint64_t>(); d.ht_cap = b_ht_cap.as<uint32_t>();
@@ -301,7 +304,8 @@ struct Engine {
     lmbe::toc("k_map_lww", times, profiling);
     lmbe::tic();
     dir_cap = (dir_cap + 3) & ~3u;
-    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 2 * pmax) * 4 + dir_cap, d, g, dir_cap, pmax, (const OpRow*)d.op,
+    size_t lds_pad = getenv("LM_LDS_PAD") ? (size_t)atoi(getenv("LM_LDS_PAD")) : 0;  // occupancy experiments only
+    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 2 * pmax) * 4 + lds_pad, d, g, dir_cap, pmax, (const OpRow*)d.op,
                   (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh);
     lmbe::toc("k_integrate", times, profiling);
     // 6. emit: size pass, offsets, write pass
