@@ -112,6 +112,14 @@ class Context:
             raise RuntimeError(self.b.last_error(self.h).decode())
         return st, jl, vl, pe
 
+    def sizing(self):
+        """(max leaves used, max leaf capacity, max elements, documents re-run with the worst-case directory)"""
+        out = (ctypes.c_uint32 * 4)()
+        f = getattr(self.b.lib, [k for k in ("lm_sizing", "lmemu_sizing") if hasattr(self.b.lib, k)][0])
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        f(self.h, out)
+        return tuple(out)
+
     def merge_batch(self, docs):
         self.stage(docs)
         self.run()

@@ -76,6 +76,14 @@ int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   s->n_kernels = (uint32_t)x->eng.times.size();
   return 0;
 }
+// sizing diagnostics of the last run: max over documents of (leaves used, leaf capacity, elements)
+int LM_API(sizing)(void* c, uint32_t* out3) {  // out3[3] = documents re-run with the worst-case directory
+  auto* x = (lm_ctx_impl*)c;
+  out3[0] = out3[1] = out3[2] = 0;
+  out3[3] = x->eng.last_retries;
+  for (auto& m : x->eng.h_doc) { if (m.pad0 > out3[0]) out3[0] = m.pad0; if (m.leaf_cap > out3[1]) out3[1] = m.leaf_cap; if (m.n_elems > out3[2]) out3[2] = m.n_elems; }
+  return 0;
+}
 // returns the number of mismatches of the wave-primitive self test (0 = ok)
 int LM_API(selftest)(void* c) {
   auto* x = (lm_ctx_impl*)c;

@@ -119,7 +119,8 @@ LM_DEV void dir_update(Tr& t, uint32_t p, uint32_t chunk, uint32_t old_e, uint32
 // insert entry e right after position p (`chunk` = chunk of p)
 LM_DEV void dir_insert_after(Tr& t, uint32_t p, uint32_t chunk, uint32_t e) {
   int lane = lmw::lane();
-  if (t.n_dir >= t.dir_cap || t.n_dir >= 64 * t.CH) { LM_SETERR(t.err, ST_INTERNAL); return; }
+  if (t.n_dir >= t.dir_cap) { t.err = ST_RETRY; return; }   // optimistic directory size exceeded
+  if (t.n_dir >= 64 * t.CH) { LM_SETERR(t.err, ST_INTERNAL); return; }
   lmw::wave_sync();
   uint32_t q = p + 1, n_old = t.n_dir;
   uint32_t cq = q == (chunk + 1) * t.CH ? chunk + 1 : chunk;
@@ -523,7 +524,8 @@ inline bool tr_check(Tr& t, const char* what, uint32_t row) {
 // Dynamic LDS: [dir_cap] directory entries, then MAX_PEERS element bases, then MAX_PEERS tracker versions.
 LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                            const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
-                           const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro) {
+                           const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro,
+                           uint32_t retry_pass, uint32_t* retry_count) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   LM_DYN_SHARED(uint32_t, s_mem);
@@ -531,11 +533,21 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   uint32_t* s_ebase = s_mem + dir_cap;           // [pmax]
   uint32_t* s_cur = s_ebase + pmax;              // [pmax]
   DocMeta m = d.doc[doc];
+  uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
+  if (retry_pass) {
+    // second launch: only the documents whose optimistic directory overflowed, from a clean element map
+    if (m.status != ST_RETRY) return;
+    for (uint32_t i = (uint32_t)lane; i < m.atoms; i += 64) d.loc[elem0 + i] = NONE;
+    for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) d.cont[m.cid0 + c].touched = 0;
+    lmw::block_sync();  // every lane has read the status before it is cleared
+    if (lane == 0) d.doc[doc].status = ST_OK;
+    m.status = ST_OK;
+    lmw::block_sync();
+  }
   if (status_fatal(m.status)) return;
   uint32_t P = m.n_peers;
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_ebase[p] = d.elem_base[m.praw0 + p];
   lmw::block_sync();
-  uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
   uint64_t vvh0 = ((uint64_t)m.vvh0_hi << 32) | m.vvh0_lo;
   Tr t;
   t.it_id = d.it_id + (uint64_t)m.leaf0 * 64; t.it_ol = d.it_ol + (uint64_t)m.leaf0 * 64;
@@ -553,7 +565,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   uint64_t pf_begin = lmw::clock();
 #endif
   uint32_t dir_used = 0;  // directory entries already flushed to HBM by earlier containers of this doc
-  if (m.leaf_cap > MAX_LEAVES_PER_DOC || m.leaf_cap > dir_cap || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
+  if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
   for (uint32_t cidx = 0; cidx < m.n_cont && !t.err; cidx++) {
     uint32_t kr = d.cont[m.cid0 + cidx].kind_root;
     uint32_t ckind = kr & 0xff;
@@ -646,7 +658,11 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
     dir_used += t.n_dir;
     lmw::block_sync();
   }
-  if (t.err && lane == 0) d.doc[doc].status = t.err;
+  if (t.err && lane == 0) {
+    d.doc[doc].status = t.err;
+    if (t.err == ST_RETRY) lmw::atomic_add(retry_count, 1u);
+  }
+  if (lane == 0) d.doc[doc].pad0 = dir_used;  // leaves actually used (sizing diagnostics)
 #ifdef LM_PROF
   t.prof[PF_TOTAL] = lmw::clock() - pf_begin;
   if (lane == 0) for (int i = 0; i < PF_N; i++) d.prof[(uint64_t)doc * PF_N + i] = t.prof[i];

@@ -26,6 +26,11 @@ with loro_amd.MergeEngine(0) as e:
     for it in range(3):
         t = time.time(); e.run(); dt = time.time() - t
         print("run(noprof) %d: %.1f ms  -> %.0f docs/s" % (it, dt * 1e3, n_docs / dt), flush=True)
+    import ctypes
+    out3 = (ctypes.c_uint32 * 4)()
+    e.b.lib.lm_sizing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+    e.b.lib.lm_sizing(e.h, out3)
+    print("sizing: leaves used max %d, leaf_cap max %d, n_elems max %d, retried docs %d" % (out3[0], out3[1], out3[2], out3[3]))
     res = e.fetch()
     st = e.stats()
     print("in_bytes %d out_bytes %d device_alloc %.2f GB" % (st.in_bytes, st.out_bytes, st.device_bytes_allocated / 1e9))

@@ -55,3 +55,25 @@ def test_trace_shaped_documents_both_import_orders():
     got, _ = _check(docs)
     for k in range(0, len(docs), 3):
         assert got[k][1] == got[k + 1][1] and got[k][2] == got[k + 1][2]
+
+
+def test_optimistic_directory_overflow_is_retried():
+    """Sequential appends leave every leaf half full (the worst case the optimistic LDS directory does not cover):
+    the document must be re-run with the worst-case directory and still match the oracle."""
+    from loro_amd import wire
+    from loro_amd._cabi import Context
+    r = wire.Replica(77)
+    n = 0
+    for i in range(3500):
+        r.text_insert("text", n, "abcdefg"[: 1 + i % 7]); n += 1 + i % 7
+        if i % 3 == 0:
+            r.text_delete("text", n - 1, 1); n -= 1     # keeps the runs from merging into one op
+        if i % 100 == 0:
+            r.commit()
+    r.commit()
+    docs = [[r.export()], _cases.fuzz_docs(1)[0]]
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        sizing = c.sizing()
+    assert got == _oracle.merge_batch(docs)
+    assert sizing[3] >= 1, f"expected a directory retry, sizing={sizing}"
