@@ -71,7 +71,7 @@ int LM_API(result_meta)(void* c, int32_t* status, uint64_t* json_len, uint64_t* 
 int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   auto* x = (lm_ctx_impl*)c;
   s->n_docs = x->eng.n_docs; s->n_blobs = x->eng.n_blobs; s->in_bytes = x->eng.in_bytes;
-  s->out_bytes = x->eng.out_bytes + x->eng.vv_bytes;
+  s->out_bytes = x->eng.payload_bytes;
   s->device_bytes_allocated = lmbe::allocated_bytes();
   s->n_kernels = (uint32_t)x->eng.times.size();
   return 0;

@@ -213,7 +213,7 @@ LM_KERNEL void k_emit(Dev d, uint32_t* ht_list, int mode) {
   int lane = lmw::lane();
   LM_SHARED(uint32_t, s_order, MAX_CONTAINERS);
   DocMeta m = d.doc[doc];
-  if (status_fatal(m.status)) { if (lane == 0 && mode == 0) { d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; } return; }
+  if (status_fatal(m.status)) { if (lane == 0) { d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; } return; }
   int32_t err = 0;
   // ---- root containers that received an applied op, ordered bytewise by name
   uint32_t C = m.n_cont;
@@ -380,7 +380,29 @@ LM_KERNEL void k_emit(Dev d, uint32_t* ht_list, int mode) {
   }
   if (lane == 0) {
     if (err) { d.doc[doc].status = err; d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; }
-    else if (mode == 0) { d.doc[doc].out_len = (uint32_t)s.pos; d.doc[doc].vv_len = vvn; }
+    else { d.doc[doc].out_len = (uint32_t)s.pos; d.doc[doc].vv_len = vvn; }
+  }
+}
+
+// K12: one wave per doc — copy the rendered JSON / VV from the worst-case slabs into the compact result buffers.
+// All four offset tables are 16-byte aligned, so the copy runs on 16-byte vectors.
+LM_KERNEL void k_compact(Dev d, const uint64_t* slab_off, const uint64_t* vv_slab_off, const uint8_t* slab, const uint8_t* vv_slab) {
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  const DocMeta& m = d.doc[doc];
+  if (status_fatal(m.status)) return;
+  struct V16 { uint32_t x, y, z, w; };
+  {
+    const V16* src = (const V16*)(slab + slab_off[doc]);
+    V16* dst = (V16*)(d.out + d.out_off[doc]);
+    uint32_t n = (m.out_len + 15) / 16;
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
+  }
+  {
+    const V16* src = (const V16*)(vv_slab + vv_slab_off[doc]);
+    V16* dst = (V16*)(d.vv_out + d.vv_off[doc]);
+    uint32_t n = (m.vv_len + 15) / 16;
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
   }
 }
 

@@ -57,7 +57,8 @@ struct Engine {
   DBuf b_it_id, b_it_ol, b_it_or, b_it_st, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list;
-  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof;
+  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off;
+  uint64_t payload_bytes = 0;   // Σ json_len + Σ vv_len of the last run (without alignment padding)
   std::vector<uint64_t> h_prof;
   // results
   std::vector<DocMeta> h_doc;
@@ -80,7 +81,7 @@ struct Engine {
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it_id,
                    &b_it_ol, &b_it_or, &b_it_st, &b_dir_out, &b_lf_chunk,
-                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_out, &b_out_off,
+                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
   }
@@ -326,17 +327,35 @@ struct Engine {
     }
     last_retries = n_retry;
     lmbe::toc("k_integrate", times, profiling);
-    // 6. emit: size pass, offsets, write pass
+    // 6. emit in one pass into worst-case slabs (every input byte renders to at most 6 output bytes), then compact
+    {
+      std::vector<uint64_t> slab_off(n_docs + 1, 0), vslab_off(n_docs + 1, 0);
+      for (uint32_t i = 0; i < n_docs; i++) {
+        uint64_t in_b = 0;
+        for (uint32_t b = h_doc_blob[i]; b < h_doc_blob[i + 1]; b++) in_b += h_blob_len[b];
+        bool ok = h_doc[i].status == ST_OK;
+        uint64_t cap = ok ? 6 * in_b + 64ull * h_doc[i].n_cont + 64 : 0;
+        uint64_t vcap = ok ? 16ull * h_doc[i].n_peers + 16 : 0;
+        slab_off[i + 1] = slab_off[i] + ((cap + 15) & ~15ull);
+        vslab_off[i + 1] = vslab_off[i] + ((vcap + 15) & ~15ull);
+      }
+      b_slab.ensure(slab_off[n_docs] + 64); b_vslab.ensure(vslab_off[n_docs] + 64);
+      b_slab_off.ensure((size_t)(n_docs + 1) * 8); b_vslab_off.ensure((size_t)(n_docs + 1) * 8);
+      lmbe::h2d(b_slab_off.p, slab_off.data(), (size_t)(n_docs + 1) * 8);
+      lmbe::h2d(b_vslab_off.p, vslab_off.data(), (size_t)(n_docs + 1) * 8);
+      d.out = b_slab.as<uint8_t>(); d.out_off = b_slab_off.as<uint64_t>();
+      d.vv_out = b_vslab.as<uint8_t>(); d.vv_off = b_vslab_off.as<uint64_t>();
+    }
     lmbe::tic();
-    LM_LAUNCH(k_emit, n_docs, 64, d, b_ht_list.as<uint32_t>(), 0);
-    lmbe::toc("k_emit(size)", times, profiling);
+    LM_LAUNCH(k_emit, n_docs, 64, d, b_ht_list.as<uint32_t>(), 1);
+    lmbe::toc("k_emit", times, profiling);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
     h_out_off.assign(n_docs + 1, 0);
     h_vv_off.assign(n_docs + 1, 0);
     for (uint32_t i = 0; i < n_docs; i++) {
       bool ok = h_doc[i].status == ST_OK;
-      h_out_off[i + 1] = h_out_off[i] + (ok ? h_doc[i].out_len : 0);
-      h_vv_off[i + 1] = h_vv_off[i] + (ok ? h_doc[i].vv_len : 0);
+      h_out_off[i + 1] = h_out_off[i] + (ok ? ((uint64_t)h_doc[i].out_len + 15) & ~15ull : 0);
+      h_vv_off[i + 1] = h_vv_off[i] + (ok ? ((uint64_t)h_doc[i].vv_len + 15) & ~15ull : 0);
     }
     out_bytes = h_out_off[n_docs];
     vv_bytes = h_vv_off[n_docs];
@@ -344,12 +363,19 @@ struct Engine {
     b_out_off.ensure((size_t)(n_docs + 1) * 8); b_vv_off.ensure((size_t)(n_docs + 1) * 8);
     lmbe::h2d(b_out_off.p, h_out_off.data(), (size_t)(n_docs + 1) * 8);
     lmbe::h2d(b_vv_off.p, h_vv_off.data(), (size_t)(n_docs + 1) * 8);
-    d.out = b_out.as<uint8_t>(); d.out_off = b_out_off.as<uint64_t>();
-    d.vv_out = b_vv_out.as<uint8_t>(); d.vv_off = b_vv_off.as<uint64_t>();
-    lmbe::tic();
-    LM_LAUNCH(k_emit, n_docs, 64, d, b_ht_list.as<uint32_t>(), 1);
-    lmbe::toc("k_emit(write)", times, profiling);
-    lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+    {
+      const uint64_t* so = b_slab_off.as<uint64_t>();
+      const uint64_t* vo = b_vslab_off.as<uint64_t>();
+      const uint8_t* sl = b_slab.as<uint8_t>();
+      const uint8_t* vs = b_vslab.as<uint8_t>();
+      d.out = b_out.as<uint8_t>(); d.out_off = b_out_off.as<uint64_t>();
+      d.vv_out = b_vv_out.as<uint8_t>(); d.vv_off = b_vv_off.as<uint64_t>();
+      lmbe::tic();
+      LM_LAUNCH(k_compact, n_docs, 64, d, so, vo, sl, vs);
+      lmbe::toc("k_compact", times, profiling);
+    }
+    payload_bytes = 0;
+    for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) payload_bytes += (uint64_t)h_doc[i].out_len + h_doc[i].vv_len;
 #ifdef LM_PROF
     h_prof.resize((size_t)n_docs * 16);
     lmbe::d2h(h_prof.data(), d.prof, (size_t)n_docs * 16 * 8);
