@@ -31,7 +31,7 @@ LM_DEV uint32_t de_n(uint32_t e) { return (e >> 18) & 0x7f; }
 LM_DEV uint32_t de_act(uint32_t e) { return e >> 25; }
 
 // optional cycle accounting (compile with -DLM_PROF): slots of the per-document profile record
-enum { PF_ROW = 0, PF_FIND, PF_LEAF, PF_ORIGHT, PF_BETWEEN, PF_PLACE, PF_DELETE, PF_CHECKOUT, PF_NINS, PF_NDEL, PF_NEXTRA, PF_NHEAD, PF_TOTAL, PF_N = 16 };
+enum { PF_ROW = 0, PF_FIND, PF_LEAF, PF_ORIGHT, PF_BETWEEN, PF_PLACE, PF_DELETE, PF_CHECKOUT, PF_NINS, PF_NDEL, PF_NEXTRA, PF_NHEAD, PF_TOTAL, PF_NHIT, PF_NDHIT, PF_N = 16 };
 #ifdef LM_PROF
 #define PROF_T0() uint64_t pf_t0_ = lmw::clock()
 #define PROF_ADD(t, slot) do { uint64_t pf_t1_ = lmw::clock(); (t).prof[slot] += pf_t1_ - pf_t0_; pf_t0_ = pf_t1_; } while (0)
@@ -41,6 +41,8 @@ enum { PF_ROW = 0, PF_FIND, PF_LEAF, PF_ORIGHT, PF_BETWEEN, PF_PLACE, PF_DELETE,
 #define PROF_ADD(t, slot) do {} while (0)
 #define PROF_CNT(t, slot, v) do {} while (0)
 #endif
+
+struct LeafRegs { uint32_t n, id, ol, orr, st; };   // one leaf in registers: lane i holds slot i
 
 struct Tr {  // wave-uniform context of one (document, sequence container) replay
   uint32_t *it_id, *it_ol, *it_or, *it_st;   // HBM leaves: [leaf*64 + slot]
@@ -52,6 +54,9 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   uint32_t my_sum;                // PER-LANE: Σ active counts of this lane's chunk, maintained incrementally
   uint32_t n_leaf, leaf_cap;
   uint32_t tot_active;
+  uint32_t cache_p;               // directory position of the cached leaf (positions only shift on splits, which drop the cache)
+  uint32_t cache_leaf;            // leaf currently mirrored in `cr` (NONE = none): typing stays in one leaf for many ops
+  LeafRegs cr;                    // write-through register copy of that leaf
   int32_t err;
 #ifdef LM_PROF
   uint64_t prof[PF_N];
@@ -153,7 +158,6 @@ LM_DEV void dir_insert_after(Tr& t, uint32_t p, uint32_t chunk, uint32_t e) {
   lmw::wave_sync();
 }
 
-struct LeafRegs { uint32_t n, id, ol, orr, st; };
 LM_DEV LeafRegs tr_leaf_load(const Tr& t, uint32_t L, uint32_t n) {
   int lane = lmw::lane();
   lmw::wave_sync();
@@ -189,7 +193,8 @@ LM_DEV int tr_cmp_pos(Tr& t, uint32_t a, uint32_t b) {
 // write `cnt` consecutive items of the logical sequence Q into leaf `dst` starting at Q index q0.
 // Q = old[0,ins) ++ new run[0,len) ++ old[ins,n).  `old` lives in registers (R), new items are synthesised.
 LM_DEV uint32_t tr_write_items(Tr& t, uint32_t dst, uint32_t q0, uint32_t cnt, const LeafRegs& R, uint32_t ins, uint32_t len,
-                               uint32_t pid0, uint32_t ol0, uint32_t orr, bool update_loc_old, uint32_t first_changed) {
+                               uint32_t pid0, uint32_t ol0, uint32_t orr, bool update_loc_old, uint32_t first_changed,
+                               LeafRegs* out = nullptr) {
   int lane = lmw::lane();
   uint32_t q = q0 + (uint32_t)lane;
   bool in = (uint32_t)lane < cnt;
@@ -208,6 +213,10 @@ LM_DEV uint32_t tr_write_items(Tr& t, uint32_t dst, uint32_t q0, uint32_t cnt, c
     t.it_id[dst * 64 + lane] = vid; t.it_ol[dst * 64 + lane] = vol; t.it_or[dst * 64 + lane] = vor; t.it_st[dst * 64 + lane] = vst;
     if (is_new || update_loc_old) t.loc[tr_g(t, vid)] = dst;
   }
+  if (out) {  // the new contents of `dst`, for the register-resident leaf cache
+    out->n = cnt;
+    out->id = in ? vid : NONE; out->ol = in ? vol : NONE; out->orr = in ? vor : NONE; out->st = in ? vst : ST_FUT;
+  }
   return (uint32_t)lmw::popc64(lmw::ballot(in && st_active(vst)));
 }
 
@@ -221,20 +230,22 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
     lmw::wave_sync();
     uint32_t e = lmw::first(t.dir[p]);
     uint32_t L = de_leaf(e), n = de_n(e), old_act = de_act(e);
-    if (!have_R) R = tr_leaf_load(t, L, n);
+    if (!have_R) { if (L == t.cache_leaf) R = t.cr; else R = tr_leaf_load(t, L, n); }
     have_R = false;
     uint32_t total = n + piece;
     uint32_t p_ol = done == 0 ? ol0 : pid0 + done - 1;
     uint32_t chunk = dir_chunk_at(t, p);
     (void)old_act;
     if (total <= 64) {
-      uint32_t na = tr_write_items(t, L, 0, total, R, ins, piece, pid0 + done, p_ol, orr, false, ins);
+      uint32_t na = tr_write_items(t, L, 0, total, R, ins, piece, pid0 + done, p_ol, orr, false, ins, &t.cr);
+      t.cache_leaf = L; t.cache_p = p;
       dir_update(t, p, chunk, e, de_make(L, total, na));
       ins += piece;
     } else {
       // even split into two leaves (total <= 128); both halves keep >= 32 elements
       if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
       uint32_t NL = t.n_leaf++;
+      t.cache_leaf = NONE;
       uint32_t left = (total + 1) / 2, right = total - left;
       uint32_t na_l = tr_write_items(t, L, 0, left, R, ins, piece, pid0 + done, p_ol, orr, false, ins < left ? ins : left);
       uint32_t na_r = tr_write_items(t, NL, left, right, R, ins, piece, pid0 + done, p_ol, orr, true, 0);
@@ -266,7 +277,9 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   lmw::wave_sync();
   PROF_ADD(t, PF_FIND);
   uint32_t e0 = lmw::first(t.dir[p]);
-  LeafRegs R = tr_leaf_load(t, de_leaf(e0), de_n(e0));
+  LeafRegs R;
+  if (de_leaf(e0) == t.cache_leaf) { R = t.cr; PROF_CNT(t, PF_NHIT, 1); }
+  else R = tr_leaf_load(t, de_leaf(e0), de_n(e0));
   if (pos != 0) {
     // slot of the k-th active element of this leaf; the cursor sits right after it
     uint64_t am = lmw::ballot(st_active(R.st));
@@ -415,6 +428,33 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     lmw::wave_sync();
     uint32_t c = cb + (uint32_t)lane;
     bool valid = c < c1;
+    uint32_t chi_ = cb + 64 < c1 ? cb + 64 : c1;
+    if (t.cache_leaf != NONE) {
+      // every target of this step inside the cached leaf?  then no gather and no leaf load are needed
+      uint32_t lo_ = pid_make(peer, cb), hi_ = pid_make(peer, chi_ - 1);
+      bool chit = (uint32_t)lane < t.cr.n && t.cr.id >= lo_ && t.cr.id <= hi_;
+      uint64_t cm = lmw::ballot(chit);
+      if ((uint32_t)lmw::popc64(cm) == chi_ - cb) {
+        uint32_t Lc = t.cache_leaf;
+        uint32_t p = t.cache_p;
+        {
+          uint32_t st = t.cr.st;
+          if (chit) {
+            if (mode == UPD_SET_FUT) st |= ST_FUT;
+            else if (mode == UPD_CLR_FUT) st &= ~ST_FUT;
+            else if (mode == UPD_DEL_INC) st = (st + ST_DEL1) | ST_EVER;
+            else if (st & ST_DELMASK) st -= ST_DEL1;
+            t.it_st[Lc * 64 + lane] = st;
+          }
+          t.cr.st = st;
+          uint32_t e = lmw::first(t.dir[p]);
+          uint32_t new_act = (uint32_t)lmw::popc64(lmw::ballot((uint32_t)lane < t.cr.n && st_active(st)));
+          if (new_act != de_act(e)) dir_update(t, p, dir_chunk_at(t, p), e, de_make(Lc, t.cr.n, new_act));
+          PROF_CNT(t, PF_NDHIT, 1);
+          continue;
+        }
+      }
+    }
     uint32_t lf = valid ? t.loc[eb + c] : NONE;
     if (valid && lf >= t.n_leaf) lf = NONE;  // not an element of this container (malformed target): ignored
     uint64_t pend = lmw::ballot(lf != NONE);
@@ -442,6 +482,7 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
         else if (st & ST_DELMASK) st -= ST_DEL1;
         t.it_st[Lf * 64 + lane] = st;
       }
+      if (Lf == t.cache_leaf) t.cr.st = in ? st : t.cr.st;   // keep the register copy coherent
       uint32_t new_act = (uint32_t)lmw::popc64(lmw::ballot(in && st_active(st)));
 #ifdef LM_EMU_CHECK
       if (lane == 0 && getenv("LM_DBG")) fprintf(stderr, "  upd peer=%u [%u,%u) mode=%d leaf=%u p=%u chunk=%u act %u->%u CH=%u\n", peer, c0, c1, mode, Lf, p, (unsigned)t.lchunk[Lf], de_act(e), new_act, t.CH);
@@ -574,7 +615,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     uint32_t L0 = t.n_leaf++;
     if (lane == 0) { s_dir[0] = de_make(L0, 0, 0); t.lchunk[L0] = 0; }
-    t.n_dir = 1; t.tot_active = 0; t.my_sum = 0;
+    t.n_dir = 1; t.tot_active = 0; t.my_sum = 0; t.cache_leaf = NONE;
     // chunk size: the leaves this container can still create spread over 64 lanes, kept odd
     t.CH = ((m.leaf_cap - L0 + 63) / 64) | 1u;
     if (t.CH < 3) t.CH = 3;  // keeps the 32-bit reciprocal below representable
