@@ -247,13 +247,15 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
       uint32_t NL = t.n_leaf++;
       t.cache_leaf = NONE;
       uint32_t left = (total + 1) / 2, right = total - left;
-      uint32_t na_l = tr_write_items(t, L, 0, left, R, ins, piece, pid0 + done, p_ol, orr, false, ins < left ? ins : left);
-      uint32_t na_r = tr_write_items(t, NL, left, right, R, ins, piece, pid0 + done, p_ol, orr, true, 0);
+      LeafRegs outL, outR;
+      uint32_t na_l = tr_write_items(t, L, 0, left, R, ins, piece, pid0 + done, p_ol, orr, false, ins < left ? ins : left, &outL);
+      uint32_t na_r = tr_write_items(t, NL, left, right, R, ins, piece, pid0 + done, p_ol, orr, true, 0, &outR);
       dir_update(t, p, chunk, e, de_make(L, left, na_l));
       dir_insert_after(t, p, chunk, de_make(NL, right, na_r));
       uint32_t endq = ins + piece;  // Q index right after the piece
-      if (endq <= left) ins = endq;
-      else { p = p + 1; ins = endq - left; }
+      if (endq <= left) { ins = endq; t.cr = outL; t.cache_leaf = L; t.cache_p = p; }
+      else { p = p + 1; ins = endq - left; t.cr = outR; t.cache_leaf = NL; t.cache_p = p; }
+      if (t.err) t.cache_leaf = NONE;
     }
     done += piece;
     lmw::wave_sync();
