@@ -32,24 +32,33 @@ def build_docs(n_docs, first_doc, n_base, n_branch, commit_every, seed):
     return tpl, [tpl.stamp(first_doc + d) for d in range(n_docs)]
 
 
-def cpu_baseline(docs, sample, threads):
+def cpu_baseline(docs, sample, cores):
     """The CPU restatement of the reference algorithm (oracle/, kind "port") timed on this box's host cores on a
-    bounded sample of the same workload.  Reported next to the GPU number; never the thing measured above."""
+    bounded sample of the same workload.  Reported next to the GPU number; never the thing measured above.
+    The best of {all hardware threads, half of them} after a warm run (heap already faulted in) is reported."""
     import _oracle
     sample_docs = docs[:sample]
     packed = _oracle.pack(sample_docs)
-    _oracle.merge_batch(None, threads=threads, packed=_oracle.pack(sample_docs[: max(1, threads)]))  # warm
-    t = time.perf_counter()
-    res = _oracle.merge_batch(None, threads=threads, packed=packed)
-    dt = time.perf_counter() - t
+    best = None
+    res = None
+    for threads in sorted({cores, max(1, cores // 2)}, reverse=True):
+        _oracle.merge_batch(None, threads=threads, packed=packed)          # warm
+        t = time.perf_counter()
+        res = _oracle.merge_batch(None, threads=threads, packed=packed)
+        dt = time.perf_counter() - t
+        if best is None or dt < best[0]:
+            best = (dt, threads)
+    dt, threads = best
+    one = _oracle.pack(sample_docs[: min(32, len(sample_docs))])
+    _oracle.merge_batch(None, threads=1, packed=one)
     t1 = time.perf_counter()
-    _oracle.merge_batch(None, threads=1, packed=_oracle.pack(sample_docs[: min(16, len(sample_docs))]))
-    dt1 = (time.perf_counter() - t1) / min(16, len(sample_docs))
+    _oracle.merge_batch(None, threads=1, packed=one)
+    dt1 = (time.perf_counter() - t1) / min(32, len(sample_docs))
     assert all(r[0] == 0 for r in res)
     return {
         "value": round(len(sample_docs) / dt, 1), "unit": "docs/s", "cores": threads, "kind": "port",
-        "sample": f"{len(sample_docs)} of the benchmark documents (same blobs), oracle/liblorooracle.so with {threads} threads, "
-                  f"{dt:.1f} s wall; single thread {1.0 / dt1:.1f} docs/s",
+        "sample": f"{len(sample_docs)} of the benchmark documents (same blobs), oracle/liblorooracle.so, {threads} threads "
+                  f"(of {cores} hardware threads), {dt:.2f} s wall after a warm run; single thread {1.0 / dt1:.1f} docs/s",
     }, res
 
 
@@ -62,7 +71,7 @@ def main():
     ap.add_argument("--base-ops", type=int, default=50000)
     ap.add_argument("--branch-ops", type=int, default=25000)
     ap.add_argument("--commit-every", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
