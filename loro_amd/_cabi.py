@@ -17,7 +17,7 @@ class RunStats(ctypes.Structure):
                 ("device_bytes_allocated", ctypes.c_uint64), ("n_kernels", ctypes.c_uint32)]
 
 
-SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta"]
+SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "n_streams"]
 
 
 class Binding:
@@ -38,6 +38,7 @@ class Binding:
         self.result_meta = g("result_meta"); self.result_meta.restype = ctypes.c_int
         self.result_meta.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.selftest = g("selftest"); self.selftest.restype = ctypes.c_int; self.selftest.argtypes = [ctypes.c_void_p]
+        self.n_streams = g("n_streams"); self.n_streams.restype = ctypes.c_int; self.n_streams.argtypes = [ctypes.c_void_p]
         self.kernel_time = g("kernel_time"); self.kernel_time.restype = ctypes.c_int
         self.kernel_time.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double)]
 

@@ -1,11 +1,72 @@
 // C-ABI glue shared by the product library (lm_hip.cpp) and the kernel-logic test harness (tests/emu).
 // LM_API(name) expands to the exported symbol name.
 #pragma once
+#include <memory>
+#include <thread>
 #include "lm_pipeline.h"
 
+// One lm_ctx drives up to LM_MAX_PARTS engines, each on its own HIP stream over a contiguous range of the batch's
+// documents.  lm_run launches the parts from separate host threads so the kernels of one part (latency-bound
+// integrate, LDS-limited occupancy) overlap with the decode / emit kernels of the other.  Documents never span parts.
 struct lm_ctx_impl {
-  lm::Engine eng;
+  static constexpr uint32_t LM_MAX_PARTS = 8;
+  std::vector<std::unique_ptr<lm::Engine>> parts;
+  std::vector<uint32_t> first;     // first[p] = first document of part p; first[n_parts] = n_docs
+  uint32_t n_docs = 0;
+  uint32_t want_parts = 2, part_min_docs = 128;
+  bool profiling = false;
+  bool ran = false;
+  std::vector<lm::KernelTime> times;
   std::string err;
+
+  lm_ctx_impl() {
+    if (const char* e = getenv("LM_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= (int)LM_MAX_PARTS) want_parts = (uint32_t)v; }
+    if (const char* e = getenv("LM_PART_MIN_DOCS")) { int v = atoi(e); if (v >= 1) part_min_docs = (uint32_t)v; }
+    parts.emplace_back(new lm::Engine());
+    first = {0, 0};
+  }
+  uint32_t n_parts() const { return (uint32_t)first.size() - 1; }
+
+  void stage(const lm::Engine::DocIn* docs, size_t n) {
+    n_docs = (uint32_t)n;
+    ran = false;
+    // split into contiguous ranges of about equal blob bytes; small batches stay in one part
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) for (size_t b = 0; b < docs[i].n; b++) total += docs[i].lens[b];
+    uint32_t np = want_parts;
+    while (np > 1 && (n < (size_t)np * part_min_docs)) np--;
+    first.assign(1, 0);
+    uint64_t acc = 0;
+    for (size_t i = 0; i < n && first.size() < np; i++) {
+      for (size_t b = 0; b < docs[i].n; b++) acc += docs[i].lens[b];
+      if (acc * np >= total * first.size() && i + 1 < n) first.push_back((uint32_t)i + 1);
+    }
+    first.push_back((uint32_t)n);
+    while (parts.size() < n_parts()) parts.emplace_back(new lm::Engine());
+    for (uint32_t p = 0; p < n_parts(); p++) parts[p]->stage(docs + first[p], first[p + 1] - first[p]);
+  }
+  void run() {
+    uint32_t np = n_parts();
+    for (uint32_t p = 0; p < np; p++) parts[p]->profiling = profiling;
+    std::vector<std::string> errs(np);
+    auto body = [&](uint32_t p) { try { parts[p]->run(); } catch (const std::exception& e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "error"; } };
+#ifdef LM_PARALLEL_PARTS
+    std::vector<std::thread> th;
+    for (uint32_t p = 1; p < np; p++) th.emplace_back(body, p);
+    body(0);
+    for (auto& t : th) t.join();
+#else
+    for (uint32_t p = 0; p < np; p++) body(p);
+#endif
+    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+    times.clear();
+    for (uint32_t p = 0; p < np; p++) for (auto& t : parts[p]->times) times.push_back(t);
+    ran = true;
+  }
+  template <class F> void for_docs(F f) {
+    for (uint32_t p = 0; p < n_parts(); p++)
+      for (uint32_t i = 0; i < parts[p]->n_docs; i++) f(first[p] + i, *parts[p], parts[p]->results[i]);
+  }
 };
 
 extern "C" {
@@ -16,7 +77,7 @@ typedef struct lm_run_stats_c { uint64_t n_docs, n_blobs, in_bytes, out_bytes, d
 
 void* LM_API(create)(int device) {
   if (!lmbe::init(device)) return nullptr;
-  return new lm_ctx_impl();
+  try { return new lm_ctx_impl(); } catch (const std::exception&) { return nullptr; }
 }
 void LM_API(destroy)(void* c) { delete (lm_ctx_impl*)c; }
 const char* LM_API(last_error)(void* c) { return c ? ((lm_ctx_impl*)c)->err.c_str() : "no context (HIP device unavailable)"; }
@@ -26,25 +87,25 @@ int LM_API(stage)(void* c, const lm_doc_in_c* docs, size_t n) {
   try {
     std::vector<lm::Engine::DocIn> v(n);
     for (size_t i = 0; i < n; i++) v[i] = lm::Engine::DocIn{docs[i].blobs, docs[i].blob_lens, docs[i].n_blobs};
-    x->eng.stage(v.data(), n);
+    x->stage(v.data(), n);
     return 0;
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
 int LM_API(run)(void* c) {
   auto* x = (lm_ctx_impl*)c;
-  try { x->eng.run(); return 0; } catch (const std::exception& e) { x->err = e.what(); return -1; }
+  try { x->run(); return 0; } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
 int LM_API(fetch)(void* c, lm_doc_out_c* outs) {
   auto* x = (lm_ctx_impl*)c;
   try {
-    x->eng.fetch();
-    for (uint32_t i = 0; i < x->eng.n_docs; i++) {
-      const lm::DocResult& r = x->eng.results[i];
+    if (!x->ran) throw std::runtime_error("lm_fetch before lm_run");
+    for (uint32_t p = 0; p < x->n_parts(); p++) x->parts[p]->fetch();
+    x->for_docs([&](uint32_t i, lm::Engine& e, const lm::DocResult& r) {
       outs[i].status = r.status;
-      outs[i].json = x->eng.h_out.data() + r.json_off; outs[i].json_len = (size_t)r.json_len;
-      outs[i].vv = x->eng.h_vv.data() + r.vv_off; outs[i].vv_len = (size_t)r.vv_len;
+      outs[i].json = e.h_out.data() + r.json_off; outs[i].json_len = (size_t)r.json_len;
+      outs[i].vv = e.h_vv.data() + r.vv_off; outs[i].vv_len = (size_t)r.vv_len;
       outs[i].pending_ops = r.pending;
-    }
+    });
     return 0;
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
@@ -58,52 +119,62 @@ int LM_API(merge_batch)(void* c, const lm_doc_in_c* docs, size_t n, lm_doc_out_c
 // per-document result metadata of the last lm_run without copying the rendered bytes back
 int LM_API(result_meta)(void* c, int32_t* status, uint64_t* json_len, uint64_t* vv_len, uint64_t* pending) {
   auto* x = (lm_ctx_impl*)c;
-  if (!x->eng.ran) { x->err = "lm_result_meta before lm_run"; return -1; }
-  for (uint32_t i = 0; i < x->eng.n_docs; i++) {
-    const lm::DocResult& r = x->eng.results[i];
+  if (!x->ran) { x->err = "lm_result_meta before lm_run"; return -1; }
+  x->for_docs([&](uint32_t i, lm::Engine&, const lm::DocResult& r) {
     if (status) status[i] = r.status;
     if (json_len) json_len[i] = r.json_len;
     if (vv_len) vv_len[i] = r.vv_len;
     if (pending) pending[i] = r.pending;
-  }
+  });
   return 0;
 }
 int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   auto* x = (lm_ctx_impl*)c;
-  s->n_docs = x->eng.n_docs; s->n_blobs = x->eng.n_blobs; s->in_bytes = x->eng.in_bytes;
-  s->out_bytes = x->eng.payload_bytes;
+  s->n_docs = x->n_docs; s->n_blobs = 0; s->in_bytes = 0; s->out_bytes = 0;
+  for (uint32_t p = 0; p < x->n_parts(); p++) {
+    s->n_blobs += x->parts[p]->n_blobs; s->in_bytes += x->parts[p]->in_bytes; s->out_bytes += x->parts[p]->payload_bytes;
+  }
   s->device_bytes_allocated = lmbe::allocated_bytes();
-  s->n_kernels = (uint32_t)x->eng.times.size();
+  s->n_kernels = (uint32_t)x->times.size();
   return 0;
 }
 // sizing diagnostics of the last run: max over documents of (leaves used, leaf capacity, elements)
 int LM_API(sizing)(void* c, uint32_t* out3) {  // out3[3] = documents re-run with the worst-case directory
   auto* x = (lm_ctx_impl*)c;
-  out3[0] = out3[1] = out3[2] = 0;
-  out3[3] = x->eng.last_retries;
-  for (auto& m : x->eng.h_doc) { if (m.pad0 > out3[0]) out3[0] = m.pad0; if (m.leaf_cap > out3[1]) out3[1] = m.leaf_cap; if (m.n_elems > out3[2]) out3[2] = m.n_elems; }
+  out3[0] = out3[1] = out3[2] = out3[3] = 0;
+  for (uint32_t p = 0; p < x->n_parts(); p++) {
+    out3[3] += x->parts[p]->last_retries;
+    for (auto& m : x->parts[p]->h_doc) { if (m.pad0 > out3[0]) out3[0] = m.pad0; if (m.leaf_cap > out3[1]) out3[1] = m.leaf_cap; if (m.n_elems > out3[2]) out3[2] = m.n_elems; }
+  }
   return 0;
 }
 // returns the number of mismatches of the wave-primitive self test (0 = ok)
 int LM_API(selftest)(void* c) {
   auto* x = (lm_ctx_impl*)c;
   try {
-    return x->eng.selftest();
+    return x->parts[0]->selftest();
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
 // LM_PROF builds only: sum over documents of the 16 cycle-accounting slots of k_integrate
 int LM_API(prof_sum)(void* c, uint64_t* out16) {
   auto* x = (lm_ctx_impl*)c;
   for (int i = 0; i < 16; i++) out16[i] = 0;
-  for (size_t k = 0; k < x->eng.h_prof.size(); k++) out16[k % 16] += x->eng.h_prof[k];
-  return x->eng.h_prof.empty() ? -1 : 0;
+  bool any = false;
+  for (uint32_t p = 0; p < x->n_parts(); p++) {
+    auto& h = x->parts[p]->h_prof;
+    for (size_t k = 0; k < h.size(); k++) out16[k % 16] += h[k];
+    any |= !h.empty();
+  }
+  return any ? 0 : -1;
 }
-int LM_API(set_profiling)(void* c, int en) { ((lm_ctx_impl*)c)->eng.profiling = en != 0; return 0; }
+int LM_API(set_profiling)(void* c, int en) { ((lm_ctx_impl*)c)->profiling = en != 0; return 0; }
 int LM_API(kernel_time)(void* c, uint32_t i, const char** name, double* ms) {
   auto* x = (lm_ctx_impl*)c;
-  if (i >= x->eng.times.size()) return -1;
-  *name = x->eng.times[i].name.c_str();
-  *ms = x->eng.times[i].ms;
+  if (i >= x->times.size()) return -1;
+  *name = x->times[i].name.c_str();
+  *ms = x->times[i].ms;
   return 0;
 }
+// number of engine parts (HIP streams) the last staged batch was split into
+int LM_API(n_streams)(void* c) { return (int)((lm_ctx_impl*)c)->n_parts(); }
 }

@@ -11,8 +11,16 @@
 namespace lm { struct KernelTime; }
 
 namespace lmbe {
-static hipStream_t g_stream = nullptr;
-static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+// Every Engine owns one StreamCtx (a non-blocking HIP stream + two timing events).  The host thread that drives an
+// engine binds it with bind(); all stream-ordered calls below go to the bound context, so several engines (the
+// sub-batches of one lm_ctx, or several lm_ctx) can be driven from different host threads and overlap on the device.
+struct StreamCtx {
+  hipStream_t s = nullptr;
+  std::vector<hipEvent_t> ev;            // pairs (start, stop), one pair per timed stage of a run
+  std::vector<const char*> names;        // stages recorded since the last flush
+  bool open = false;
+};
+static thread_local StreamCtx* cur = nullptr;
 static std::atomic<uint64_t> g_alloc{0};
 static int g_device = -1;
 
@@ -27,13 +35,23 @@ inline bool init(int device) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return false;
   if (hipSetDevice(device) != hipSuccess) return false;
   g_device = device;
-  if (!g_stream) {
-    if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return false;
-    hipEventCreate(&g_ev0);
-    hipEventCreate(&g_ev1);
-  }
   return true;
 }
+inline StreamCtx* stream_create() {
+  (void)hipSetDevice(g_device);
+  StreamCtx* c = new StreamCtx();
+  if (hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) != hipSuccess) { delete c; throw std::runtime_error("hipStreamCreate failed"); }
+  return c;
+}
+inline void stream_destroy(StreamCtx* c) {
+  if (!c) return;
+  if (cur == c) cur = nullptr;
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->s);
+  delete c;
+}
+// bind the calling host thread to a stream context (HIP's current device is per host thread)
+inline void bind(StreamCtx* c) { (void)hipSetDevice(g_device); cur = c; }
 inline void* dalloc(size_t n) {
   void* p = nullptr;
   if (hipMalloc(&p, n) != hipSuccess) return nullptr;
@@ -41,22 +59,40 @@ inline void* dalloc(size_t n) {
   return p;
 }
 inline void dfree(void* p) { (void)hipFree(p); }
-inline void dmemset(void* p, int v, size_t n) { LM_HIP_CHECK(hipMemsetAsync(p, v, n, g_stream)); }
-inline void h2d(void* d, const void* h, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); LM_HIP_CHECK(hipStreamSynchronize(g_stream)); }
-inline void d2h(void* h, const void* d, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); LM_HIP_CHECK(hipStreamSynchronize(g_stream)); }
-inline void sync() { LM_HIP_CHECK(hipStreamSynchronize(g_stream)); }
+inline void dmemset(void* p, int v, size_t n) { LM_HIP_CHECK(hipMemsetAsync(p, v, n, cur->s)); }
+inline void h2d(void* d, const void* h, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, cur->s)); LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
+inline void d2h(void* h, const void* d, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, cur->s)); LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
+inline void sync() { LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
 inline void* halloc(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
 inline void hfree(void* p) { (void)hipHostFree(p); }
 inline uint64_t allocated_bytes() { return g_alloc.load(); }
-inline void tic() { (void)hipEventRecord(g_ev0, g_stream); }
-template <class V>
-inline void toc(const char* name, V& times, bool profiling) {
+// Stage timing: events are recorded on the engine's stream without any host synchronisation, so a profiled run
+// overlaps its streams exactly like an unprofiled one; flush_times() waits once, at the end of the run.
+inline void tic(bool profiling) {
   if (!profiling) return;
-  (void)hipEventRecord(g_ev1, g_stream);
-  LM_HIP_CHECK(hipEventSynchronize(g_ev1));
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, g_ev0, g_ev1);
-  times.push_back({name, (double)ms});
+  size_t k = cur->names.size();
+  while (cur->ev.size() < 2 * (k + 1)) { hipEvent_t e; LM_HIP_CHECK(hipEventCreate(&e)); cur->ev.push_back(e); }
+  (void)hipEventRecord(cur->ev[2 * k], cur->s);
+  cur->open = true;
+}
+template <class V>
+inline void toc(const char* name, V&, bool profiling) {
+  if (!profiling || !cur->open) return;
+  (void)hipEventRecord(cur->ev[2 * cur->names.size() + 1], cur->s);
+  cur->names.push_back(name);
+  cur->open = false;
+}
+inline void reset_times() { cur->names.clear(); cur->open = false; }
+template <class V>
+inline void flush_times(V& times) {
+  if (cur->names.empty()) return;
+  LM_HIP_CHECK(hipStreamSynchronize(cur->s));
+  for (size_t k = 0; k < cur->names.size(); k++) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, cur->ev[2 * k], cur->ev[2 * k + 1]);
+    times.push_back({cur->names[k], (double)ms});
+  }
+  cur->names.clear();
 }
 inline void check_launch(const char* name) {
   hipError_t e = hipGetLastError();
@@ -66,15 +102,16 @@ inline void check_launch(const char* name) {
 
 #define LM_LAUNCH(kern, grid, block, ...)                                                          \
   do {                                                                                             \
-    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, lmbe::g_stream, __VA_ARGS__); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, lmbe::cur->s, __VA_ARGS__); \
     lmbe::check_launch(#kern);                                                                     \
   } while (0)
 #define LM_LAUNCH_DYN(kern, grid, block, shmem, ...)                                               \
   do {                                                                                             \
     LM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shmem))); \
-    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (shmem), lmbe::g_stream, __VA_ARGS__); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (shmem), lmbe::cur->s, __VA_ARGS__); \
     lmbe::check_launch(#kern);                                                                     \
   } while (0)
 #define LM_API(name) lm_##name
+#define LM_PARALLEL_PARTS 1
 
 #include "lm_capi_impl.h"

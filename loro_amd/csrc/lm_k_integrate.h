@@ -577,10 +577,11 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   uint32_t* s_cur = s_ebase + pmax;              // [pmax]
   DocMeta m = d.doc[doc];
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
+  if (retry_pass && m.status != ST_RETRY) return;  // second launch: only the documents whose optimistic directory overflowed
+  if (status_fatal(m.status) && !retry_pass) return;
+  // the element map starts empty (this wave owns it: no separate fill pass over the whole batch)
+  for (uint32_t i = (uint32_t)lane; i < m.atoms; i += 64) d.loc[elem0 + i] = NONE;
   if (retry_pass) {
-    // second launch: only the documents whose optimistic directory overflowed, from a clean element map
-    if (m.status != ST_RETRY) return;
-    for (uint32_t i = (uint32_t)lane; i < m.atoms; i += 64) d.loc[elem0 + i] = NONE;
     for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) d.cont[m.cid0 + c].touched = 0;
     lmw::block_sync();  // every lane has read the status before it is cleared
     if (lane == 0) d.doc[doc].status = ST_OK;

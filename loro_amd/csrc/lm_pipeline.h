@@ -72,8 +72,12 @@ struct Engine {
   std::string last_error;
   uint64_t device_bytes = 0;
   uint32_t last_retries = 0;
+  lmbe::StreamCtx* sc = nullptr;   // this engine's HIP stream + timing events
 
-  ~Engine() { release_all(); }
+  Engine() { sc = lmbe::stream_create(); }
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+  ~Engine() { release_all(); lmbe::stream_destroy(sc); }
   void release_all() {
     DBuf* all[] = {&b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
@@ -89,6 +93,7 @@ struct Engine {
   // ---- stage: pack the blobs (16-byte aligned starts) and upload
   struct DocIn { const uint8_t* const* blobs; const size_t* lens; size_t n; };
   void stage(const DocIn* docs, size_t nd) {
+    lmbe::bind(sc);
     n_docs = (uint32_t)nd;
     h_doc_blob.assign(nd + 1, 0);
     size_t nb = 0;
@@ -139,6 +144,7 @@ struct Engine {
   }
 
   int selftest() {
+    lmbe::bind(sc);
     DBuf b;
     b.ensure(64 * 4);
     LM_LAUNCH(k_selftest, 64, 64, b.as<uint32_t>(), 200u);
@@ -154,7 +160,9 @@ struct Engine {
 
   // ---- run: the device pipeline over the staged batch
   void run() {
+    lmbe::bind(sc);
     times.clear();
+    lmbe::reset_times();
     Dev d;
     memset(&d, 0, sizeof d);
     d.data = b_data.as<uint8_t>();
@@ -173,7 +181,7 @@ struct Engine {
     d.blob_nblk = b_blob_nblk.as<uint32_t>();
     d.blob_blk0 = b_blob_blk0.as<uint32_t>();
     d.blob_doc = b_blob_doc.as<uint32_t>();
-    lmbe::tic();
+    lmbe::tic(profiling);
     if (n_blobs) LM_LAUNCH(k_frame_count, cdiv(n_blobs, 64), 64, d);
     lmbe::toc("k_frame_count", times, profiling);
     scan(d.blob_nblk, d.blob_blk0, n_blobs, 1);
@@ -187,7 +195,7 @@ struct Engine {
     d.blk = b_blk.as<BlockDesc>();
     d.bcnt = b_bcnt.as<uint32_t>();
     d.boff = b_boff.as<uint32_t>();
-    lmbe::tic();
+    lmbe::tic(profiling);
     if (n_blobs) LM_LAUNCH(k_frame_fill, cdiv(n_blobs, 64), 64, d);
     if (NB) LM_LAUNCH(k_block_count, cdiv(NB, 64), 64, d);
     lmbe::toc("k_frame_fill+k_block_count", times, profiling);
@@ -230,16 +238,16 @@ struct Engine {
     lmbe::dmemset(b_chg_flag.p, 0, (size_t)(NC + 1) * 4);
     lmbe::dmemset(b_chg_skip.p, 0, (size_t)(NC + 1) * 4);
     lmbe::dmemset(b_chg_lamport.p, 0, (size_t)(NC + 1) * 4);
-    lmbe::tic();
+    lmbe::tic(profiling);
     if (NB) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
     lmbe::toc("k_block_decode", times, profiling);
-    lmbe::tic();
+    lmbe::tic(profiling);
     LM_LAUNCH(k_doc_ranges, cdiv(n_docs, 64), 64, d);
     LM_LAUNCH(k_doc_tables, n_docs, 64, d);
     uint32_t nmax = NO > NC ? NO : NC;
     if (nmax) LM_LAUNCH(k_remap, cdiv(nmax, 256), 256, d, NO, NC);
     lmbe::toc("k_doc_tables+k_remap", times, profiling);
-    lmbe::tic();
+    lmbe::tic(profiling);
     LM_LAUNCH(k_dag_a, n_docs, 64, d, g);
     lmbe::toc("k_dag_a", times, profiling);
     // 4. per-doc pool sizing on the host (one small round trip)
@@ -293,22 +301,22 @@ struct Engine {
     d.vvh = b_vvh.as<uint32_t>();
     d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>();
     d.ht0 = b_ht0.as<uint64_t>(); d.ht_cap = b_ht_cap.as<uint32_t>();
-    lmbe::dmemset(b_loc.p, 0xff, (elem + 1) * 4);
-    lmbe::dmemset(b_cp.p, 0xff, (elem + 1) * 4);
+    // loc[] is initialised by k_integrate (each document's wave clears its own slice); cp[] needs no fill: every
+    // element that can be placed was written by k_elem_fill
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
     lmbe::dmemset(b_cont_root0.p, 0, (size_t)(NCID + 1) * 4);
     lmbe::dmemset(b_cont_nroot.p, 0, (size_t)(NCID + 1) * 4);
     // 5. causal order, element payloads, LWW, integrate
-    lmbe::tic();
+    lmbe::tic(profiling);
     LM_LAUNCH(k_dag_b, n_docs, 64, d, g);
     lmbe::toc("k_dag_b", times, profiling);
-    lmbe::tic();
+    lmbe::tic(profiling);
     if (NB) LM_LAUNCH(k_elem_fill, NB, 64, d);
     lmbe::toc("k_elem_fill", times, profiling);
-    lmbe::tic();
+    lmbe::tic(profiling);
     if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
     lmbe::toc("k_map_lww", times, profiling);
-    lmbe::tic();
+    lmbe::tic(profiling);
     dir_cap = (dir_cap + 3) & ~3u;
     dir_opt = (dir_opt + 3) & ~3u;
     if (dir_opt > DIR_CAP_MAX) dir_opt = DIR_CAP_MAX;
@@ -346,7 +354,7 @@ struct Engine {
       d.out = b_slab.as<uint8_t>(); d.out_off = b_slab_off.as<uint64_t>();
       d.vv_out = b_vslab.as<uint8_t>(); d.vv_off = b_vslab_off.as<uint64_t>();
     }
-    lmbe::tic();
+    lmbe::tic(profiling);
     LM_LAUNCH(k_emit, n_docs, 64, d, b_ht_list.as<uint32_t>(), 1);
     lmbe::toc("k_emit", times, profiling);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
@@ -370,7 +378,7 @@ struct Engine {
       const uint8_t* vs = b_vslab.as<uint8_t>();
       d.out = b_out.as<uint8_t>(); d.out_off = b_out_off.as<uint64_t>();
       d.vv_out = b_vv_out.as<uint8_t>(); d.vv_off = b_vv_off.as<uint64_t>();
-      lmbe::tic();
+      lmbe::tic(profiling);
       LM_LAUNCH(k_compact, n_docs, 64, d, so, vo, sl, vs);
       lmbe::toc("k_compact", times, profiling);
     }
@@ -389,12 +397,14 @@ struct Engine {
       r.vv_off = h_vv_off[i]; r.vv_len = ok ? h_doc[i].vv_len : 0;
       r.pending = ok ? (((uint64_t)h_doc[i].pending_hi << 32) | h_doc[i].pending_lo) : 0;
     }
+    lmbe::flush_times(times);
     ran = true;
     fetched = false;
   }
 
   // ---- fetch: copy the rendered states back to the host
   void fetch() {
+    lmbe::bind(sc);
     if (!ran) throw std::runtime_error("lm_fetch before lm_run");
     h_out.resize(out_bytes + 1);
     h_vv.resize(vv_bytes + 1);

@@ -14,7 +14,11 @@ namespace lmbe {
 static uint64_t g_alloc = 0;
 static std::chrono::steady_clock::time_point g_t0;
 inline bool init(int) { return true; }
-inline void* dalloc(size_t n) { g_alloc += n; return malloc(n ? n : 1); }
+struct StreamCtx { int unused = 0; };
+inline StreamCtx* stream_create() { return new StreamCtx(); }
+inline void stream_destroy(StreamCtx* c) { delete c; }
+inline void bind(StreamCtx*) {}
+inline void* dalloc(size_t n) { g_alloc += n; void* p = malloc(n ? n : 1); memset(p, 0xA5, n); return p; }  // poisoned: kernels must not rely on fresh memory
 inline void dfree(void* p) { free(p); }
 inline void dmemset(void* p, int v, size_t n) { memset(p, v, n); }
 inline void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
@@ -23,7 +27,9 @@ inline void sync() {}
 inline void* halloc(size_t n) { return malloc(n ? n : 1); }
 inline void hfree(void* p) { free(p); }
 inline uint64_t allocated_bytes() { return g_alloc; }
-inline void tic() { g_t0 = std::chrono::steady_clock::now(); }
+inline void tic(bool) { g_t0 = std::chrono::steady_clock::now(); }
+template <class V> inline void flush_times(V&) {}
+inline void reset_times() {}
 template <class V>
 inline void toc(const char* name, V& times, bool profiling) {
   if (!profiling) return;

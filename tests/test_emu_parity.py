@@ -77,3 +77,24 @@ def test_optimistic_directory_overflow_is_retried():
         sizing = c.sizing()
     assert got == _oracle.merge_batch(docs)
     assert sizing[3] >= 1, f"expected a directory retry, sizing={sizing}"
+
+
+def test_batch_split_over_several_streams(monkeypatch):
+    """lm_ctx splits a batch into contiguous document ranges, one engine (HIP stream) each; results must come back in
+    document order whatever the split."""
+    from loro_amd._cabi import Context
+    monkeypatch.setenv("LM_STREAMS", "3")
+    monkeypatch.setenv("LM_PART_MIN_DOCS", "2")
+    names, docs = _cases.edge_case_docs()
+    docs = docs + _cases.fuzz_docs(10, base=4000)
+    want = _oracle.merge_batch(docs)
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        assert c.b.n_streams(c.h) == 3
+        got2 = c.merge_batch(docs[:3])          # shrinking batch re-uses the context
+        assert c.b.n_streams(c.h) == 1
+    for i, (g, w) in enumerate(zip(got, want)):
+        if w[0] == 0 and g[0] == 4 and i < len(names) and names[i] in DEVICE_SCOPE_GAPS:
+            continue
+        assert g == w, i
+    assert got2 == got[:3]
