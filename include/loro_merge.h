@@ -36,7 +36,8 @@ enum {
   LM_CHECKSUM_MISMATCH = 2,  /* LoroError::DecodeChecksumMismatchError */
   LM_DATA_CORRUPTION = 3,    /* LoroError::DecodeDataCorruptionError */
   LM_UNSUPPORTED = 4,        /* container kind / value shape / size outside the device path's scope */
-  LM_INTERNAL = 5
+  LM_INTERNAL = 5,
+  LM_FRONTIERS_NOT_FOUND = 6 /* LoroError::FrontiersNotFound: a checkout id the imported history does not hold */
 };
 
 typedef struct lm_ctx lm_ctx;
@@ -45,6 +46,12 @@ typedef struct lm_doc_in {
   const uint8_t* const* blobs; /* n_blobs update blobs (EncodeMode::FastUpdates), imported in order */
   const size_t* blob_lens;
   size_t n_blobs;
+  /* Optional checkout (LoroDoc::checkout, crates/loro-internal/src/loro.rs:1625-1760): render the state at
+   * these frontiers instead of the latest version.  Bytes = Frontiers::encode() (version/frontiers.rs:219-223:
+   * postcard Vec<ID>, sorted).  NULL = latest.  The one-byte encoding 00 is the empty version.  With a checkout
+   * the vv output is the version of the rendered state (state_vv), not oplog_vv. */
+  const uint8_t* checkout_frontiers;
+  size_t checkout_len;
 } lm_doc_in;
 
 typedef struct lm_doc_out {

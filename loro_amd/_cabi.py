@@ -4,7 +4,8 @@ import ctypes
 
 
 class DocIn(ctypes.Structure):
-    _fields_ = [("blobs", ctypes.POINTER(ctypes.c_char_p)), ("blob_lens", ctypes.POINTER(ctypes.c_size_t)), ("n_blobs", ctypes.c_size_t)]
+    _fields_ = [("blobs", ctypes.POINTER(ctypes.c_char_p)), ("blob_lens", ctypes.POINTER(ctypes.c_size_t)), ("n_blobs", ctypes.c_size_t),
+                ("checkout_frontiers", ctypes.c_char_p), ("checkout_len", ctypes.c_size_t)]
 
 
 class DocOut(ctypes.Structure):
@@ -65,8 +66,9 @@ class Context:
         self.close()
 
     @staticmethod
-    def _pack(docs):
+    def _pack(docs, frontiers=None):
         n = len(docs)
+        assert frontiers is None or len(frontiers) == n
         arr = (DocIn * max(n, 1))()
         keep = []
         for i, blobs in enumerate(docs):
@@ -77,10 +79,18 @@ class Context:
             arr[i].blobs = ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_char_p))
             arr[i].blob_lens = lens
             arr[i].n_blobs = len(blobs)
+            f = frontiers[i] if frontiers is not None else None
+            if f is not None:
+                f = bytes(f)
+                keep.append(f)
+                arr[i].checkout_frontiers = f
+                arr[i].checkout_len = len(f)
         return arr, keep
 
-    def stage(self, docs):
-        arr, keep = self._pack(docs)
+    def stage(self, docs, frontiers=None):
+        """docs: list of lists of update blobs.  frontiers: optional list (one per document) of None or encoded
+        Frontiers (loro_amd.wire.encode_frontiers) = render the state at that version (LoroDoc::checkout)."""
+        arr, keep = self._pack(docs, frontiers)
         self.n = len(docs)
         if self.b.stage(self.h, arr, self.n) != 0:
             raise RuntimeError(self.b.last_error(self.h).decode())
@@ -121,8 +131,8 @@ class Context:
         f(self.h, out)
         return tuple(out)
 
-    def merge_batch(self, docs):
-        self.stage(docs)
+    def merge_batch(self, docs, frontiers=None):
+        self.stage(docs, frontiers)
         self.run()
         return self.fetch()
 

@@ -71,7 +71,7 @@ struct lm_ctx_impl {
 
 extern "C" {
 
-typedef struct lm_doc_in_c { const uint8_t* const* blobs; const size_t* blob_lens; size_t n_blobs; } lm_doc_in_c;
+typedef struct lm_doc_in_c { const uint8_t* const* blobs; const size_t* blob_lens; size_t n_blobs; const uint8_t* checkout_frontiers; size_t checkout_len; } lm_doc_in_c;
 typedef struct lm_doc_out_c { int32_t status; const uint8_t* json; size_t json_len; const uint8_t* vv; size_t vv_len; uint64_t pending_ops; } lm_doc_out_c;
 typedef struct lm_run_stats_c { uint64_t n_docs, n_blobs, in_bytes, out_bytes, device_bytes_allocated; uint32_t n_kernels; } lm_run_stats_c;
 
@@ -86,7 +86,7 @@ int LM_API(stage)(void* c, const lm_doc_in_c* docs, size_t n) {
   auto* x = (lm_ctx_impl*)c;
   try {
     std::vector<lm::Engine::DocIn> v(n);
-    for (size_t i = 0; i < n; i++) v[i] = lm::Engine::DocIn{docs[i].blobs, docs[i].blob_lens, docs[i].n_blobs};
+    for (size_t i = 0; i < n; i++) v[i] = lm::Engine::DocIn{docs[i].blobs, docs[i].blob_lens, docs[i].n_blobs, docs[i].checkout_frontiers, docs[i].checkout_len};
     x->stage(v.data(), n);
     return 0;
   } catch (const std::exception& e) { x->err = e.what(); return -1; }

@@ -422,6 +422,50 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
       lmw::block_sync();
     }
   }
+  // ---- optional checkout (loro.rs:1625-1760): frontiers → version vector (AppDag::frontiers_to_vv,
+  // loro_dag.rs:1190-1207) = merge over the ids of (vv at the head of the id's node) ∪ {peer: counter+1}.
+  // The version replaces peer_end: integrate / LWW / emit only see ops below it.
+  uint64_t f0 = d.front_off[doc], f1 = d.front_off[doc + 1];
+  if (f1 == f0) return;
+  int32_t ferr = ST_OK;
+  uint64_t cnt = 0;
+  {
+    // pass 1 (every lane parses the same bytes): well-formed, and every id inside the applied history
+    Rd r = rd_make(d.front + f0, f1 - f0);
+    cnt = rd_uleb(r);
+    if (r.bad || cnt > f1 - f0) ferr = ST_DECODE_ERROR;
+    for (uint64_t i = 0; i < cnt && !ferr; i++) {
+      uint64_t peer = rd_uleb(r);
+      int64_t ctr = rd_zigzag(r);
+      if (r.bad) { ferr = ST_DECODE_ERROR; break; }
+      uint32_t lo = 0, hi = P;
+      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.peer_uniq[m.praw0 + mid] < peer) lo = mid + 1; else hi = mid; }
+      if (lo >= P || d.peer_uniq[m.praw0 + lo] != peer || ctr < 0 || (uint64_t)ctr >= d.peer_end[m.praw0 + lo] ||
+          find_change(d, m, lo, (uint32_t)ctr) == NONE)
+        ferr = ST_FRONTIERS_NOT_FOUND;
+    }
+    if (!ferr && rd_left(r) != 0) ferr = ST_DECODE_ERROR;
+  }
+  lmw::block_sync();  // every lane has read peer_end before it is rewritten
+  if (ferr) { if (lane == 0) LM_SETERR(d.doc[doc].status, ferr); return; }
+  for (uint32_t p0 = 0; p0 < P; p0 += 64) {
+    uint32_t p = p0 + (uint32_t)lane, acc = 0;
+    Rd r = rd_make(d.front + f0, f1 - f0);
+    (void)rd_uleb(r);
+    for (uint64_t i = 0; i < cnt; i++) {
+      uint64_t peer = rd_uleb(r);
+      uint32_t ctr = (uint32_t)rd_zigzag(r);
+      uint32_t lo = 0, hi = P;
+      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.peer_uniq[m.praw0 + mid] < peer) lo = mid + 1; else hi = mid; }
+      uint32_t ci = find_change(d, m, lo, ctr);
+      if (p < P) {
+        uint32_t x = d.vvh[vvh0 + (uint64_t)g.chg_node[m.chg0 + ci] * P + p];
+        if (p == lo && ctr + 1 > x) x = ctr + 1;
+        acc = x > acc ? x : acc;
+      }
+    }
+    if (p < P) d.peer_end[m.praw0 + p] = acc;
+  }
 }
 
 // K8: one wave per change block — element payload table (unicode scalars / list value offsets).

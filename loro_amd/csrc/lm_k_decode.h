@@ -19,6 +19,8 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   const uint32_t* blob_len;   // [n_blobs] exact byte length
   const uint32_t* doc_blob;   // [n_docs+1] first blob of each doc
   uint32_t n_blobs, n_docs;
+  const uint8_t* front;       // optional checkout frontiers (postcard Vec<ID>), front_off[n_docs+1]; empty range = latest
+  const uint64_t* front_off;
   // per blob
   int32_t* blob_status;
   uint32_t* blob_nblk;
@@ -45,7 +47,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   // per doc
   DocMeta* doc;
   uint64_t* peer_uniq;   // [praw0 + i], i < n_peers, ascending
-  uint32_t* peer_end;    // applied (exclusive) counter end == final VV
+  uint32_t* peer_end;    // applied (exclusive) counter end == final VV; lowered to the checkout version by k_dag_b
   uint32_t* peer_ext;    // contiguous covered end
   uint32_t* elem_base;   // first element slot of the peer inside the doc's element range
   uint32_t* peer_chg0;   // range of the peer's changes in chg_sorted

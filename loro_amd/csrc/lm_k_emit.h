@@ -44,6 +44,9 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
   uint32_t cap = d.ht_cap[doc];
   if (cap == 0) { LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }
   uint32_t cidx = r.cidx_kind & 0xffff;
+  // checked-out documents: writes after the version do not compete (MapHistoryCache::get_container_latest_op_at_vv,
+  // history_cache.rs:630-703); the container itself stays known to the state store
+  if (r.ctr >= d.peer_end[m.praw0 + ch.peer]) { d.cont[m.cid0 + cidx].touched = 1; return; }
   uint32_t krow = d.boff[(uint64_t)blk * BCN + BC_KEY] + (uint32_t)r.prop;
   const uint8_t* ks = d.data + d.key_off[krow];
   uint32_t kl = d.key_len[krow];

@@ -575,6 +575,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   uint32_t* s_dir = s_mem;                       // [dir_cap]
   uint32_t* s_ebase = s_mem + dir_cap;           // [pmax]
   uint32_t* s_cur = s_ebase + pmax;              // [pmax]
+  uint32_t* s_end = s_cur + pmax;                // [pmax] version being rendered (applied end, or the checkout target)
   DocMeta m = d.doc[doc];
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
   if (retry_pass && m.status != ST_RETRY) return;  // second launch: only the documents whose optimistic directory overflowed
@@ -590,7 +591,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   }
   if (status_fatal(m.status)) return;
   uint32_t P = m.n_peers;
-  for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_ebase[p] = d.elem_base[m.praw0 + p];
+  for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_ebase[p] = d.elem_base[m.praw0 + p]; s_end[p] = d.peer_end[m.praw0 + p]; }
   lmw::block_sync();
   uint64_t vvh0 = ((uint64_t)m.vvh0_hi << 32) | m.vvh0_lo;
   Tr t;
@@ -636,6 +637,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
         uint32_t crow = sorted_ro[m.chg0 + ci];
         const ChangeRow ch = chg_ro[crow];
         uint32_t skip_to = ch.ctr + skip_ro[crow];
+        uint32_t pe = s_end[node_peer];
         for (uint32_t row = ch.op0; row < ch.op0 + ch.n_op && !t.err; row++) {
           PROF_T0();
           const OpRow r = op_ro[row];
@@ -644,6 +646,8 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
           uint32_t kind = (r.cidx_kind >> 16) & 0xff;
           uint32_t a = skip_to > r.ctr ? skip_to - r.ctr : 0;  // already-known prefix of a sliced change
           touched = true;
+          if (r.ctr + a >= pe) continue;                        // past the version being rendered (checkout)
+          uint32_t b = r.ctr + r.len <= pe ? r.len : pe - r.ctr; // op offsets [a, b) are replayed
           if (!checked_out) {
             // move the tracker to the version the node's first op sees (tracker.rs:354-461)
             checked_out = true;
@@ -659,13 +663,13 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
           }
           PROF_ADD(t, PF_ROW);
           if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
-            tr_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), r.len - a);
+            tr_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
             TR_CHECK("insert", row);
           } else if (kind == OK_DEL) {
             uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
             uint32_t t0, t1;
-            if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + Ln; }
-            else { t0 = r.a1; t1 = r.a1 + (Ln - a); }
+            if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
+            else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }  // op offset j deletes target + (L-1-j)
             tr_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
             PROF_ADD(t, PF_DELETE);
             PROF_CNT(t, PF_NDEL, 1);
@@ -686,7 +690,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
           }
         }
         // the node's own ops advance the tracker version
-        if (checked_out && lane == 0) s_cur[node_peer] = ch.ctr + ch.len;
+        if (checked_out && lane == 0) s_cur[node_peer] = ch.ctr + ch.len < pe ? ch.ctr + ch.len : pe;
       }
       lmw::block_sync();
     }

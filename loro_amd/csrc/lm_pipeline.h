@@ -43,9 +43,9 @@ struct Engine {
   // staged input
   uint32_t n_docs = 0, n_blobs = 0;
   uint64_t data_bytes = 0, in_bytes = 0;
-  std::vector<uint64_t> h_blob_off;
+  std::vector<uint64_t> h_blob_off, h_front_off;
   std::vector<uint32_t> h_blob_len, h_doc_blob, h_blob_doc;
-  DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc;
+  DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc, b_front, b_front_off;
   // work buffers
   DBuf b_blob_status, b_blob_nblk, b_blob_blk0, b_tile, b_tot;
   DBuf b_blk, b_bcnt, b_boff;
@@ -79,7 +79,7 @@ struct Engine {
   Engine& operator=(const Engine&) = delete;
   ~Engine() { release_all(); lmbe::stream_destroy(sc); }
   void release_all() {
-    DBuf* all[] = {&b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
+    DBuf* all[] = {&b_front, &b_front_off, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
@@ -91,7 +91,7 @@ struct Engine {
   }
 
   // ---- stage: pack the blobs (16-byte aligned starts) and upload
-  struct DocIn { const uint8_t* const* blobs; const size_t* lens; size_t n; };
+  struct DocIn { const uint8_t* const* blobs; const size_t* lens; size_t n; const uint8_t* front; size_t front_len; };
   void stage(const DocIn* docs, size_t nd) {
     lmbe::bind(sc);
     n_docs = (uint32_t)nd;
@@ -130,6 +130,19 @@ struct Engine {
     b_blob_len.ensure(nb * 4 + 4); if (nb) lmbe::h2d(b_blob_len.p, h_blob_len.data(), nb * 4);
     b_doc_blob.ensure((nd + 1) * 4); lmbe::h2d(b_doc_blob.p, h_doc_blob.data(), (nd + 1) * 4);
     b_blob_doc.ensure(nb * 4 + 4); if (nb) lmbe::h2d(b_blob_doc.p, h_blob_doc.data(), nb * 4);
+    // optional checkout frontiers, back to back
+    h_front_off.assign(nd + 1, 0);
+    std::vector<uint8_t> fr;
+    for (size_t i = 0; i < nd; i++) {
+      h_front_off[i] = fr.size();
+      if (docs[i].front) {
+        if (docs[i].front_len == 0) throw std::runtime_error("checkout_frontiers with zero length (the empty version is the byte 00)");
+        fr.insert(fr.end(), docs[i].front, docs[i].front + docs[i].front_len);
+      }
+    }
+    h_front_off[nd] = fr.size();
+    b_front.ensure(fr.size() + 16); if (!fr.empty()) lmbe::h2d(b_front.p, fr.data(), fr.size());
+    b_front_off.ensure((nd + 1) * 8); lmbe::h2d(b_front_off.p, h_front_off.data(), (nd + 1) * 8);
     lmbe::sync();
     ran = fetched = false;
   }
@@ -166,6 +179,7 @@ struct Engine {
     Dev d;
     memset(&d, 0, sizeof d);
     d.data = b_data.as<uint8_t>();
+    d.front = b_front.as<uint8_t>(); d.front_off = b_front_off.as<uint64_t>();
     d.blob_off = b_blob_off.as<uint64_t>();
     d.blob_len = b_blob_len.as<uint32_t>();
     d.doc_blob = b_doc_blob.as<uint32_t>();
@@ -325,12 +339,12 @@ struct Engine {
     b_tot.ensure(64 * 4);
     uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
     lmbe::dmemset(retry_cnt, 0, 4);
-    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 2 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                   (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
     uint32_t n_retry = 0;
     lmbe::d2h(&n_retry, retry_cnt, 4);
     if (n_retry) {  // rare: re-run the overflowed documents with the worst-case directory
-      LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 2 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+      LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                     (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
     }
     last_retries = n_retry;

@@ -14,6 +14,7 @@ enum : int32_t {
   ST_DATA_CORRUPTION = 3,
   ST_UNSUPPORTED = 4,
   ST_INTERNAL = 5,
+  ST_FRONTIERS_NOT_FOUND = 6,
   ST_RETRY = 100,   // internal: the optimistic LDS directory overflowed; the document is re-run with the worst-case size
 };
 

@@ -485,6 +485,16 @@ def encode_vv(vv: Dict[int, int]) -> bytes:
     return bytes(out)
 
 
+def encode_frontiers(ids) -> bytes:
+    """Frontiers::encode (version/frontiers.rs:219-223): postcard Vec<ID> sorted by (peer, counter);
+    ID = varint u64 peer, zigzag varint i32 counter.  `ids` = iterable of (peer, counter); [] = the empty version."""
+    ids = sorted(ids)
+    out = bytearray(uleb(len(ids)))
+    for p, c in ids:
+        out += uleb(p) + zigzag(c)
+    return bytes(out)
+
+
 # ---------------------------------------------------------------- op RLE merge (RleVec push)
 def _del_start(o: Op) -> int:
     return o.pos if o.signed_len > 0 else o.pos + 1 + o.signed_len

@@ -230,3 +230,41 @@ def cfg3_doc(d: int, n_peers=16, n_writes=10000, n_keys=1024, combined=True, per
             all_.changes[r.peer] = r.changes[r.peer]
         return [all_.export()]
     return [r.export() for r in reps]
+
+
+def cfg5_doc(d: int, n_ops=20000, turn=1000, mark_prob=0.01, n_checkouts=16, commit_every=10):
+    """Config 5: one Text edited by two peers that alternate every `turn` trace actions (a linear
+    hand-over history like automerge_x100.rs:16-24), ≈1 % of the actions replaced by a bold mark (StyleStart/StyleEnd
+    anchors), rendered at `n_checkouts` random versions.  Returns (blobs, [encoded Frontiers] * n_checkouts)."""
+    rng = random.Random(0xC5 + d)
+    acts = synthetic_trace(n_ops, seed=d)
+    peers = [wire.Replica(2 * d + 1), wire.Replica(2 * d + 2)]
+    cid = wire.root_cid("text", wire.KIND_TEXT)
+    cur = 0
+    for t0 in range(0, n_ops, turn):
+        r = peers[cur]
+        ids = r.seq.setdefault(cid, [])
+        for k, (pos, dl, ch) in enumerate(acts[t0:t0 + turn]):
+            if len(ids) >= 2 and rng.random() < mark_prob:
+                s = rng.randrange(len(ids) - 1)
+                r.text_mark("text", s, rng.randrange(s + 1, min(len(ids), s + 40)), "bold", True)
+            elif dl:
+                r.text_delete("text", min(pos, len(ids) - 1), 1)
+            else:
+                r.text_insert("text", min(pos, len(ids)), ch)
+            if commit_every and (k + 1) % commit_every == 0:
+                r.commit()
+        r.commit()
+        o = peers[1 - cur]                     # hand the whole history over (nothing concurrent on the other side)
+        o.changes = {p: list(v) for p, v in r.changes.items()}
+        o.vv = dict(r.vv)
+        o.frontiers = list(r.frontiers)
+        o.seq = {k: list(v) for k, v in r.seq.items()}
+        cur = 1 - cur
+    last = peers[1 - cur]
+    blob = last.export()
+    fronts = []
+    for _ in range(n_checkouts):
+        p = rng.choice([q for q in last.vv if last.vv[q] > 0])
+        fronts.append(wire.encode_frontiers([(p, rng.randrange(last.vv[p]))]))
+    return [blob], fronts

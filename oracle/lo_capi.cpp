@@ -16,10 +16,11 @@ struct Batch {
   std::vector<DocResult> res;
 };
 
-static void run_one(const uint8_t* data, const uint64_t* blob_off, uint32_t b0, uint32_t b1, DocResult& r) {
+static void run_one(const uint8_t* data, const uint64_t* blob_off, uint32_t b0, uint32_t b1, const uint8_t* front, size_t front_len, DocResult& r) {
   try {
     Doc d;
     for (uint32_t b = b0; b < b1; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    if (front) d.set_checkout(front, front_len);
     r.json = d.to_json();
     r.vv = d.vv_bytes();
     r.pending = d.pending_atoms();
@@ -38,7 +39,10 @@ static void run_one(const uint8_t* data, const uint64_t* blob_off, uint32_t b0, 
 extern "C" {
 
 // data: all blobs back to back; blob_off[n_blobs+1]; doc_blob[n_docs+1] = first blob index of each doc
-void* lo_batch_run(const uint8_t* data, const uint64_t* blob_off, const uint32_t* doc_blob, uint32_t n_docs, int n_threads) {
+// optional checkout: front_off[n_docs+1] into front_data; an empty range = render the latest version
+// (an encoded Frontiers is never empty: the empty version is the single byte 00)
+void* lo_batch_run_at(const uint8_t* data, const uint64_t* blob_off, const uint32_t* doc_blob, uint32_t n_docs,
+                      const uint8_t* front_data, const uint64_t* front_off, int n_threads) {
   Batch* b = new Batch();
   b->res.resize(n_docs);
   if (n_threads < 1) n_threads = 1;
@@ -47,7 +51,10 @@ void* lo_batch_run(const uint8_t* data, const uint64_t* blob_off, const uint32_t
     for (;;) {
       uint32_t i = next.fetch_add(1);
       if (i >= n_docs) return;
-      run_one(data, blob_off, doc_blob[i], doc_blob[i + 1], b->res[i]);
+      const uint8_t* f = nullptr;
+      size_t fl = 0;
+      if (front_off && front_off[i + 1] > front_off[i]) { f = front_data + front_off[i]; fl = (size_t)(front_off[i + 1] - front_off[i]); }
+      run_one(data, blob_off, doc_blob[i], doc_blob[i + 1], f, fl, b->res[i]);
     }
   };
   if (n_threads == 1) worker();
@@ -57,6 +64,9 @@ void* lo_batch_run(const uint8_t* data, const uint64_t* blob_off, const uint32_t
     for (auto& t : ts) t.join();
   }
   return b;
+}
+void* lo_batch_run(const uint8_t* data, const uint64_t* blob_off, const uint32_t* doc_blob, uint32_t n_docs, int n_threads) {
+  return lo_batch_run_at(data, blob_off, doc_blob, n_docs, nullptr, nullptr, n_threads);
 }
 int32_t lo_batch_status(void* h, uint32_t i) { return ((Batch*)h)->res[i].status; }
 uint64_t lo_batch_pending(void* h, uint32_t i) { return ((Batch*)h)->res[i].pending; }

@@ -39,6 +39,7 @@ enum Status : int32_t {
   ST_DATA_CORRUPTION = 3,         // LoroError::DecodeDataCorruptionError
   ST_UNSUPPORTED = 4,             // container kind / feature outside the hot-path scope
   ST_INTERNAL = 5,
+  ST_FRONTIERS_NOT_FOUND = 6,     // LoroError::FrontiersNotFound (checkout target outside the OpLog)
 };
 
 struct DecodeErr {

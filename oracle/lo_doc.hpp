@@ -108,6 +108,28 @@ struct Doc {
   std::map<uint32_t, std::unique_ptr<SeqState>> seqs;
   std::map<uint32_t, std::map<std::string, MapEntry>> maps;
   std::set<uint32_t> touched;  // containers that received at least one applied op
+  // optional checkout (LoroDoc::checkout, loro.rs:1625-1760): the state is rendered at `frontiers` instead of the
+  // latest version; the OpLog (and so the set of root containers the state store knows) stays the imported one
+  bool has_target = false;
+  std::vector<ID> frontiers;
+  VV target;
+
+  // Frontiers::decode (version/frontiers.rs:226-231): postcard Vec<ID>, ID = { varint u64 peer, zigzag varint i32 counter }
+  void set_checkout(const uint8_t* p, size_t n) {
+    Reader r(p, n);
+    uint64_t cnt = r.uleb();
+    if (cnt > n) fail(ST_DECODE_ERROR, "frontiers length");
+    frontiers.clear();
+    for (uint64_t i = 0; i < cnt; i++) {
+      ID id;
+      id.peer = r.uleb();
+      id.counter = (Counter)r.zigzag();
+      frontiers.push_back(id);
+    }
+    if (!r.eof()) fail(ST_DECODE_ERROR, "trailing bytes after frontiers");
+    has_target = true;
+    materialized = false;
+  }
 
   uint32_t reg(const ContainerID& c) {
     auto it = container_idx.find(c);
@@ -280,20 +302,35 @@ struct Doc {
       for (size_t s : nodes[n].succ) if (--nodes[s].indeg == 0) stack.push_back(s);
     }
     if (order.size() != nodes.size()) fail(ST_INTERNAL, "cycle in DAG");
-    // replay; vv_head[n] = version seen by the first op of node n (loro_dag.rs:1083-1154)
+    // vv_head[n] = version seen by the first op of node n (loro_dag.rs:1083-1154)
     std::vector<VV> vv_head(nodes.size());
     for (size_t ni : order) {
       Node& n = nodes[ni];
-      auto& v = changes[n.peer];
-      {
-        VV& out = vv_head[ni];
-        for (const ID& d : n.deps) {
-          const Change* dc = find_change(d);
-          const VV& sub = vv_head[node_of_change[{dc->id.peer, dc->id.counter}]];
-          for (auto& kv : sub) Tracker::bump(out, kv.first, kv.second);
-          Tracker::bump(out, d.peer, d.counter + 1);
-        }
+      VV& out = vv_head[ni];
+      for (const ID& d : n.deps) {
+        const Change* dc = find_change(d);
+        const VV& sub = vv_head[node_of_change[{dc->id.peer, dc->id.counter}]];
+        for (auto& kv : sub) Tracker::bump(out, kv.first, kv.second);
+        Tracker::bump(out, d.peer, d.counter + 1);
       }
+    }
+    // checkout target: frontiers → version vector (AppDag::frontiers_to_vv, loro_dag.rs:1190-1207); an id the
+    // OpLog does not hold is LoroError::FrontiersNotFound (loro.rs:1699-1701)
+    target = vv;
+    if (has_target) {
+      target.clear();
+      for (const ID& f : frontiers) {
+        if (f.counter < 0 || !has_id(f)) fail(ST_FRONTIERS_NOT_FOUND, "frontiers not found in the OpLog");
+        const Change* fc = find_change(f);
+        for (auto& kv : vv_head[node_of_change[{fc->id.peer, fc->id.counter}]]) Tracker::bump(target, kv.first, kv.second);
+        Tracker::bump(target, f.peer, f.counter + 1);
+      }
+    }
+    auto in_target = [&](PeerID p, Counter c) { auto it = target.find(p); return it != target.end() && c < it->second; };
+    // replay
+    for (size_t ni : order) {
+      Node& n = nodes[ni];
+      auto& v = changes[n.peer];
       VV cur = vv_head[ni];
       for (size_t ci = n.first; ci <= n.last; ci++) {
         const Change& ch = v[ci];
@@ -303,6 +340,7 @@ struct Doc {
           const ContainerID& cid = containers[op.container];
           if (cid.kind == CK_MAP) {
             if (op.kind != OP_MAP_SET && op.kind != OP_MAP_DELETE) continue;
+            if (!in_target(ch.id.peer, op.counter)) continue;  // MapHistoryCache::get_container_latest_op_at_vv (history_cache.rs:630-703)
             Lamport lamp = ch.lamport + (Lamport)(op.counter - ch.id.counter);
             auto& m = maps[op.container];
             auto it = m.find(op.key);
@@ -374,7 +412,7 @@ struct Doc {
         Tracker::bump(cur, ch.id.peer, ch.ctr_end());
       }
     }
-    for (auto& kv : seqs) kv.second->tr.checkout(vv);
+    for (auto& kv : seqs) kv.second->tr.checkout(target);   // tracker.rs:354-461: ops outside the version become future / un-deleted
     materialized = true;
   }
 
@@ -444,7 +482,10 @@ struct Doc {
     out.push_back('}');
     return out;
   }
-  std::string vv_bytes() const {  // postcard map, entries sorted by peer
+  // postcard map, entries sorted by peer: the version of the rendered state (= oplog_vv() unless checked out)
+  std::string vv_bytes() {
+    materialize();
+    const VV& vv = target;
     std::string out;
     auto uleb = [&](uint64_t v) {
       do { uint8_t b = v & 0x7f; v >>= 7; if (v) b |= 0x80; out.push_back((char)b); } while (v);

@@ -19,6 +19,6 @@ def binding():
     return _B
 
 
-def merge_batch(docs):
+def merge_batch(docs, frontiers=None):
     with Context(binding()) as c:
-        return c.merge_batch(docs)
+        return c.merge_batch(docs, frontiers)

@@ -7,7 +7,7 @@ ALPHA = "abcdefghijklmnopqrstuvwxyz ABCDEFGH\n\"\\\t" + "äßλ中😀"
 
 
 def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15, max_ins=6, commit_prob=0.4,
-                   peer_base=None, styles=False):
+                   peer_base=None, styles=False, snapshots=None):
     """Returns (list of blobs in a random delivery order, replicas).  Replicas edit concurrently and sync
     pairwise; after a sync the receiver's visible sequences are refreshed from the oracle."""
     rng = random.Random(seed)
@@ -60,6 +60,9 @@ def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15,
                 r.map_set("map", key, rng.choice([None, True, rng.randint(-5, 5), "v\"%d" % rng.randint(0, 9), [1, 2, "z"]]))
         if rng.random() < commit_prob:
             r.commit()
+            if snapshots is not None and r.frontiers and rng.random() < 0.5:
+                # (version, updates holding exactly that version's causal history)
+                snapshots.append((list(r.frontiers), r.export()))
         if rng.random() < sync_prob and n_peers > 1:
             a, b = rng.sample(reps, 2)
             a.commit(); b.commit()

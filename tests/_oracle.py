@@ -15,6 +15,8 @@ def lib():
         L = ctypes.CDLL(so)
         L.lo_batch_run.restype = ctypes.c_void_p
         L.lo_batch_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
+        L.lo_batch_run_at.restype = ctypes.c_void_p
+        L.lo_batch_run_at.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.lo_batch_status.restype = ctypes.c_int32
         L.lo_batch_status.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         L.lo_batch_pending.restype = ctypes.c_uint64
@@ -46,12 +48,21 @@ def pack(docs):
     return data, off, doc_blob
 
 
-def merge_batch(docs, threads=1, packed=None):
-    """Returns list of (status, json bytes, vv bytes, pending) — same tuple the HIP path returns."""
+def merge_batch(docs, threads=1, packed=None, frontiers=None):
+    """Returns list of (status, json bytes, vv bytes, pending) — same tuple the HIP path returns.
+    frontiers: optional list (one entry per document) of None or encoded Frontiers bytes = checkout target."""
     L = lib()
     data, off, doc_blob = packed if packed is not None else pack(docs)
     n = len(doc_blob) - 1
-    h = L.lo_batch_run(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, threads)
+    if frontiers is not None:
+        assert len(frontiers) == n
+        fb = [f or b"" for f in frontiers]
+        foff = np.zeros(n + 1, dtype=np.uint64)
+        foff[1:] = np.cumsum([len(f) for f in fb], dtype=np.uint64)
+        fdata = np.frombuffer(b"".join(fb) or b"\0", dtype=np.uint8).copy()
+        h = L.lo_batch_run_at(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, fdata.ctypes.data, foff.ctypes.data, threads)
+    else:
+        h = L.lo_batch_run(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, threads)
     out = []
     try:
         ln = ctypes.c_uint64()
@@ -67,8 +78,8 @@ def merge_batch(docs, threads=1, packed=None):
     return out
 
 
-def merge(blobs):
-    return merge_batch([list(blobs)])[0]
+def merge(blobs, frontiers=None):
+    return merge_batch([list(blobs)], frontiers=None if frontiers is None else [frontiers])[0]
 
 
 def xxh32(b, seed=0x4F524F4C):

@@ -98,3 +98,65 @@ def test_batch_split_over_several_streams(monkeypatch):
             continue
         assert g == w, i
     assert got2 == got[:3]
+
+
+def _checkout_cases():
+    """(docs, frontiers): reference known answers (test.rs:518-603,659-693) + every recorded version of random
+    concurrent sessions + malformed / unknown frontiers."""
+    import _fuzz
+    from loro_amd import wire
+    docs, fronts = [], []
+    r = wire.Replica(1)
+    r.text_insert("text", 0, "你界"); r.text_insert("text", 1, "好世"); r.commit()
+    r.text_delete("text", 3, 1); r.text_delete("text", 2, 1); r.commit()
+    tb = [r.export()]
+    for ids in [[(1, c)] for c in range(6)] + [[], [(1, 6)], [(2, 0)], [(1, -1)]]:
+        docs.append(tb); fronts.append(wire.encode_frontiers(ids))
+    docs.append(tb); fronts.append(b"\x05\x01")            # truncated Vec<ID>
+    docs.append(tb); fronts.append(wire.encode_frontiers([(1, 2)]) + b"\x00")   # trailing byte
+    docs.append(tb); fronts.append(None)
+    a, b = wire.Replica(1), wire.Replica(2)
+    a.map_set("meta", "key", 0); a.commit(); va = list(a.frontiers)
+    b.map_set("meta", "s", 1); b.commit(); vb0 = list(b.frontiers)
+    b.map_set("meta", "key", 1); b.commit(); vb1 = list(b.frontiers)
+    a.merge_from(b)
+    a.map_set("meta", "key", 2); a.commit(); vm = list(a.frontiers)
+    mb = [a.export()]
+    for v in (va, vb0, vb1, vm, va + vb1, []):
+        docs.append(mb); fronts.append(wire.encode_frontiers(v))
+    for s in range(6):
+        snaps = []
+        reps = _fuzz.random_session(900 + s, n_peers=3, n_steps=60, kinds=("text", "list", "map"), styles=True, snapshots=snaps)
+        full = _fuzz.blobs_of(reps)
+        for fr, _ in snaps:
+            docs.append(full); fronts.append(wire.encode_frontiers(fr))
+            if len(fr) == 1 and fr[0][1] > 0:   # a version cutting through the middle of a change / op run
+                docs.append(full); fronts.append(wire.encode_frontiers([(fr[0][0], fr[0][1] - 1)]))
+    return docs, fronts
+
+
+def test_checkout_versions():
+    docs, fronts = _checkout_cases()
+    want = _oracle.merge_batch(docs, frontiers=fronts)
+    got = _emu.merge_batch(docs, fronts)
+    assert [w[0] for w in want[:13]] == [0] * 7 + [6, 6, 6, 1, 1, 0]
+    n_ok = 0
+    for i, (g, w) in enumerate(zip(got, want)):
+        if w[0] == 0:
+            assert g == w, (i, g[:3], w[:3])
+            n_ok += 1
+        else:
+            assert g[0] == w[0], (i, g[0], w[0])
+    assert n_ok > 60
+
+
+def test_config5_alternating_peers_marks_and_checkouts():
+    from loro_amd import workload
+    docs, fronts = [], []
+    for d in range(2):
+        blobs, fr = workload.cfg5_doc(d, n_ops=3000, turn=400, n_checkouts=8)
+        docs += [blobs] * len(fr)
+        fronts += fr
+    want = _oracle.merge_batch(docs, frontiers=fronts)
+    assert all(w[0] == 0 for w in want) and len({w[1] for w in want}) > 8
+    assert _emu.merge_batch(docs, fronts) == want

@@ -111,3 +111,33 @@ def test_full_size_config2_properties(engine):
         assert got[d][0] == 0 and got[d][3] == 0
         assert got[d][1] == got_alt[d][1] and got[d][2] == got_alt[d][2], f"doc {d}: import order / duplicate changed the result"
     assert len({g[1] for g in got}) == n      # every document carries its own letters
+
+
+def test_checkout_known_answers_and_random_versions(engine):
+    """LoroDoc::checkout through lm_doc_in.checkout_frontiers: reference known answers (test.rs:518-603,659-693),
+    every recorded version of random concurrent sessions (incl. versions cutting through an op run), and
+    malformed / unknown frontiers."""
+    import test_emu_parity
+    docs, fronts = test_emu_parity._checkout_cases()
+    want = _oracle.merge_batch(docs, threads=8, frontiers=fronts)
+    got = engine.merge_batch(docs, fronts)
+    assert json.loads(got[2][1]) == {"text": "你好界"} and json.loads(got[5][1]) == {"text": "你好"}
+    assert [g[0] for g in got[:13]] == [0] * 7 + [6, 6, 6, 1, 1, 0]
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert (g == w) if w[0] == 0 else (g[0] == w[0]), (i, g[:3], w[:3])
+
+
+def test_config5_checkouts(engine):
+    """configs[4] shape: 2 peers alternating every 1k trace actions, ~1 % bold marks, 16 versions per document."""
+    docs, fronts = [], []
+    for d in range(6):
+        blobs, fr = workload.cfg5_doc(d, n_ops=20000, turn=1000, n_checkouts=16)
+        docs += [blobs] * len(fr)
+        fronts += fr
+    want = _oracle.merge_batch(docs, threads=8, frontiers=fronts)
+    got = engine.merge_batch(docs, fronts)
+    assert all(w[0] == 0 for w in want)
+    assert got == want
+    # the latest version through a checkout equals no checkout at all
+    latest = engine.merge_batch(docs[:1])[0]
+    assert latest[0] == 0 and latest == _oracle.merge(docs[0])

@@ -164,3 +164,81 @@ def test_automerge_paper_trace_end_content():
     st, js, vv, pend = _oracle.merge([r.export()])
     assert st == 0 and pend == 0
     assert json.loads(js)["text"] == d["endContent"]
+
+
+# ---- checkout (time travel): known answers of crates/loro-internal/tests/test.rs
+def _at(blobs, ids):
+    return _oracle.merge(blobs, frontiers=wire.encode_frontiers(ids))
+
+
+def test_text_checkout_known_answers():
+    """test.rs:518-585 `test_text_checkout`: state of the text after each op counter."""
+    r = wire.Replica(1)
+    r.text_insert("text", 0, "你界")
+    r.text_insert("text", 1, "好世")
+    r.commit()
+    blobs = [r.export()]
+    for ctr, want in enumerate(["你", "你界", "你好界", "你好世界"]):
+        st, js, vv, _ = _at(blobs, [(1, ctr)])
+        assert st == 0 and json.loads(js) == {"text": want}
+        assert vv == wire.encode_vv({1: ctr + 1})
+    r.text_delete("text", 3, 1)
+    r.text_delete("text", 2, 1)
+    r.commit()
+    blobs = [r.export()]
+    assert json.loads(_oracle.merge(blobs)[1]) == {"text": "你好"}
+    for ctr, want in [(3, "你好世界"), (4, "你好世"), (5, "你好"), (0, "你"), (1, "你界"), (2, "你好界")]:
+        assert json.loads(_at(blobs, [(1, ctr)])[1]) == {"text": want}
+    # the empty version keeps the root container the state store knows, with an empty value
+    st, js, vv, _ = _at(blobs, [])
+    assert (st, js, vv) == (0, b'{"text":""}', wire.encode_vv({}))
+    # FrontiersNotFound (loro.rs:1699-1701)
+    assert _at(blobs, [(1, 6)])[0] == 6 and _at(blobs, [(2, 0)])[0] == 6
+
+
+def test_map_checkout_known_answers():
+    """test.rs:587-603 `map_checkout` and :659-693 `map_concurrent_checkout`."""
+    r = wire.Replica(5)
+    r.map_set("meta", "key", 0); r.commit()
+    r.map_set("meta", "key", 1); r.commit()
+    blobs = [r.export()]
+    assert json.loads(_at(blobs, [(5, 0)])[1]) == {"meta": {"key": 0}}
+    assert json.loads(_at(blobs, [])[1]) == {"meta": {}}
+    assert json.loads(_at(blobs, [(5, 1)])[1]) == {"meta": {"key": 1}}
+    a, b = wire.Replica(1), wire.Replica(2)
+    a.map_set("meta", "key", 0); a.commit()
+    va = list(a.frontiers)
+    b.map_set("meta", "s", 1); b.commit()
+    vb0 = list(b.frontiers)
+    b.map_set("meta", "key", 1); b.commit()
+    vb1 = list(b.frontiers)
+    a.merge_from(b)
+    a.map_set("meta", "key", 2); a.commit()
+    vm = list(a.frontiers)
+    blobs = [a.export()]
+    for v, want in [(va, {"key": 0}), (vb0, {"s": 1}), (vb1, {"s": 1, "key": 1}), (vm, {"s": 1, "key": 2})]:
+        assert json.loads(_at(blobs, v)[1]) == {"meta": want}
+    # a frontier with both heads before the merge: both branches, LWW between key=0 (lamport 0, peer 1) and key=1 (lamport 1)
+    assert json.loads(_at(blobs, va + vb1)[1]) == {"meta": {"s": 1, "key": 1}}
+
+
+def test_checkout_equals_import_of_the_prefix():
+    """Checking out version V of the full history equals importing only the updates up to V (CRDT state is a
+    function of the op set): random concurrent sessions, every intermediate frontier of one replica."""
+    import _fuzz
+    n = 0
+    for s in range(8):
+        snaps = []
+        reps = _fuzz.random_session(900 + s, n_peers=3, n_steps=60, kinds=("text", "list", "map"), styles=True, snapshots=snaps)
+        full = _fuzz.blobs_of(reps)
+        for fr, blob in snaps:
+            got = _oracle.merge(full, frontiers=wire.encode_frontiers(fr))
+            want = _oracle.merge([blob])
+            assert got[0] == want[0] == 0
+            # same value for every container the prefix knows; containers created later render empty
+            gj, wj = json.loads(got[1]), json.loads(want[1])
+            for k, v in gj.items():
+                assert wj.get(k, type(v)()) == v, (s, fr, k)
+            assert got[2] == want[2], (s, fr)
+            n += 1
+    assert n > 20
