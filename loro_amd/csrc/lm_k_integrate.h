@@ -337,7 +337,9 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       uint32_t prev_id = lmw::shfl_up(C.id, 1);
       if (lane == 0) prev_id = carry_id;
       bool inr = (uint32_t)lane >= ci && (uint32_t)lane < limit;
-      bool is_head = inr && (C.ol != prev_id || (cp == p && (uint32_t)lane == ins));
+      // (an element whose origin_left is OUR origin_left is a sibling and always examined — the element right
+      //  after the cursor is the usual case, also when it is the first slot of the next leaf)
+      bool is_head = inr && (C.ol != prev_id || C.ol == origin_left);
       uint64_t hm = lmw::ballot(is_head);
       while (hm && !stop && !t.err) {
         int h = lmw::ffs64(hm);

@@ -348,6 +348,24 @@ struct Engine {
                     (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
     }
     last_retries = n_retry;
+#ifdef LM_EMU_TRACE
+    if (getenv("LM_EMU_DUMP")) {  // kernel-logic harness only: leaves of document 0 in document order
+      lmbe::d2h(h_doc.data(), b_doc.p, (size_t)n_docs * sizeof(DocMeta));
+      const DocMeta& m0 = h_doc[0];
+      for (uint32_t c = 0; c < m0.n_cont; c++) {
+        uint32_t r0 = d.cont_root0[m0.cid0 + c], nr = d.cont_nroot[m0.cid0 + c];
+        for (uint32_t q = 0; q < nr; q++) {
+          uint32_t e = d.dir_out[m0.leaf0 + r0 + q], L = e & 0x3FFFFu, n = (e >> 18) & 0x7f;
+          for (uint32_t i = 0; i < n; i++) {
+            uint64_t x = ((uint64_t)m0.leaf0 + L) * 64 + i;
+            fprintf(stderr, "DUMP c%u %u:%u ol=%d:%d or=%d:%d st=%x\n", c, d.it_id[x] >> 24, d.it_id[x] & 0xffffff,
+                    d.it_ol[x] == NONE ? -1 : (int)(d.it_ol[x] >> 24), d.it_ol[x] == NONE ? -1 : (int)(d.it_ol[x] & 0xffffff),
+                    d.it_or[x] == NONE ? -1 : (int)(d.it_or[x] >> 24), d.it_or[x] == NONE ? -1 : (int)(d.it_or[x] & 0xffffff), d.it_st[x]);
+          }
+        }
+      }
+    }
+#endif
     lmbe::toc("k_integrate", times, profiling);
     // 6. emit in one pass into worst-case slabs (every input byte renders to at most 6 output bytes), then compact
     {

@@ -95,4 +95,34 @@ int64_t lo_visible_ids(const uint8_t* data, const uint64_t* blob_off, uint32_t n
     return -1;
   }
 }
+
+// debug helper for tests: spans of the root sequence container `name` in document order, 9 int64 per span:
+// peer, counter, len, ol.peer, ol.counter (-1 = none), or.peer, or.counter (-1 = none), future, delete count
+int64_t lo_dump_spans(const uint8_t* data, const uint64_t* blob_off, uint32_t n_blobs, const char* name, int kind, int64_t* out, uint64_t cap) {
+  try {
+    Doc d;
+    for (uint32_t b = 0; b < n_blobs; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    d.materialize();
+    ContainerID cid;
+    cid.root = true;
+    cid.kind = (uint8_t)kind;
+    cid.name = name;
+    auto ci = d.container_idx.find(cid);
+    if (ci == d.container_idx.end()) return 0;
+    auto it = d.seqs.find(ci->second);
+    if (it == d.seqs.end()) return 0;
+    uint64_t n = 0;
+    for (Span* sp = it->second->tr.head; sp; sp = sp->next, n++) {
+      if (n >= cap) continue;
+      int64_t* o = out + n * 9;
+      o[0] = (int64_t)sp->id.peer; o[1] = sp->id.counter; o[2] = sp->len;
+      o[3] = sp->ol.some ? (int64_t)sp->ol.id.peer : -1; o[4] = sp->ol.some ? sp->ol.id.counter : -1;
+      o[5] = sp->orr.some ? (int64_t)sp->orr.id.peer : -1; o[6] = sp->orr.some ? sp->orr.id.counter : -1;
+      o[7] = sp->future; o[8] = sp->del;
+    }
+    return (int64_t)n;
+  } catch (...) {
+    return -1;
+  }
+}
 }

@@ -99,3 +99,10 @@ def trace_docs(n_base, variants=((10, True), (10, False), (0, True)), n_docs=2, 
             docs.append([s[0], s[2], s[1]])
             docs.append([s[0], s[1]])
     return docs
+
+
+def cfg4_docs(n, first=1000, n_steps=1000):
+    """BASELINE.json configs[3] shape: root List + Map + Text, 4 peers, ≈1k ops mixed, pairwise syncs every ≈50 ops
+    (real DAG merges), bold marks on the text."""
+    return [_fuzz.blobs_of(_fuzz.random_session(first + d, n_peers=4, n_steps=n_steps, kinds=("text", "list", "map"), sync_prob=0.02, styles=True))
+            for d in range(n)]

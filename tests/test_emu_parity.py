@@ -160,3 +160,15 @@ def test_config5_alternating_peers_marks_and_checkouts():
     want = _oracle.merge_batch(docs, frontiers=fronts)
     assert all(w[0] == 0 for w in want) and len({w[1] for w in want}) > 8
     assert _emu.merge_batch(docs, fronts) == want
+
+
+def test_sibling_in_the_first_slot_of_the_next_leaf():
+    """Regression: a concurrent sibling (same origin_left) that sits in slot 0 of the leaf after the cursor's leaf was
+    taken for a continuation of the previous leaf's last element and skipped by the run-head scan."""
+    import _fuzz
+    reps = _fuzz.random_session(1032, n_peers=4, n_steps=525, kinds=("text",), sync_prob=0.02, styles=True)
+    _check([_fuzz.blobs_of(reps)])
+
+
+def test_config4_mixed_containers_with_dag_merges():
+    _check(_cases.cfg4_docs(10, first=1016))

@@ -141,3 +141,15 @@ def test_config5_checkouts(engine):
     # the latest version through a checkout equals no checkout at all
     latest = engine.merge_batch(docs[:1])[0]
     assert latest[0] == 0 and latest == _oracle.merge(docs[0])
+
+
+def test_config4_mixed_containers(engine):
+    """configs[3] shape: List + Map + Text roots, 4 peers x ~1k mixed ops with pairwise syncs, marks; 96 distinct
+    documents replicated to a 6k batch (both streams busy)."""
+    base = _cases.cfg4_docs(96)
+    want = _oracle.merge_batch(base, threads=8)
+    docs = [base[i % len(base)] for i in range(6144)]
+    got = engine.merge_batch(docs)
+    assert all(w[0] == 0 for w in want)
+    for i, g in enumerate(got):
+        assert g == want[i % len(base)], i
