@@ -388,6 +388,7 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
         }
       }
       uint64_t rm = lmw::ballot(ready);
+      // (replaying the higher peer first among nodes that become ready together was measured: no gain on configs[1])
       if (ready) d.node_order[m.chg0 + n_done + (uint32_t)lmw::popc64(rm & ((1ull << lane) - 1))] = n;
       n_done += (uint32_t)lmw::popc64(rm);
     }

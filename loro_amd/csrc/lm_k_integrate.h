@@ -48,6 +48,7 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   uint32_t *it_id, *it_ol, *it_or, *it_st;   // HBM leaves: [leaf*64 + slot]
   uint32_t* loc;                  // doc element → leaf
   const uint32_t* ebase;          // LDS: element base per peer
+  const uint32_t* cur;            // LDS: the tracker's version per peer at the head of the node being replayed
   uint32_t* dir;                  // LDS leaf directory in document order
   uint8_t* lchunk;                // HBM: leaf → chunk (= owning lane) of its directory entry (kept out of LDS for occupancy)
   uint32_t n_dir, dir_cap, CH, inv_CH;    // lane c owns directory entries [c*CH, (c+1)*CH); CH is odd (bank-conflict free)
@@ -352,9 +353,14 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
           // is o_ol one of the in-between elements already visited?  (position in [cursor, (cp,h)))
           bool visited = false;
           uint64_t here = lmw::ballot((uint32_t)lane < C.n && C.id == o_ol);
+          uint64_t in_r = cp != p ? lmw::ballot((uint32_t)lane < R.n && R.id == o_ol) : 0ull;   // cursor leaf (still in registers)
           if (here) {
             uint32_t xs = (uint32_t)lmw::ffs64(here);
             visited = xs < (uint32_t)h && (cp != p || xs >= ins);
+          } else if (in_r) {
+            visited = (uint32_t)lmw::ffs64(in_r) >= ins;
+          } else if (o_ol != NONE && pid_ctr(o_ol) < t.cur[pid_peer(o_ol)]) {
+            visited = false;   // inside the tracker's version ⇒ not future ⇒ cannot be one of the in-between elements
           } else if (o_ol != NONE) {
             lmw::wave_sync();
             uint32_t xl = t.loc[tr_g(t, o_ol)];
@@ -380,22 +386,33 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
             if (pid_peer(o_id) > my_peer) { stop = true; break; }
             scanning = false;
           } else {
-            uint32_t opr = NONE;
+            // the other element's right parent (crdt_rope.rs:205-216): its origin_right if that is a sibling too.
+            // Its position (directory position, slot) comes with the lookup, so no second search is needed to
+            // compare it with our origin_right at (r_p, r_slot).  The two leaves held in registers are tried first.
+            uint32_t opr = NONE, o_p = NONE, o_s = 0;
             if (o_or != NONE) {
-              lmw::wave_sync();
-              uint32_t xl = t.loc[tr_g(t, o_or)];
-              if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
-              uint32_t xp = dir_find_leaf(t, xl);
-              if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
-              uint32_t xn = de_n(lmw::first(t.dir[xp]));
-              uint32_t xid = (uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE;
-              uint32_t xol = (uint32_t)lane < xn ? t.it_ol[xl * 64 + lane] : NONE;
-              uint64_t xm = lmw::ballot(xid == o_or);
-              if (!xm) { LM_SETERR(t.err, ST_INTERNAL); break; }
-              if (lmw::bcast(xol, lmw::ffs64(xm)) == origin_left) opr = o_or;
+              uint32_t x_ol;
+              uint64_t hc = lmw::ballot((uint32_t)lane < C.n && C.id == o_or);
+              uint64_t hr = (!hc && cp != p) ? lmw::ballot((uint32_t)lane < R.n && R.id == o_or) : 0ull;
+              if (hc) { o_s = (uint32_t)lmw::ffs64(hc); o_p = cp; x_ol = lmw::bcast(C.ol, (int)o_s); }
+              else if (hr) { o_s = (uint32_t)lmw::ffs64(hr); o_p = p; x_ol = lmw::bcast(R.ol, (int)o_s); }
+              else {
+                lmw::wave_sync();
+                uint32_t xl = t.loc[tr_g(t, o_or)];
+                if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
+                uint32_t xp = dir_find_leaf(t, xl);
+                if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
+                uint32_t xn = de_n(lmw::first(t.dir[xp]));
+                uint32_t xid = (uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE;
+                uint32_t xol = (uint32_t)lane < xn ? t.it_ol[xl * 64 + lane] : NONE;
+                uint64_t xm = lmw::ballot(xid == o_or);
+                if (!xm) { LM_SETERR(t.err, ST_INTERNAL); break; }
+                o_s = (uint32_t)lmw::ffs64(xm); o_p = xp; x_ol = lmw::bcast(xol, (int)o_s);
+              }
+              if (x_ol == origin_left) opr = o_or;
             }
             int c;
-            if (opr != NONE && parent_right) c = tr_cmp_pos(t, opr, origin_right);
+            if (opr != NONE && parent_right) c = (o_p < r_p || (o_p == r_p && o_s < r_slot)) ? -1 : 1;
             else if (opr != NONE) c = -1;
             else if (parent_right) c = 1;
             else c = 0;
@@ -601,6 +618,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   t.it_or = d.it_or + (uint64_t)m.leaf0 * 64; t.it_st = d.it_st + (uint64_t)m.leaf0 * 64;
   t.loc = d.loc + elem0;
   t.ebase = s_ebase;
+  t.cur = s_cur;
   t.dir = s_dir;
   t.lchunk = d.lf_chunk + m.leaf0;
   t.dir_cap = dir_cap;
@@ -640,9 +658,16 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
         const ChangeRow ch = chg_ro[crow];
         uint32_t skip_to = ch.ctr + skip_ro[crow];
         uint32_t pe = s_end[node_peer];
+        // the next row is fetched one iteration ahead with a VECTOR load (lanes 0-7, one dword each): scalar loads
+        // share their wait counter with LDS, so a scalar prefetch would be waited for at the first directory access
+        const uint32_t* op_w = (const uint32_t*)op_ro;
+        uint32_t nx = (lane < 8 && ch.n_op) ? op_w[(uint64_t)ch.op0 * 8 + (uint32_t)lane] : 0u;
         for (uint32_t row = ch.op0; row < ch.op0 + ch.n_op && !t.err; row++) {
           PROF_T0();
-          const OpRow r = op_ro[row];
+          OpRow r;
+          r.cidx_kind = lmw::bcast(nx, 0); r.prop = (int32_t)lmw::bcast(nx, 1); r.len = lmw::bcast(nx, 2); r.ctr = lmw::bcast(nx, 3);
+          r.a0 = lmw::bcast(nx, 4); r.a1 = lmw::bcast(nx, 5); r.a2 = (int32_t)lmw::bcast(nx, 6); r.chg = lmw::bcast(nx, 7);
+          if (row + 1 < ch.op0 + ch.n_op) nx = lane < 8 ? op_w[(uint64_t)(row + 1) * 8 + (uint32_t)lane] : 0u;
           if ((r.cidx_kind & 0xffff) != cidx) continue;
           if (r.ctr + r.len <= skip_to) continue;
           uint32_t kind = (r.cidx_kind >> 16) & 0xff;
