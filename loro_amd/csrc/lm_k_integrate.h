@@ -22,11 +22,13 @@ namespace lm {
 static constexpr uint32_t ST_FUT = 1u, ST_EVER = 2u, ST_DEL1 = 0x100u, ST_DELMASK = 0x00FFFF00u;
 LM_DEV bool st_active(uint32_t st) { return (st & (ST_FUT | ST_DELMASK)) == 0; }
 
-// directory entry: leaf id (18 bits) | element count (7 bits) | active count (7 bits)
-static constexpr uint32_t DIR_LEAF_MASK = 0x3FFFFu;
-static constexpr uint32_t MAX_LEAVES_PER_DOC = 1u << 18;
-LM_DEV uint32_t de_make(uint32_t leaf, uint32_t n, uint32_t act) { return leaf | (n << 18) | (act << 25); }
+// directory entry: leaf id (17 bits) | "holds a non-future element" (1 bit) | element count (7 bits) | active count (7 bits)
+static constexpr uint32_t DIR_LEAF_MASK = 0x1FFFFu;
+static constexpr uint32_t MAX_LEAVES_PER_DOC = 1u << 17;
+static constexpr uint32_t DIR_NF = 1u << 17;
+LM_DEV uint32_t de_make(uint32_t leaf, uint32_t n, uint32_t act, bool nf) { return leaf | (nf ? DIR_NF : 0u) | (n << 18) | (act << 25); }
 LM_DEV uint32_t de_leaf(uint32_t e) { return e & DIR_LEAF_MASK; }
+LM_DEV bool de_nf(uint32_t e) { return (e & DIR_NF) != 0; }
 LM_DEV uint32_t de_n(uint32_t e) { return (e >> 18) & 0x7f; }
 LM_DEV uint32_t de_act(uint32_t e) { return e >> 25; }
 
@@ -195,7 +197,7 @@ LM_DEV int tr_cmp_pos(Tr& t, uint32_t a, uint32_t b) {
 // Q = old[0,ins) ++ new run[0,len) ++ old[ins,n).  `old` lives in registers (R), new items are synthesised.
 LM_DEV uint32_t tr_write_items(Tr& t, uint32_t dst, uint32_t q0, uint32_t cnt, const LeafRegs& R, uint32_t ins, uint32_t len,
                                uint32_t pid0, uint32_t ol0, uint32_t orr, bool update_loc_old, uint32_t first_changed,
-                               LeafRegs* out = nullptr) {
+                               bool& nf, LeafRegs* out = nullptr) {
   int lane = lmw::lane();
   uint32_t q = q0 + (uint32_t)lane;
   bool in = (uint32_t)lane < cnt;
@@ -218,6 +220,7 @@ LM_DEV uint32_t tr_write_items(Tr& t, uint32_t dst, uint32_t q0, uint32_t cnt, c
     out->n = cnt;
     out->id = in ? vid : NONE; out->ol = in ? vol : NONE; out->orr = in ? vor : NONE; out->st = in ? vst : ST_FUT;
   }
+  nf = lmw::ballot(in && !(vst & ST_FUT)) != 0;
   return (uint32_t)lmw::popc64(lmw::ballot(in && st_active(vst)));
 }
 
@@ -238,9 +241,10 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
     uint32_t chunk = dir_chunk_at(t, p);
     (void)old_act;
     if (total <= 64) {
-      uint32_t na = tr_write_items(t, L, 0, total, R, ins, piece, pid0 + done, p_ol, orr, false, ins, &t.cr);
+      bool nf;
+      uint32_t na = tr_write_items(t, L, 0, total, R, ins, piece, pid0 + done, p_ol, orr, false, ins, nf, &t.cr);
       t.cache_leaf = L; t.cache_p = p;
-      dir_update(t, p, chunk, e, de_make(L, total, na));
+      dir_update(t, p, chunk, e, de_make(L, total, na, nf));
       ins += piece;
     } else {
       // even split into two leaves (total <= 128); both halves keep >= 32 elements
@@ -249,10 +253,11 @@ LM_DEV void tr_place_run(Tr& t, uint32_t p, uint32_t ins, uint32_t pid0, uint32_
       t.cache_leaf = NONE;
       uint32_t left = (total + 1) / 2, right = total - left;
       LeafRegs outL, outR;
-      uint32_t na_l = tr_write_items(t, L, 0, left, R, ins, piece, pid0 + done, p_ol, orr, false, ins < left ? ins : left, &outL);
-      uint32_t na_r = tr_write_items(t, NL, left, right, R, ins, piece, pid0 + done, p_ol, orr, true, 0, &outR);
-      dir_update(t, p, chunk, e, de_make(L, left, na_l));
-      dir_insert_after(t, p, chunk, de_make(NL, right, na_r));
+      bool nf_l, nf_r;
+      uint32_t na_l = tr_write_items(t, L, 0, left, R, ins, piece, pid0 + done, p_ol, orr, false, ins < left ? ins : left, nf_l, &outL);
+      uint32_t na_r = tr_write_items(t, NL, left, right, R, ins, piece, pid0 + done, p_ol, orr, true, 0, nf_r, &outR);
+      dir_update(t, p, chunk, e, de_make(L, left, na_l, nf_l));
+      dir_insert_after(t, p, chunk, de_make(NL, right, na_r, nf_r));
       uint32_t endq = ins + piece;  // Q index right after the piece
       if (endq <= left) { ins = endq; t.cr = outL; t.cache_leaf = L; t.cache_p = p; }
       else { p = p + 1; ins = endq - left; t.cr = outR; t.cache_leaf = NL; t.cache_p = p; }
@@ -294,29 +299,38 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     ins = (uint32_t)slot + 1;
   }
   PROF_ADD(t, PF_LEAF);
-  // origin_right = first non-future element at/after the cursor; everything before it is "in between"
+  // origin_right = first non-future element at/after the cursor; everything before it is "in between".
+  // Leaves holding only future elements (a concurrent run being skipped) are passed over in the LDS directory
+  // through the entries' non-future bit: at most ONE leaf is loaded here, and the sibling scan reuses it.
   uint32_t origin_right = NONE, r_ol = NONE, r_p = NONE, r_slot = 0;
   bool between = false;
+  LeafRegs RR = R;   // the leaf that holds origin_right
   {
-    uint32_t cp = p, from = ins;
-    LeafRegs C = R;
-    for (;;) {
-      uint64_t nf = lmw::ballot((uint32_t)lane >= from && (uint32_t)lane < C.n && !(C.st & ST_FUT));
-      if (nf) {
-        int s = lmw::ffs64(nf);
-        origin_right = lmw::bcast(C.id, s);
-        r_ol = lmw::bcast(C.ol, s);
-        r_p = cp; r_slot = (uint32_t)s;
-        if ((uint32_t)s > from) between = true;
-        break;
+    uint64_t nf = lmw::ballot((uint32_t)lane >= ins && (uint32_t)lane < R.n && !(R.st & ST_FUT));
+    if (nf) {
+      int s = lmw::ffs64(nf);
+      r_p = p; r_slot = (uint32_t)s;
+      if ((uint32_t)s > ins) between = true;
+    } else {
+      if (R.n > ins) between = true;
+      lmw::wave_sync();
+      for (uint32_t q0 = p + 1; q0 < t.n_dir && r_p == NONE; q0 += 64) {
+        uint32_t q = q0 + (uint32_t)lane;
+        uint64_t hm = lmw::ballot(q < t.n_dir && de_nf(t.dir[q]));
+        if (hm) r_p = q0 + (uint32_t)lmw::ffs64(hm);
       }
-      if (C.n > from) between = true;
-      if (cp + 1 >= t.n_dir) break;
-      cp++; from = 0;
-      uint32_t e = lmw::first(t.dir[cp]);
-      C = tr_leaf_load(t, de_leaf(e), de_n(e));
-      PROF_CNT(t, PF_NEXTRA, 1);
+      if (r_p != NONE) {
+        if (r_p > p + 1) between = true;
+        uint32_t e = lmw::first(t.dir[r_p]);
+        RR = tr_leaf_load(t, de_leaf(e), de_n(e));
+        PROF_CNT(t, PF_NEXTRA, 1);
+        uint64_t nf2 = lmw::ballot((uint32_t)lane < RR.n && !(RR.st & ST_FUT));
+        if (!nf2) { LM_SETERR(t.err, ST_INTERNAL); return; }   // directory bit out of sync with the leaf
+        r_slot = (uint32_t)lmw::ffs64(nf2);
+        if (r_slot > 0) between = true;
+      } else if (p + 1 < t.n_dir) between = true;
     }
+    if (r_p != NONE) { origin_right = lmw::bcast(RR.id, (int)r_slot); r_ol = lmw::bcast(RR.ol, (int)r_slot); }
   }
   PROF_ADD(t, PF_ORIGHT);
   uint32_t ins_p = p, ins_idx = ins;
@@ -431,8 +445,8 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       if (cp + 1 >= t.n_dir) break;
       carry_id = C.n ? lmw::bcast(C.id, (int)(C.n - 1)) : carry_id;
       cp++; ci = 0;
-      uint32_t e = lmw::first(t.dir[cp]);
-      C = tr_leaf_load(t, de_leaf(e), de_n(e));
+      if (origin_right != NONE && cp == r_p) C = RR;
+      else { uint32_t e = lmw::first(t.dir[cp]); C = tr_leaf_load(t, de_leaf(e), de_n(e)); }
     }
   }
   PROF_ADD(t, PF_BETWEEN);
@@ -470,7 +484,8 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
           t.cr.st = st;
           uint32_t e = lmw::first(t.dir[p]);
           uint32_t new_act = (uint32_t)lmw::popc64(lmw::ballot((uint32_t)lane < t.cr.n && st_active(st)));
-          if (new_act != de_act(e)) dir_update(t, p, dir_chunk_at(t, p), e, de_make(Lc, t.cr.n, new_act));
+          uint32_t new_e = de_make(Lc, t.cr.n, new_act, lmw::ballot((uint32_t)lane < t.cr.n && !(st & ST_FUT)) != 0);
+          if (new_e != e) dir_update(t, p, dir_chunk_at(t, p), e, new_e);
           PROF_CNT(t, PF_NDHIT, 1);
           continue;
         }
@@ -508,7 +523,8 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
 #ifdef LM_EMU_CHECK
       if (lane == 0 && getenv("LM_DBG")) fprintf(stderr, "  upd peer=%u [%u,%u) mode=%d leaf=%u p=%u chunk=%u act %u->%u CH=%u\n", peer, c0, c1, mode, Lf, p, (unsigned)t.lchunk[Lf], de_act(e), new_act, t.CH);
 #endif
-      if (new_act != de_act(e)) dir_update(t, p, dir_chunk_at(t, p), e, de_make(Lf, n, new_act));
+      uint32_t new_e = de_make(Lf, n, new_act, lmw::ballot(in && !(st & ST_FUT)) != 0);
+      if (new_e != e) dir_update(t, p, dir_chunk_at(t, p), e, new_e);
     }
   }
 }
@@ -555,6 +571,9 @@ inline bool tr_check(Tr& t, const char* what, uint32_t row) {
     for (uint32_t q = 0; q < t.n_dir && ok; q++) {
       uint32_t e = t.dir[q], L = de_leaf(e), a = 0;
       for (uint32_t i = 0; i < de_n(e); i++) a += st_active(t.it_st[L * 64 + i]) ? 1 : 0;
+      bool nfb = false;
+      for (uint32_t i = 0; i < de_n(e); i++) nfb |= !(t.it_st[L * 64 + i] & ST_FUT);
+      if (nfb != de_nf(e)) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u non-future bit %d, leaf says %d\n", what, row, q, L, (int)de_nf(e), (int)nfb); ok = false; }
       if (a != de_act(e)) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u act=%u cached=%u n=%u\n", what, row, q, L, a, de_act(e), de_n(e)); ok = false; }
       tot += a;
     }
@@ -638,7 +657,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
     // fresh tracker: one empty leaf
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     uint32_t L0 = t.n_leaf++;
-    if (lane == 0) { s_dir[0] = de_make(L0, 0, 0); t.lchunk[L0] = 0; }
+    if (lane == 0) { s_dir[0] = de_make(L0, 0, 0, false); t.lchunk[L0] = 0; }
     t.n_dir = 1; t.tot_active = 0; t.my_sum = 0; t.cache_leaf = NONE;
     // chunk size: the leaves this container can still create spread over 64 lanes, kept odd
     t.CH = ((m.leaf_cap - L0 + 63) / 64) | 1u;

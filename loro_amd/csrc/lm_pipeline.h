@@ -355,7 +355,7 @@ struct Engine {
       for (uint32_t c = 0; c < m0.n_cont; c++) {
         uint32_t r0 = d.cont_root0[m0.cid0 + c], nr = d.cont_nroot[m0.cid0 + c];
         for (uint32_t q = 0; q < nr; q++) {
-          uint32_t e = d.dir_out[m0.leaf0 + r0 + q], L = e & 0x3FFFFu, n = (e >> 18) & 0x7f;
+          uint32_t e = d.dir_out[m0.leaf0 + r0 + q], L = de_leaf(e), n = de_n(e);
           for (uint32_t i = 0; i < n; i++) {
             uint64_t x = ((uint64_t)m0.leaf0 + L) * 64 + i;
             fprintf(stderr, "DUMP c%u %u:%u ol=%d:%d or=%d:%d st=%x\n", c, d.it_id[x] >> 24, d.it_id[x] & 0xffffff,
