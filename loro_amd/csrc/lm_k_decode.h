@@ -66,7 +66,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* cp;          // text: unicode scalar (0xFFFFFFFF = style anchor) | list: value offset rel. to the doc's first byte
   uint32_t* loc;         // element → leaf
   // tracker pools
-  uint32_t* it_id; uint32_t* it_ol; uint32_t* it_or; uint32_t* it_st;
+  uint32_t* it;          // leaf records, 256 dwords each: id[64] | origin_left[64] | origin_right[64] | status[64]
   uint8_t* lf_chunk;     // [leaf0 + leaf] chunk (owning lane) of the leaf's directory entry
   uint32_t* dir_out;     // [leaf0 + i] flushed leaf directories (entry = leaf | n<<18 | act<<25)
   uint32_t* cont_root0;  // per doc container: first directory entry (doc-relative) / number of entries

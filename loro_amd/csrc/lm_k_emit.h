@@ -268,7 +268,7 @@ LM_KERNEL void k_emit(Dev d, uint32_t* ht_list, int mode) {
         if (ri < nr) {
           uint32_t de = dirp[ri];
           uint32_t L = de_leaf(de), n = de_n(de);
-          if ((uint32_t)lane < n) { id = d.it_id[(uint64_t)(m.leaf0 + L) * 64 + lane]; st = d.it_st[(uint64_t)(m.leaf0 + L) * 64 + lane]; }
+          if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * 256; id = rec[lane]; st = rec[192 + lane]; }
         }
       };
       auto gather = [&](uint32_t id, uint32_t st, bool& vis) -> uint32_t {

@@ -47,7 +47,7 @@ enum { PF_ROW = 0, PF_FIND, PF_LEAF, PF_ORIGHT, PF_BETWEEN, PF_PLACE, PF_DELETE,
 struct LeafRegs { uint32_t n, id, ol, orr, st; };   // one leaf in registers: lane i holds slot i
 
 struct Tr {  // wave-uniform context of one (document, sequence container) replay
-  uint32_t *it_id, *it_ol, *it_or, *it_st;   // HBM leaves: [leaf*64 + slot]
+  uint32_t* it;                   // HBM leaves, 1 KiB records: [leaf*256 + {0 id, 64 origin_left, 128 origin_right, 192 status} + slot]
   uint32_t* loc;                  // doc element → leaf
   const uint32_t* ebase;          // LDS: element base per peer
   const uint32_t* cur;            // LDS: the tracker's version per peer at the head of the node being replayed
@@ -167,10 +167,10 @@ LM_DEV LeafRegs tr_leaf_load(const Tr& t, uint32_t L, uint32_t n) {
   LeafRegs r;
   r.n = n;
   bool in = (uint32_t)lane < n;
-  r.id = in ? t.it_id[L * 64 + lane] : NONE;
-  r.ol = in ? t.it_ol[L * 64 + lane] : NONE;
-  r.orr = in ? t.it_or[L * 64 + lane] : NONE;
-  r.st = in ? t.it_st[L * 64 + lane] : ST_FUT;
+  r.id = in ? t.it[L * 256 + lane] : NONE;
+  r.ol = in ? t.it[L * 256 + 64 + lane] : NONE;
+  r.orr = in ? t.it[L * 256 + 128 + lane] : NONE;
+  r.st = in ? t.it[L * 256 + 192 + lane] : ST_FUT;
   return r;
 }
 
@@ -182,7 +182,7 @@ LM_DEV int tr_cmp_pos(Tr& t, uint32_t a, uint32_t b) {
   uint32_t la = t.loc[tr_g(t, a)], lb = t.loc[tr_g(t, b)];
   if (la >= t.n_leaf || lb >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); return 0; }
   if (la == lb) {
-    uint32_t id = t.it_id[la * 64 + lane];
+    uint32_t id = t.it[la * 256 + lane];
     uint32_t pa = dir_find_leaf(t, la);
     if (pa == NONE) { LM_SETERR(t.err, ST_INTERNAL); return 0; }
     uint32_t n = de_n(lmw::first(t.dir[pa]));
@@ -213,7 +213,7 @@ LM_DEV uint32_t tr_write_items(Tr& t, uint32_t dst, uint32_t q0, uint32_t cnt, c
     vst = 0;
   }
   if (in && (uint32_t)lane >= first_changed) {  // slots before the cursor keep their contents when rewriting in place
-    t.it_id[dst * 64 + lane] = vid; t.it_ol[dst * 64 + lane] = vol; t.it_or[dst * 64 + lane] = vor; t.it_st[dst * 64 + lane] = vst;
+    t.it[dst * 256 + lane] = vid; t.it[dst * 256 + 64 + lane] = vol; t.it[dst * 256 + 128 + lane] = vor; t.it[dst * 256 + 192 + lane] = vst;
     if (is_new || update_loc_old) t.loc[tr_g(t, vid)] = dst;
   }
   if (out) {  // the new contents of `dst`, for the register-resident leaf cache
@@ -384,7 +384,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
                 if (xp > p && xp < cp) visited = true;
                 else {
                   uint32_t xn = de_n(lmw::first(t.dir[xp]));
-                  uint32_t xid = xp == cp ? C.id : ((uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE);
+                  uint32_t xid = xp == cp ? C.id : ((uint32_t)lane < xn ? t.it[xl * 256 + lane] : NONE);
                   uint64_t xm = lmw::ballot((uint32_t)lane < xn && xid == o_ol);
                   if (xm) {
                     uint32_t xs = (uint32_t)lmw::ffs64(xm);
@@ -417,8 +417,8 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
                 uint32_t xp = dir_find_leaf(t, xl);
                 if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
                 uint32_t xn = de_n(lmw::first(t.dir[xp]));
-                uint32_t xid = (uint32_t)lane < xn ? t.it_id[xl * 64 + lane] : NONE;
-                uint32_t xol = (uint32_t)lane < xn ? t.it_ol[xl * 64 + lane] : NONE;
+                uint32_t xid = (uint32_t)lane < xn ? t.it[xl * 256 + lane] : NONE;
+                uint32_t xol = (uint32_t)lane < xn ? t.it[xl * 256 + 64 + lane] : NONE;
                 uint64_t xm = lmw::ballot(xid == o_or);
                 if (!xm) { LM_SETERR(t.err, ST_INTERNAL); break; }
                 o_s = (uint32_t)lmw::ffs64(xm); o_p = xp; x_ol = lmw::bcast(xol, (int)o_s);
@@ -479,7 +479,7 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
             else if (mode == UPD_CLR_FUT) st &= ~ST_FUT;
             else if (mode == UPD_DEL_INC) st = (st + ST_DEL1) | ST_EVER;
             else if (st & ST_DELMASK) st -= ST_DEL1;
-            t.it_st[Lc * 64 + lane] = st;
+            t.it[Lc * 256 + 192 + lane] = st;
           }
           t.cr.st = st;
           uint32_t e = lmw::first(t.dir[p]);
@@ -502,8 +502,8 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       pend &= ~lmw::ballot(lf == Lf);
       // the leaf's chunk byte, ids and statuses are fetched together (one round trip); counts come from LDS
       uint32_t cbyte = t.lchunk[Lf];
-      uint32_t id = t.it_id[Lf * 64 + lane];
-      uint32_t st = t.it_st[Lf * 64 + lane];
+      uint32_t id = t.it[Lf * 256 + lane];
+      uint32_t st = t.it[Lf * 256 + 192 + lane];
       uint32_t p = dir_find_leaf_in(t, Lf, lmw::first(cbyte));
       if (p == NONE) continue;  // leaf of another container of the same document (malformed target)
       uint32_t e = lmw::first(t.dir[p]);
@@ -516,7 +516,7 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
         else if (mode == UPD_CLR_FUT) st &= ~ST_FUT;
         else if (mode == UPD_DEL_INC) st = (st + ST_DEL1) | ST_EVER;
         else if (st & ST_DELMASK) st -= ST_DEL1;
-        t.it_st[Lf * 64 + lane] = st;
+        t.it[Lf * 256 + 192 + lane] = st;
       }
       if (Lf == t.cache_leaf) t.cr.st = in ? st : t.cr.st;   // keep the register copy coherent
       uint32_t new_act = (uint32_t)lmw::popc64(lmw::ballot(in && st_active(st)));
@@ -570,9 +570,9 @@ inline bool tr_check(Tr& t, const char* what, uint32_t row) {
     uint32_t tot = 0;
     for (uint32_t q = 0; q < t.n_dir && ok; q++) {
       uint32_t e = t.dir[q], L = de_leaf(e), a = 0;
-      for (uint32_t i = 0; i < de_n(e); i++) a += st_active(t.it_st[L * 64 + i]) ? 1 : 0;
+      for (uint32_t i = 0; i < de_n(e); i++) a += st_active(t.it[L * 256 + 192 + i]) ? 1 : 0;
       bool nfb = false;
-      for (uint32_t i = 0; i < de_n(e); i++) nfb |= !(t.it_st[L * 64 + i] & ST_FUT);
+      for (uint32_t i = 0; i < de_n(e); i++) nfb |= !(t.it[L * 256 + 192 + i] & ST_FUT);
       if (nfb != de_nf(e)) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u non-future bit %d, leaf says %d\n", what, row, q, L, (int)de_nf(e), (int)nfb); ok = false; }
       if (a != de_act(e)) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u act=%u cached=%u n=%u\n", what, row, q, L, a, de_act(e), de_n(e)); ok = false; }
       tot += a;
@@ -633,8 +633,7 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
   lmw::block_sync();
   uint64_t vvh0 = ((uint64_t)m.vvh0_hi << 32) | m.vvh0_lo;
   Tr t;
-  t.it_id = d.it_id + (uint64_t)m.leaf0 * 64; t.it_ol = d.it_ol + (uint64_t)m.leaf0 * 64;
-  t.it_or = d.it_or + (uint64_t)m.leaf0 * 64; t.it_st = d.it_st + (uint64_t)m.leaf0 * 64;
+  t.it = d.it + (uint64_t)m.leaf0 * 256;
   t.loc = d.loc + elem0;
   t.ebase = s_ebase;
   t.cur = s_cur;

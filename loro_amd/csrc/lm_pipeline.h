@@ -54,7 +54,7 @@ struct Engine {
   DBuf b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
   DBuf b_cp, b_loc;
-  DBuf b_it_id, b_it_ol, b_it_or, b_it_st, b_dir_out, b_lf_chunk;
+  DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list;
   DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off;
@@ -83,8 +83,8 @@ struct Engine {
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
-                   &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it_id,
-                   &b_it_ol, &b_it_or, &b_it_st, &b_dir_out, &b_lf_chunk,
+                   &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
+                   &b_dir_out, &b_lf_chunk,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
@@ -297,7 +297,7 @@ struct Engine {
     if (dir_cap > DIR_CAP_MAX) dir_cap = DIR_CAP_MAX;  // larger documents are reported LM_UNSUPPORTED by k_integrate
     lmbe::h2d(d.doc, h_doc.data(), (size_t)n_docs * sizeof(DocMeta));
     b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
-    b_it_id.ensure((leaves + 1) * 64 * 4); b_it_ol.ensure((leaves + 1) * 64 * 4); b_it_or.ensure((leaves + 1) * 64 * 4); b_it_st.ensure((leaves + 1) * 64 * 4);
+    b_it.ensure((leaves + 1) * 256 * 4);
     b_dir_out.ensure((leaves + 1) * 4);
     b_lf_chunk.ensure(leaves + 64);
     b_vvh.ensure((vvh + 1) * 4);
@@ -309,7 +309,7 @@ struct Engine {
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
     d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>();
-    d.it_id = b_it_id.as<uint32_t>(); d.it_ol = b_it_ol.as<uint32_t>(); d.it_or = b_it_or.as<uint32_t>(); d.it_st = b_it_st.as<uint32_t>();
+    d.it = b_it.as<uint32_t>();
     d.dir_out = b_dir_out.as<uint32_t>();
     d.lf_chunk = b_lf_chunk.as<uint8_t>();
     d.vvh = b_vvh.as<uint32_t>();
@@ -357,10 +357,10 @@ struct Engine {
         for (uint32_t q = 0; q < nr; q++) {
           uint32_t e = d.dir_out[m0.leaf0 + r0 + q], L = de_leaf(e), n = de_n(e);
           for (uint32_t i = 0; i < n; i++) {
-            uint64_t x = ((uint64_t)m0.leaf0 + L) * 64 + i;
-            fprintf(stderr, "DUMP c%u %u:%u ol=%d:%d or=%d:%d st=%x\n", c, d.it_id[x] >> 24, d.it_id[x] & 0xffffff,
-                    d.it_ol[x] == NONE ? -1 : (int)(d.it_ol[x] >> 24), d.it_ol[x] == NONE ? -1 : (int)(d.it_ol[x] & 0xffffff),
-                    d.it_or[x] == NONE ? -1 : (int)(d.it_or[x] >> 24), d.it_or[x] == NONE ? -1 : (int)(d.it_or[x] & 0xffffff), d.it_st[x]);
+            const uint32_t* rec = d.it + ((uint64_t)m0.leaf0 + L) * 256; uint32_t x = i;
+            fprintf(stderr, "DUMP c%u %u:%u ol=%d:%d or=%d:%d st=%x\n", c, rec[x] >> 24, rec[x] & 0xffffff,
+                    rec[64 + x] == NONE ? -1 : (int)(rec[64 + x] >> 24), rec[64 + x] == NONE ? -1 : (int)(rec[64 + x] & 0xffffff),
+                    rec[128 + x] == NONE ? -1 : (int)(rec[128 + x] >> 24), rec[128 + x] == NONE ? -1 : (int)(rec[128 + x] & 0xffffff), rec[192 + x]);
           }
         }
       }
