@@ -469,9 +469,44 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
   }
 }
 
+// cooperative UTF-8 → scalars of ONE long string: 61 bytes per step with coalesced loads; scalar boundaries come
+// from a ballot over the lead bytes and each lead lane assembles its scalar from the following lanes
+LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint64_t nbytes, uint64_t e0, uint32_t len) {
+  int lane = lmw::lane();
+  bool bad = false;
+  uint32_t n = 0;  // scalars emitted so far
+  // a scalar spans at most 4 bytes: advance 61 bytes per step so a lead byte below lane 61 has its tail loaded
+  for (uint64_t c = 0; c < nbytes; c += 61) {
+    uint64_t i = c + (uint64_t)lane;
+    uint32_t b = i < nbytes ? s[i] : 0x80u;
+    bool last_chunk = c + 61 >= nbytes;
+    bool lead = i < nbytes && (b & 0xC0) != 0x80 && (last_chunk || lane < 61);
+    uint32_t b1 = lmw::shfl(b, (lane + 1) & 63), b2 = lmw::shfl(b, (lane + 2) & 63), b3 = lmw::shfl(b, (lane + 3) & 63);
+    uint64_t lm_ = lmw::ballot(lead);
+    uint32_t rank = (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1));
+    if (lead) {
+      uint32_t cpv, extra;
+      if (b < 0x80) { cpv = b; extra = 0; }
+      else if ((b & 0xE0) == 0xC0) { cpv = ((b & 0x1F) << 6) | (b1 & 0x3F); extra = 1; }
+      else if ((b & 0xF0) == 0xE0) { cpv = ((b & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F); extra = 2; }
+      else if ((b & 0xF8) == 0xF0) { cpv = ((b & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F); extra = 3; }
+      else { cpv = 0; extra = 0; bad = true; }
+      if (i + extra >= nbytes) bad = true;
+      if (extra >= 1 && (b1 & 0xC0) != 0x80) bad = true;
+      if (extra >= 2 && (b2 & 0xC0) != 0x80) bad = true;
+      if (extra >= 3 && (b3 & 0xC0) != 0x80) bad = true;
+      if ((uint32_t)lane + extra > 63) bad = true;  // cannot happen: leads above lane 60 only exist in the last chunk
+      if (n + rank < len) d.cp[e0 + n + rank] = cpv;
+    }
+    n += (uint32_t)lmw::popc64(lm_);
+  }
+  return lmw::any(bad) || n != len;
+}
+
 // K8: one wave per change block — element payload table (unicode scalars / list value offsets).
-// Strings are read 64 bytes per step with coalesced loads; scalar boundaries come from a ballot over the
-// UTF-8 lead bytes and each lead lane assembles its scalar from the following lanes.
+// Rows are taken 64 at a time, ONE ROW PER LANE: typing produces short runs, so each lane decodes its own string
+// (neighbouring rows' payloads and element slots are adjacent, so the per-lane byte loads and scalar stores of a
+// wave fall into the same few cache lines).  Strings longer than 64 bytes are left to the cooperative routine above.
 LM_KERNEL void k_elem_fill(Dev d) {
   uint32_t bi = (uint32_t)lmw::bid();
   int lane = lmw::lane();
@@ -487,59 +522,90 @@ LM_KERNEL void k_elem_fill(Dev d) {
   uint64_t ebase = (((uint64_t)m.elem0_hi << 32) | m.elem0_lo) + d.elem_base[m.praw0 + peer];
   uint32_t ext = d.peer_ext[m.praw0 + peer];
   uint64_t doc_data0 = d.blob_off[d.doc_blob[doc]];
-  const uint8_t* lim = d.data + bd.base + bd.sec_rel[SEC_VALUES] + bd.sec_len[SEC_VALUES];
+  // the block's value section is staged in LDS with coalesced dword loads (it is ≈3 KiB for a full block); the
+  // per-lane parsers then chase bytes at LDS latency.  Oversized sections are parsed straight from HBM.
+  LM_SHARED(uint32_t, s_val, 2048 + 4);
+  uint64_t sec0 = bd.base + bd.sec_rel[SEC_VALUES];
+  uint32_t secn = bd.sec_len[SEC_VALUES];
+  uint64_t al0 = sec0 & ~(uint64_t)3;
+  uint32_t tot = (uint32_t)(sec0 - al0) + secn;
+  bool staged = tot <= 8192;
+  if (staged) {
+    const uint32_t* src = (const uint32_t*)(d.data + al0);
+    for (uint32_t i = (uint32_t)lane; i < (tot + 3) / 4; i += 64) s_val[i] = src[i];
+    lmw::block_sync();
+  }
+  // byte at offset `goff` of d.data / offset of a byte pointer (offsets are formed as integers first: LDS pointers are
+  // 32-bit, so a biased base pointer would wrap)
+  const uint8_t* lbase = (const uint8_t*)s_val;
+  auto at = [&](uint64_t goff) -> const uint8_t* { return staged ? lbase + (uint32_t)(goff - al0) : d.data + goff; };
+  auto goff_of = [&](const uint8_t* q) -> uint64_t { return staged ? (uint64_t)(q - lbase) + al0 : (uint64_t)(q - d.data); };
+  const uint8_t* lim = at(sec0 + secn);
   bool bad = false;
-  for (uint32_t row = op0; row < op0 + n_op; row++) {
-    const OpRow r = d.op[row];
+  for (uint32_t g0 = 0; g0 < n_op; g0 += 64) {
+    uint32_t row = op0 + g0 + (uint32_t)lane;
+    bool valid = g0 + (uint32_t)lane < n_op;
+    OpRow r;
+    r.cidx_kind = 0; r.prop = 0; r.len = 0; r.ctr = 0; r.a0 = r.a1 = 0; r.a2 = 0; r.chg = 0;
+    if (valid) r = d.op[row];
     uint32_t kind = (r.cidx_kind >> 16) & 0xff;
-    if (kind != OK_TEXT_INS && kind != OK_LIST_INS && kind != OK_STYLE_START && kind != OK_STYLE_END) continue;
-    if (!d.chg_flag[r.chg]) continue;
-    if (r.ctr + r.len > ext) continue;
+    bool want = valid && (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END);
+    if (want && !d.chg_flag[r.chg]) want = false;
+    if (want && r.ctr + r.len > ext) want = false;
     uint64_t e0 = ebase + r.ctr;
-    if (kind == OK_STYLE_START || kind == OK_STYLE_END) { if (lane == 0) d.cp[e0] = 0xFFFFFFFFu; continue; }
-    const uint8_t* p = d.data + d.op_val[row];
+    if (want && (kind == OK_STYLE_START || kind == OK_STYLE_END)) { d.cp[e0] = 0xFFFFFFFFu; want = false; }
+    const uint8_t* p = want ? at(d.op_val[row]) : lim;
     Rd v = rd_make(p, (uint64_t)(lim - p));
-    if (kind == OK_TEXT_INS) {
-      uint64_t nbytes = rd_uleb(v);
-      if (v.bad || nbytes > rd_left(v)) { bad = true; continue; }
-      const uint8_t* s = v.p;
-      uint32_t n = 0;  // scalars emitted so far
-      // a scalar spans at most 4 bytes: advance 61 bytes per step so a lead byte below lane 61 has its tail loaded
-      for (uint64_t c = 0; c < nbytes; c += 61) {
-        uint64_t i = c + (uint64_t)lane;
-        uint32_t b = i < nbytes ? s[i] : 0x80u;
-        bool last_chunk = c + 61 >= nbytes;
-        bool lead = i < nbytes && (b & 0xC0) != 0x80 && (last_chunk || lane < 61);
-        uint32_t b1 = lmw::shfl(b, (lane + 1) & 63), b2 = lmw::shfl(b, (lane + 2) & 63), b3 = lmw::shfl(b, (lane + 3) & 63);
-        uint64_t lm_ = lmw::ballot(lead);
-        uint32_t rank = (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1));
-        if (lead) {
-          uint32_t cpv, extra;
+    uint64_t nbytes = 0;
+    bool is_long = false;
+    if (want && kind == OK_TEXT_INS) {
+      nbytes = rd_uleb(v);
+      if (v.bad || nbytes > rd_left(v)) { bad = true; want = false; }
+      else if (nbytes > 64) { is_long = true; }
+      else {
+        const uint8_t* s = v.p;
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < (uint32_t)nbytes;) {
+          uint32_t b = s[i], cpv, extra;
           if (b < 0x80) { cpv = b; extra = 0; }
-          else if ((b & 0xE0) == 0xC0) { cpv = ((b & 0x1F) << 6) | (b1 & 0x3F); extra = 1; }
-          else if ((b & 0xF0) == 0xE0) { cpv = ((b & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F); extra = 2; }
-          else if ((b & 0xF8) == 0xF0) { cpv = ((b & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F); extra = 3; }
-          else { cpv = 0; extra = 0; bad = true; }
-          if (i + extra >= nbytes) bad = true;
-          if (extra >= 1 && (b1 & 0xC0) != 0x80) bad = true;
-          if (extra >= 2 && (b2 & 0xC0) != 0x80) bad = true;
-          if (extra >= 3 && (b3 & 0xC0) != 0x80) bad = true;
-          if ((uint32_t)lane + extra > 63) bad = true;  // cannot happen: leads above lane 60 only exist in the last chunk
-          if (n + rank < r.len) d.cp[e0 + n + rank] = cpv;
+          else if ((b & 0xE0) == 0xC0) { cpv = b & 0x1F; extra = 1; }
+          else if ((b & 0xF0) == 0xE0) { cpv = b & 0x0F; extra = 2; }
+          else if ((b & 0xF8) == 0xF0) { cpv = b & 0x07; extra = 3; }
+          else { bad = true; break; }
+          if (i + extra >= (uint32_t)nbytes) { bad = true; break; }
+          for (uint32_t k = 1; k <= extra; k++) {
+            uint32_t t = s[i + k];
+            if ((t & 0xC0) != 0x80) bad = true;
+            cpv = (cpv << 6) | (t & 0x3F);
+          }
+          if (n < r.len) d.cp[e0 + n] = cpv;
+          n++;
+          i += extra + 1;
         }
-        n += (uint32_t)lmw::popc64(lm_);
+        if (n != r.len) bad = true;
       }
-      if (n != r.len) bad = true;
-    } else {  // list insert: tag 7, count, then items (walked by every lane; lane 0 stores)
+    } else if (want) {  // list insert: tag 7, count, then the items; the element table keeps each item's byte offset
       (void)rd_u8(v);
       uint64_t cnt = rd_uleb(v);
       if (cnt != r.len) bad = true;
       for (uint32_t k = 0; k < r.len && !bad; k++) {
-        if (lane == 0) d.cp[e0 + k] = (uint32_t)((uint64_t)(v.p - d.data) - doc_data0);
+        d.cp[e0 + k] = (uint32_t)(goff_of(v.p) - doc_data0);
         bool u = false;
         skip_loro_value(v, u);
         if (v.bad) bad = true;
       }
+    }
+    // long strings: the whole wave works on one at a time
+    uint64_t lm_ = lmw::ballot(is_long);
+    while (lm_) {
+      int l = lmw::ffs64(lm_);
+      lm_ &= lm_ - 1;
+      uint64_t sp = goff_of(v.p);
+      uint32_t sp_lo = lmw::bcast((uint32_t)sp, l), sp_hi = lmw::bcast((uint32_t)(sp >> 32), l);
+      uint32_t nb = lmw::bcast((uint32_t)nbytes, l);
+      uint32_t e_lo = lmw::bcast((uint32_t)e0, l), e_hi = lmw::bcast((uint32_t)(e0 >> 32), l);
+      uint32_t ln = lmw::bcast(r.len, l);
+      if (fill_text_coop(d, at(((uint64_t)sp_hi << 32) | sp_lo), nb, ((uint64_t)e_hi << 32) | e_lo, ln)) bad = true;
     }
   }
   if (lmw::any(bad) && lane == 0) LM_SETERR(d.doc[doc].status, ST_DATA_CORRUPTION);
