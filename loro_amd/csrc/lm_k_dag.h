@@ -522,25 +522,7 @@ LM_KERNEL void k_elem_fill(Dev d) {
   uint64_t ebase = (((uint64_t)m.elem0_hi << 32) | m.elem0_lo) + d.elem_base[m.praw0 + peer];
   uint32_t ext = d.peer_ext[m.praw0 + peer];
   uint64_t doc_data0 = d.blob_off[d.doc_blob[doc]];
-  // the block's value section is staged in LDS with coalesced dword loads (it is ≈3 KiB for a full block); the
-  // per-lane parsers then chase bytes at LDS latency.  Oversized sections are parsed straight from HBM.
-  LM_SHARED(uint32_t, s_val, 2048 + 4);
-  uint64_t sec0 = bd.base + bd.sec_rel[SEC_VALUES];
-  uint32_t secn = bd.sec_len[SEC_VALUES];
-  uint64_t al0 = sec0 & ~(uint64_t)3;
-  uint32_t tot = (uint32_t)(sec0 - al0) + secn;
-  bool staged = tot <= 8192;
-  if (staged) {
-    const uint32_t* src = (const uint32_t*)(d.data + al0);
-    for (uint32_t i = (uint32_t)lane; i < (tot + 3) / 4; i += 64) s_val[i] = src[i];
-    lmw::block_sync();
-  }
-  // byte at offset `goff` of d.data / offset of a byte pointer (offsets are formed as integers first: LDS pointers are
-  // 32-bit, so a biased base pointer would wrap)
-  const uint8_t* lbase = (const uint8_t*)s_val;
-  auto at = [&](uint64_t goff) -> const uint8_t* { return staged ? lbase + (uint32_t)(goff - al0) : d.data + goff; };
-  auto goff_of = [&](const uint8_t* q) -> uint64_t { return staged ? (uint64_t)(q - lbase) + al0 : (uint64_t)(q - d.data); };
-  const uint8_t* lim = at(sec0 + secn);
+  const uint8_t* lim = d.data + bd.base + bd.sec_rel[SEC_VALUES] + bd.sec_len[SEC_VALUES];
   bool bad = false;
   for (uint32_t g0 = 0; g0 < n_op; g0 += 64) {
     uint32_t row = op0 + g0 + (uint32_t)lane;
@@ -554,7 +536,7 @@ LM_KERNEL void k_elem_fill(Dev d) {
     if (want && r.ctr + r.len > ext) want = false;
     uint64_t e0 = ebase + r.ctr;
     if (want && (kind == OK_STYLE_START || kind == OK_STYLE_END)) { d.cp[e0] = 0xFFFFFFFFu; want = false; }
-    const uint8_t* p = want ? at(d.op_val[row]) : lim;
+    const uint8_t* p = want ? d.data + d.op_val[row] : lim;
     Rd v = rd_make(p, (uint64_t)(lim - p));
     uint64_t nbytes = 0;
     bool is_long = false;
@@ -589,7 +571,7 @@ LM_KERNEL void k_elem_fill(Dev d) {
       uint64_t cnt = rd_uleb(v);
       if (cnt != r.len) bad = true;
       for (uint32_t k = 0; k < r.len && !bad; k++) {
-        d.cp[e0 + k] = (uint32_t)(goff_of(v.p) - doc_data0);
+        d.cp[e0 + k] = (uint32_t)((uint64_t)(v.p - d.data) - doc_data0);
         bool u = false;
         skip_loro_value(v, u);
         if (v.bad) bad = true;
@@ -600,12 +582,12 @@ LM_KERNEL void k_elem_fill(Dev d) {
     while (lm_) {
       int l = lmw::ffs64(lm_);
       lm_ &= lm_ - 1;
-      uint64_t sp = goff_of(v.p);
+      uint64_t sp = (uint64_t)(v.p - d.data);
       uint32_t sp_lo = lmw::bcast((uint32_t)sp, l), sp_hi = lmw::bcast((uint32_t)(sp >> 32), l);
       uint32_t nb = lmw::bcast((uint32_t)nbytes, l);
       uint32_t e_lo = lmw::bcast((uint32_t)e0, l), e_hi = lmw::bcast((uint32_t)(e0 >> 32), l);
       uint32_t ln = lmw::bcast(r.len, l);
-      if (fill_text_coop(d, at(((uint64_t)sp_hi << 32) | sp_lo), nb, ((uint64_t)e_hi << 32) | e_lo, ln)) bad = true;
+      if (fill_text_coop(d, d.data + (((uint64_t)sp_hi << 32) | sp_lo), nb, ((uint64_t)e_hi << 32) | e_lo, ln)) bad = true;
     }
   }
   if (lmw::any(bad) && lane == 0) LM_SETERR(d.doc[doc].status, ST_DATA_CORRUPTION);
