@@ -76,6 +76,8 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   unsigned long long* ht_best;
   uint64_t* ht0;                // per doc first slot; ht_cap per doc
   uint32_t* ht_cap;
+  uint32_t* ht_list;            // per doc [ht0, ht0+cap): lower half = slots claimed (one per distinct key), upper half = sort scratch
+  uint32_t* ht_cnt;             // per doc number of claimed slots
   unsigned long long* prof;     // [doc*16 + slot] cycle accounting (LM_PROF builds)
   // outputs
   uint8_t* out;          // JSON bytes

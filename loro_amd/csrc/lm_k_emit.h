@@ -59,7 +59,10 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
     unsigned long long cur = keys[slot];
     if (cur == HT_EMPTY) {
       cur = lmw::atomic_cas64(&keys[slot], HT_EMPTY, mine);
-      if (cur == HT_EMPTY) cur = mine;
+      if (cur == HT_EMPTY) {   // this thread claimed the slot: one list entry per distinct (container, key)
+        cur = mine;
+        d.ht_list[d.ht0[doc] + lmw::atomic_add(&d.ht_cnt[doc], 1u)] = slot;
+      }
     }
     bool same = cur == mine;
     if (!same && (uint32_t)(cur >> 32) == cidx) {
@@ -211,7 +214,7 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err) {
 }
 
 // K11: one wave per doc — JSON of the deep value (mode 0: size only, mode 1: write) and the VV bytes.
-LM_KERNEL void k_emit(Dev d, uint32_t* ht_list, int mode) {
+LM_KERNEL void k_emit(Dev d, int mode) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   LM_SHARED(uint32_t, s_order, MAX_CONTAINERS);
@@ -307,42 +310,57 @@ LM_KERNEL void k_emit(Dev d, uint32_t* ht_list, int mode) {
       }
       if (kind == CK_TEXT) sink_byte(s, '"'); else sink_byte(s, ']');
     } else if (kind == CK_MAP) {
-      // collect this container's winning SET entries, rank them by key, emit in order
+      // this container's winning SET entries out of the document's claimed slots, then a bitonic sort by key
       uint32_t cap = d.ht_cap[doc];
       const unsigned long long* keys = d.ht_key + d.ht0[doc];
       const unsigned long long* best = d.ht_best + d.ht0[doc];
-      uint32_t* list = ht_list + d.ht0[doc];
+      const uint32_t* list = d.ht_list + d.ht0[doc];
+      uint32_t* sorted = d.ht_list + d.ht0[doc] + cap / 2;   // claimed slots <= Map op rows <= cap/2
+      uint32_t n_claimed = cap ? d.ht_cnt[doc] : 0;
       uint32_t K = 0;
-      for (uint32_t c0 = 0; c0 < cap; c0 += 64) {
-        uint32_t sl = c0 + (uint32_t)lane;
+      for (uint32_t c0 = 0; c0 < n_claimed; c0 += 64) {
+        uint32_t i = c0 + (uint32_t)lane;
         bool live = false;
-        if (sl < cap) {
+        uint32_t sl = 0;
+        if (i < n_claimed) {
+          sl = list[i];
           unsigned long long k = keys[sl], b = best[sl];
-          if (k != HT_EMPTY && (uint32_t)(k >> 32) == cidx && b != 0) {
+          if ((uint32_t)(k >> 32) == cidx && b != 0) {
             uint32_t row = m.op0 + (uint32_t)((b - 1) & 0xffffffu);
             live = ((d.op[row].cidx_kind >> 16) & 0xff) == OK_MAP_SET;
           }
         }
         uint64_t lm_ = lmw::ballot(live);
-        if (live) list[K + (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1))] = sl;
+        if (live) sorted[K + (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1))] = sl;
         K += (uint32_t)lmw::popc64(lm_);
       }
+      uint32_t Kp = 1;
+      while (Kp < K) Kp <<= 1;
+      if (Kp > cap / 2) { err = ST_INTERNAL; Kp = K = 0; }
+      for (uint32_t i = K + (uint32_t)lane; i < Kp; i += 64) sorted[i] = NONE;   // padding sorts last
       lmw::block_sync();
-      // rank sort into the upper half of the list scratch (cap entries are available: K <= cap/2)
-      uint32_t* sorted = list + cap / 2;
-      for (uint32_t e = (uint32_t)lane; e < K; e += 64) {
-        uint32_t krow = (uint32_t)keys[list[e]];
-        const uint8_t* ka = d.data + d.key_off[krow];
-        uint32_t la = d.key_len[krow];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < K; j++) {
-          if (j == e) continue;
-          uint32_t kj = (uint32_t)keys[list[j]];
-          if (bytes_cmp(d.data + d.key_off[kj], d.key_len[kj], ka, la) < 0) rank++;
+      auto key_less = [&](uint32_t sa, uint32_t sb) -> bool {   // NONE is the largest
+        if (sa == NONE) return false;
+        if (sb == NONE) return true;
+        uint32_t ra = (uint32_t)keys[sa], rb = (uint32_t)keys[sb];
+        return bytes_cmp(d.data + d.key_off[ra], d.key_len[ra], d.data + d.key_off[rb], d.key_len[rb]) < 0;
+      };
+      for (uint32_t k2 = 2; k2 <= Kp; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+          for (uint32_t t0 = 0; t0 < Kp / 2; t0 += 64) {
+            uint32_t t = t0 + (uint32_t)lane;
+            if (t < Kp / 2) {
+              uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+              uint32_t q = i | j;
+              uint32_t a = sorted[i], b = sorted[q];
+              bool up = (i & k2) == 0;
+              bool swap = up ? key_less(b, a) : key_less(a, b);
+              if (swap) { sorted[i] = b; sorted[q] = a; }
+            }
+          }
+          lmw::block_sync();
         }
-        sorted[rank] = list[e];
       }
-      lmw::block_sync();
       sink_byte(s, '{');
       for (uint32_t e = 0; e < K && !err; e++) {
         uint32_t sl = sorted[e];

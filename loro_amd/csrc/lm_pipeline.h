@@ -56,7 +56,7 @@ struct Engine {
   DBuf b_cp, b_loc;
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
-  DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list;
+  DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
   DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off;
   uint64_t payload_bytes = 0;   // Σ json_len + Σ vv_len of the last run (without alignment padding)
   std::vector<uint64_t> h_prof;
@@ -85,7 +85,7 @@ struct Engine {
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
-                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_out, &b_out_off,
+                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
   }
@@ -305,7 +305,7 @@ struct Engine {
     d.prof = b_prof.as<unsigned long long>();
     lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
     b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 4);
-    b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4);
+    b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4); b_ht_cnt.ensure((size_t)n_docs * 4 + 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
     d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>();
@@ -315,6 +315,8 @@ struct Engine {
     d.vvh = b_vvh.as<uint32_t>();
     d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>();
     d.ht0 = b_ht0.as<uint64_t>(); d.ht_cap = b_ht_cap.as<uint32_t>();
+    d.ht_list = b_ht_list.as<uint32_t>(); d.ht_cnt = b_ht_cnt.as<uint32_t>();
+    lmbe::dmemset(b_ht_cnt.p, 0, (size_t)n_docs * 4 + 4);
     // loc[] is initialised by k_integrate (each document's wave clears its own slice); cp[] needs no fill: every
     // element that can be placed was written by k_elem_fill
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
@@ -387,7 +389,7 @@ struct Engine {
       d.vv_out = b_vslab.as<uint8_t>(); d.vv_off = b_vslab_off.as<uint64_t>();
     }
     lmbe::tic(profiling);
-    LM_LAUNCH(k_emit, n_docs, 64, d, b_ht_list.as<uint32_t>(), 1);
+    LM_LAUNCH(k_emit, n_docs, 64, d, 1);
     lmbe::toc("k_emit", times, profiling);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
     h_out_off.assign(n_docs + 1, 0);
