@@ -172,3 +172,16 @@ def test_sibling_in_the_first_slot_of_the_next_leaf():
 
 def test_config4_mixed_containers_with_dag_merges():
     _check(_cases.cfg4_docs(10, first=1016))
+
+
+def test_huge_paste_next_to_small_blocks():
+    """A single 30 KB paste: one change block far above the usual 4 KiB and
+    a string far above the 64-byte per-lane limit of k_elem_fill (cooperative routine); small blocks ride beside it."""
+    from loro_amd import wire
+    a, b = wire.Replica(7), wire.Replica(9)
+    a.text_insert("text", 0, "start "); a.commit()
+    b.merge_from(a); b.set_visible("text", wire.KIND_TEXT, _oracle.visible_ids([a.export()], "text", wire.KIND_TEXT))
+    a.text_insert("text", 3, "".join(chr(0x4E00 + (i * 7) % 500) if i % 5 == 0 else "abcdefghij"[i % 10] for i in range(12000))); a.commit()
+    b.text_insert("text", 6, "tail"); b.text_delete("text", 0, 2); b.commit()
+    a.text_insert("text", 100, "xyz"); a.commit()
+    _check([[a.export(), b.export()], [b.export(), a.export()]])
