@@ -124,6 +124,10 @@ def _checkout_cases():
     mb = [a.export()]
     for v in (va, vb0, vb1, vm, va + vb1, []):
         docs.append(mb); fronts.append(wire.encode_frontiers(v))
+    import test_oracle_golden as tog
+    for blobs, ids in ((tog._two_peer_delete_doc(True), [(2, 4)]), (tog._two_peer_delete_doc(True), [(2, 0)]),
+                       (tog._two_peer_delete_doc(False), [(2, 3)]), (tog._two_peer_delete_doc(False), [(1, 9)])):
+        docs.append(blobs); fronts.append(wire.encode_frontiers(ids))     # tracker.rs:734-773 known answers
     for s in range(6):
         snaps = []
         reps = _fuzz.random_session(900 + s, n_peers=3, n_steps=60, kinds=("text", "list", "map"), styles=True, snapshots=snaps)

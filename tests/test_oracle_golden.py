@@ -242,3 +242,42 @@ def test_checkout_equals_import_of_the_prefix():
             assert got[2] == want[2], (s, fr)
             n += 1
     assert n > 20
+
+
+def _two_peer_delete_doc(backspace):
+    """peer 1 types 10 chars; peer 2 (having seen them) deletes all ten — forward in one op, or by ten backspaces
+    that the writer RLE-merges into one reversed DeleteSeq (signed_len = -10)."""
+    a, b = wire.Replica(1), wire.Replica(2)
+    a.text_insert("text", 0, "abcdefghij"); a.commit()
+    b.merge_from(a)
+    b.set_visible("text", wire.KIND_TEXT, _oracle.visible_ids([a.export()], "text", wire.KIND_TEXT))
+    if backspace:
+        for i in range(9, -1, -1):
+            b.text_delete("text", i, 1)
+    else:
+        b.text_delete("text", 0, 10)
+    b.commit()
+    ops = b.changes[2][0].ops
+    assert len(ops) == 1 and ops[0].signed_len == (-10 if backspace else 10)
+    return [b.export()]
+
+
+def test_tracker_known_answers_through_checkout():
+    """container/richtext/tracker.rs:734-773 — `test_retreat_and_forward_delete` (reversed delete: checking out
+    2=>5 of 10 leaves 5 elements, 2=>0 all 10, 2=>10 none) and `test_checkout_in_doc_with_del_span` (forward delete,
+    2=>4: the first 4 elements inactive, the other 6 active), restated as documents + checkouts."""
+    rev = _two_peer_delete_doc(True)
+    assert json.loads(_at(rev, [(2, 4)])[1]) == {"text": "abcde"}
+    assert json.loads(_at(rev, [(1, 9)])[1]) == {"text": "abcdefghij"}
+    assert json.loads(_at(rev, [(2, 9)])[1]) == {"text": ""}
+    fwd = _two_peer_delete_doc(False)
+    assert json.loads(_at(fwd, [(2, 3)])[1]) == {"text": "efghij"}
+    assert _at(fwd, [(2, 3)])[2] == wire.encode_vv({1: 10, 2: 4})
+    # tracker.rs:720-732 `test_len`: two peers insert 2 elements each at position 0 from the empty version
+    a, b = wire.Replica(1), wire.Replica(2)
+    a.text_insert("text", 0, "ab"); a.commit()
+    b.text_insert("text", 0, "cd"); b.commit()
+    both = [a.export(), b.export()]
+    assert len(json.loads(_oracle.merge(both)[1])["text"]) == 4
+    assert json.loads(_at(both, [(1, 1)])[1]) == {"text": "ab"}
+    assert json.loads(_at(both, [])[1]) == {"text": ""}
