@@ -3,6 +3,7 @@
 #include <thread>
 #include <atomic>
 #include <cstdlib>
+#include <malloc.h>
 #include "lo_doc.hpp"
 
 using namespace lo;
@@ -43,6 +44,10 @@ extern "C" {
 // (an encoded Frontiers is never empty: the empty version is the single byte 00)
 void* lo_batch_run_at(const uint8_t* data, const uint64_t* blob_off, const uint32_t* doc_blob, uint32_t n_docs,
                       const uint8_t* front_data, const uint64_t* front_off, int n_threads) {
+  // many threads each build and drop a few MB per document: keep freed memory in the arenas instead of returning it
+  // to the kernel after every document (trim / munmap serialise all threads on the process's mmap lock)
+  static bool tuned = false;
+  if (!tuned) { mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_MMAP_THRESHOLD, 64 << 20); tuned = true; }
   Batch* b = new Batch();
   b->res.resize(n_docs);
   if (n_threads < 1) n_threads = 1;
