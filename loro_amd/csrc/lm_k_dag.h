@@ -103,23 +103,26 @@ LM_KERNEL void k_doc_tables(Dev d) {
     uint32_t nlen = 0, cpeer = 0, cctr = 0;
     if (is_root) { noff = d.key_off[bo[BC_KEY] + w[2]]; nlen = d.key_len[bo[BC_KEY] + w[2]]; }
     else { cpeer = d.peer_map[bo[BC_PEER] + w[1]]; cctr = w[2]; }
-    bool match = false;
-    if ((uint32_t)lane < C) {
-      ContRow c = d.cont[m.cid0 + lane];
-      if (c.kind_root == kr) {
-        if (is_root) {
-          if (c.name_len == nlen) {
-            match = true;
-            const uint8_t* a = d.data + c.name_off;
-            const uint8_t* b = d.data + noff;
-            for (uint32_t k = 0; k < nlen; k++) if (a[k] != b[k]) { match = false; break; }
-          }
-        } else match = c.peer == cpeer && c.counter == cctr;
+    uint32_t idx = NONE;
+    for (uint32_t c0 = 0; c0 < C && idx == NONE; c0 += 64) {
+      bool match = false;
+      if (c0 + (uint32_t)lane < C) {
+        ContRow c = d.cont[m.cid0 + c0 + lane];
+        if (c.kind_root == kr) {
+          if (is_root) {
+            if (c.name_len == nlen) {
+              match = true;
+              const uint8_t* a = d.data + c.name_off;
+              const uint8_t* b = d.data + noff;
+              for (uint32_t k = 0; k < nlen; k++) if (a[k] != b[k]) { match = false; break; }
+            }
+          } else match = c.peer == cpeer && c.counter == cctr;
+        }
       }
+      uint64_t mm = lmw::ballot(match);
+      if (mm) idx = c0 + (uint32_t)lmw::ffs64(mm);
     }
-    uint64_t mm = lmw::ballot(match);
-    uint32_t idx;
-    if (mm) idx = (uint32_t)lmw::ffs64(mm);
+    if (idx != NONE) {}
     else {
       if (C >= MAX_CONTAINERS) { cont_overflow = true; break; }
       idx = C;

@@ -226,8 +226,10 @@ LM_KERNEL void k_block_count(Dev d) {
 }
 
 // skip one nested LoroValue (docs/encoding.md §10.1); iterative with an explicit frame stack.
-// `unsupported` is raised for shapes the device emitter does not render yet (maps, child containers, f64).
-LM_DEV void skip_loro_value(Rd& r, bool& unsupported) {
+// `unsupported` is raised for shapes the device emitter does not render yet (map values, f64, containers of other
+// kinds).  A child container (tag 9 + kind Map/List/Text) is accepted down to nesting depth `cdepth`: 0 for a Map
+// value, 1 for the items of a List insert; -1 nowhere.
+LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
   uint32_t f_cnt[16];
   uint32_t f_map = 0;  // bit i: frame i is a map (each item is preceded by a key index)
   int sp = 0;
@@ -260,7 +262,7 @@ LM_DEV void skip_loro_value(Rd& r, bool& unsupported) {
         if (tag == 8) unsupported = true;
         break;
       }
-      case 9: (void)rd_u8(r); unsupported = true; break;
+      case 9: { uint32_t ck = rd_u8(r); if (sp > cdepth || ck > CK_TEXT) unsupported = true; break; }
       default: r.bad = true; return;
     }
   }
@@ -459,7 +461,7 @@ LM_KERNEL void k_block_decode(Dev d) {
             (void)rd_u8(t);
             r.a0 = (uint32_t)rd_uleb(t);
           }
-          skip_loro_value(v, unsupported);
+          skip_loro_value(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && ckind == CK_LIST ? 1 : -1));
           break;
         }
         case 12: {

@@ -61,7 +61,7 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
       cur = lmw::atomic_cas64(&keys[slot], HT_EMPTY, mine);
       if (cur == HT_EMPTY) {   // this thread claimed the slot: one list entry per distinct (container, key)
         cur = mine;
-        d.ht_list[d.ht0[doc] + lmw::atomic_add(&d.ht_cnt[doc], 1u)] = slot;
+        d.ht_list[2 * d.ht0[doc] + lmw::atomic_add(&d.ht_cnt[doc], 1u)] = slot;
       }
     }
     bool same = cur == mine;
@@ -161,7 +161,8 @@ LM_DEV void cp_bytes(uint32_t cp, uint64_t& bytes, uint32_t& n) {
   }
 }
 
-// render one nested LoroValue at `r` (wave-uniform parse; lists only — maps/containers/f64 were rejected at decode)
+// render one plain LoroValue at `r` (wave-uniform parse; nested lists — map values, f64 and containers below the top
+// level were rejected at decode; a top-level child container is resolved by the caller)
 LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err) {
   uint32_t f_cnt[16];
   uint32_t f_first = 0;
@@ -213,27 +214,39 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err) {
   }
 }
 
+static constexpr uint32_t EMIT_MAX_DEPTH = 16;   // nesting depth of child containers the emitter follows
+
 // K11: one wave per doc — JSON of the deep value (mode 0: size only, mode 1: write) and the VV bytes.
 LM_KERNEL void k_emit(Dev d, int mode) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
-  LM_SHARED(uint32_t, s_order, MAX_CONTAINERS);
+  LM_SHARED(uint32_t, s_order, MAX_ROOTS);
   DocMeta m = d.doc[doc];
   if (status_fatal(m.status)) { if (lane == 0) { d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; } return; }
   int32_t err = 0;
   // ---- root containers that received an applied op, ordered bytewise by name
   uint32_t C = m.n_cont;
-  bool mine = false;
-  ContRow my;
-  my.name_off = 0; my.name_len = 0; my.kind_root = 0; my.touched = 0;
-  if ((uint32_t)lane < C) { my = d.cont[m.cid0 + lane]; mine = (my.kind_root & 0x100) && my.touched; }
-  uint32_t n_roots = (uint32_t)lmw::popc64(lmw::ballot(mine));
+  LM_SHARED(uint32_t, s_root, MAX_ROOTS);
+  uint32_t n_roots = 0;
+  for (uint32_t c0 = 0; c0 < C; c0 += 64) {
+    bool isr = false;
+    if (c0 + (uint32_t)lane < C) { const ContRow o = d.cont[m.cid0 + c0 + lane]; isr = (o.kind_root & 0x100) && o.touched; }
+    uint64_t rm = lmw::ballot(isr);
+    uint32_t at = n_roots + (uint32_t)lmw::popc64(rm & ((1ull << lane) - 1));
+    if (isr && at < MAX_ROOTS) s_root[at] = c0 + (uint32_t)lane;
+    n_roots += (uint32_t)lmw::popc64(rm);
+  }
+  if (n_roots > MAX_ROOTS) { err = ST_UNSUPPORTED; n_roots = 0; }
+  lmw::block_sync();
   {
+    bool mine = (uint32_t)lane < n_roots;
+    ContRow my;
+    my.name_off = 0; my.name_len = 0; my.kind_root = 0; my.touched = 0;
+    if (mine) my = d.cont[m.cid0 + s_root[lane]];
     uint32_t rank = 0;
     bool dup = false;
-    for (uint32_t j = 0; j < C; j++) {
-      const ContRow o = d.cont[m.cid0 + j];
-      if (!((o.kind_root & 0x100) && o.touched)) continue;
+    for (uint32_t j = 0; j < n_roots; j++) {
+      const ContRow o = d.cont[m.cid0 + s_root[j]];
       if (mine && j != (uint32_t)lane) {
         int c = bytes_cmp(d.data + o.name_off, o.name_len, d.data + my.name_off, my.name_len);
         if (c < 0) rank++;
@@ -241,7 +254,7 @@ LM_KERNEL void k_emit(Dev d, int mode) {
       }
     }
     if (lmw::any(mine && dup)) err = ST_UNSUPPORTED;  // two roots share a name (state.rs:1352-1392 picks by registration order)
-    if (mine && !dup) s_order[rank] = (uint32_t)lane;
+    if (mine && !dup) s_order[rank] = s_root[lane];
   }
   lmw::block_sync();
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
@@ -249,135 +262,221 @@ LM_KERNEL void k_emit(Dev d, int mode) {
   Sink s;
   s.out = mode ? d.out + d.out_off[doc] : nullptr;
   s.pos = 0;
+  // Containers nest: a Map value or a List item may be a child container (LoroValue::Container — on the wire only
+  // the kind; its id is the id of the op / list element that created it, docs/encoding.md:967-1003, state.rs:1550-1616).
+  // Rendering is therefore a small stack machine; a frame = (container, resume position).
+  //   List:  a = next leaf of the container's directory, b = next slot in that leaf, c = 1 until an item was written
+  //   Map :  a = next entry of the sorted key list, b = start of that list in the document's sort scratch, c = #entries
+  LM_SHARED(uint32_t, s_frame, 4 * EMIT_MAX_DEPTH);
+  auto frame_set = [&](int i, uint32_t cidx, uint32_t fa, uint32_t fb, uint32_t fc) {
+    lmw::block_sync();
+    if (lane == 0) { s_frame[4 * i] = cidx; s_frame[4 * i + 1] = fa; s_frame[4 * i + 2] = fb; s_frame[4 * i + 3] = fc; }
+    lmw::block_sync();
+  };
+  // child container (peer idx, counter, kind) → container index of the document, NONE when it never received an op
+  auto find_child = [&](uint32_t peer, uint32_t ctr, uint32_t ckind) -> uint32_t {
+    for (uint32_t c0 = 0; c0 < C; c0 += 64) {
+      bool hit = false;
+      if (c0 + (uint32_t)lane < C) { const ContRow o = d.cont[m.cid0 + c0 + lane]; hit = !(o.kind_root & 0x100) && (o.kind_root & 0xff) == ckind && o.peer == peer && o.counter == ctr; }
+      uint64_t hm = lmw::ballot(hit);
+      if (hm) return c0 + (uint32_t)lmw::ffs64(hm);
+    }
+    return NONE;
+  };
+  auto empty_child = [&](uint32_t ckind) {
+    if (ckind == CK_TEXT) sink_lit(s, "\"\"", 2);
+    else if (ckind == CK_LIST) sink_lit(s, "[]", 2);
+    else if (ckind == CK_MAP) sink_lit(s, "{}", 2);
+    else err = ST_UNSUPPORTED;
+  };
+  const uint32_t ht_capd = d.ht_cap[doc];
+  const unsigned long long* keys = d.ht_key + d.ht0[doc];
+  const unsigned long long* best = d.ht_best + d.ht0[doc];
+  const uint32_t* claimed = d.ht_list + 2 * d.ht0[doc];            // [0, cap/2): one slot per distinct (container, key)
+  uint32_t* scratch = d.ht_list + 2 * d.ht0[doc] + ht_capd / 2;     // [cap/2, 2·cap): sorted key lists of the open maps
+  uint32_t scratch_top = 0;
+  uint64_t doc_end = 0;   // list item values are bounded by the end of the document's last blob
+  if (d.doc_blob[doc + 1] > d.doc_blob[doc]) doc_end = d.blob_off[d.doc_blob[doc + 1] - 1] + d.blob_len[d.doc_blob[doc + 1] - 1];
   sink_byte(s, '{');
   for (uint32_t oi = 0; oi < n_roots && !err; oi++) {
-    uint32_t cidx = s_order[oi];
-    const ContRow c = d.cont[m.cid0 + cidx];
-    uint32_t kind = c.kind_root & 0xff;
-    if (oi) sink_byte(s, ',');
-    sink_string(s, d.data + c.name_off, c.name_len);
-    sink_byte(s, ':');
-    if (kind == CK_TEXT || kind == CK_LIST) {
-      if (kind == CK_TEXT) sink_byte(s, '"'); else sink_byte(s, '[');
-      bool first_item = true;
-      uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
-      // software pipeline over the leaves: (id,status) of leaf i+2 and the payload gather of leaf i+1 are in
-      // flight while leaf i is rendered, so the three dependent HBM round trips overlap
-      const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
-      uint32_t id1 = NONE, st1 = ST_EVER, id2 = NONE, st2 = ST_EVER, pay1 = 0;
-      bool vis1 = false;
-      auto load_leaf = [&](uint32_t ri, uint32_t& id, uint32_t& st) {
-        id = NONE; st = ST_EVER;
-        if (ri < nr) {
-          uint32_t de = dirp[ri];
-          uint32_t L = de_leaf(de), n = de_n(de);
-          if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * 256; id = rec[lane]; st = rec[192 + lane]; }
-        }
-      };
-      auto gather = [&](uint32_t id, uint32_t st, bool& vis) -> uint32_t {
-        vis = id != NONE && !(st & ST_EVER);
-        return vis ? d.cp[elem0 + d.elem_base[m.praw0 + pid_peer(id)] + pid_ctr(id)] : 0u;
-      };
-      load_leaf(0, id1, st1);
-      load_leaf(1, id2, st2);
-      pay1 = gather(id1, st1, vis1);
-      for (uint32_t ri = 0; ri < nr && !err; ri++) {
-        bool vis = vis1;
-        uint32_t payload = pay1;
-        // advance the pipeline
-        id1 = id2; st1 = st2;
-        load_leaf(ri + 2, id2, st2);
+    {
+      const ContRow c = d.cont[m.cid0 + s_order[oi]];
+      if (oi) sink_byte(s, ',');
+      sink_string(s, d.data + c.name_off, c.name_len);
+      sink_byte(s, ':');
+    }
+    int sp = 1;
+    frame_set(0, s_order[oi], 0, 0, 0x3);   // c bit 1 = frame not entered yet
+    while (sp > 0 && !err) {
+      lmw::block_sync();
+      uint32_t cidx = s_frame[4 * (sp - 1)], fa = s_frame[4 * (sp - 1) + 1], fb = s_frame[4 * (sp - 1) + 2], fc = s_frame[4 * (sp - 1) + 3];
+      uint32_t kind = d.cont[m.cid0 + cidx].kind_root & 0xff;
+      if (kind == CK_TEXT) {
+        sink_byte(s, '"');
+        uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
+        // software pipeline over the leaves: (id,status) of leaf i+2 and the payload gather of leaf i+1 are in
+        // flight while leaf i is rendered, so the three dependent HBM round trips overlap
+        const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
+        uint32_t id1 = NONE, st1 = ST_EVER, id2 = NONE, st2 = ST_EVER, pay1 = 0;
+        bool vis1 = false;
+        auto load_leaf = [&](uint32_t ri, uint32_t& id, uint32_t& st) {
+          id = NONE; st = ST_EVER;
+          if (ri < nr) {
+            uint32_t de = dirp[ri];
+            uint32_t L = de_leaf(de), n = de_n(de);
+            if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * 256; id = rec[lane]; st = rec[192 + lane]; }
+          }
+        };
+        auto gather = [&](uint32_t id, uint32_t st, bool& vis) -> uint32_t {
+          vis = id != NONE && !(st & ST_EVER);
+          return vis ? d.cp[elem0 + d.elem_base[m.praw0 + pid_peer(id)] + pid_ctr(id)] : 0u;
+        };
+        load_leaf(0, id1, st1);
+        load_leaf(1, id2, st2);
         pay1 = gather(id1, st1, vis1);
-        if (kind == CK_TEXT) {
+        for (uint32_t ri = 0; ri < nr && !err; ri++) {
+          bool vis = vis1;
+          uint32_t payload = pay1;
+          id1 = id2; st1 = st2;
+          load_leaf(ri + 2, id2, st2);
+          pay1 = gather(id1, st1, vis1);
           uint64_t bytes = 0;
           uint32_t nb = 0;
           if (vis) cp_bytes(payload, bytes, nb);
           sink_lanes(s, bytes, nb);
-        } else {
+        }
+        sink_byte(s, '"');
+        sp--;
+      } else if (kind == CK_LIST) {
+        if (fc & 2) { sink_byte(s, '['); fc &= ~2u; }
+        uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
+        const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
+        bool pushed = false;
+        uint32_t ri = fa, slot0 = fb;
+        for (; ri < nr && !err && !pushed; ri++, slot0 = 0) {
+          uint32_t de = dirp[ri];
+          uint32_t L = de_leaf(de), n = de_n(de);
+          uint32_t id = NONE, st = ST_EVER;
+          if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * 256; id = rec[lane]; st = rec[192 + lane]; }
+          bool vis = id != NONE && !(st & ST_EVER) && (uint32_t)lane >= slot0;
+          uint32_t payload = vis ? d.cp[elem0 + d.elem_base[m.praw0 + pid_peer(id)] + pid_ctr(id)] : 0u;
           uint64_t vm = lmw::ballot(vis);
           while (vm && !err) {
             int l0 = lmw::ffs64(vm);
             vm &= vm - 1;
             uint32_t off = lmw::bcast(payload, l0);
-            if (!first_item) sink_byte(s, ',');
-            first_item = false;
-            // bounded by the end of the doc's last blob
-            uint64_t doc_end = d.blob_off[d.doc_blob[doc + 1] - 1] + d.blob_len[d.doc_blob[doc + 1] - 1];
+            if (!(fc & 1)) sink_byte(s, ',');
+            fc &= ~1u;
             Rd r = rd_make(d.data + doc_data0 + off, doc_end - (doc_data0 + off));
+            if (r.p < r.end && *r.p == 9) {   // child container created by this list element
+              (void)rd_u8(r);
+              uint32_t ckind = rd_u8(r);
+              uint32_t eid = lmw::bcast(id, l0);
+              uint32_t child = find_child(pid_peer(eid), pid_ctr(eid), ckind);
+              if (child == NONE) { empty_child(ckind); continue; }
+              if (sp >= (int)EMIT_MAX_DEPTH) { err = ST_UNSUPPORTED; break; }
+              frame_set(sp - 1, cidx, ri, (uint32_t)l0 + 1, fc);
+              frame_set(sp, child, 0, 0, 0x3);
+              sp++;
+              pushed = true;
+              break;
+            }
             sink_value(s, r, err);
           }
         }
-      }
-      if (kind == CK_TEXT) sink_byte(s, '"'); else sink_byte(s, ']');
-    } else if (kind == CK_MAP) {
-      // this container's winning SET entries out of the document's claimed slots, then a bitonic sort by key
-      uint32_t cap = d.ht_cap[doc];
-      const unsigned long long* keys = d.ht_key + d.ht0[doc];
-      const unsigned long long* best = d.ht_best + d.ht0[doc];
-      const uint32_t* list = d.ht_list + d.ht0[doc];
-      uint32_t* sorted = d.ht_list + d.ht0[doc] + cap / 2;   // claimed slots <= Map op rows <= cap/2
-      uint32_t n_claimed = cap ? d.ht_cnt[doc] : 0;
-      uint32_t K = 0;
-      for (uint32_t c0 = 0; c0 < n_claimed; c0 += 64) {
-        uint32_t i = c0 + (uint32_t)lane;
-        bool live = false;
-        uint32_t sl = 0;
-        if (i < n_claimed) {
-          sl = list[i];
-          unsigned long long k = keys[sl], b = best[sl];
-          if ((uint32_t)(k >> 32) == cidx && b != 0) {
-            uint32_t row = m.op0 + (uint32_t)((b - 1) & 0xffffffu);
-            live = ((d.op[row].cidx_kind >> 16) & 0xff) == OK_MAP_SET;
+        if (!pushed && !err) { sink_byte(s, ']'); sp--; }
+      } else if (kind == CK_MAP) {
+        if (fc & 2) {
+          // first visit: this container's winning SET entries out of the document's claimed slots, bitonic-sorted by key
+          uint32_t n_claimed = ht_capd ? d.ht_cnt[doc] : 0;
+          uint32_t* sorted = scratch + scratch_top;
+          uint32_t K = 0;
+          for (uint32_t c0 = 0; c0 < n_claimed; c0 += 64) {
+            uint32_t i = c0 + (uint32_t)lane;
+            bool live = false;
+            uint32_t sl = 0;
+            if (i < n_claimed) {
+              sl = claimed[i];
+              unsigned long long k = keys[sl], bv = best[sl];
+              if ((uint32_t)(k >> 32) == cidx && bv != 0) {
+                uint32_t row = m.op0 + (uint32_t)((bv - 1) & 0xffffffu);
+                live = ((d.op[row].cidx_kind >> 16) & 0xff) == OK_MAP_SET;
+              }
+            }
+            uint64_t lm_ = lmw::ballot(live);
+            if (live) sorted[K + (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1))] = sl;
+            K += (uint32_t)lmw::popc64(lm_);
           }
-        }
-        uint64_t lm_ = lmw::ballot(live);
-        if (live) sorted[K + (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1))] = sl;
-        K += (uint32_t)lmw::popc64(lm_);
-      }
-      uint32_t Kp = 1;
-      while (Kp < K) Kp <<= 1;
-      if (Kp > cap / 2) { err = ST_INTERNAL; Kp = K = 0; }
-      for (uint32_t i = K + (uint32_t)lane; i < Kp; i += 64) sorted[i] = NONE;   // padding sorts last
-      lmw::block_sync();
-      auto key_less = [&](uint32_t sa, uint32_t sb) -> bool {   // NONE is the largest
-        if (sa == NONE) return false;
-        if (sb == NONE) return true;
-        uint32_t ra = (uint32_t)keys[sa], rb = (uint32_t)keys[sb];
-        return bytes_cmp(d.data + d.key_off[ra], d.key_len[ra], d.data + d.key_off[rb], d.key_len[rb]) < 0;
-      };
-      for (uint32_t k2 = 2; k2 <= Kp; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-          for (uint32_t t0 = 0; t0 < Kp / 2; t0 += 64) {
-            uint32_t t = t0 + (uint32_t)lane;
-            if (t < Kp / 2) {
-              uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
-              uint32_t q = i | j;
-              uint32_t a = sorted[i], b = sorted[q];
-              bool up = (i & k2) == 0;
-              bool swap = up ? key_less(b, a) : key_less(a, b);
-              if (swap) { sorted[i] = b; sorted[q] = a; }
+          uint32_t Kp = 1;
+          while (Kp < K) Kp <<= 1;
+          if (scratch_top + Kp > ht_capd + ht_capd / 2) { err = ST_INTERNAL; break; }
+          for (uint32_t i = K + (uint32_t)lane; i < Kp; i += 64) sorted[i] = NONE;   // padding sorts last
+          lmw::block_sync();
+          auto key_less = [&](uint32_t sa, uint32_t sb) -> bool {   // NONE is the largest
+            if (sa == NONE) return false;
+            if (sb == NONE) return true;
+            uint32_t ra = (uint32_t)keys[sa], rb = (uint32_t)keys[sb];
+            return bytes_cmp(d.data + d.key_off[ra], d.key_len[ra], d.data + d.key_off[rb], d.key_len[rb]) < 0;
+          };
+          for (uint32_t k2 = 2; k2 <= Kp; k2 <<= 1) {
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+              for (uint32_t t0 = 0; t0 < Kp / 2; t0 += 64) {
+                uint32_t t = t0 + (uint32_t)lane;
+                if (t < Kp / 2) {
+                  uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+                  uint32_t q = i | j;
+                  uint32_t x = sorted[i], y = sorted[q];
+                  bool up = (i & k2) == 0;
+                  bool swap = up ? key_less(y, x) : key_less(x, y);
+                  if (swap) { sorted[i] = y; sorted[q] = x; }
+                }
+              }
+              lmw::block_sync();
             }
           }
-          lmw::block_sync();
+          sink_byte(s, '{');
+          fa = 0; fb = scratch_top; fc = K << 2;
+          scratch_top += Kp;
         }
+        uint32_t K = fc >> 2;
+        const uint32_t* sorted = scratch + fb;
+        bool pushed = false;
+        uint32_t e = fa;
+        for (; e < K && !err; e++) {
+          uint32_t sl = sorted[e];
+          uint32_t krow = (uint32_t)keys[sl];
+          uint32_t row = m.op0 + (uint32_t)((best[sl] - 1) & 0xffffffu);
+          if (e) sink_byte(s, ',');
+          sink_string(s, d.data + d.key_off[krow], d.key_len[krow]);
+          sink_byte(s, ':');
+          const BlockDesc& bd = d.blk[d.op_blk[row]];
+          const uint8_t* lim = d.data + bd.base + bd.sec_rel[SEC_VALUES] + bd.sec_len[SEC_VALUES];
+          const uint8_t* p = d.data + d.op_val[row];
+          Rd r = rd_make(p, (uint64_t)(lim - p));
+          if (r.p < r.end && *r.p == 9) {   // child container created by the winning set op
+            (void)rd_u8(r);
+            uint32_t ckind = rd_u8(r);
+            const OpRow wr = d.op[row];
+            uint32_t child = find_child(d.chg[wr.chg].peer, wr.ctr, ckind);
+            if (child == NONE) { empty_child(ckind); continue; }
+            if (sp >= (int)EMIT_MAX_DEPTH) { err = ST_UNSUPPORTED; break; }
+            frame_set(sp - 1, cidx, e + 1, fb, K << 2);
+            frame_set(sp, child, 0, 0, 0x3);
+            sp++;
+            pushed = true;
+            break;
+          }
+          sink_value(s, r, err);
+        }
+        if (!pushed && !err) {
+          sink_byte(s, '}');
+          scratch_top = fb;   // lists of deeper maps were released when those frames closed
+          sp--;
+        }
+      } else {
+        sink_lit(s, "null", 4);
+        sp--;
       }
-      sink_byte(s, '{');
-      for (uint32_t e = 0; e < K && !err; e++) {
-        uint32_t sl = sorted[e];
-        uint32_t krow = (uint32_t)keys[sl];
-        uint32_t row = m.op0 + (uint32_t)((best[sl] - 1) & 0xffffffu);
-        if (e) sink_byte(s, ',');
-        sink_string(s, d.data + d.key_off[krow], d.key_len[krow]);
-        sink_byte(s, ':');
-        const BlockDesc& bd = d.blk[d.op_blk[row]];
-        const uint8_t* lim = d.data + bd.base + bd.sec_rel[SEC_VALUES] + bd.sec_len[SEC_VALUES];
-        const uint8_t* p = d.data + d.op_val[row];
-        Rd r = rd_make(p, (uint64_t)(lim - p));
-        sink_value(s, r, err);
-      }
-      sink_byte(s, '}');
-    } else {
-      sink_lit(s, "null", 4);
     }
   }
   sink_byte(s, '}');

@@ -304,7 +304,7 @@ struct Engine {
     b_prof.ensure((size_t)n_docs * 16 * 8);
     d.prof = b_prof.as<unsigned long long>();
     lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
-    b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 4);
+    b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 8);   // per doc 2·cap entries: claimed slots [0, cap/2) + sort scratch
     b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4); b_ht_cnt.ensure((size_t)n_docs * 4 + 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);

@@ -31,7 +31,8 @@ enum : uint32_t {
 // limits of the packed element id (peer_idx:8 | counter:24)
 static constexpr uint32_t MAX_PEERS = 256;
 static constexpr uint32_t MAX_COUNTER = 1u << 24;
-static constexpr uint32_t MAX_CONTAINERS = 64;
+static constexpr uint32_t MAX_CONTAINERS = 256;  // containers (roots + children) per document
+static constexpr uint32_t MAX_ROOTS = 64;        // root containers per document
 
 struct BlockDesc {           // one per change block; owned by one lane during decode
   uint64_t base;             // absolute byte offset of the block in `data`

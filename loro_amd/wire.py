@@ -578,6 +578,14 @@ class Replica:
         self.next_counter = 0
 
     # -- helpers
+    @staticmethod
+    def _cid(target, kind: int) -> CID:
+        """`target` is a root container name, or the CID of any container (e.g. a child made by *_container)."""
+        if isinstance(target, CID):
+            assert target.kind == kind, "container kind mismatch"
+            return target
+        return root_cid(target, kind)
+
     def _push(self, op: Op):
         if self.pending_ops and try_merge(self.pending_ops[-1], op):
             pass
@@ -605,7 +613,7 @@ class Replica:
 
     # -- text / list
     def text_insert(self, name: str, pos: int, s: str, kind: int = KIND_TEXT):
-        cid = root_cid(name, kind)
+        cid = self._cid(name, kind)
         ids = self.seq.setdefault(cid, [])
         assert 0 <= pos <= len(ids)
         c0 = self._alloc(len(s))
@@ -613,7 +621,7 @@ class Replica:
         ids[pos:pos] = [(self.peer, c0 + i) for i in range(len(s))]
 
     def list_insert(self, name: str, pos: int, values: list):
-        cid = root_cid(name, KIND_LIST)
+        cid = self._cid(name, KIND_LIST)
         ids = self.seq.setdefault(cid, [])
         assert 0 <= pos <= len(ids)
         c0 = self._alloc(len(values))
@@ -622,7 +630,7 @@ class Replica:
 
     def seq_delete(self, name: str, pos: int, n: int, kind: int = KIND_TEXT):
         """handler.rs:2245-2288: id-contiguous ranges, emitted right to left."""
-        cid = root_cid(name, kind)
+        cid = self._cid(name, kind)
         ids = self.seq.setdefault(cid, [])
         assert 0 <= pos and pos + n <= len(ids)
         ranges = []  # (start_pos, len, id_start)
@@ -646,7 +654,7 @@ class Replica:
 
     def text_mark(self, name: str, start: int, end: int, key: str, value: Any, info: int = 0x80 | 0x04):
         """StyleStart at entity `start`, StyleEnd after entity `end` (both anchors occupy a position)."""
-        cid = root_cid(name, KIND_TEXT)
+        cid = self._cid(name, KIND_TEXT)
         ids = self.seq.setdefault(cid, [])
         c0 = self._alloc(2)
         self._push(Op(cid, c0, "style_start", pos=start, key=key, value=value, mark_len=end - start, mark_info=info))
@@ -656,11 +664,28 @@ class Replica:
 
     # -- map
     def map_set(self, name: str, key: str, value: Any):
-        cid = root_cid(name, KIND_MAP)
+        cid = self._cid(name, KIND_MAP)
         self._push(Op(cid, self._alloc(1), "map_set", key=key, value=value))
 
+    def map_set_container(self, name, key: str, kind: int) -> CID:
+        """map.insert_container(key, kind): the child's id is the id of this op (docs/encoding.md:967-1003)."""
+        cid = self._cid(name, KIND_MAP)
+        c0 = self._alloc(1)
+        self._push(Op(cid, c0, "map_set", key=key, value=ContainerValue(kind)))
+        return CID(False, kind, "", self.peer, c0)
+
+    def list_insert_container(self, name, pos: int, kind: int) -> CID:
+        """list.insert_container(pos, kind): the child's id is the id of the new list element."""
+        cid = self._cid(name, KIND_LIST)
+        ids = self.seq.setdefault(cid, [])
+        assert 0 <= pos <= len(ids)
+        c0 = self._alloc(1)
+        self._push(Op(cid, c0, "list_insert", pos=pos, values=[ContainerValue(kind)]))
+        ids[pos:pos] = [(self.peer, c0)]
+        return CID(False, kind, "", self.peer, c0)
+
     def map_delete(self, name: str, key: str):
-        cid = root_cid(name, KIND_MAP)
+        cid = self._cid(name, KIND_MAP)
         self._push(Op(cid, self._alloc(1), "map_delete", key=key))
 
     # -- commit / exchange
@@ -736,5 +761,5 @@ class Replica:
                 blocks += split_blocks(sel, max_block)
         return encode_updates(blocks)
 
-    def set_visible(self, name: str, kind: int, ids: List[Tuple[int, int]]):
-        self.seq[root_cid(name, kind)] = list(ids)
+    def set_visible(self, name, kind: int, ids: List[Tuple[int, int]]):
+        self.seq[self._cid(name, kind)] = list(ids)

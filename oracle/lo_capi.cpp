@@ -84,6 +84,23 @@ uint32_t lo_xxh32(const uint8_t* p, uint64_t n, uint32_t seed) { return xxh32(p,
 
 // visible element ids of the root sequence container `name` (kind 1 List / 2 Text) after importing the blobs.
 // Returns the count, writes up to cap (peer, counter) pairs.  Generator helper for tests.
+// `name` != NULL: root container; NULL: the child container Normal{cpeer, ccounter}.
+int64_t lo_visible_ids2(const uint8_t* data, const uint64_t* blob_off, uint32_t n_blobs, const char* name, uint64_t cpeer,
+                        int32_t ccounter, int kind, uint64_t* peers, int32_t* counters, uint64_t cap) {
+  try {
+    Doc d;
+    for (uint32_t b = 0; b < n_blobs; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    ContainerID cid;
+    cid.root = name != nullptr;
+    cid.kind = (uint8_t)kind;
+    if (name) cid.name = name; else { cid.peer = cpeer; cid.counter = ccounter; }
+    std::vector<ID> ids = d.visible_ids(cid);
+    for (size_t i = 0; i < ids.size() && i < cap; i++) { peers[i] = ids[i].peer; counters[i] = ids[i].counter; }
+    return (int64_t)ids.size();
+  } catch (...) {
+    return -1;
+  }
+}
 int64_t lo_visible_ids(const uint8_t* data, const uint64_t* blob_off, uint32_t n_blobs, const char* name, int kind,
                        uint64_t* peers, int32_t* counters, uint64_t cap) {
   try {

@@ -84,3 +84,64 @@ def blobs_of(reps, rng=None, split=False):
     if rng:
         rng.shuffle(out)
     return out
+
+
+def nested_session(seed, n_peers=3, n_steps=120, sync_prob=0.1, max_depth=4):
+    """Random concurrent session over NESTED containers: root Map "nm" and root List "nl" hold child Map / List / Text
+    containers (created with insert_container), which hold further children; peers edit any container whose creating
+    op they have seen, children get overwritten / deleted (unreachable afterwards), some children never receive an op."""
+    rng = random.Random(seed)
+    base = rng.randrange(1, 1 << 40)
+    reps = [wire.Replica(base + 7 * i) for i in range(n_peers)]
+    K = wire
+    conts = [(wire.root_cid("nm", K.KIND_MAP), None, 0), (wire.root_cid("nl", K.KIND_LIST), None, 0)]   # (cid, creator id, depth)
+
+    def usable(r):
+        return [c for c in conts if c[1] is None or r.vv.get(c[1][0], 0) > c[1][1] or (c[1][0] == r.peer and c[1][1] < r.next_counter)]
+
+    def refresh(r):
+        blob = r.export()
+        for cid, _, _ in usable(r):
+            if cid.kind in (K.KIND_TEXT, K.KIND_LIST):
+                r.set_visible(cid, cid.kind, _oracle.visible_ids([blob], cid, cid.kind))
+
+    for _ in range(n_steps):
+        r = rng.choice(reps)
+        cid, _, depth = rng.choice(usable(r))
+        roll = rng.random()
+        if cid.kind == K.KIND_MAP:
+            key = "k%d" % rng.randint(0, 5)
+            if roll < 0.25 and depth < max_depth:
+                ch = r.map_set_container(cid, key, rng.choice([K.KIND_MAP, K.KIND_LIST, K.KIND_TEXT]))
+                conts.append((ch, (r.peer, ch.counter), depth + 1))
+            elif roll < 0.4:
+                r.map_delete(cid, key)
+            else:
+                r.map_set(cid, key, rng.choice([None, False, rng.randint(-99, 99), "s%d" % rng.randint(0, 9), [1, ["a"]]]))
+        elif cid.kind == K.KIND_LIST:
+            ids = r.seq.setdefault(cid, [])
+            if roll < 0.25 and depth < max_depth:
+                ch = r.list_insert_container(cid, rng.randint(0, len(ids)), rng.choice([K.KIND_MAP, K.KIND_LIST, K.KIND_TEXT]))
+                conts.append((ch, (r.peer, ch.counter), depth + 1))
+            elif roll < 0.45 and ids:
+                pos = rng.randrange(len(ids))
+                r.list_delete(cid, pos, min(len(ids) - pos, rng.randint(1, 2)))
+            else:
+                r.list_insert(cid, rng.randint(0, len(ids)), [rng.choice([True, rng.randint(0, 9), "v"]) for _ in range(rng.randint(1, 3))])
+        else:
+            ids = r.seq.setdefault(cid, [])
+            if roll < 0.3 and ids:
+                pos = rng.randrange(len(ids))
+                r.text_delete(cid, pos, min(len(ids) - pos, rng.randint(1, 3)))
+            else:
+                r.text_insert(cid, rng.randint(0, len(ids)), "".join(rng.choice(ALPHA) for _ in range(rng.randint(1, 5))))
+        if rng.random() < 0.4:
+            r.commit()
+        if rng.random() < sync_prob and n_peers > 1:
+            a, b = rng.sample(reps, 2)
+            a.commit(); b.commit()
+            if a.merge_from(b):
+                refresh(a)
+    for r in reps:
+        r.commit()
+    return reps

@@ -32,6 +32,9 @@ def lib():
         L.lo_visible_ids.restype = ctypes.c_int64
         L.lo_visible_ids.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        L.lo_visible_ids2.restype = ctypes.c_int64
+        L.lo_visible_ids2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int32,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         _LIB = L
     return _LIB
 
@@ -87,12 +90,17 @@ def xxh32(b, seed=0x4F524F4C):
 
 
 def visible_ids(blobs, name, kind):
+    """visible element ids of a sequence container; `name` = root container name or a loro_amd.wire.CID"""
     L = lib()
     data, off, _ = pack([list(blobs)])
     cap = 1 << 20
     peers = np.zeros(cap, dtype=np.uint64)
     ctrs = np.zeros(cap, dtype=np.int32)
-    n = L.lo_visible_ids(data.ctypes.data, off.ctypes.data, len(blobs), name.encode(), kind, peers.ctypes.data,
-                         ctrs.ctypes.data, cap)
+    if isinstance(name, str):
+        n = L.lo_visible_ids2(data.ctypes.data, off.ctypes.data, len(blobs), name.encode(), 0, 0, kind, peers.ctypes.data, ctrs.ctypes.data, cap)
+    elif name.root:
+        n = L.lo_visible_ids2(data.ctypes.data, off.ctypes.data, len(blobs), name.name.encode(), 0, 0, kind, peers.ctypes.data, ctrs.ctypes.data, cap)
+    else:
+        n = L.lo_visible_ids2(data.ctypes.data, off.ctypes.data, len(blobs), None, name.peer, name.counter, kind, peers.ctypes.data, ctrs.ctypes.data, cap)
     assert n >= 0
     return list(zip(peers[:n].tolist(), ctrs[:n].tolist()))

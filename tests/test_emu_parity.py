@@ -189,3 +189,49 @@ def test_huge_paste_next_to_small_blocks():
     b.text_insert("text", 6, "tail"); b.text_delete("text", 0, 2); b.commit()
     a.text_insert("text", 100, "xyz"); a.commit()
     _check([[a.export(), b.export()], [b.export(), a.export()]])
+
+
+def _nested_docs(n, first=7000, **kw):
+    import _fuzz
+    return [_fuzz.blobs_of(_fuzz.nested_session(first + s, **kw)) for s in range(n)]
+
+
+def test_child_containers_hand_built():
+    """Child Map / List / Text containers (insert_container): nested rendering, a child that never gets an op (empty
+    value of its kind), a child made unreachable by a later write to its slot, edits to a child from two peers."""
+    from loro_amd import wire
+    K = wire
+    a = wire.Replica(3)
+    m1 = a.map_set_container("root", "profile", K.KIND_MAP)
+    a.map_set(m1, "name", "Ada"); a.map_set(m1, "age", 36)
+    t1 = a.map_set_container(m1, "bio", K.KIND_TEXT)
+    a.text_insert(t1, 0, "hello")
+    l1 = a.map_set_container("root", "items", K.KIND_LIST)
+    a.list_insert(l1, 0, [1, "two"])
+    c1 = a.list_insert_container(l1, 1, K.KIND_MAP)
+    a.map_set(c1, "k", [1, 2, 3])
+    a.list_insert_container(l1, 3, K.KIND_TEXT)            # never receives an op → ""
+    c3 = a.list_insert_container("rl", 0, K.KIND_LIST)
+    a.list_insert(c3, 0, ["x"])
+    a.map_set_container("root", "empty", K.KIND_LIST)      # no ops → []
+    a.commit()
+    first = a.export()
+    b = wire.Replica(5)
+    b.merge_from(a)
+    b.set_visible(t1, K.KIND_TEXT, _oracle.visible_ids([first], t1, K.KIND_TEXT))
+    b.text_insert(t1, 5, " world"); b.map_set(m1, "age", 37); b.commit()
+    a.text_insert(t1, 0, ">> "); a.map_set_container("root", "old", K.KIND_MAP); a.map_set("root", "old", 1)
+    a.commit()
+    docs = [[first], [a.export(), b.export()], [b.export(), a.export()]]
+    got, want = _check(docs)
+    import json
+    assert json.loads(got[0][1]) == {"rl": [["x"]], "root": {"empty": [], "items": [1, {"k": [1, 2, 3]}, "two", ""],
+                                                             "profile": {"age": 36, "bio": "hello", "name": "Ada"}}}
+    assert json.loads(got[1][1])["root"]["profile"] == {"age": 37, "bio": ">> hello world", "name": "Ada"}
+    assert json.loads(got[1][1])["root"]["old"] == 1 and got[1][1] == got[2][1]
+
+
+def test_child_containers_random_sessions():
+    docs = _nested_docs(24, n_peers=3, n_steps=150)
+    got, want = _check(docs)
+    assert all(w[0] == 0 for w in want) and max(w[1].count(b"{") for w in want) > 4

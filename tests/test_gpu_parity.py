@@ -153,3 +153,29 @@ def test_config4_mixed_containers(engine):
     assert all(w[0] == 0 for w in want)
     for i, g in enumerate(got):
         assert g == want[i % len(base)], i
+
+
+def test_child_containers(engine):
+    """Nested Map / List / Text child containers: random concurrent sessions (children created, edited by several
+    peers, overwritten, left empty), replicated to a batch large enough for both streams."""
+    import test_emu_parity
+    base = test_emu_parity._nested_docs(48, n_peers=3, n_steps=200) + test_emu_parity._nested_docs(8, first=9000, n_peers=4, n_steps=900, sync_prob=0.05, max_depth=6)
+    want = _oracle.merge_batch(base, threads=8)
+    assert all(w[0] == 0 for w in want)
+    docs = [base[i % len(base)] for i in range(1024)]
+    got = engine.merge_batch(docs)
+    for i, g in enumerate(got):
+        assert g == want[i % len(base)], i
+
+
+def test_container_limit_is_reported(engine):
+    """More than MAX_CONTAINERS (256) containers in one document: LM_UNSUPPORTED, never a wrong answer."""
+    r = wire.Replica(11)
+    for i in range(300):
+        c = r.map_set_container("root", "k%d" % i, wire.KIND_MAP)
+        r.map_set(c, "v", i)
+    r.commit()
+    small = wire.Replica(12)
+    small.map_set("root", "a", 1); small.commit()
+    got = engine.merge_batch([[r.export()], [small.export()]])
+    assert got[0][0] == 4 and got[1][:2] == (0, b'{"root":{"a":1}}')
