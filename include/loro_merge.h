@@ -36,7 +36,7 @@ enum {
   LM_CHECKSUM_MISMATCH = 2,  /* LoroError::DecodeChecksumMismatchError */
   LM_DATA_CORRUPTION = 3,    /* LoroError::DecodeDataCorruptionError */
   LM_UNSUPPORTED = 4,        /* outside the device path's scope: Tree / MovableList / Counter containers,
-                              * f64 or map-typed plain values, snapshot blobs, > 256 containers or > 255 peers per document */
+                              * snapshot blobs, > 256 containers or > 255 peers per document */
   LM_INTERNAL = 5,
   LM_FRONTIERS_NOT_FOUND = 6 /* LoroError::FrontiersNotFound: a checkout id the imported history does not hold */
 };

@@ -1,0 +1,155 @@
+// f64 → JSON number text, shortest digits that round-trip, laid out like serde_json / ryu's "pretty" printer
+// (what `LoroValue::to_json_value` produces for LoroValue::Double; reference: crates/loro-common/src/value.rs:719-738).
+// Digit generation is the free-format algorithm of Burger & Dybvig ("Printing Floating-Point Numbers Quickly and
+// Accurately", PLDI'96, figure 3: scale by an estimate of log10, fix up, generate) on a small fixed-width bignum:
+// integer arithmetic only, so the host build and the gfx950 build agree bit for bit.  f64 values are rare in the
+// documents this engine merges; the routine favours being obviously exact over being fast.
+#pragma once
+#include <cstdint>
+#include "lm_wave.h"
+
+namespace lm {
+
+struct Big {                      // little-endian magnitude, 40 × 32 bits (≥ 2^55 · 2^1077 · small slack)
+  static constexpr int N = 40;
+  uint32_t w[N];
+};
+// every routine works on the low `nl` limbs only: nl is chosen per value from its binary and decimal exponents, so an
+// everyday double costs 4-5 limbs per operation instead of 40
+LM_DEV void big_set(Big& a, uint64_t v, int nl) { for (int i = 0; i < nl; i++) a.w[i] = 0; a.w[0] = (uint32_t)v; a.w[1] = (uint32_t)(v >> 32); }
+LM_DEV void big_mul_small(Big& a, uint32_t m, int nl) {
+  uint64_t c = 0;
+  for (int i = 0; i < nl; i++) { uint64_t t = (uint64_t)a.w[i] * m + c; a.w[i] = (uint32_t)t; c = t >> 32; }
+}
+LM_DEV void big_shl(Big& a, uint32_t bits, int nl) {
+  uint32_t ws = bits >> 5, bs = bits & 31;
+  for (int i = nl - 1; i >= 0; i--) {
+    uint32_t lo = (i >= (int)ws) ? a.w[i - (int)ws] : 0u;
+    uint32_t lo2 = (i >= (int)ws + 1) ? a.w[i - (int)ws - 1] : 0u;
+    a.w[i] = bs ? ((lo << bs) | (lo2 >> (32 - bs))) : lo;
+  }
+}
+LM_DEV int big_cmp(const Big& a, const Big& b, int nl) {
+  for (int i = nl - 1; i >= 0; i--) if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1;
+  return 0;
+}
+LM_DEV void big_add(Big& a, const Big& b, int nl) {
+  uint64_t c = 0;
+  for (int i = 0; i < nl; i++) { uint64_t t = (uint64_t)a.w[i] + b.w[i] + c; a.w[i] = (uint32_t)t; c = t >> 32; }
+}
+LM_DEV void big_sub(Big& a, const Big& b, int nl) {   // a >= b
+  uint64_t br = 0;
+  for (int i = 0; i < nl; i++) { uint64_t t = (uint64_t)a.w[i] - b.w[i] - br; a.w[i] = (uint32_t)t; br = (t >> 63) & 1; }
+}
+LM_DEV void big_copy(Big& a, const Big& b, int nl) { for (int i = 0; i < nl; i++) a.w[i] = b.w[i]; }
+LM_DEV void big_mul_pow10(Big& a, uint32_t e, int nl) {
+  while (e >= 9) { big_mul_small(a, 1000000000u, nl); e -= 9; }
+  static const uint32_t P[9] = {1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u, 100000000u};
+  if (e) big_mul_small(a, P[e], nl);
+}
+
+// writes at most 32 bytes to `out`, returns the length.  `ws` = workspace of 6 bignums (the device keeps it in LDS and
+// lets one lane run the routine: the data is wave-uniform, and 1 KiB of per-lane scratch would cost every wave of the
+// emit kernel occupancy for a value that almost never occurs).
+LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
+  int n = 0;
+  uint32_t be = (uint32_t)((bits >> 52) & 0x7ff);
+  uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
+  bool neg = (bits >> 63) != 0;
+  if (be == 0x7ff) { out[0] = 'n'; out[1] = 'u'; out[2] = 'l'; out[3] = 'l'; return 4; }   // NaN / inf: serde_json prints null
+  if (be == 0 && frac == 0) { if (neg) out[n++] = '-'; out[n++] = '0'; out[n++] = '.'; out[n++] = '0'; return n; }
+  uint64_t f = be ? (frac | (1ull << 52)) : frac;
+  int e2 = be ? (int)be - 1075 : -1074;
+  // integers below 10^16 print as "<n>.0" (the layout rule for k >= #digits); no bignum needed
+  if (e2 <= 0 && e2 > -53 && (f & ((1ull << (-e2)) - 1)) == 0) {
+    uint64_t iv = f >> (-e2);
+    if (iv < 10000000000000000ull) {
+      if (neg) out[n++] = '-';
+      char tmp[20];
+      int tn = 0;
+      do { tmp[tn++] = (char)('0' + iv % 10); iv /= 10; } while (iv);
+      while (tn) out[n++] = tmp[--tn];
+      out[n++] = '.'; out[n++] = '0';
+      return n;
+    }
+  }
+  bool even = (f & 1) == 0;                    // round-to-even: the interval ends belong to v
+  bool lower_closer = be > 1 && frac == 0;      // v is a power of two: the gap below is half the gap above
+  Big &r = ws[0], &s = ws[1], &mp = ws[2], &mm = ws[3], &hi = ws[4], &r2 = ws[5];
+  int bitlen = 64 - __builtin_clzll(f);
+  double t = (double)(e2 + bitlen - 1) * 0.30102999566398120;   // log10(2); a lower bound of log10(v)
+  int est = (int)t;
+  if ((double)est < t - 1e-10) est++;           // ceil(t - 1e-10)
+  if (t < 0 && (double)est > t + 1.0) est--;    // (int) truncates toward zero for negative t
+  // limbs: the largest value formed is below 2^(57 + |e2| + 3.33·|est| + 8)
+  int aest = est < 0 ? -est : est, ae2 = e2 < 0 ? -e2 : e2;
+  int nl = (57 + ae2 + (aest * 3322 + 999) / 1000 + 8 + 31) / 32 + 1;
+  if (nl > Big::N) nl = Big::N;
+  if (e2 >= 0) {
+    big_set(r, f, nl); big_shl(r, (uint32_t)e2 + (lower_closer ? 2u : 1u), nl);
+    big_set(s, lower_closer ? 4 : 2, nl);
+    big_set(mp, 1, nl); big_shl(mp, (uint32_t)e2 + (lower_closer ? 1u : 0u), nl);
+    big_set(mm, 1, nl); big_shl(mm, (uint32_t)e2, nl);
+  } else {
+    big_set(r, f, nl); big_shl(r, lower_closer ? 2u : 1u, nl);
+    big_set(s, 1, nl); big_shl(s, (uint32_t)(-e2) + (lower_closer ? 2u : 1u), nl);
+    big_set(mp, lower_closer ? 2 : 1, nl);
+    big_set(mm, 1, nl);
+  }
+  if (est >= 0) big_mul_pow10(s, (uint32_t)est, nl);
+  else { big_mul_pow10(r, (uint32_t)(-est), nl); big_mul_pow10(mp, (uint32_t)(-est), nl); big_mul_pow10(mm, (uint32_t)(-est), nl); }
+  int k = est;
+  {
+    big_copy(hi, r, nl);
+    big_add(hi, mp, nl);
+    int c = big_cmp(hi, s, nl);
+    if (even ? c >= 0 : c > 0) k++;              // estimate was one too low
+    else { big_mul_small(r, 10, nl); big_mul_small(mp, 10, nl); big_mul_small(mm, 10, nl); }
+  }
+  char dig[20];
+  int nd = 0;
+  for (int guard = 0; guard < 19; guard++) {
+    int d = 0;
+    while (big_cmp(r, s, nl) >= 0) { big_sub(r, s, nl); d++; }
+    int c1 = big_cmp(r, mm, nl);
+    bool tc1 = even ? c1 <= 0 : c1 < 0;
+    big_copy(hi, r, nl);
+    big_add(hi, mp, nl);
+    int c2 = big_cmp(hi, s, nl);
+    bool tc2 = even ? c2 >= 0 : c2 > 0;
+    if (!tc1 && !tc2) { dig[nd++] = (char)('0' + d); big_mul_small(r, 10, nl); big_mul_small(mp, 10, nl); big_mul_small(mm, 10, nl); continue; }
+    if (tc1 && tc2) { big_copy(r2, r, nl); big_shl(r2, 1, nl); int c3 = big_cmp(r2, s, nl); if (c3 > 0 || (c3 == 0 && (d & 1))) d++; }   // nearer digit; an exact tie goes to the even digit (as ryu / std::to_chars)
+    else if (tc2) d++;
+    dig[nd++] = (char)('0' + d);
+    break;
+  }
+  // v = 0.d1d2…dn × 10^k ; layout rules of ryu's pretty printer (as serde_json prints f64)
+  if (neg) out[n++] = '-';
+  int kk = k;                                   // position of the decimal point relative to the first digit
+  if (nd <= kk && kk <= 16) {                   // integer value: digits, zeros, ".0"
+    for (int i = 0; i < nd; i++) out[n++] = dig[i];
+    for (int i = nd; i < kk; i++) out[n++] = '0';
+    out[n++] = '.'; out[n++] = '0';
+  } else if (0 < kk && kk <= 16) {              // point inside the digits
+    for (int i = 0; i < kk; i++) out[n++] = dig[i];
+    out[n++] = '.';
+    for (int i = kk; i < nd; i++) out[n++] = dig[i];
+  } else if (-5 < kk && kk <= 0) {              // 0.000ddd
+    out[n++] = '0'; out[n++] = '.';
+    for (int i = 0; i < -kk; i++) out[n++] = '0';
+    for (int i = 0; i < nd; i++) out[n++] = dig[i];
+  } else {                                      // d[.ddd]e[-]xx
+    out[n++] = dig[0];
+    if (nd > 1) { out[n++] = '.'; for (int i = 1; i < nd; i++) out[n++] = dig[i]; }
+    out[n++] = 'e';
+    int ex = kk - 1;
+    if (ex < 0) { out[n++] = '-'; ex = -ex; }
+    char eb[4];
+    int en = 0;
+    do { eb[en++] = (char)('0' + ex % 10); ex /= 10; } while (ex);
+    while (en) out[n++] = eb[--en];
+  }
+  return n;
+}
+
+}  // namespace lm

@@ -226,8 +226,8 @@ LM_KERNEL void k_block_count(Dev d) {
 }
 
 // skip one nested LoroValue (docs/encoding.md §10.1); iterative with an explicit frame stack.
-// `unsupported` is raised for shapes the device emitter does not render yet (map values, f64, containers of other
-// kinds).  A child container (tag 9 + kind Map/List/Text) is accepted down to nesting depth `cdepth`: 0 for a Map
+// `unsupported` is raised for shapes the device emitter does not render (containers of other kinds, containers below
+// the accepted depth).  A child container (tag 9 + kind Map/List/Text) is accepted down to nesting depth `cdepth`: 0 for a Map
 // value, 1 for the items of a List insert; -1 nowhere.
 LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
   uint32_t f_cnt[16];
@@ -249,7 +249,7 @@ LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
     switch (tag) {
       case 0: case 1: case 2: break;
       case 3: (void)rd_sleb(r); break;
-      case 4: rd_skip(r, 8); unsupported = true; break;
+      case 4: rd_skip(r, 8); break;
       case 5: case 6: { uint64_t l = rd_uleb(r); rd_skip(r, l); break; }
       case 7: case 8: {
         uint64_t n = rd_uleb(r);
@@ -259,7 +259,6 @@ LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
         sp++;
         cnt = (uint32_t)n;
         in_map = tag == 8;
-        if (tag == 8) unsupported = true;
         break;
       }
       case 9: { uint32_t ck = rd_u8(r); if (sp > cdepth || ck > CK_TEXT) unsupported = true; break; }

@@ -6,6 +6,7 @@
 //   JSON rendering                            loro-common/src/value.rs:719-738 (serde_json, keys sorted)
 //   VersionVector::encode                     loro-internal/src/version.rs:962-964 (entries sorted by peer here)
 #pragma once
+#include "lm_f64.h"
 #include "lm_k_integrate.h"
 
 namespace lm {
@@ -161,34 +162,95 @@ LM_DEV void cp_bytes(uint32_t cp, uint64_t& bytes, uint32_t& n) {
   }
 }
 
-// render one plain LoroValue at `r` (wave-uniform parse; nested lists — map values, f64 and containers below the top
-// level were rejected at decode; a top-level child container is resolved by the caller)
-LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err) {
-  uint32_t f_cnt[16];
-  uint32_t f_first = 0;
+// render one plain LoroValue at `r` (wave-uniform parse): scalars, f64, binary, nested lists and map values.
+// Map values are written with their keys in bytewise order (canonical JSON): the entries of a map frame are re-scanned
+// for the next larger key each time — O(K²) parses, but map VALUES are small (a child container is the tool for big
+// maps).  Key indices refer to the key table of the value's own block (`key0`, `n_keys`).  A container below the top
+// level of a value was rejected at decode; a top-level child container is resolved by the caller.
+// `vb` = the value's block, or NONE: then it is looked up (last block of [blk0, blk0+n_blk) starting at or before the
+// value) only if a map-typed value actually turns up.
+LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err, const Dev& d, uint32_t vb, uint32_t blk0, uint32_t n_blk) {
+  const uint8_t* base = r.p;
+  uint32_t key0 = 0, n_keys = 0;
+  bool have_keys = false;
+  // frame stack in LDS (the parse is wave-uniform; per-lane arrays would be scratch memory for every wave of the kernel):
+  // 5 words per frame = remaining items | items written | first entry offset | end offset | last key row; lane 0 writes
+  LM_SHARED(uint32_t, s_vf, 5 * 16);
+  int lane = lmw::lane();
+  auto fset = [&](int f, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4) {
+    lmw::wave_sync();
+    if (lane == 0) { s_vf[5 * f] = c0; s_vf[5 * f + 1] = c1; s_vf[5 * f + 2] = c2; s_vf[5 * f + 3] = c3; s_vf[5 * f + 4] = c4; }
+    lmw::wave_sync();
+  };
+  uint32_t f_map = 0;   // bit i: frame i is a map
   int sp = 0;
-  uint32_t cnt = 1;
-  bool in_list = false, first = true;
+  bool pending = true;  // a value waits at r.p
   for (uint32_t guard = 0; guard < (1u << 28); guard++) {
-    while (cnt == 0) {
-      if (sp == 0) return;
-      sink_byte(s, ']');
-      sp--;
-      cnt = f_cnt[sp] & 0x7fffffffu;
-      in_list = (f_cnt[sp] >> 31) != 0;
-      first = false;
-      (void)f_first;
-    }
     if (r.bad) { err = ST_DATA_CORRUPTION; return; }
-    cnt--;
-    if (in_list && !first) sink_byte(s, ',');
-    first = false;
+    if (!pending) {
+      if (sp == 0) return;
+      int top = sp - 1;
+      lmw::wave_sync();
+      uint32_t cnt = s_vf[5 * top], done = s_vf[5 * top + 1], start = s_vf[5 * top + 2], endo = s_vf[5 * top + 3], last = s_vf[5 * top + 4];
+      if (!((f_map >> top) & 1)) {
+        if (cnt == 0) { sink_byte(s, ']'); sp--; continue; }
+        if (done) sink_byte(s, ',');
+        fset(top, cnt - 1, done + 1, start, endo, last);
+      } else {
+        bool fin = done >= cnt;
+        uint32_t best_row = NONE, best_pos = 0;
+        if (!fin) {
+          // next key in bytewise order: the smallest key greater than the last one written (of equal keys the last
+          // occurrence wins, like a map built by successive inserts)
+          const uint8_t* sp0 = base + start;
+          Rd q = rd_make(sp0, (uint64_t)(r.end - sp0));
+          for (uint32_t i = 0; i < cnt && !q.bad; i++) {
+            uint64_t kidx = rd_uleb(q);
+            if (kidx >= n_keys) { err = ST_DATA_CORRUPTION; return; }
+            uint32_t row = key0 + (uint32_t)kidx;
+            uint32_t vpos = (uint32_t)(q.p - base);
+            bool u = false;
+            skip_loro_value(q, u);
+            bool gt = last == NONE || bytes_cmp(d.data + d.key_off[row], d.key_len[row], d.data + d.key_off[last], d.key_len[last]) > 0;
+            if (gt && (best_row == NONE ||
+                       bytes_cmp(d.data + d.key_off[row], d.key_len[row], d.data + d.key_off[best_row], d.key_len[best_row]) <= 0)) {
+              best_row = row; best_pos = vpos;
+            }
+          }
+          if (q.bad) { err = ST_DATA_CORRUPTION; return; }
+          if (best_row == NONE) fin = true;   // the remaining entries repeat keys already written
+        }
+        if (fin) { sink_byte(s, '}'); r.p = base + endo; sp--; continue; }
+        if (done) sink_byte(s, ',');
+        sink_string(s, d.data + d.key_off[best_row], d.key_len[best_row]);
+        sink_byte(s, ':');
+        fset(top, cnt, done + 1, start, endo, best_row);
+        r.p = base + best_pos;
+      }
+      pending = true;
+      continue;
+    }
+    pending = false;
     uint32_t tag = rd_u8(r);
     switch (tag) {
       case 0: sink_lit(s, "null", 4); break;
       case 1: sink_lit(s, "true", 4); break;
       case 2: sink_lit(s, "false", 5); break;
       case 3: sink_i64(s, rd_sleb(r)); break;
+      case 4: {  // f64, big endian (docs/encoding.md §10.1)
+        uint64_t bits = 0;
+        for (int k = 0; k < 8; k++) bits = (bits << 8) | rd_u8(r);
+        // one lane formats (bignum workspace and text in LDS), every lane learns the length
+        LM_SHARED(Big, s_big, 6);
+        LM_SHARED(uint32_t, s_f64, 9);
+        lmw::block_sync();
+        if (lane == 0) s_f64[8] = (uint32_t)f64_json(bits, (char*)s_f64, s_big);
+        lmw::block_sync();
+        uint32_t n = s_f64[8];
+        if (s.out && lane == 0) for (uint32_t i = 0; i < n; i++) s.out[s.pos + i] = ((const uint8_t*)s_f64)[i];
+        s.pos += n;
+        break;
+      }
       case 5: { uint64_t l = rd_uleb(r); if (l > rd_left(r)) { err = ST_DATA_CORRUPTION; return; } sink_string(s, r.p, (uint32_t)l); rd_skip(r, l); break; }
       case 6: {  // binary → array of ints
         uint64_t l = rd_uleb(r);
@@ -199,14 +261,33 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err) {
         rd_skip(r, l);
         break;
       }
-      case 7: {
+      case 7: case 8: {
         uint64_t n = rd_uleb(r);
         if (sp >= 16 || n > (1u << 28)) { err = ST_UNSUPPORTED; return; }
-        sink_byte(s, '[');
-        f_cnt[sp++] = cnt | (in_list ? 0x80000000u : 0u);
-        cnt = (uint32_t)n;
-        in_list = true;
-        first = true;
+        uint32_t start = (uint32_t)(r.p - base), endo = 0;
+        if (tag == 8 && !have_keys) {
+          if (vb == NONE) {
+            uint32_t lo = 0, hi = n_blk;
+            uint64_t at = (uint64_t)(base - d.data);
+            while (lo + 1 < hi) { uint32_t mid = (lo + hi) >> 1; if (d.blk[blk0 + mid].base <= at) lo = mid; else hi = mid; }
+            vb = blk0 + lo;
+          }
+          key0 = d.boff[(uint64_t)vb * BCN + BC_KEY]; n_keys = d.bcnt[(uint64_t)vb * BCN + BC_KEY];
+          have_keys = true;
+        }
+        if (tag == 8) {
+          Rd q = r;   // the map frame jumps around inside its entries: find where the map ends first
+          for (uint64_t i = 0; i < n && !q.bad; i++) { (void)rd_uleb(q); bool u = false; skip_loro_value(q, u); }
+          if (q.bad) { err = ST_DATA_CORRUPTION; return; }
+          endo = (uint32_t)(q.p - base);
+          f_map |= 1u << sp;
+          sink_byte(s, '{');
+        } else {
+          f_map &= ~(1u << sp);
+          sink_byte(s, '[');
+        }
+        fset(sp, (uint32_t)n, 0, start, endo, NONE);
+        sp++;
         break;
       }
       default: err = ST_UNSUPPORTED; return;
@@ -217,15 +298,24 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err) {
 static constexpr uint32_t EMIT_MAX_DEPTH = 16;   // nesting depth of child containers the emitter follows
 
 // K11: one wave per doc — JSON of the deep value (mode 0: size only, mode 1: write) and the VV bytes.
-LM_KERNEL void k_emit(Dev d, int mode) {
+// Two instantiations share this body: documents made of Text containers only (the streaming pipeline, few registers,
+// five waves per SIMD) and everything else (List / Map rendering, child containers, map-typed values, f64).
+template <bool TEXT_ONLY>
+LM_DEV void emit_doc(Dev d, int mode) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   LM_SHARED(uint32_t, s_order, MAX_ROOTS);
   DocMeta m = d.doc[doc];
-  if (status_fatal(m.status)) { if (lane == 0) { d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; } return; }
+  uint32_t C = m.n_cont;
+  bool failed = status_fatal(m.status);
+  {
+    bool other = false;
+    if (!failed) for (uint32_t c0 = (uint32_t)lane; c0 < C; c0 += 64) other |= (d.cont[m.cid0 + c0].kind_root & 0xff) != CK_TEXT;
+    if (TEXT_ONLY == lmw::any(other)) return;   // failed documents are closed by the text-only instantiation
+  }
+  if (failed) { if (lane == 0) { d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; } return; }
   int32_t err = 0;
   // ---- root containers that received an applied op, ordered bytewise by name
-  uint32_t C = m.n_cont;
   LM_SHARED(uint32_t, s_root, MAX_ROOTS);
   uint32_t n_roots = 0;
   for (uint32_t c0 = 0; c0 < C; c0 += 64) {
@@ -347,7 +437,7 @@ LM_KERNEL void k_emit(Dev d, int mode) {
         }
         sink_byte(s, '"');
         sp--;
-      } else if (kind == CK_LIST) {
+      } else if (!TEXT_ONLY && kind == CK_LIST) {
         if (fc & 2) { sink_byte(s, '['); fc &= ~2u; }
         uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
         const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
@@ -381,11 +471,11 @@ LM_KERNEL void k_emit(Dev d, int mode) {
               pushed = true;
               break;
             }
-            sink_value(s, r, err);
+            sink_value(s, r, err, d, NONE, m.blk0, m.n_blk);   // the item's block is found only if its key table is needed
           }
         }
         if (!pushed && !err) { sink_byte(s, ']'); sp--; }
-      } else if (kind == CK_MAP) {
+      } else if (!TEXT_ONLY && kind == CK_MAP) {
         if (fc & 2) {
           // first visit: this container's winning SET entries out of the document's claimed slots, bitonic-sorted by key
           uint32_t n_claimed = ht_capd ? d.ht_cnt[doc] : 0;
@@ -466,7 +556,7 @@ LM_KERNEL void k_emit(Dev d, int mode) {
             pushed = true;
             break;
           }
-          sink_value(s, r, err);
+          sink_value(s, r, err, d, d.op_blk[row], m.blk0, m.n_blk);
         }
         if (!pushed && !err) {
           sink_byte(s, '}');
@@ -503,6 +593,9 @@ LM_KERNEL void k_emit(Dev d, int mode) {
     else { d.doc[doc].out_len = (uint32_t)s.pos; d.doc[doc].vv_len = vvn; }
   }
 }
+
+LM_KERNEL void k_emit_text(Dev d, int mode) { emit_doc<true>(d, mode); }
+LM_KERNEL void k_emit_any(Dev d, int mode) { emit_doc<false>(d, mode); }
 
 // K12: one wave per doc — copy the rendered JSON / VV from the worst-case slabs into the compact result buffers.
 // All four offset tables are 16-byte aligned, so the copy runs on 16-byte vectors.

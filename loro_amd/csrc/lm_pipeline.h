@@ -389,7 +389,8 @@ struct Engine {
       d.vv_out = b_vslab.as<uint8_t>(); d.vv_off = b_vslab_off.as<uint64_t>();
     }
     lmbe::tic(profiling);
-    LM_LAUNCH(k_emit, n_docs, 64, d, 1);
+    LM_LAUNCH(k_emit_text, n_docs, 64, d, 1);
+    LM_LAUNCH(k_emit_any, n_docs, 64, d, 1);
     lmbe::toc("k_emit", times, profiling);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
     h_out_off.assign(n_docs + 1, 0);

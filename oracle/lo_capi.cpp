@@ -147,4 +147,12 @@ int64_t lo_dump_spans(const uint8_t* data, const uint64_t* blob_off, uint32_t n_
     return -1;
   }
 }
+
+// test hook: the oracle's f64 → JSON text (std::to_chars shortest digits + ryu layout)
+int lo_json_f64(double v, char* out) {
+  std::string t;
+  json_f64(v, t);
+  memcpy(out, t.data(), t.size());
+  return (int)t.size();
+}
 }

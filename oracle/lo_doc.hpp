@@ -103,7 +103,7 @@ struct Doc {
   std::vector<Change> pending;
   std::vector<ContainerID> containers;
   std::map<ContainerID, uint32_t> container_idx;
-  bool unsupported = false;   // met a container kind outside Map/List/Text
+  mutable bool unsupported = false;   // met a container kind outside Map/List/Text (registered, or as a child value)
   bool materialized = false;
   std::map<uint32_t, std::unique_ptr<SeqState>> seqs;
   std::map<uint32_t, std::map<std::string, MapEntry>> maps;
@@ -556,7 +556,7 @@ inline void json_value(const Doc& d, const Value& v, std::string& out, int depth
         if (v.cid.kind == CK_TEXT) out += "\"\"";
         else if (v.cid.kind == CK_MAP) out += "{}";
         else if (v.cid.kind == CK_LIST) out += "[]";
-        else out += "null";
+        else { out += "null"; d.unsupported = true; }   // Tree / MovableList / Counter child: outside the scope
       } else d.container_json(it->second, out, depth + 1);
       break;
     }

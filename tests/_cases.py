@@ -72,11 +72,17 @@ def edge_case_docs():
     w1 = wire.Replica(5); w1.map_set("map", "k", "from5"); w1.map_set("map", "gone", 1); w1.commit()
     w2 = wire.Replica(9); w2.map_set("map", "k", "from9"); w2.map_delete("map", "gone"); w2.commit()
     add("map tie break", [w1.export(), w2.export()])
-    # unsupported shapes must be flagged, not guessed
-    u = wire.Replica(51); u.map_set("map", "f", 1.5); u.commit()
+    # f64 and map-typed plain values (rendered canonically: shortest round-trip digits, keys in bytewise order)
+    u = wire.Replica(51); u.map_set("map", "f", 1.5); u.map_set("map", "g", [0.1, -2.5e-7, 1e21, 3.0, float("inf")]); u.commit()
     add("f64 value", [u.export()])
-    u2 = wire.Replica(52); u2.map_set("map", "nested", {"a": 1}); u2.commit()
-    add("nested map value", [u2.export()])
+    u2 = wire.Replica(52)
+    u2.map_set("map", "nested", {"b": 1, "a": {"z": [1, {"y": None, "x": 2.25}], "k": "v"}, "": True})
+    u2.list_insert("list", 0, [{"q": 1, "p": [{"b": 2, "a": 1}]}, "tail"]); u2.commit()
+    u3 = wire.Replica(53); u3.map_set("map", "other", {"k2": 2, "k1": 1}); u3.commit()
+    add("nested map value", [u2.export(), u3.export()])
+    # still outside the device scope: flagged, never guessed
+    t = wire.Replica(54); t.map_set_container("map", "tree", 3); t.commit()
+    add("tree child container", [t.export()])
     return names, docs
 
 

@@ -50,14 +50,16 @@ def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15,
                 r.list_delete("list", pos, min(len(ids) - pos, rng.randint(1, 3)))
             else:
                 vals = [rng.choice([None, True, False, rng.randint(-10**12, 10**12), "s%d" % rng.randint(0, 99), b"\x00\x01\xff",
-                                    [1, "x", [None]]]) for _ in range(rng.randint(1, 3))]
+                                    [1, "x", [None]], rng.uniform(-1e3, 1e3), rng.choice([0.5, 1e-9, 3.0e22, -0.0]),
+                                    {"b": rng.randint(0, 9), "a": [1.25, {"d": None, "c": "x"}]}]) for _ in range(rng.randint(1, 3))]
                 r.list_insert("list", rng.randint(0, len(ids)), vals)
         else:
             key = "k%d" % rng.randint(0, 7)
             if rng.random() < 0.2:
                 r.map_delete("map", key)
             else:
-                r.map_set("map", key, rng.choice([None, True, rng.randint(-5, 5), "v\"%d" % rng.randint(0, 9), [1, 2, "z"]]))
+                r.map_set("map", key, rng.choice([None, True, rng.randint(-5, 5), "v\"%d" % rng.randint(0, 9), [1, 2, "z"], rng.random() * 10 ** rng.randint(-8, 20),
+                                                  {"k%d" % rng.randint(0, 3): rng.randint(0, 5), "z": {"y": 1, "x": [2.5]}, "": "e"}]))
         if rng.random() < commit_prob:
             r.commit()
             if snapshots is not None and r.frontiers and rng.random() < 0.5:

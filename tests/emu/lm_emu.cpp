@@ -43,3 +43,6 @@ inline void toc(const char* name, V& times, bool profiling) {
 #define LM_API(name) lmemu_##name
 
 #include "../../loro_amd/csrc/lm_capi_impl.h"
+
+#include "../../loro_amd/csrc/lm_f64.h"
+extern "C" int lmemu_f64_json(uint64_t bits, char* out) { static lm::Big ws[6]; return lm::f64_json(bits, out, ws); }

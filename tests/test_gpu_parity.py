@@ -7,7 +7,7 @@ from loro_amd import workload, wire
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_fixtures.json")
-DEVICE_SCOPE_GAPS = {"f64 value", "nested map value"}
+DEVICE_SCOPE_GAPS = set()   # every edge-case document is rendered by the device path
 
 
 @pytest.fixture(scope="module")
