@@ -147,6 +147,7 @@ LM_KERNEL void k_doc_tables(Dev d) {
 // K6: grid-stride — translate block-local peer/container indices to document-level ones.
 LM_KERNEL void k_remap(Dev d, uint32_t n_ops, uint32_t n_chg) {
   uint32_t t = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  uint32_t m_chg = NONE, m_bit = 0;   // (change, container bit) this row contributes to the per-change container mask
   if (t < n_ops) {
     uint32_t blk = d.op_blk[t];
     const BlockDesc& bd = d.blk[blk];
@@ -158,7 +159,14 @@ LM_KERNEL void k_remap(Dev d, uint32_t n_ops, uint32_t n_chg) {
       r.cidx_kind = ci | (kind << 16);
       if (kind == OK_DEL) r.a0 = d.peer_map[bo[BC_PEER] + r.a0];
       d.op[t] = r;
+      m_chg = r.chg; m_bit = ci & 63;
     }
+  }
+  // rows of a change are consecutive and mostly hit one container: only the first lane of a run issues the atomic
+  {
+    uint32_t p_chg = lmw::shfl_up(m_chg, 1), p_bit = lmw::shfl_up(m_bit, 1);
+    bool lead = m_chg != NONE && (lmw::lane() == 0 || p_chg != m_chg || p_bit != m_bit);
+    if (lead) lmw::atomic_or(&d.chg_mask[2 * (uint64_t)m_chg + (m_bit >> 5)], 1u << (m_bit & 31));
   }
   if (t < n_chg) {
     ChangeRow c = d.chg[t];

@@ -58,6 +58,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* chg_lamport; // per global change row
   uint32_t* chg_skip;    // atoms to skip at the start of a change (already known prefix)
   uint32_t* chg_flag;    // 1 = applied
+  uint32_t* chg_mask;    // per change 2 words: bit (container idx & 63) set for every container its ops touch
   uint32_t* node_first;  // [chg0 + n] indices into chg_sorted (doc-relative)
   uint32_t* node_last;
   uint32_t* node_order;  // replay order (doc-relative node ids)

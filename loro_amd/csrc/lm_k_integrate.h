@@ -538,6 +538,7 @@ LM_DEV void tr_move_ops(Tr& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
     uint32_t crow = d.chg_sorted[m.chg0 + ci];
     const ChangeRow ch = d.chg[crow];
     if (ch.ctr >= c1) break;
+    if (!((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1)) continue;   // no op of this change belongs to the container
     // first row whose end is past c0 (rows are counter-ordered inside a change)
     uint32_t lo = ch.op0, hr = ch.op0 + ch.n_op;
     while (lo < hr) { uint32_t mid = (lo + hr) >> 1; if (d.op[mid].ctr + d.op[mid].len <= c0) lo = mid + 1; else hr = mid; }
@@ -676,16 +677,18 @@ LM_KERNEL void k_integrate(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, con
         const ChangeRow ch = chg_ro[crow];
         uint32_t skip_to = ch.ctr + skip_ro[crow];
         uint32_t pe = s_end[node_peer];
+        // documents with many containers: a change that does not touch this container contributes no rows
+        uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
         // the next row is fetched one iteration ahead with a VECTOR load (lanes 0-7, one dword each): scalar loads
         // share their wait counter with LDS, so a scalar prefetch would be waited for at the first directory access
         const uint32_t* op_w = (const uint32_t*)op_ro;
-        uint32_t nx = (lane < 8 && ch.n_op) ? op_w[(uint64_t)ch.op0 * 8 + (uint32_t)lane] : 0u;
-        for (uint32_t row = ch.op0; row < ch.op0 + ch.n_op && !t.err; row++) {
+        uint32_t nx = (lane < 8 && n_rows) ? op_w[(uint64_t)ch.op0 * 8 + (uint32_t)lane] : 0u;
+        for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
           OpRow r;
           r.cidx_kind = lmw::bcast(nx, 0); r.prop = (int32_t)lmw::bcast(nx, 1); r.len = lmw::bcast(nx, 2); r.ctr = lmw::bcast(nx, 3);
           r.a0 = lmw::bcast(nx, 4); r.a1 = lmw::bcast(nx, 5); r.a2 = (int32_t)lmw::bcast(nx, 6); r.chg = lmw::bcast(nx, 7);
-          if (row + 1 < ch.op0 + ch.n_op) nx = lane < 8 ? op_w[(uint64_t)(row + 1) * 8 + (uint32_t)lane] : 0u;
+          if (row + 1 < ch.op0 + n_rows) nx = lane < 8 ? op_w[(uint64_t)(row + 1) * 8 + (uint32_t)lane] : 0u;
           if ((r.cidx_kind & 0xffff) != cidx) continue;
           if (r.ctr + r.len <= skip_to) continue;
           uint32_t kind = (r.cidx_kind >> 16) & 0xff;

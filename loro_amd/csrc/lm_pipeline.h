@@ -51,7 +51,7 @@ struct Engine {
   DBuf b_blk, b_bcnt, b_boff;
   DBuf b_chg, b_dep_peer, b_dep_ctr, b_op, b_op_val, b_op_blk, b_key_off, b_key_len, b_cid_raw, b_cid_map, b_peer_raw, b_peer_map;
   DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
-  DBuf b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
+  DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
   DBuf b_cp, b_loc;
   DBuf b_it, b_dir_out, b_lf_chunk;
@@ -82,7 +82,7 @@ struct Engine {
     DBuf* all[] = {&b_front, &b_front_off, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_elem_base,
-                   &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
+                   &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_out, &b_out_off,
@@ -232,6 +232,7 @@ struct Engine {
                     &b_node_done, &b_node_lam})
       b->ensure((size_t)(NC + 1) * 4);
     b_blk_sorted.ensure((size_t)(NB + 1) * 4);
+    b_chg_mask.ensure((size_t)(NC + 1) * 8);
     b_cont_root0.ensure((size_t)(NCID + 1) * 4); b_cont_nroot.ensure((size_t)(NCID + 1) * 4);
     d.chg = b_chg.as<ChangeRow>(); d.dep_peer = b_dep_peer.as<uint32_t>(); d.dep_ctr = b_dep_ctr.as<uint32_t>();
     d.op = b_op.as<OpRow>(); d.op_val = b_op_val.as<uint64_t>(); d.op_blk = b_op_blk.as<uint32_t>();
@@ -243,13 +244,14 @@ struct Engine {
     d.peer_chg0 = b_peer_chg0.as<uint32_t>(); d.peer_chg1 = b_peer_chg1.as<uint32_t>();
     d.cont = b_cont.as<ContRow>();
     d.chg_sorted = b_chg_sorted.as<uint32_t>(); d.chg_lamport = b_chg_lamport.as<uint32_t>();
-    d.chg_skip = b_chg_skip.as<uint32_t>(); d.chg_flag = b_chg_flag.as<uint32_t>();
+    d.chg_skip = b_chg_skip.as<uint32_t>(); d.chg_flag = b_chg_flag.as<uint32_t>(); d.chg_mask = b_chg_mask.as<uint32_t>();
     d.node_first = b_node_first.as<uint32_t>(); d.node_last = b_node_last.as<uint32_t>(); d.node_order = b_node_order.as<uint32_t>();
     d.cont_root0 = b_cont_root0.as<uint32_t>(); d.cont_nroot = b_cont_nroot.as<uint32_t>();
     DevDag g;
     g.blk_sorted = b_blk_sorted.as<uint32_t>(); g.chg_node = b_chg_node.as<uint32_t>();
     g.node_done = b_node_done.as<uint32_t>(); g.node_lam = b_node_lam.as<uint32_t>();
     lmbe::dmemset(b_chg_flag.p, 0, (size_t)(NC + 1) * 4);
+    lmbe::dmemset(b_chg_mask.p, 0, (size_t)(NC + 1) * 8);
     lmbe::dmemset(b_chg_skip.p, 0, (size_t)(NC + 1) * 4);
     lmbe::dmemset(b_chg_lamport.p, 0, (size_t)(NC + 1) * 4);
     lmbe::tic(profiling);

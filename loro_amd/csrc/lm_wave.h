@@ -39,6 +39,7 @@ LM_DEV uint32_t first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstl
 LM_DEV uint32_t atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 LM_DEV uint32_t atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 LM_DEV uint64_t atomic_max64(unsigned long long* p, uint64_t v) { return atomicMax(p, (unsigned long long)v); }
+LM_DEV uint32_t atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 LM_DEV uint64_t atomic_cas64(unsigned long long* p, uint64_t cmp, uint64_t v) {
   return atomicCAS(p, (unsigned long long)cmp, (unsigned long long)v);
 }
@@ -219,6 +220,7 @@ inline uint32_t first(uint32_t v) {
 inline uint32_t atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 inline uint32_t atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 inline uint64_t atomic_max64(unsigned long long* p, uint64_t v) { uint64_t o = *p; if (v > o) *p = v; return o; }
+inline uint32_t atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 inline uint64_t atomic_cas64(unsigned long long* p, uint64_t cmp, uint64_t v) { uint64_t o = *p; if (o == cmp) *p = v; return o; }
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
