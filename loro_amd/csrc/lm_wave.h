@@ -14,6 +14,7 @@
 #define LM_DEV __device__ __forceinline__
 #define LM_DEV_NOINLINE __device__ __noinline__
 #define LM_KERNEL extern "C" __global__
+#define LM_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget: 512 / n VGPRs
 #define LM_SHARED(type, name, n) __shared__ type name[n]
 #define LM_DYN_SHARED(type, name) extern __shared__ type name[]
 
@@ -62,6 +63,7 @@ LM_DEV uint64_t clock() { return __builtin_readcyclecounter(); }
 #define LM_DEV inline
 #define LM_DEV_NOINLINE inline
 #define LM_KERNEL inline
+#define LM_WAVES_PER_SIMD(n)
 #define LM_SHARED(type, name, n) static type name[n]
 #define LM_DYN_SHARED(type, name) type* name = (type*)lmw::emu_dyn_shared()
 
