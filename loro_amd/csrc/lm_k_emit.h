@@ -349,6 +349,9 @@ LM_DEV void emit_doc(Dev d, int mode) {
   lmw::block_sync();
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
   uint64_t doc_data0 = d.blob_off[d.doc_blob[doc]];
+  LM_SHARED(uint32_t, s_eb, MAX_PEERS);   // element base per peer (the text gather reads it once per lane and leaf)
+  for (uint32_t p = (uint32_t)lane; p < m.n_peers && p < MAX_PEERS; p += 64) s_eb[p] = d.elem_base[m.praw0 + p];
+  lmw::block_sync();
   Sink s;
   s.out = mode ? d.out + d.out_off[doc] : nullptr;
   s.pos = 0;
@@ -404,36 +407,31 @@ LM_DEV void emit_doc(Dev d, int mode) {
       if (kind == CK_TEXT) {
         sink_byte(s, '"');
         uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
-        // software pipeline over the leaves: (id,status) of leaf i+2 and the payload gather of leaf i+1 are in
-        // flight while leaf i is rendered, so the three dependent HBM round trips overlap
+        // software pipeline over the leaves, six iterations deep: the directory entry of leaf i+6, the (id, status) of
+        // leaf i+4 and the payload gather of leaf i+2 are in flight while leaf i is rendered — every dependent HBM
+        // round trip has two iterations to complete (element bases come from LDS, so the gather is a single load)
         const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
-        uint32_t id1 = NONE, st1 = ST_EVER, id2 = NONE, st2 = ST_EVER, pay1 = 0;
-        bool vis1 = false;
-        auto load_leaf = [&](uint32_t ri, uint32_t& id, uint32_t& st) {
-          id = NONE; st = ST_EVER;
-          if (ri < nr) {
-            uint32_t de = dirp[ri];
-            uint32_t L = de_leaf(de), n = de_n(de);
-            if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * 256; id = rec[lane]; st = rec[192 + lane]; }
+        uint32_t de_a = 0, de_b = 0, id_a = NONE, id_b = NONE, st_a = ST_EVER, st_b = ST_EVER, pay_a = 0, pay_b = 0;
+        bool dev_a = false, dev_b = false, vis_a = false, vis_b = false;
+        for (uint32_t it = 0; it < nr + 6 && !err; it++) {
+          if (it >= 6) {                                   // render leaf it-6
+            uint64_t bytes = 0;
+            uint32_t nb = 0;
+            if (vis_b) cp_bytes(pay_b, bytes, nb);
+            sink_lanes(s, bytes, nb);
           }
-        };
-        auto gather = [&](uint32_t id, uint32_t st, bool& vis) -> uint32_t {
-          vis = id != NONE && !(st & ST_EVER);
-          return vis ? d.cp[elem0 + d.elem_base[m.praw0 + pid_peer(id)] + pid_ctr(id)] : 0u;
-        };
-        load_leaf(0, id1, st1);
-        load_leaf(1, id2, st2);
-        pay1 = gather(id1, st1, vis1);
-        for (uint32_t ri = 0; ri < nr && !err; ri++) {
-          bool vis = vis1;
-          uint32_t payload = pay1;
-          id1 = id2; st1 = st2;
-          load_leaf(ri + 2, id2, st2);
-          pay1 = gather(id1, st1, vis1);
-          uint64_t bytes = 0;
-          uint32_t nb = 0;
-          if (vis) cp_bytes(payload, bytes, nb);
-          sink_lanes(s, bytes, nb);
+          bool n_vis = id_b != NONE && !(st_b & ST_EVER);   // gather for leaf it-4
+          uint32_t n_pay = n_vis ? d.cp[elem0 + s_eb[pid_peer(id_b)] + pid_ctr(id_b)] : 0u;
+          uint32_t n_id = NONE, n_st = ST_EVER;             // (id, status) of leaf it-2
+          if (dev_b) {
+            uint32_t L = de_leaf(de_b), n = de_n(de_b);
+            if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * 256; n_id = rec[lane]; n_st = rec[192 + lane]; }
+          }
+          bool n_dev = it < nr;                             // directory entry of leaf it
+          uint32_t n_de = n_dev ? dirp[it] : 0u;
+          pay_b = pay_a; vis_b = vis_a; pay_a = n_pay; vis_a = n_vis;
+          id_b = id_a; st_b = st_a; id_a = n_id; st_a = n_st;
+          de_b = de_a; dev_b = dev_a; de_a = n_de; dev_a = n_dev;
         }
         sink_byte(s, '"');
         sp--;
