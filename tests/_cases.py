@@ -1,7 +1,7 @@
 """Hand-built edge cases shared by the CPU (kernel-logic harness) and GPU parity tests."""
 import random
 from loro_amd import wire, workload
-import _fuzz
+import _fuzz, _oracle
 
 
 def edge_case_docs():
@@ -112,3 +112,40 @@ def cfg4_docs(n, first=1000, n_steps=1000):
     (real DAG merges), bold marks on the text."""
     return [_fuzz.blobs_of(_fuzz.random_session(first + d, n_peers=4, n_steps=n_steps, kinds=("text", "list", "map"), sync_prob=0.02, styles=True))
             for d in range(n)]
+
+
+def corrupted_docs(n, seed=1):
+    """Valid documents with one blob damaged (byte flips, truncation, splices) and the envelope checksum re-fitted so the
+    decoder is reached.  For robustness tests: nothing may crash, and a damaged document must not take the batch down."""
+    import random, struct
+    rng = random.Random(seed)
+    base = fuzz_docs(12, base=5000) + [_fuzz.blobs_of(_fuzz.nested_session(8000 + i, n_steps=80)) for i in range(6)] + cfg4_docs(4, first=3000, n_steps=200)
+
+    def refit(blob):
+        body = blob[20:]
+        return blob[:16] + struct.pack("<I", _oracle.xxh32(body)) + body
+
+    def corrupt(blob):
+        b = bytearray(blob)
+        k = rng.random()
+        if k < 0.5:
+            for _ in range(rng.choice([1, 1, 2, 5])):
+                i = rng.randrange(22, len(b))
+                b[i] = rng.choice([b[i] ^ (1 << rng.randrange(8)), rng.randrange(256), 0xFF, 0x80, 0])
+        elif k < 0.7:
+            del b[rng.randrange(22, len(b)):]
+        elif k < 0.85:
+            i = rng.randrange(22, len(b)); j = min(len(b), i + rng.randrange(1, 40))
+            b[i:j] = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 50)))
+        else:
+            i = rng.randrange(22, len(b))
+            b[i:i] = b[rng.randrange(22, len(b)):][: rng.randrange(1, 64)]
+        return refit(bytes(b)) if len(b) > 22 and rng.random() < 0.9 else bytes(b)
+
+    docs = []
+    for _ in range(n):
+        d = list(rng.choice(base))
+        j = rng.randrange(len(d))
+        d[j] = corrupt(d[j])
+        docs.append(d)
+    return docs
