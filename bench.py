@@ -134,7 +134,8 @@ def main():
     # per-kernel durations from HIP events on the engine's own stream (2 extra profiled passes)
     eng.set_profiling(True)
     # (a context splits the batch over lm_n_streams HIP streams: every stage is launched once per stream, on that
-    # stream's share of the documents, and the streams overlap — durations are per launch, as rocprofv3 reports them)
+    # stream's share of the documents.  In the timed steps the streams overlap; in these two profiled passes they run
+    # one after the other, so a kernel's duration is its own — durations are per launch, as rocprofv3 reports them)
     ktimes = {}
     for _ in range(2):
         eng.run()

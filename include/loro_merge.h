@@ -96,7 +96,8 @@ typedef struct lm_run_stats {
   uint32_t n_kernels;
 } lm_run_stats;
 int lm_get_stats(lm_ctx* ctx, lm_run_stats* out);
-int lm_set_profiling(lm_ctx* ctx, int enabled);               /* record hipEvents around every stage of lm_run */
+int lm_set_profiling(lm_ctx* ctx, int enabled);               /* record hipEvents around every stage of lm_run; while
+                                                                * enabled the streams of a context run one after the other */
 int lm_kernel_time(lm_ctx* ctx, uint32_t i, const char** name, double* ms); /* i < n_kernels, after lm_run */
 /* A context splits a staged batch into contiguous document ranges, one engine on its own HIP stream each
  * (env LM_STREAMS, default 2; batches under 128 documents per stream stay whole) and lm_run drives them from

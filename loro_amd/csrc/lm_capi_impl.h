@@ -51,10 +51,16 @@ struct lm_ctx_impl {
     std::vector<std::string> errs(np);
     auto body = [&](uint32_t p) { try { parts[p]->run(); } catch (const std::exception& e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "error"; } };
 #ifdef LM_PARALLEL_PARTS
-    std::vector<std::thread> th;
-    for (uint32_t p = 1; p < np; p++) th.emplace_back(body, p);
-    body(0);
-    for (auto& t : th) t.join();
+    if (profiling) {
+      // stage timing: one part after the other, so a kernel's duration is its own and not a function of whatever the
+      // other stream happened to run beside it (overlapped, the same kernel measures anywhere between 26 and 33 ms)
+      for (uint32_t p = 0; p < np; p++) body(p);
+    } else {
+      std::vector<std::thread> th;
+      for (uint32_t p = 1; p < np; p++) th.emplace_back(body, p);
+      body(0);
+      for (auto& t : th) t.join();
+    }
 #else
     for (uint32_t p = 0; p < np; p++) body(p);
 #endif
