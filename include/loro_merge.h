@@ -79,6 +79,11 @@ int lm_merge_batch(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs, lm_doc_out
 int lm_stage(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs);
 int lm_run(lm_ctx* ctx);
 int lm_fetch(lm_ctx* ctx, lm_doc_out* outs);
+/* Asynchronous lm_run: lm_run_async returns at once, lm_wait blocks until that run is finished (0 = ok).  Between the
+ * two calls only other contexts may be used.  Two contexts in flight overlap one batch's decode stages with the other's
+ * integrate kernels (double buffering). */
+int lm_run_async(lm_ctx* ctx);
+int lm_wait(lm_ctx* ctx);
 
 /* Per-document metadata of the last lm_run (arrays of n_docs entries, any may be NULL) without copying the
  * rendered bytes back: what a sharded deployment all-gathers as the merged-state summary. */
@@ -96,8 +101,10 @@ typedef struct lm_run_stats {
   uint32_t n_kernels;
 } lm_run_stats;
 int lm_get_stats(lm_ctx* ctx, lm_run_stats* out);
-int lm_set_profiling(lm_ctx* ctx, int enabled);               /* record hipEvents around every stage of lm_run; while
-                                                                * enabled the streams of a context run one after the other */
+int lm_set_profiling(lm_ctx* ctx, int mode);                  /* hipEvents around every stage of lm_run (recorded without
+                                                                * host syncs): 0 off | 1 and the context's streams run one after
+                                                                * the other (a stage's own duration) | 2 streams overlapped as
+                                                                * usual (durations as they occur in production) */
 int lm_kernel_time(lm_ctx* ctx, uint32_t i, const char** name, double* ms); /* i < n_kernels, after lm_run */
 /* A context splits a staged batch into contiguous document ranges, one engine on its own HIP stream each
  * (env LM_STREAMS, default 2; batches under 128 documents per stream stay whole) and lm_run drives them from

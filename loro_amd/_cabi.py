@@ -18,7 +18,7 @@ class RunStats(ctypes.Structure):
                 ("device_bytes_allocated", ctypes.c_uint64), ("n_kernels", ctypes.c_uint32)]
 
 
-SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "n_streams"]
+SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "n_streams", "run_async", "wait"]
 
 
 class Binding:
@@ -33,6 +33,8 @@ class Binding:
         self.stage = g("stage"); self.stage.restype = ctypes.c_int
         self.stage.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocIn), ctypes.c_size_t]
         self.run = g("run"); self.run.restype = ctypes.c_int; self.run.argtypes = [ctypes.c_void_p]
+        self.run_async = g("run_async"); self.run_async.restype = ctypes.c_int; self.run_async.argtypes = [ctypes.c_void_p]
+        self.wait = g("wait"); self.wait.restype = ctypes.c_int; self.wait.argtypes = [ctypes.c_void_p]
         self.fetch = g("fetch"); self.fetch.restype = ctypes.c_int; self.fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocOut)]
         self.get_stats = g("get_stats"); self.get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(RunStats)]
         self.set_profiling = g("set_profiling"); self.set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -100,6 +102,14 @@ class Context:
         if self.b.run(self.h) != 0:
             raise RuntimeError(self.b.last_error(self.h).decode())
 
+    def run_async(self):
+        if self.b.run_async(self.h) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+
+    def wait(self):
+        if self.b.wait(self.h) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+
     def fetch(self):
         outs = (DocOut * max(self.n, 1))()
         if self.b.fetch(self.h, outs) != 0:
@@ -137,7 +147,8 @@ class Context:
         return self.fetch()
 
     def set_profiling(self, on=True):
-        self.b.set_profiling(self.h, 1 if on else 0)
+        """False/0 off | True/1 stage events with the context's streams run one after the other | 2 events, streams overlapped"""
+        self.b.set_profiling(self.h, int(on))
 
     def stats(self):
         s = RunStats()

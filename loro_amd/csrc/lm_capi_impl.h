@@ -14,10 +14,13 @@ struct lm_ctx_impl {
   std::vector<uint32_t> first;     // first[p] = first document of part p; first[n_parts] = n_docs
   uint32_t n_docs = 0;
   uint32_t want_parts = 2, part_min_docs = 128;
-  bool profiling = false;
+  int profiling = 0;               // 0 off | 1 stage events, streams one after the other | 2 stage events, streams overlapped
   bool ran = false;
   std::vector<lm::KernelTime> times;
   std::string err;
+  std::thread runner;              // lm_run_async: the run in flight
+  std::string async_err;
+  bool in_flight = false;
 
   lm_ctx_impl() {
     if (const char* e = getenv("LM_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= (int)LM_MAX_PARTS) want_parts = (uint32_t)v; }
@@ -25,6 +28,7 @@ struct lm_ctx_impl {
     parts.emplace_back(new lm::Engine());
     first = {0, 0};
   }
+  ~lm_ctx_impl() { if (runner.joinable()) runner.join(); }
   uint32_t n_parts() const { return (uint32_t)first.size() - 1; }
 
   void stage(const lm::Engine::DocIn* docs, size_t n) {
@@ -47,11 +51,11 @@ struct lm_ctx_impl {
   }
   void run() {
     uint32_t np = n_parts();
-    for (uint32_t p = 0; p < np; p++) parts[p]->profiling = profiling;
+    for (uint32_t p = 0; p < np; p++) parts[p]->profiling = profiling != 0;
     std::vector<std::string> errs(np);
     auto body = [&](uint32_t p) { try { parts[p]->run(); } catch (const std::exception& e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "error"; } };
 #ifdef LM_PARALLEL_PARTS
-    if (profiling) {
+    if (profiling == 1) {
       // stage timing: one part after the other, so a kernel's duration is its own and not a function of whatever the
       // other stream happened to run beside it (overlapped, the same kernel measures anywhere between 26 and 33 ms)
       for (uint32_t p = 0; p < np; p++) body(p);
@@ -100,6 +104,31 @@ int LM_API(stage)(void* c, const lm_doc_in_c* docs, size_t n) {
 int LM_API(run)(void* c) {
   auto* x = (lm_ctx_impl*)c;
   try { x->run(); return 0; } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
+// Asynchronous form of lm_run: returns at once, the pipeline runs on the context's own host threads and HIP streams.
+// A server keeps two contexts in flight (double buffering): while one batch is in its integrate kernels the next
+// batch's decode stages run beside it.  lm_wait blocks until the run is finished and reports its result.
+int LM_API(run_async)(void* c) {
+  auto* x = (lm_ctx_impl*)c;
+  if (x->in_flight) { x->err = "lm_run_async: a run is already in flight"; return -1; }
+  if (x->runner.joinable()) x->runner.join();
+  x->async_err.clear();
+  x->in_flight = true;
+  auto job = [x]() { try { x->run(); } catch (const std::exception& e) { x->async_err = e.what(); if (x->async_err.empty()) x->async_err = "error"; } };
+#ifdef LM_PARALLEL_PARTS
+  try { x->runner = std::thread(job); } catch (const std::exception& e) { x->in_flight = false; x->err = e.what(); return -1; }
+#else
+  job();   // the kernel-logic test harness is single-threaded: the run completes here, lm_wait only reports it
+#endif
+  return 0;
+}
+int LM_API(wait)(void* c) {
+  auto* x = (lm_ctx_impl*)c;
+  if (!x->in_flight) return 0;
+  if (x->runner.joinable()) x->runner.join();
+  x->in_flight = false;
+  if (!x->async_err.empty()) { x->err = x->async_err; return -1; }
+  return 0;
 }
 int LM_API(fetch)(void* c, lm_doc_out_c* outs) {
   auto* x = (lm_ctx_impl*)c;
@@ -173,7 +202,7 @@ int LM_API(prof_sum)(void* c, uint64_t* out16) {
   }
   return any ? 0 : -1;
 }
-int LM_API(set_profiling)(void* c, int en) { ((lm_ctx_impl*)c)->profiling = en != 0; return 0; }
+int LM_API(set_profiling)(void* c, int en) { ((lm_ctx_impl*)c)->profiling = en < 0 ? 0 : (en > 2 ? 2 : en); return 0; }
 int LM_API(kernel_time)(void* c, uint32_t i, const char** name, double* ms) {
   auto* x = (lm_ctx_impl*)c;
   if (i >= x->times.size()) return -1;

@@ -264,3 +264,22 @@ def test_damaged_blobs_never_take_the_batch_down():
             assert got[k] == want[k] and want[k][0] == 0      # the healthy neighbour
             k += 1
     assert n_both_ok > 0 and n_same >= 0.8 * n_both_ok
+
+
+def test_run_async_and_wait_with_two_contexts():
+    """lm_run_async / lm_wait: two contexts alternate (the double-buffered serving loop of bench.py)."""
+    from loro_amd._cabi import Context
+    docs_a = _cases.fuzz_docs(6, base=7100)
+    docs_b = _cases.fuzz_docs(6, base=7200)
+    want_a, want_b = _oracle.merge_batch(docs_a), _oracle.merge_batch(docs_b)
+    with Context(_emu.binding()) as a, Context(_emu.binding()) as b:
+        a.stage(docs_a); b.stage(docs_b)
+        for _ in range(3):
+            a.run_async(); b.run_async()
+            a.wait(); b.wait()
+        a.wait()                                   # waiting with nothing in flight is a no-op
+        assert a.fetch() == want_a and b.fetch() == want_b
+        a.run_async()
+        with pytest.raises(RuntimeError):
+            a.run_async()                          # one run in flight per context
+        a.wait()

@@ -207,3 +207,21 @@ def test_damaged_blobs_never_take_the_batch_down(engine):
             assert got[k] == want[k] and want[k][0] == 0      # the healthy neighbour
             k += 1
     assert n_both_ok > 0 and n_same >= 0.8 * n_both_ok
+
+
+def test_two_contexts_in_flight(engine):
+    """lm_run_async / lm_wait on real host threads and HIP streams: two contexts alternate like bench.py's serving loop."""
+    import loro_amd
+    tpl = workload.Cfg2Template(6000, 3000, seed=3, commit_every=10, fuse=True)
+    docs_a = [tpl.stamp(d) for d in range(600)]
+    docs_b = _cases.cfg4_docs(40, first=2000, n_steps=300) * 8
+    want_a = _oracle.merge_batch(docs_a[:24], threads=8)
+    want_b = _oracle.merge_batch(docs_b[:40], threads=8)
+    with loro_amd.MergeEngine(0) as b:
+        engine.stage(docs_a); b.stage(docs_b)
+        for _ in range(4):
+            engine.run_async(); b.run_async()
+            engine.wait(); b.wait()
+        ra, rb = engine.fetch(), b.fetch()
+    assert ra[:24] == want_a and all(r[0] == 0 for r in ra)
+    assert rb[:40] == want_b and rb[40:80] == want_b
