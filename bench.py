@@ -233,6 +233,8 @@ def main():
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(alg_per_launch), "launches_per_step": n_streams, "kernel_ms": round(kavg[dom], 3),
+                "kernel_ms_alone": round(kalone.get(dom, 0.0), 3),
+                "frac_alone": round(alg_per_launch / (kalone[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kalone.get(dom) else None,
                 "pipeline_achieved": round(alg_bytes / (dt / args.steps) / 1e9, 2),
             },
             "kernels_ms_per_launch": {k: round(v, 3) for k, v in kavg.items()},

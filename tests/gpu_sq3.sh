@@ -1,0 +1,12 @@
+#!/bin/bash
+# ad-hoc: instruction-cache / scalar-cache counters of k_integrate (run on the GPU box through gpurun)
+R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof_sq3
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $R/gpurun_out/prof_sq3 -o sq -- python $R/tests/gpu_probe.py ${1:-5000} 50000 > $R/gpurun_out/sq3.log 2>&1
+python3 - <<PY
+import sqlite3
+c=sqlite3.connect('$R/gpurun_out/prof_sq3/sq_results.db')
+n=${1:-5000}
+for r in c.execute("select counter_name, avg(value) from counters_collection where kernel_name='k_integrate' group by counter_name"): print(r[0], 'per doc %.3e'%(r[1]/n))
+PY
+grep -E "k_integrate" $R/gpurun_out/sq3.log
