@@ -1,7 +1,7 @@
 """Ad-hoc: thread scaling of the CPU oracle on the configs[1] documents (run on the measurement box)."""
 import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import _oracle
 from loro_amd import workload
 tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)

@@ -2,8 +2,8 @@
 the decoder is reached, and run them through the kernel-logic harness (optionally an ASan build) and the oracle.
 Requirement: no crash / out-of-bounds access, and a document the oracle accepts must never come back different."""
 import sys, os, random, struct, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import _oracle, _fuzz, _cases
 from loro_amd import wire
 from loro_amd._cabi import Binding, Context

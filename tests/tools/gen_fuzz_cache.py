@@ -1,8 +1,8 @@
 """Pre-generate a large fuzz corpus (docs + optional checkout frontiers + oracle answers) into tests/_fuzz_cache.pkl so a
 GPU box only has to run the engine (generation is CPU-bound Python).  Ad-hoc tool; the cache is not committed."""
 import sys, os, pickle, random, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import _oracle, _fuzz
 from loro_amd import wire
 
@@ -31,4 +31,4 @@ for i in range(n):
 print("generated %d sessions → %d cases in %.0fs" % (n, len(docs), time.time() - t), flush=True)
 want = _oracle.merge_batch(docs, threads=8, frontiers=fronts)
 print("oracle statuses", sorted(set(w[0] for w in want)))
-pickle.dump((docs, fronts, want), open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "_fuzz_cache.pkl"), "wb"))
+pickle.dump((docs, fronts, want), open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_fuzz_cache.pkl"), "wb"))

@@ -1,7 +1,7 @@
 """Ad-hoc GPU probe: BASELINE.json configs[2] (LWW map, 16 peers x 10k writes) and configs[3] (mixed containers)."""
 import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import loro_amd
 from loro_amd import workload
 import _oracle, _fuzz

@@ -1,7 +1,7 @@
 """Ad-hoc GPU fuzz campaign: random multi-peer sessions of varied shapes, HIP path vs oracle."""
 import sys, time, os, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import loro_amd
 import _oracle, _fuzz
 

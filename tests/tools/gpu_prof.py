@@ -1,10 +1,10 @@
 """Ad-hoc: cycle accounting of k_integrate from the LM_PROF build (loro_amd/csrc/libloromerge_prof.so)."""
 import sys, os, ctypes, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from loro_amd._cabi import Binding, Context
 from loro_amd import workload
 
-so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "loro_amd", "csrc", "libloromerge_prof.so")
+so = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "loro_amd", "csrc", "libloromerge_prof.so")
 b = Binding(so, "lm_")
 b.lib.lm_prof_sum.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
 n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 256

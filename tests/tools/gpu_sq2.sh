@@ -2,7 +2,7 @@
 # ad-hoc: wave-state counters of k_integrate (run on the GPU box through gpurun)
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_sq2
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU -d $R/gpurun_out/prof_sq2 -o sq -- python $R/tools/gpu_probe.py ${1:-5000} 50000 > $R/gpurun_out/sq2.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU -d $R/gpurun_out/prof_sq2 -o sq -- python $R/tests/tools/gpu_probe.py ${1:-5000} 50000 > $R/gpurun_out/sq2.log 2>&1
 python3 - <<PY
 import sqlite3
 c=sqlite3.connect('$R/gpurun_out/prof_sq2/sq_results.db')

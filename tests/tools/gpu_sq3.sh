@@ -2,7 +2,7 @@
 # ad-hoc: instruction-cache / scalar-cache counters of k_integrate (run on the GPU box through gpurun)
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_sq3
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $R/gpurun_out/prof_sq3 -o sq -- python $R/tools/gpu_probe.py ${1:-5000} 50000 > $R/gpurun_out/sq3.log 2>&1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $R/gpurun_out/prof_sq3 -o sq -- python $R/tests/tools/gpu_probe.py ${1:-5000} 50000 > $R/gpurun_out/sq3.log 2>&1
 python3 - <<PY
 import sqlite3
 c=sqlite3.connect('$R/gpurun_out/prof_sq3/sq_results.db')

@@ -1,7 +1,7 @@
 """Ad-hoc GPU probe: throughput of configs[1] vs the number of streams a context splits the batch into."""
 import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import loro_amd
 from loro_amd import workload
 import _oracle
