@@ -19,6 +19,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   const uint32_t* blob_len;   // [n_blobs] exact byte length
   const uint32_t* doc_blob;   // [n_docs+1] first blob of each doc
   uint32_t n_blobs, n_docs;
+  uint32_t span;              // 1: leaves hold runs (lm_k_integrate_span.h, SP_REC dwords per leaf), 0: one element per slot
   const uint8_t* front;       // optional checkout frontiers (postcard Vec<ID>), front_off[n_docs+1]; empty range = latest
   const uint64_t* front_off;
   // per blob

@@ -7,7 +7,7 @@
 //   VersionVector::encode                     loro-internal/src/version.rs:962-964 (entries sorted by peer here)
 #pragma once
 #include "lm_f64.h"
-#include "lm_k_integrate.h"
+#include "lm_k_integrate_span.h"
 
 namespace lm {
 
@@ -404,7 +404,43 @@ LM_DEV void emit_doc(Dev d, int mode) {
       lmw::block_sync();
       uint32_t cidx = s_frame[4 * (sp - 1)], fa = s_frame[4 * (sp - 1) + 1], fb = s_frame[4 * (sp - 1) + 2], fc = s_frame[4 * (sp - 1) + 3];
       uint32_t kind = d.cont[m.cid0 + cidx].kind_root & 0xff;
-      if (kind == CK_TEXT) {
+      if (kind == CK_TEXT && d.span) {
+        // span-granular leaves: per leaf, the visible runs are flattened 64 elements per step — lane → (run, offset)
+        // by a search over the running lengths kept in LDS; a run's scalars are consecutive in cp[]
+        sink_byte(s, '"');
+        uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
+        const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
+        LM_SHARED(uint32_t, s_inc, 64);
+        LM_SHARED(uint32_t, s_g0, 64);
+        for (uint32_t ri = 0; ri < nr && !err; ri++) {
+          uint32_t de = dirp[ri];
+          uint32_t L = de_leaf(de), n = de_n(de);
+          const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * SP_REC;
+          bool in = (uint32_t)lane < n;
+          uint32_t id0 = in ? rec[lane] : NONE, ln = in ? rec[64 + lane] : 0u, st = in ? rec[256 + lane] : ST_EVER;
+          uint32_t vl = (in && !(st & ST_EVER)) ? ln : 0u;
+          uint32_t inc = lmw::scan_incl_add(vl);
+          uint32_t total = lmw::bcast(inc, 63);
+          lmw::block_sync();
+          s_inc[lane] = inc;
+          s_g0[lane] = vl ? s_eb[pid_peer(id0)] + pid_ctr(id0) - (inc - vl) : 0u;   // element index minus position: cp index = g0 + position
+          lmw::block_sync();
+          for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+            uint32_t e = e0 + (uint32_t)lane;
+            uint64_t bytes = 0;
+            uint32_t nb = 0;
+            if (e < total) {
+              uint32_t lo = 0, hi = 63;                    // first run whose running length exceeds e
+              while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_inc[mid] > e) hi = mid; else lo = mid + 1; }
+              uint32_t gi = s_g0[lo] + e;                  // 32-bit wrap-around arithmetic: g0 may be "negative"
+              cp_bytes(d.cp[elem0 + gi], bytes, nb);
+            }
+            sink_lanes(s, bytes, nb);
+          }
+        }
+        sink_byte(s, '"');
+        sp--;
+      } else if (kind == CK_TEXT) {
         sink_byte(s, '"');
         uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
         // software pipeline over the leaves, six iterations deep: the directory entry of leaf i+6, the (id, status) of
@@ -440,36 +476,44 @@ LM_DEV void emit_doc(Dev d, int mode) {
         uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
         const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
         bool pushed = false;
-        uint32_t ri = fa, slot0 = fb;
-        for (; ri < nr && !err && !pushed; ri++, slot0 = 0) {
+        uint32_t ri = fa, slot0 = fb, k0 = fc >> 2;   // resume: leaf, slot, element of the slot's run (span-granular leaves)
+        fc &= 3u;
+        for (; ri < nr && !err && !pushed; ri++, slot0 = 0, k0 = 0) {
           uint32_t de = dirp[ri];
           uint32_t L = de_leaf(de), n = de_n(de);
-          uint32_t id = NONE, st = ST_EVER;
-          if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * 256; id = rec[lane]; st = rec[192 + lane]; }
+          uint32_t id = NONE, st = ST_EVER, ln = 1;
+          if ((uint32_t)lane < n) {
+            const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * (d.span ? SP_REC : 256u);
+            id = rec[lane];
+            if (d.span) { ln = rec[64 + lane]; st = rec[256 + lane]; } else st = rec[192 + lane];
+          }
           bool vis = id != NONE && !(st & ST_EVER) && (uint32_t)lane >= slot0;
-          uint32_t payload = vis ? d.cp[elem0 + d.elem_base[m.praw0 + pid_peer(id)] + pid_ctr(id)] : 0u;
           uint64_t vm = lmw::ballot(vis);
-          while (vm && !err) {
+          while (vm && !err && !pushed) {
             int l0 = lmw::ffs64(vm);
             vm &= vm - 1;
-            uint32_t off = lmw::bcast(payload, l0);
-            if (!(fc & 1)) sink_byte(s, ',');
-            fc &= ~1u;
-            Rd r = rd_make(d.data + doc_data0 + off, doc_end - (doc_data0 + off));
-            if (r.p < r.end && *r.p == 9) {   // child container created by this list element
-              (void)rd_u8(r);
-              uint32_t ckind = rd_u8(r);
-              uint32_t eid = lmw::bcast(id, l0);
-              uint32_t child = find_child(pid_peer(eid), pid_ctr(eid), ckind);
-              if (child == NONE) { empty_child(ckind); continue; }
-              if (sp >= (int)EMIT_MAX_DEPTH) { err = ST_UNSUPPORTED; break; }
-              frame_set(sp - 1, cidx, ri, (uint32_t)l0 + 1, fc);
-              frame_set(sp, child, 0, 0, 0x3);
-              sp++;
-              pushed = true;
-              break;
+            uint32_t eid0 = lmw::bcast(id, l0), elen = lmw::bcast(ln, l0);
+            uint64_t g = elem0 + s_eb[pid_peer(eid0)] + pid_ctr(eid0);
+            for (uint32_t k = ((uint32_t)l0 == slot0 ? k0 : 0u); k < elen && !err; k++) {
+              uint32_t off = d.cp[g + k];
+              if (!(fc & 1)) sink_byte(s, ',');
+              fc &= ~1u;
+              Rd r = rd_make(d.data + doc_data0 + off, doc_end - (doc_data0 + off));
+              if (r.p < r.end && *r.p == 9) {   // child container created by this list element
+                (void)rd_u8(r);
+                uint32_t ckind = rd_u8(r);
+                uint32_t eid = eid0 + k;
+                uint32_t child = find_child(pid_peer(eid), pid_ctr(eid), ckind);
+                if (child == NONE) { empty_child(ckind); continue; }
+                if (sp >= (int)EMIT_MAX_DEPTH) { err = ST_UNSUPPORTED; break; }
+                frame_set(sp - 1, cidx, ri, (uint32_t)l0, fc | ((k + 1) << 2));
+                frame_set(sp, child, 0, 0, 0x3);
+                sp++;
+                pushed = true;
+                break;
+              }
+              sink_value(s, r, err, d, NONE, m.blk0, m.n_blk);   // the item's block is found only if its key table is needed
             }
-            sink_value(s, r, err, d, NONE, m.blk0, m.n_blk);   // the item's block is found only if its key table is needed
           }
         }
         if (!pushed && !err) { sink_byte(s, ']'); sp--; }

@@ -624,7 +624,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
   // the element map starts empty (this wave owns it: no separate fill pass over the whole batch)
   for (uint32_t i = (uint32_t)lane; i < m.atoms; i += 64) d.loc[elem0 + i] = NONE;
   if (retry_pass) {
-    for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) d.cont[m.cid0 + c].touched = 0;
+    for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {   // sequence containers only: a Map's flag belongs to k_map_lww
+      uint32_t ck = d.cont[m.cid0 + c].kind_root & 0xff;
+      if (ck == CK_TEXT || ck == CK_LIST) d.cont[m.cid0 + c].touched = 0;
+    }
     lmw::block_sync();  // every lane has read the status before it is cleared
     if (lane == 0) d.doc[doc].status = ST_OK;
     m.status = ST_OK;

@@ -1,0 +1,575 @@
+// Integrate stage, span-granular variant (selected with LM_SPAN=1 until it replaces lm_k_integrate.h).
+// Same replay as lm_k_integrate.h — one wavefront per document, Event-Graph-Walker over every Text / List container —
+// but a leaf slot holds a RUN of elements (the reference's FugueSpan, container/richtext/fugue_span.rs:191-279):
+//   id0 (peer:8 | counter:24), len, origin_left (of the first element), origin_right (shared), status (shared);
+//   element k > 0 of a run has origin_left = id0 + k - 1.
+// A document typed in runs of ≈20 characters needs ≈10x fewer leaves than with one slot per element: the LDS directory
+// shrinks to a few hundred entries (searched linearly, 64 entries per step), a concurrent run of the other peer is ONE
+// item for the sibling scan instead of a chain of leaves, and the emit stage streams runs.
+// Reference algorithm: container/richtext/tracker.rs:88-160,193-252,354-546, tracker/crdt_rope.rs:63-247,256-381.
+#pragma once
+#include "lm_k_integrate.h"
+
+namespace lm {
+
+static constexpr uint32_t SP_REC = 320;   // dwords per leaf record: id0[64] | len[64] | origin_left[64] | origin_right[64] | status[64]
+// directory word A: leaf (17 bits) | holds a non-future item (bit 17) | item count (7 bits at 18) ; word B: active length
+LM_DEV uint32_t sa_make(uint32_t leaf, uint32_t n, bool nf) { return leaf | (nf ? DIR_NF : 0u) | (n << 18); }
+LM_DEV uint32_t sa_leaf(uint32_t a) { return a & DIR_LEAF_MASK; }
+LM_DEV uint32_t sa_n(uint32_t a) { return (a >> 18) & 0x7f; }
+LM_DEV bool sa_nf(uint32_t a) { return (a & DIR_NF) != 0; }
+
+struct SpanRegs { uint32_t n, id, len, ol, orr, st; };   // one leaf in registers: lane i holds item i
+struct SpanItem { uint32_t id, len, ol, orr, st; };
+
+struct Ts {   // wave-uniform context of one (document, sequence container) replay
+  uint32_t* it;                   // HBM leaf records of the document: [leaf * SP_REC + field * 64 + slot]
+  uint32_t* loc;                  // doc element → leaf
+  const uint32_t* ebase;          // LDS: element base per peer
+  const uint32_t* cur;            // LDS: tracker version per peer at the head of the node being replayed
+  uint32_t* da;                   // LDS directory, word A per leaf in document order
+  uint32_t* db;                   // LDS directory, word B (active length)
+  uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
+  uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); write-through
+  SpanRegs cr;
+  int32_t err;
+};
+
+LM_DEV uint32_t ts_g(const Ts& t, uint32_t pid) { return t.ebase[pid_peer(pid)] + pid_ctr(pid); }
+LM_DEV bool sp_has(uint32_t id0, uint32_t len, uint32_t x) { return x >= id0 && x - id0 < len; }   // element x inside the run (same peer implied)
+
+// ---- leaf access
+LM_DEV SpanRegs sp_load(const Ts& t, uint32_t L, uint32_t n) {
+  int lane = lmw::lane();
+  lmw::wave_sync();
+  if (L == t.cache_leaf) return t.cr;
+  SpanRegs r;
+  r.n = n;
+  bool in = (uint32_t)lane < n;
+  const uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+  r.id = in ? rec[lane] : NONE;
+  r.len = in ? rec[64 + lane] : 0u;
+  r.ol = in ? rec[128 + lane] : NONE;
+  r.orr = in ? rec[192 + lane] : NONE;
+  r.st = in ? rec[256 + lane] : ST_FUT;
+  return r;
+}
+// store lanes [from, R.n) of leaf L and make it the cached leaf
+LM_DEV void sp_store(Ts& t, uint32_t L, const SpanRegs& R, uint32_t from) {
+  int lane = lmw::lane();
+  if ((uint32_t)lane < R.n && (uint32_t)lane >= from) {
+    uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+    rec[lane] = R.id; rec[64 + lane] = R.len; rec[128 + lane] = R.ol; rec[192 + lane] = R.orr; rec[256 + lane] = R.st;
+  }
+  t.cache_leaf = L;
+  t.cr = R;
+}
+LM_DEV uint32_t sp_alen(const SpanRegs& R) { return ((uint32_t)lmw::lane() < R.n && st_active(R.st)) ? R.len : 0u; }
+LM_DEV bool sp_nf(const SpanRegs& R) { return lmw::ballot((uint32_t)lmw::lane() < R.n && !(R.st & ST_FUT)) != 0; }
+// loc[] of every element of one item := leaf L
+LM_DEV void sp_set_loc(Ts& t, uint32_t id0, uint32_t len, uint32_t L) {
+  uint32_t g = ts_g(t, id0);
+  for (uint32_t k = (uint32_t)lmw::lane(); k < len; k += 64) t.loc[g + k] = L;
+}
+
+// ---- directory (LDS, a few hundred entries: linear, 64 per step)
+LM_DEV void sd_set(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
+  lmw::wave_sync();
+  uint32_t old = t.db[p];
+  lmw::wave_sync();
+  if (lmw::lane() == 0) { t.da[p] = a; t.db[p] = b; }
+  t.tot_active += b - old;
+  lmw::wave_sync();
+}
+LM_DEV void sd_insert_after(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
+  int lane = lmw::lane();
+  if (t.n_dir >= t.dir_cap) { t.err = ST_RETRY; return; }
+  lmw::wave_sync();
+  uint32_t q = p + 1;
+  for (uint32_t hi = t.n_dir; hi > q;) {
+    uint32_t c0 = hi > q + 64 ? hi - 64 : q;
+    uint32_t i = c0 + (uint32_t)lane;
+    bool in = i < hi;
+    uint32_t va = in ? t.da[i] : 0u, vb = in ? t.db[i] : 0u;
+    lmw::wave_sync();
+    if (in) { t.da[i + 1] = va; t.db[i + 1] = vb; }
+    lmw::wave_sync();
+    hi = c0;
+  }
+  if (lane == 0) { t.da[q] = a; t.db[q] = b; }
+  t.n_dir++;
+  t.tot_active += b;
+  lmw::wave_sync();
+}
+// k-th active element (1 <= k <= tot_active) → directory position; k becomes the rank inside that leaf
+LM_DEV uint32_t sd_find_kth(const Ts& t, uint32_t& k) {
+  int lane = lmw::lane();
+  lmw::wave_sync();
+  for (uint32_t i0 = 0; i0 < t.n_dir; i0 += 64) {
+    uint32_t i = i0 + (uint32_t)lane;
+    uint32_t a = i < t.n_dir ? t.db[i] : 0u;
+    uint32_t inc = lmw::scan_incl_add(a);
+    uint64_t m = lmw::ballot(inc >= k);
+    if (m) {
+      int s = lmw::ffs64(m);
+      k -= lmw::bcast(inc, s) - lmw::bcast(a, s);
+      return i0 + (uint32_t)s;
+    }
+    k -= lmw::bcast(inc, 63);
+  }
+  return NONE;
+}
+LM_DEV uint32_t sd_find_leaf(const Ts& t, uint32_t L) {
+  int lane = lmw::lane();
+  lmw::wave_sync();
+  for (uint32_t i0 = 0; i0 < t.n_dir; i0 += 64) {
+    uint32_t i = i0 + (uint32_t)lane;
+    uint64_t m = lmw::ballot(i < t.n_dir && sa_leaf(t.da[i]) == L);
+    if (m) return i0 + (uint32_t)lmw::ffs64(m);
+  }
+  return NONE;
+}
+LM_DEV void sd_refresh(Ts& t, uint32_t p, uint32_t L, const SpanRegs& R) {   // directory entry of leaf L from its registers
+  sd_set(t, p, sa_make(L, R.n, sp_nf(R)), lmw::reduce_add(sp_alen(R)));
+}
+
+// ---- leaf edits
+// Insert `it` as item `idx` of the leaf at directory position p (registers R).  A full leaf is split in half first.
+// `dirty_from` = lowest lane of R the caller modified in registers (R.n if none).  `new_elems`: the item's elements are
+// new to this container (loc[] must be written); otherwise it is the right part of a split and only needs loc[] when it
+// lands in another leaf.  On return (p, idx) address the inserted item and R holds its leaf.
+LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& it, uint32_t dirty_from, bool new_elems) {
+  int lane = lmw::lane();
+  lmw::wave_sync();
+  uint32_t a0 = lmw::first(t.da[p]);
+  uint32_t L = sa_leaf(a0);
+  bool moved = false;   // the item ends up in a leaf other than L
+  if (R.n >= 64) {
+    if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    uint32_t NL = t.n_leaf++;
+    SpanRegs U;   // upper half → new leaf
+    U.n = 32;
+    U.id = lmw::shfl(R.id, (lane + 32) & 63); U.len = lmw::shfl(R.len, (lane + 32) & 63); U.ol = lmw::shfl(R.ol, (lane + 32) & 63);
+    U.orr = lmw::shfl(R.orr, (lane + 32) & 63); U.st = lmw::shfl(R.st, (lane + 32) & 63);
+    if (lane >= 32) { U.id = NONE; U.len = 0; U.ol = NONE; U.orr = NONE; U.st = ST_FUT; }
+    SpanRegs Lo = R;
+    Lo.n = 32;
+    if (lane >= 32) { Lo.id = NONE; Lo.len = 0; Lo.ol = NONE; Lo.orr = NONE; Lo.st = ST_FUT; }
+    for (int j = 0; j < 32; j++) sp_set_loc(t, lmw::bcast(U.id, j), lmw::bcast(U.len, j), NL);
+    if (idx > 32 || (idx == 32 && dirty_from >= 32)) {
+      // the edit goes to the upper half: the lower half only needs its modified lanes stored
+      sp_store(t, L, Lo, dirty_from < 32 ? dirty_from : 32);
+      sd_refresh(t, p, L, Lo);
+      sd_insert_after(t, p, sa_make(NL, 32, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
+      if (t.err) return;
+      sp_store(t, NL, U, 0);
+      p = p + 1; idx -= 32; R = U; L = NL;
+      dirty_from = 0;
+      moved = true;
+    } else {
+      sp_store(t, NL, U, 0);
+      sd_insert_after(t, p, sa_make(NL, 32, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
+      if (t.err) return;
+      R = Lo;
+      if (dirty_from > 32) dirty_from = 32;
+    }
+  }
+  // shift lanes >= idx up by one and drop the item in
+  SpanRegs N;
+  N.n = R.n + 1;
+  uint32_t pid = lmw::shfl_up(R.id, 1), pln = lmw::shfl_up(R.len, 1), pol = lmw::shfl_up(R.ol, 1), por = lmw::shfl_up(R.orr, 1), pst = lmw::shfl_up(R.st, 1);
+  bool sh = (uint32_t)lane > idx;
+  N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
+  if ((uint32_t)lane == idx) { N.id = it.id; N.len = it.len; N.ol = it.ol; N.orr = it.orr; N.st = it.st; }
+  if ((uint32_t)lane >= N.n) { N.id = NONE; N.len = 0; N.ol = NONE; N.orr = NONE; N.st = ST_FUT; }
+  sp_store(t, L, N, dirty_from < idx ? dirty_from : idx);
+  if (new_elems || moved) sp_set_loc(t, it.id, it.len, L);
+  sd_refresh(t, p, L, N);
+  R = N;
+}
+
+// split item `slot` of the leaf at p at element offset `off` (0 < off < len); afterwards (p, slot) address the RIGHT part
+LM_DEV void sp_split_at(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& slot, uint32_t off) {
+  int lane = lmw::lane();
+  SpanItem rt;
+  uint32_t id0 = lmw::bcast(R.id, (int)slot), ln = lmw::bcast(R.len, (int)slot);
+  rt.id = id0 + off; rt.len = ln - off; rt.ol = id0 + off - 1; rt.orr = lmw::bcast(R.orr, (int)slot); rt.st = lmw::bcast(R.st, (int)slot);
+  if ((uint32_t)lane == slot) R.len = off;
+  uint32_t idx = slot + 1;
+  sp_insert_item(t, p, R, idx, rt, slot, false);
+  slot = idx;
+}
+
+// ---- insert (Fugue integrate, crdt_rope.rs:63-247) of run [pid0, pid0+len) at active position pos
+LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
+  int lane = lmw::lane();
+  if (pos > t.tot_active) pos = t.tot_active;
+  uint32_t p = 0, idx = 0, origin_left = NONE;
+  SpanRegs R;
+  SpanItem nw;
+  nw.id = pid0; nw.len = len; nw.st = 0;
+  if (pos == 0) {
+    R = sp_load(t, sa_leaf(lmw::first(t.da[0])), sa_n(lmw::first(t.da[0])));
+  } else {
+    uint32_t k = pos;
+    p = sd_find_kth(t, k);
+    if (p == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    lmw::wave_sync();
+    uint32_t a = lmw::first(t.da[p]);
+    R = sp_load(t, sa_leaf(a), sa_n(a));
+    uint32_t al = sp_alen(R);
+    uint32_t inc = lmw::scan_incl_add(al);
+    uint64_t hit = lmw::ballot(al != 0 && inc >= k);
+    if (!hit) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    uint32_t slot = (uint32_t)lmw::ffs64(hit);
+    uint32_t off = k - (lmw::bcast(inc, (int)slot) - lmw::bcast(al, (int)slot));   // 1..len: cursor right after element off-1
+    uint32_t sid = lmw::bcast(R.id, (int)slot), sln = lmw::bcast(R.len, (int)slot);
+    origin_left = sid + off - 1;
+    if (off < sln) {
+      // cursor inside an active run: the run's next element is the (non-future) origin_right, nothing lies in between
+      sp_split_at(t, p, R, slot, off);
+      if (t.err) return;
+      nw.ol = origin_left; nw.orr = sid + off;
+      idx = slot;
+      sp_insert_item(t, p, R, idx, nw, R.n, true);
+      return;
+    }
+    idx = slot + 1;
+  }
+  // origin_right = first non-future item at/after the cursor; items before it are "in between"
+  uint32_t origin_right = NONE, r_ol = NONE, r_p = NONE, r_slot = 0;
+  bool between = false;
+  SpanRegs RR = R;
+  {
+    uint64_t nf = lmw::ballot((uint32_t)lane >= idx && (uint32_t)lane < R.n && !(R.st & ST_FUT));
+    if (nf) {
+      r_p = p; r_slot = (uint32_t)lmw::ffs64(nf);
+      if (r_slot > idx) between = true;
+    } else {
+      if (R.n > idx) between = true;
+      lmw::wave_sync();
+      for (uint32_t q0 = p + 1; q0 < t.n_dir && r_p == NONE; q0 += 64) {
+        uint32_t q = q0 + (uint32_t)lane;
+        uint64_t hm = lmw::ballot(q < t.n_dir && sa_nf(t.da[q]));
+        if (hm) r_p = q0 + (uint32_t)lmw::ffs64(hm);
+      }
+      if (r_p != NONE) {
+        if (r_p > p + 1) between = true;
+        uint32_t a = lmw::first(t.da[r_p]);
+        RR = sp_load(t, sa_leaf(a), sa_n(a));
+        uint64_t nf2 = lmw::ballot((uint32_t)lane < RR.n && !(RR.st & ST_FUT));
+        if (!nf2) { LM_SETERR(t.err, ST_INTERNAL); return; }
+        r_slot = (uint32_t)lmw::ffs64(nf2);
+        if (r_slot > 0) between = true;
+      } else if (p + 1 < t.n_dir) between = true;
+    }
+    if (r_p != NONE) { origin_right = lmw::bcast(RR.id, (int)r_slot); r_ol = lmw::bcast(RR.ol, (int)r_slot); }
+  }
+  uint32_t ins_p = p, ins_idx = idx;
+  if (between) {
+    // sibling scan over the future ITEMS between the cursor and origin_right (crdt_rope.rs:156-237); the elements inside a
+    // run are continuations by construction, so every item is examined exactly once through its first element
+    bool parent_right = origin_right != NONE && r_ol == origin_left;
+    bool scanning = false, stop = false;
+    uint32_t my_peer = pid_peer(pid0);
+    uint32_t cp = p, ci = idx;
+    SpanRegs C = R;
+    for (uint32_t guard = 0; guard <= t.n_dir && !t.err && !stop; guard++) {
+      uint32_t limit = (origin_right != NONE && cp == r_p) ? r_slot : C.n;
+      for (uint32_t h = ci; h < limit && !stop && !t.err; h++) {
+        uint32_t o_id = lmw::bcast(C.id, (int)h), o_ol = lmw::bcast(C.ol, (int)h), o_or = lmw::bcast(C.orr, (int)h);
+        if (o_ol != origin_left) {
+          // is o_ol one of the in-between elements already passed?  (inside an item at a position in [cursor, (cp,h)))
+          bool visited = false;
+          uint64_t here = lmw::ballot((uint32_t)lane < C.n && pid_peer(C.id) == pid_peer(o_ol) && sp_has(C.id, C.len, o_ol));
+          uint64_t in_r = cp != p ? lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == pid_peer(o_ol) && sp_has(R.id, R.len, o_ol)) : 0ull;
+          if (o_ol == NONE) visited = false;
+          else if (here) { uint32_t xs = (uint32_t)lmw::ffs64(here); visited = xs < h && (cp != p || xs >= idx); }
+          else if (in_r) visited = (uint32_t)lmw::ffs64(in_r) >= idx;
+          else if (pid_ctr(o_ol) < t.cur[pid_peer(o_ol)]) visited = false;   // inside the tracker's version: not future
+          else {
+            lmw::wave_sync();
+            uint32_t xl = t.loc[ts_g(t, o_ol)];
+            if (xl < t.n_leaf) { uint32_t xp = sd_find_leaf(t, xl); visited = xp != NONE && xp > p && xp < cp; }
+          }
+          if (!visited) { stop = true; break; }
+        } else {
+          if (o_or == origin_right) {
+            if (pid_peer(o_id) > my_peer) { stop = true; break; }
+            scanning = false;
+          } else {
+            // the other item's right parent (crdt_rope.rs:205-216): its origin_right if that element is a sibling too
+            uint32_t opr = NONE, o_p = NONE, o_s = 0;
+            if (o_or != NONE) {
+              uint32_t x_ol = NONE;
+              uint64_t hc = lmw::ballot((uint32_t)lane < C.n && pid_peer(C.id) == pid_peer(o_or) && sp_has(C.id, C.len, o_or));
+              uint64_t hr = (!hc && cp != p) ? lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == pid_peer(o_or) && sp_has(R.id, R.len, o_or)) : 0ull;
+              uint64_t hq = (!hc && !hr && r_p != NONE && r_p != cp && r_p != p) ? lmw::ballot((uint32_t)lane < RR.n && pid_peer(RR.id) == pid_peer(o_or) && sp_has(RR.id, RR.len, o_or)) : 0ull;
+              if (hc) { o_s = (uint32_t)lmw::ffs64(hc); o_p = cp; x_ol = lmw::bcast(C.id, (int)o_s) == o_or ? lmw::bcast(C.ol, (int)o_s) : o_or - 1; }
+              else if (hr) { o_s = (uint32_t)lmw::ffs64(hr); o_p = p; x_ol = lmw::bcast(R.id, (int)o_s) == o_or ? lmw::bcast(R.ol, (int)o_s) : o_or - 1; }
+              else if (hq) { o_s = (uint32_t)lmw::ffs64(hq); o_p = r_p; x_ol = lmw::bcast(RR.id, (int)o_s) == o_or ? lmw::bcast(RR.ol, (int)o_s) : o_or - 1; }
+              else {
+                lmw::wave_sync();
+                uint32_t xl = t.loc[ts_g(t, o_or)];
+                if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
+                uint32_t xp = sd_find_leaf(t, xl);
+                if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
+                SpanRegs X = sp_load(t, xl, sa_n(lmw::first(t.da[xp])));
+                uint64_t xm = lmw::ballot((uint32_t)lane < X.n && pid_peer(X.id) == pid_peer(o_or) && sp_has(X.id, X.len, o_or));
+                if (!xm) { LM_SETERR(t.err, ST_INTERNAL); break; }
+                o_s = (uint32_t)lmw::ffs64(xm); o_p = xp;
+                x_ol = lmw::bcast(X.id, (int)o_s) == o_or ? lmw::bcast(X.ol, (int)o_s) : o_or - 1;
+              }
+              if (x_ol == origin_left) opr = o_or;
+            }
+            int c;
+            if (opr != NONE && parent_right) c = (o_p < r_p || (o_p == r_p && o_s < r_slot)) ? -1 : 1;
+            else if (opr != NONE) c = -1;
+            else if (parent_right) c = 1;
+            else c = 0;
+            if (c < 0) scanning = true;
+            else if (c == 0 && pid_peer(o_id) > my_peer) { stop = true; break; }
+            else scanning = false;
+          }
+        }
+        if (!scanning) { ins_p = cp; ins_idx = h + 1; }
+      }
+      if (stop || t.err) break;
+      if (origin_right != NONE && cp == r_p) break;
+      if (cp + 1 >= t.n_dir) break;
+      cp++; ci = 0;
+      if (origin_right != NONE && cp == r_p) C = RR;
+      else { uint32_t a = lmw::first(t.da[cp]); C = sp_load(t, sa_leaf(a), sa_n(a)); }
+    }
+    if (t.err) return;
+  }
+  nw.ol = origin_left; nw.orr = origin_right;
+  SpanRegs D;
+  if (ins_p == p) D = R;
+  else if (r_p != NONE && ins_p == r_p) D = RR;
+  else { lmw::wave_sync(); uint32_t a = lmw::first(t.da[ins_p]); D = sp_load(t, sa_leaf(a), sa_n(a)); }
+  sp_insert_item(t, ins_p, D, ins_idx, nw, D.n, true);
+}
+
+// ---- status update of the elements with ids [c0,c1) of `peer` (crdt_rope.rs:345-381 by id): walk run by run
+LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int mode) {
+  int lane = lmw::lane();
+  uint32_t eb = t.ebase[peer];
+  uint32_t c = c0;
+  for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
+    lmw::wave_sync();
+    uint32_t x = pid_make(peer, c);
+    uint32_t p;
+    SpanRegs R;
+    uint64_t hm = 0;
+    if (t.cache_leaf != NONE) hm = lmw::ballot((uint32_t)lane < t.cr.n && pid_peer(t.cr.id) == peer && sp_has(t.cr.id, t.cr.len, x));
+    if (hm) { R = t.cr; p = sd_find_leaf(t, t.cache_leaf); }
+    else {
+      uint32_t lf = lmw::first(t.loc[eb + c]);
+      if (lf >= t.n_leaf) { c++; continue; }          // not an element of this container (malformed target): ignored
+      p = sd_find_leaf(t, lf);
+      if (p == NONE) { c++; continue; }                // leaf of another container of the same document
+      R = sp_load(t, lf, sa_n(lmw::first(t.da[p])));
+      hm = lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
+      if (!hm) { c++; continue; }
+    }
+    if (p == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    uint32_t slot = (uint32_t)lmw::ffs64(hm);
+    uint32_t id0 = lmw::bcast(R.id, (int)slot), ln = lmw::bcast(R.len, (int)slot);
+    if (x > id0) { sp_split_at(t, p, R, slot, x - id0); if (t.err) return; id0 = x; ln = lmw::bcast(R.len, (int)slot); }
+    uint32_t endc = pid_ctr(id0) + ln;
+    if (endc > c1) {
+      uint32_t s2 = slot;
+      sp_split_at(t, p, R, s2, c1 - pid_ctr(id0));      // (p, s2) now address the part beyond the range: the part inside sits right before it
+      if (t.err) return;
+      if (s2 == 0) {   // the leaf was split exactly between the two parts: the inside part is the last item of the previous leaf
+        p = p - 1;
+        lmw::wave_sync();
+        uint32_t a = lmw::first(t.da[p]);
+        R = sp_load(t, sa_leaf(a), sa_n(a));
+        slot = R.n - 1;
+      } else slot = s2 - 1;
+      endc = c1;
+    }
+    uint32_t st = R.st;
+    if ((uint32_t)lane == slot) {
+      if (mode == UPD_SET_FUT) st |= ST_FUT;
+      else if (mode == UPD_CLR_FUT) st &= ~ST_FUT;
+      else if (mode == UPD_DEL_INC) st = (st + ST_DEL1) | ST_EVER;
+      else if (st & ST_DELMASK) st -= ST_DEL1;
+    }
+    R.st = st;
+    lmw::wave_sync();
+    uint32_t L = sa_leaf(lmw::first(t.da[p]));
+    if ((uint32_t)lane == slot) t.it[(uint64_t)L * SP_REC + 256 + lane] = st;
+    if (L == t.cache_leaf) t.cr.st = R.st;
+    sd_refresh(t, p, L, R);
+    c = endc;
+  }
+}
+
+// retreat (dir < 0) / forward (dir > 0) every op of `peer` with id in [c0,c1) that belongs to container `cidx`
+LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t peer, uint32_t c0, uint32_t c1, int dir) {
+  uint32_t ci = find_change(d, m, peer, c0);
+  if (ci == NONE) return;
+  uint32_t hi = d.peer_chg1[m.praw0 + peer];
+  for (; ci < hi && !t.err; ci++) {
+    uint32_t crow = d.chg_sorted[m.chg0 + ci];
+    const ChangeRow ch = d.chg[crow];
+    if (ch.ctr >= c1) break;
+    if (!((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1)) continue;
+    uint32_t lo = ch.op0, hr = ch.op0 + ch.n_op;
+    while (lo < hr) { uint32_t mid = (lo + hr) >> 1; if (d.op[mid].ctr + d.op[mid].len <= c0) lo = mid + 1; else hr = mid; }
+    for (uint32_t row = lo; row < ch.op0 + ch.n_op && !t.err; row++) {
+      const OpRow r = d.op[row];
+      if (r.ctr >= c1) break;
+      if ((r.cidx_kind & 0xffff) != cidx) continue;
+      uint32_t kind = (r.cidx_kind >> 16) & 0xff;
+      uint32_t a = (c0 > r.ctr ? c0 : r.ctr) - r.ctr, b = (c1 < r.ctr + r.len ? c1 : r.ctr + r.len) - r.ctr;
+      if (a >= b) continue;
+      if (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END) {
+        ts_update_range(t, peer, r.ctr + a, r.ctr + b, dir < 0 ? UPD_SET_FUT : UPD_CLR_FUT);
+      } else if (kind == OK_DEL) {
+        uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+        uint32_t t0, t1;
+        if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
+        else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
+        ts_update_range(t, r.a0, t0, t1, dir < 0 ? UPD_DEL_DEC : UPD_DEL_INC);
+      }
+    }
+  }
+}
+
+// K9 (span-granular): one wave per document.  Dynamic LDS: [dir_cap] word A, [dir_cap] word B, then 3 × pmax.
+LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate_span(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count) {
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  LM_DYN_SHARED(uint32_t, s_mem);
+  uint32_t* s_da = s_mem;
+  uint32_t* s_db = s_mem + dir_cap;
+  uint32_t* s_ebase = s_db + dir_cap;
+  uint32_t* s_cur = s_ebase + pmax;
+  uint32_t* s_end = s_cur + pmax;
+  DocMeta m = d.doc[doc];
+  uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
+  if (retry_pass && m.status != ST_RETRY) return;
+  if (status_fatal(m.status) && !retry_pass) return;
+  for (uint32_t i = (uint32_t)lane; i < m.atoms; i += 64) d.loc[elem0 + i] = NONE;
+  if (retry_pass) {
+    for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {   // sequence containers only: a Map's flag belongs to k_map_lww
+      uint32_t ck = d.cont[m.cid0 + c].kind_root & 0xff;
+      if (ck == CK_TEXT || ck == CK_LIST) d.cont[m.cid0 + c].touched = 0;
+    }
+    lmw::block_sync();
+    if (lane == 0) d.doc[doc].status = ST_OK;
+    m.status = ST_OK;
+    lmw::block_sync();
+  }
+  if (status_fatal(m.status)) return;
+  uint32_t P = m.n_peers;
+  for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_ebase[p] = d.elem_base[m.praw0 + p]; s_end[p] = d.peer_end[m.praw0 + p]; }
+  lmw::block_sync();
+  uint64_t vvh0 = ((uint64_t)m.vvh0_hi << 32) | m.vvh0_lo;
+  Ts t;
+  t.it = d.it + (uint64_t)m.leaf0 * SP_REC;
+  t.loc = d.loc + elem0;
+  t.ebase = s_ebase; t.cur = s_cur; t.da = s_da; t.db = s_db;
+  t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0;
+  uint32_t dir_used = 0;
+  if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
+  for (uint32_t cidx = 0; cidx < m.n_cont && !t.err; cidx++) {
+    uint32_t ckind = d.cont[m.cid0 + cidx].kind_root & 0xff;
+    if (ckind != CK_TEXT && ckind != CK_LIST) continue;
+    if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
+    uint32_t L0 = t.n_leaf++;
+    lmw::block_sync();
+    if (lane == 0) { s_da[0] = sa_make(L0, 0, false); s_db[0] = 0; }
+    t.n_dir = 1; t.tot_active = 0; t.cache_leaf = NONE;
+    for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
+    lmw::block_sync();
+    bool touched = false;
+    for (uint32_t oi = 0; oi < m.n_nodes && !t.err; oi++) {
+      uint32_t n = d.node_order[m.chg0 + oi];
+      uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
+      const uint32_t* vv = vvh_ro + vvh0 + (uint64_t)n * P;
+      uint32_t node_peer = chg_ro[sorted_ro[m.chg0 + first]].peer;
+      bool checked_out = false;
+      for (uint32_t ci = first; ci <= last && !t.err; ci++) {
+        uint32_t crow = sorted_ro[m.chg0 + ci];
+        const ChangeRow ch = chg_ro[crow];
+        uint32_t skip_to = ch.ctr + skip_ro[crow];
+        uint32_t pe = s_end[node_peer];
+        uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
+        const uint32_t* op_w = (const uint32_t*)op_ro;
+        uint32_t nx = (lane < 8 && n_rows) ? op_w[(uint64_t)ch.op0 * 8 + (uint32_t)lane] : 0u;
+        for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
+          OpRow r;
+          r.cidx_kind = lmw::bcast(nx, 0); r.prop = (int32_t)lmw::bcast(nx, 1); r.len = lmw::bcast(nx, 2); r.ctr = lmw::bcast(nx, 3);
+          r.a0 = lmw::bcast(nx, 4); r.a1 = lmw::bcast(nx, 5); r.a2 = (int32_t)lmw::bcast(nx, 6); r.chg = lmw::bcast(nx, 7);
+          if (row + 1 < ch.op0 + n_rows) nx = lane < 8 ? op_w[(uint64_t)(row + 1) * 8 + (uint32_t)lane] : 0u;
+          if ((r.cidx_kind & 0xffff) != cidx) continue;
+          if (r.ctr + r.len <= skip_to) continue;
+          uint32_t kind = (r.cidx_kind >> 16) & 0xff;
+          uint32_t a = skip_to > r.ctr ? skip_to - r.ctr : 0;
+          touched = true;
+          if (r.ctr + a >= pe) continue;
+          uint32_t b = r.ctr + r.len <= pe ? r.len : pe - r.ctr;
+          if (!checked_out) {
+            checked_out = true;
+            for (uint32_t p = 0; p < P && !t.err; p++) {
+              uint32_t cur = s_cur[p], tgt = vv[p];
+              if (cur > tgt) ts_move_ops(t, d, m, cidx, p, tgt, cur, -1);
+              else if (cur < tgt) ts_move_ops(t, d, m, cidx, p, cur, tgt, +1);
+            }
+            lmw::block_sync();
+            for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = vv[p];
+            lmw::block_sync();
+          }
+          if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
+            ts_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
+          } else if (kind == OK_DEL) {
+            uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+            uint32_t t0, t1;
+            if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
+            else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
+            ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
+          } else if (kind == OK_STYLE_START) {
+            ts_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
+          } else if (kind == OK_STYLE_END) {
+            uint32_t end_pos = NONE;
+            if (row > ch.op0) {
+              const OpRow pr = op_ro[row - 1];
+              if (((pr.cidx_kind >> 16) & 0xff) == OK_STYLE_START && pr.ctr + 1 == r.ctr && (pr.cidx_kind & 0xffff) == cidx)
+                end_pos = (uint32_t)pr.prop + pr.a0;
+            }
+            if (end_pos == NONE) { LM_SETERR(t.err, ST_UNSUPPORTED); break; }
+            uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
+            ts_insert(t, pos, pid_make(node_peer, r.ctr), 1);
+          }
+        }
+        if (checked_out && lane == 0) s_cur[node_peer] = ch.ctr + ch.len < pe ? ch.ctr + ch.len : pe;
+      }
+      lmw::block_sync();
+    }
+    lmw::block_sync();
+    if (dir_used + t.n_dir > m.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
+    for (uint32_t i = (uint32_t)lane; i < t.n_dir; i += 64) d.dir_out[m.leaf0 + dir_used + i] = s_da[i];
+    if (lane == 0) {
+      d.cont_root0[m.cid0 + cidx] = dir_used;
+      d.cont_nroot[m.cid0 + cidx] = t.n_dir;
+      if (touched) d.cont[m.cid0 + cidx].touched = 1;
+    }
+    dir_used += t.n_dir;
+    lmw::block_sync();
+  }
+  if (t.err && lane == 0) {
+    d.doc[doc].status = t.err;
+    if (t.err == ST_RETRY) lmw::atomic_add(retry_count, 1u);
+  }
+  if (lane == 0) d.doc[doc].pad0 = dir_used;
+}
+
+}  // namespace lm

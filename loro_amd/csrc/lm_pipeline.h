@@ -269,6 +269,8 @@ struct Engine {
     // 4. per-doc pool sizing on the host (one small round trip)
     h_doc.resize(n_docs);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+    const bool span = getenv("LM_SPAN") && atoi(getenv("LM_SPAN")) != 0;   // span-granular integrate kernel (lm_k_integrate_span.h)
+    d.span = span ? 1u : 0u;
     uint64_t elem = 0, leaves = 0, vvh = 0, ht = 0;
     uint32_t dir_cap = 64, dir_opt = 64, pmax = 2;
     static const uint32_t DIR_CAP_MAX = 36000;  // (36000 + 2·MAX_PEERS)·4 B stays inside the 160 KiB LDS of a CU
@@ -280,6 +282,13 @@ struct Engine {
       m.elem0_lo = (uint32_t)elem; m.elem0_hi = (uint32_t)(elem >> 32);
       // every split leaves both halves with >= 32 elements; each container starts with one (possibly small) leaf
       uint32_t lc = ok ? m.n_elems / 32 + 2 * m.n_cont + 2 : 0;
+      if (ok && span) {
+        // span-granular leaves: items <= one per insert row + one per boundary that ever cuts a run (op boundaries, checkout
+        // cuts); a split leaves both halves with 32 items
+        uint64_t items = 3ull * m.n_op + 2ull * m.n_nodes * m.n_peers + 64;
+        uint64_t lcs = items / 32 + 2 * m.n_cont + 2;
+        if (lcs < lc) lc = (uint32_t)lcs;
+      }
       if (leaves + lc > 0xfffffff0ull) throw std::runtime_error("batch too large for 32-bit pool indices");
       m.leaf0 = (uint32_t)leaves; m.leaf_cap = lc;
       m.vvh0_lo = (uint32_t)vvh; m.vvh0_hi = (uint32_t)(vvh >> 32);
@@ -287,6 +296,7 @@ struct Engine {
       if (lc > dir_cap) dir_cap = lc;
       // optimistic LDS directory: leaves are ≈3/4 full in practice (≈48 elements); sized for 40 per leaf
       uint32_t lo = ok ? m.n_elems / 40 + 2 * m.n_cont + 16 : 0;
+      if (ok && span) { uint32_t los = (uint32_t)((3ull * m.n_op / 2) / 40) + 2 * m.n_cont + 16; if (los < lo) lo = los; }
       if (lo > lc) lo = lc;
       if (lo > dir_opt) dir_opt = lo;
       if (ok && m.n_peers > pmax) pmax = m.n_peers;
@@ -299,7 +309,7 @@ struct Engine {
     if (dir_cap > DIR_CAP_MAX) dir_cap = DIR_CAP_MAX;  // larger documents are reported LM_UNSUPPORTED by k_integrate
     lmbe::h2d(d.doc, h_doc.data(), (size_t)n_docs * sizeof(DocMeta));
     b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
-    b_it.ensure((leaves + 1) * 256 * 4);
+    b_it.ensure((leaves + 1) * (span ? (size_t)SP_REC : 256) * 4);
     b_dir_out.ensure((leaves + 1) * 4);
     b_lf_chunk.ensure(leaves + 64);
     b_vvh.ensure((vvh + 1) * 4);
@@ -340,16 +350,28 @@ struct Engine {
     if (dir_opt > DIR_CAP_MAX) dir_opt = DIR_CAP_MAX;
     size_t lds_pad = getenv("LM_LDS_PAD") ? (size_t)atoi(getenv("LM_LDS_PAD")) : 0;  // occupancy experiments only
     if (getenv("LM_NO_OPT_DIR")) dir_opt = dir_cap;
+    if (getenv("LM_DIR_OPT_MAX")) { uint32_t mx = (uint32_t)atoi(getenv("LM_DIR_OPT_MAX")); if (mx >= 4 && mx < dir_opt) dir_opt = mx & ~3u; }   // tests: force the retry launch
     b_tot.ensure(64 * 4);
     uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
     lmbe::dmemset(retry_cnt, 0, 4);
-    LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
-                  (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+    const size_t dir_words = span ? 2 : 1;   // LDS words per directory entry
+    if (span) {
+      LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                    (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+    } else {
+      LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                    (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+    }
     uint32_t n_retry = 0;
     lmbe::d2h(&n_retry, retry_cnt, 4);
     if (n_retry) {  // rare: re-run the overflowed documents with the worst-case directory
-      LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
-                    (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
+      if (span) {
+        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                      (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
+      } else {
+        LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                      (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
+      }
     }
     last_retries = n_retry;
 #ifdef LM_EMU_TRACE
@@ -361,10 +383,14 @@ struct Engine {
         for (uint32_t q = 0; q < nr; q++) {
           uint32_t e = d.dir_out[m0.leaf0 + r0 + q], L = de_leaf(e), n = de_n(e);
           for (uint32_t i = 0; i < n; i++) {
-            const uint32_t* rec = d.it + ((uint64_t)m0.leaf0 + L) * 256; uint32_t x = i;
-            fprintf(stderr, "DUMP c%u %u:%u ol=%d:%d or=%d:%d st=%x\n", c, rec[x] >> 24, rec[x] & 0xffffff,
-                    rec[64 + x] == NONE ? -1 : (int)(rec[64 + x] >> 24), rec[64 + x] == NONE ? -1 : (int)(rec[64 + x] & 0xffffff),
-                    rec[128 + x] == NONE ? -1 : (int)(rec[128 + x] >> 24), rec[128 + x] == NONE ? -1 : (int)(rec[128 + x] & 0xffffff), rec[192 + x]);
+            const uint32_t* rec = d.it + ((uint64_t)m0.leaf0 + L) * (span ? (size_t)SP_REC : 256);
+            uint32_t id0 = rec[i], ln = span ? rec[64 + i] : 1u, ol0 = rec[(span ? 128 : 64) + i], orr = rec[(span ? 192 : 128) + i], st = rec[(span ? 256 : 192) + i];
+            for (uint32_t k = 0; k < ln; k++) {
+              uint32_t id = id0 + k, ol = k ? id - 1 : ol0;
+              fprintf(stderr, "DUMP c%u %u:%u ol=%d:%d or=%d:%d st=%x\n", c, id >> 24, id & 0xffffff,
+                      ol == NONE ? -1 : (int)(ol >> 24), ol == NONE ? -1 : (int)(ol & 0xffffff),
+                      orr == NONE ? -1 : (int)(orr >> 24), orr == NONE ? -1 : (int)(orr & 0xffffff), st);
+            }
           }
         }
       }

@@ -283,3 +283,16 @@ def test_run_async_and_wait_with_two_contexts():
         with pytest.raises(RuntimeError):
             a.run_async()                          # one run in flight per context
         a.wait()
+
+
+def test_retry_launch_keeps_map_containers(monkeypatch):
+    """Regression: the second (worst-case directory) launch reset the `touched` flag of every container, so the root Map
+    of a document whose Text overflowed the optimistic directory vanished from the JSON."""
+    from loro_amd._cabi import Context
+    monkeypatch.setenv("LM_DIR_OPT_MAX", "4")
+    docs = _cases.cfg4_docs(3, first=1016, n_steps=400) + _cases.fuzz_docs(6, base=100, steps=120)
+    want = _oracle.merge_batch(docs)
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        assert c.sizing()[3] >= 1
+    assert got == want
