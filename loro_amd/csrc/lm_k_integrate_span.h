@@ -134,33 +134,35 @@ LM_DEV void sd_refresh(Ts& t, uint32_t p, uint32_t L, const SpanRegs& R) {   // 
 }
 
 // ---- leaf edits
-// Insert `it` as item `idx` of the leaf at directory position p (registers R).  A full leaf is split in half first.
-// `dirty_from` = lowest lane of R the caller modified in registers (R.n if none).  `new_elems`: the item's elements are
-// new to this container (loc[] must be written); otherwise it is the right part of a split and only needs loc[] when it
-// lands in another leaf.  On return (p, idx) address the inserted item and R holds its leaf.
-LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& it, uint32_t dirty_from, bool new_elems) {
+// Insert `cnt` (1 or 2) items — A, then B — as items idx, idx+1 of the leaf at directory position p (registers R): ONE
+// rewrite of the leaf per edit.  A leaf without room is split first (lower half keeps 32 items).  `dirty_from` = lowest
+// lane of R the caller modified in registers (R.n if none).  newA / newB: the item's elements are new to the container
+// (loc[] must be written); a part of a split run only needs loc[] when it lands in another leaf.  On return (p, idx)
+// address item A and R holds its leaf.
+LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& A, const SpanItem& B, uint32_t cnt,
+                            uint32_t dirty_from, bool newA, bool newB) {
   int lane = lmw::lane();
   lmw::wave_sync();
-  uint32_t a0 = lmw::first(t.da[p]);
-  uint32_t L = sa_leaf(a0);
-  bool moved = false;   // the item ends up in a leaf other than L
-  if (R.n >= 64) {
+  uint32_t L = sa_leaf(lmw::first(t.da[p]));
+  bool moved = false;   // the items end up in a leaf other than L
+  if (R.n + cnt > 64) {
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
     uint32_t NL = t.n_leaf++;
-    SpanRegs U;   // upper half → new leaf
-    U.n = 32;
+    uint32_t nu = R.n - 32;
+    SpanRegs U;   // items [32, n) → new leaf
+    U.n = nu;
     U.id = lmw::shfl(R.id, (lane + 32) & 63); U.len = lmw::shfl(R.len, (lane + 32) & 63); U.ol = lmw::shfl(R.ol, (lane + 32) & 63);
     U.orr = lmw::shfl(R.orr, (lane + 32) & 63); U.st = lmw::shfl(R.st, (lane + 32) & 63);
-    if (lane >= 32) { U.id = NONE; U.len = 0; U.ol = NONE; U.orr = NONE; U.st = ST_FUT; }
+    if ((uint32_t)lane >= nu) { U.id = NONE; U.len = 0; U.ol = NONE; U.orr = NONE; U.st = ST_FUT; }
     SpanRegs Lo = R;
     Lo.n = 32;
     if (lane >= 32) { Lo.id = NONE; Lo.len = 0; Lo.ol = NONE; Lo.orr = NONE; Lo.st = ST_FUT; }
-    for (int j = 0; j < 32; j++) sp_set_loc(t, lmw::bcast(U.id, j), lmw::bcast(U.len, j), NL);
+    for (uint32_t j = 0; j < nu; j++) sp_set_loc(t, lmw::bcast(U.id, (int)j), lmw::bcast(U.len, (int)j), NL);
     if (idx > 32 || (idx == 32 && dirty_from >= 32)) {
       // the edit goes to the upper half: the lower half only needs its modified lanes stored
       sp_store(t, L, Lo, dirty_from < 32 ? dirty_from : 32);
       sd_refresh(t, p, L, Lo);
-      sd_insert_after(t, p, sa_make(NL, 32, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
+      sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
       if (t.err) return;
       sp_store(t, NL, U, 0);
       p = p + 1; idx -= 32; R = U; L = NL;
@@ -168,36 +170,30 @@ LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const
       moved = true;
     } else {
       sp_store(t, NL, U, 0);
-      sd_insert_after(t, p, sa_make(NL, 32, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
+      sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
       if (t.err) return;
       R = Lo;
       if (dirty_from > 32) dirty_from = 32;
     }
   }
-  // shift lanes >= idx up by one and drop the item in
+  // shift lanes >= idx up by cnt and drop the items in
   SpanRegs N;
-  N.n = R.n + 1;
-  uint32_t pid = lmw::shfl_up(R.id, 1), pln = lmw::shfl_up(R.len, 1), pol = lmw::shfl_up(R.ol, 1), por = lmw::shfl_up(R.orr, 1), pst = lmw::shfl_up(R.st, 1);
-  bool sh = (uint32_t)lane > idx;
+  N.n = R.n + cnt;
+  int sh_d = (int)cnt;
+  uint32_t pid = lmw::shfl_up(R.id, sh_d), pln = lmw::shfl_up(R.len, sh_d), pol = lmw::shfl_up(R.ol, sh_d), por = lmw::shfl_up(R.orr, sh_d), pst = lmw::shfl_up(R.st, sh_d);
+  bool sh = (uint32_t)lane >= idx + cnt;
   N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
-  if ((uint32_t)lane == idx) { N.id = it.id; N.len = it.len; N.ol = it.ol; N.orr = it.orr; N.st = it.st; }
+  if ((uint32_t)lane == idx) { N.id = A.id; N.len = A.len; N.ol = A.ol; N.orr = A.orr; N.st = A.st; }
+  if (cnt == 2 && (uint32_t)lane == idx + 1) { N.id = B.id; N.len = B.len; N.ol = B.ol; N.orr = B.orr; N.st = B.st; }
   if ((uint32_t)lane >= N.n) { N.id = NONE; N.len = 0; N.ol = NONE; N.orr = NONE; N.st = ST_FUT; }
   sp_store(t, L, N, dirty_from < idx ? dirty_from : idx);
-  if (new_elems || moved) sp_set_loc(t, it.id, it.len, L);
+  if (newA || moved) sp_set_loc(t, A.id, A.len, L);
+  if (cnt == 2 && (newB || moved)) sp_set_loc(t, B.id, B.len, L);
   sd_refresh(t, p, L, N);
   R = N;
 }
-
-// split item `slot` of the leaf at p at element offset `off` (0 < off < len); afterwards (p, slot) address the RIGHT part
-LM_DEV void sp_split_at(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& slot, uint32_t off) {
-  int lane = lmw::lane();
-  SpanItem rt;
-  uint32_t id0 = lmw::bcast(R.id, (int)slot), ln = lmw::bcast(R.len, (int)slot);
-  rt.id = id0 + off; rt.len = ln - off; rt.ol = id0 + off - 1; rt.orr = lmw::bcast(R.orr, (int)slot); rt.st = lmw::bcast(R.st, (int)slot);
-  if ((uint32_t)lane == slot) R.len = off;
-  uint32_t idx = slot + 1;
-  sp_insert_item(t, p, R, idx, rt, slot, false);
-  slot = idx;
+LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& it, uint32_t dirty_from, bool new_elems) {
+  sp_insert_items(t, p, R, idx, it, it, 1, dirty_from, new_elems, false);
 }
 
 // ---- insert (Fugue integrate, crdt_rope.rs:63-247) of run [pid0, pid0+len) at active position pos
@@ -226,12 +222,14 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     uint32_t sid = lmw::bcast(R.id, (int)slot), sln = lmw::bcast(R.len, (int)slot);
     origin_left = sid + off - 1;
     if (off < sln) {
-      // cursor inside an active run: the run's next element is the (non-future) origin_right, nothing lies in between
-      sp_split_at(t, p, R, slot, off);
-      if (t.err) return;
+      // cursor inside an active run: the run's next element is the (non-future) origin_right and nothing lies in between —
+      // the run is cut and the new run dropped between the halves in one rewrite of the leaf
+      SpanItem rt;
+      rt.id = sid + off; rt.len = sln - off; rt.ol = sid + off - 1; rt.orr = lmw::bcast(R.orr, (int)slot); rt.st = lmw::bcast(R.st, (int)slot);
+      if ((uint32_t)lane == slot) R.len = off;
       nw.ol = origin_left; nw.orr = sid + off;
-      idx = slot;
-      sp_insert_item(t, p, R, idx, nw, R.n, true);
+      idx = slot + 1;
+      sp_insert_items(t, p, R, idx, nw, rt, 2, slot, true, false);
       return;
     }
     idx = slot + 1;
@@ -376,34 +374,39 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     if (p == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
     uint32_t slot = (uint32_t)lmw::ffs64(hm);
     uint32_t id0 = lmw::bcast(R.id, (int)slot), ln = lmw::bcast(R.len, (int)slot);
-    if (x > id0) { sp_split_at(t, p, R, slot, x - id0); if (t.err) return; id0 = x; ln = lmw::bcast(R.len, (int)slot); }
-    uint32_t endc = pid_ctr(id0) + ln;
-    if (endc > c1) {
-      uint32_t s2 = slot;
-      sp_split_at(t, p, R, s2, c1 - pid_ctr(id0));      // (p, s2) now address the part beyond the range: the part inside sits right before it
-      if (t.err) return;
-      if (s2 == 0) {   // the leaf was split exactly between the two parts: the inside part is the last item of the previous leaf
-        p = p - 1;
-        lmw::wave_sync();
-        uint32_t a = lmw::first(t.da[p]);
-        R = sp_load(t, sa_leaf(a), sa_n(a));
-        slot = R.n - 1;
-      } else slot = s2 - 1;
-      endc = c1;
-    }
-    uint32_t st = R.st;
-    if ((uint32_t)lane == slot) {
-      if (mode == UPD_SET_FUT) st |= ST_FUT;
-      else if (mode == UPD_CLR_FUT) st &= ~ST_FUT;
-      else if (mode == UPD_DEL_INC) st = (st + ST_DEL1) | ST_EVER;
-      else if (st & ST_DELMASK) st -= ST_DEL1;
-    }
-    R.st = st;
+    uint32_t st0 = lmw::bcast(R.st, (int)slot), st1 = st0, orr0 = lmw::bcast(R.orr, (int)slot);
+    if (mode == UPD_SET_FUT) st1 |= ST_FUT;
+    else if (mode == UPD_CLR_FUT) st1 &= ~ST_FUT;
+    else if (mode == UPD_DEL_INC) st1 = (st1 + ST_DEL1) | ST_EVER;
+    else if (st1 & ST_DELMASK) st1 -= ST_DEL1;
+    uint32_t s_off = x - id0;                                   // elements of the run before the range
+    uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
+    uint32_t tail = pid_ctr(id0) + ln - endc;                   // elements of the run beyond the range
     lmw::wave_sync();
     uint32_t L = sa_leaf(lmw::first(t.da[p]));
-    if ((uint32_t)lane == slot) t.it[(uint64_t)L * SP_REC + 256 + lane] = st;
-    if (L == t.cache_leaf) t.cr.st = R.st;
-    sd_refresh(t, p, L, R);
+    if (s_off == 0 && tail == 0) {
+      // the whole run: one status word
+      if ((uint32_t)lane == slot) { R.st = st1; t.it[(uint64_t)L * SP_REC + 256 + lane] = st1; }
+      if (L == t.cache_leaf) t.cr.st = R.st;
+      sd_refresh(t, p, L, R);
+    } else {
+      // the run is cut at the range's ends and the affected part gets the new status: one rewrite of the leaf
+      SpanItem A, B;
+      uint32_t cnt, idx = slot + 1;
+      if (s_off > 0) {
+        if ((uint32_t)lane == slot) R.len = s_off;
+        A.id = x; A.len = endc - c; A.ol = x - 1; A.orr = orr0; A.st = st1;
+        B.id = pid_make(peer, endc); B.len = tail; B.ol = B.id - 1; B.orr = orr0; B.st = st0;
+        cnt = tail ? 2u : 1u;
+      } else {
+        if ((uint32_t)lane == slot) { R.len = endc - c; R.st = st1; }
+        A.id = pid_make(peer, endc); A.len = tail; A.ol = A.id - 1; A.orr = orr0; A.st = st0;
+        B = A;
+        cnt = 1;
+      }
+      sp_insert_items(t, p, R, idx, A, B, cnt, slot, false, false);
+      if (t.err) return;
+    }
     c = endc;
   }
 }
