@@ -296,3 +296,17 @@ def test_retry_launch_keeps_map_containers(monkeypatch):
         got = c.merge_batch(docs)
         assert c.sizing()[3] >= 1
     assert got == want
+
+
+def test_span_granular_kernel(monkeypatch):
+    """The experimental span-granular integrate kernel (LM_SPAN=1, lm_k_integrate_span.h) on the edge cases, random
+    concurrent sessions, nested containers, checkouts (incl. cuts through op runs) and a trace-shaped document."""
+    monkeypatch.setenv("LM_SPAN", "1")
+    names, docs = _cases.edge_case_docs()
+    _check(docs, names)
+    _check(_cases.fuzz_docs(16, base=300, steps=80) + _nested_docs(8, first=7300, n_peers=3, n_steps=120) + _cases.trace_docs(3000, n_docs=1))
+    cd, cf = _checkout_cases()
+    want = _oracle.merge_batch(cd, frontiers=cf)
+    got = _emu.merge_batch(cd, cf)
+    for g, w in zip(got, want):
+        assert (g == w) if w[0] == 0 else (g[0] == w[0])

@@ -225,3 +225,20 @@ def test_two_contexts_in_flight(engine):
         ra, rb = engine.fetch(), b.fetch()
     assert ra[:24] == want_a and all(r[0] == 0 for r in ra)
     assert rb[:40] == want_b and rb[40:80] == want_b
+
+
+def test_span_granular_kernel(engine, monkeypatch):
+    """LM_SPAN=1: the experimental span-granular integrate kernel on the GPU — configs[1]-shaped documents, mixed
+    containers with DAG merges, nested containers, checkouts."""
+    import test_emu_parity
+    monkeypatch.setenv("LM_SPAN", "1")
+    tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
+    docs = [tpl.stamp(d) for d in range(300)]
+    got = engine.merge_batch(docs)
+    assert got[:24] == _oracle.merge_batch(docs[:24], threads=8) and all(g[0] == 0 for g in got)
+    base = _cases.cfg4_docs(32) + test_emu_parity._nested_docs(24, n_peers=3, n_steps=200)
+    assert engine.merge_batch(base * 10)[: len(base)] == _oracle.merge_batch(base, threads=8)
+    cd, cf = test_emu_parity._checkout_cases()
+    want = _oracle.merge_batch(cd, threads=8, frontiers=cf)
+    for g, w in zip(engine.merge_batch(cd, cf), want):
+        assert (g == w) if w[0] == 0 else (g[0] == w[0])
