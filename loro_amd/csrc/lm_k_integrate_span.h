@@ -31,6 +31,7 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   uint32_t* db;                   // LDS directory, word B (active length)
   uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
   uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); write-through
+  uint32_t cache_p;               // its directory position (kept in step with directory inserts)
   SpanRegs cr;
   int32_t err;
 };
@@ -55,13 +56,14 @@ LM_DEV SpanRegs sp_load(const Ts& t, uint32_t L, uint32_t n) {
   return r;
 }
 // store lanes [from, R.n) of leaf L and make it the cached leaf
-LM_DEV void sp_store(Ts& t, uint32_t L, const SpanRegs& R, uint32_t from) {
+LM_DEV void sp_store(Ts& t, uint32_t L, const SpanRegs& R, uint32_t from, uint32_t p) {
   int lane = lmw::lane();
   if ((uint32_t)lane < R.n && (uint32_t)lane >= from) {
     uint32_t* rec = t.it + (uint64_t)L * SP_REC;
     rec[lane] = R.id; rec[64 + lane] = R.len; rec[128 + lane] = R.ol; rec[192 + lane] = R.orr; rec[256 + lane] = R.st;
   }
   t.cache_leaf = L;
+  t.cache_p = p;
   t.cr = R;
 }
 LM_DEV uint32_t sp_alen(const SpanRegs& R) { return ((uint32_t)lmw::lane() < R.n && st_active(R.st)) ? R.len : 0u; }
@@ -99,6 +101,7 @@ LM_DEV void sd_insert_after(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
   if (lane == 0) { t.da[q] = a; t.db[q] = b; }
   t.n_dir++;
   t.tot_active += b;
+  if (t.cache_leaf != NONE && t.cache_p >= q) t.cache_p++;
   lmw::wave_sync();
 }
 // k-th active element (1 <= k <= tot_active) → directory position; k becomes the rank inside that leaf
@@ -160,18 +163,18 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
     for (uint32_t j = 0; j < nu; j++) sp_set_loc(t, lmw::bcast(U.id, (int)j), lmw::bcast(U.len, (int)j), NL);
     if (idx > 32 || (idx == 32 && dirty_from >= 32)) {
       // the edit goes to the upper half: the lower half only needs its modified lanes stored
-      sp_store(t, L, Lo, dirty_from < 32 ? dirty_from : 32);
+      sp_store(t, L, Lo, dirty_from < 32 ? dirty_from : 32, p);
       sd_refresh(t, p, L, Lo);
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
       if (t.err) return;
-      sp_store(t, NL, U, 0);
+      sp_store(t, NL, U, 0, p + 1);
       p = p + 1; idx -= 32; R = U; L = NL;
       dirty_from = 0;
       moved = true;
     } else {
-      sp_store(t, NL, U, 0);
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
       if (t.err) return;
+      sp_store(t, NL, U, 0, p + 1);
       R = Lo;
       if (dirty_from > 32) dirty_from = 32;
     }
@@ -180,13 +183,13 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
   SpanRegs N;
   N.n = R.n + cnt;
   int sh_d = (int)cnt;
-  uint32_t pid = lmw::shfl_up(R.id, sh_d), pln = lmw::shfl_up(R.len, sh_d), pol = lmw::shfl_up(R.ol, sh_d), por = lmw::shfl_up(R.orr, sh_d), pst = lmw::shfl_up(R.st, sh_d);
+  uint32_t pid = lmw::shift_up(R.id, sh_d), pln = lmw::shift_up(R.len, sh_d), pol = lmw::shift_up(R.ol, sh_d), por = lmw::shift_up(R.orr, sh_d), pst = lmw::shift_up(R.st, sh_d);
   bool sh = (uint32_t)lane >= idx + cnt;
   N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
   if ((uint32_t)lane == idx) { N.id = A.id; N.len = A.len; N.ol = A.ol; N.orr = A.orr; N.st = A.st; }
   if (cnt == 2 && (uint32_t)lane == idx + 1) { N.id = B.id; N.len = B.len; N.ol = B.ol; N.orr = B.orr; N.st = B.st; }
   if ((uint32_t)lane >= N.n) { N.id = NONE; N.len = 0; N.ol = NONE; N.orr = NONE; N.st = ST_FUT; }
-  sp_store(t, L, N, dirty_from < idx ? dirty_from : idx);
+  sp_store(t, L, N, dirty_from < idx ? dirty_from : idx, p);
   if (newA || moved) sp_set_loc(t, A.id, A.len, L);
   if (cnt == 2 && (newB || moved)) sp_set_loc(t, B.id, B.len, L);
   sd_refresh(t, p, L, N);
@@ -361,7 +364,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     SpanRegs R;
     uint64_t hm = 0;
     if (t.cache_leaf != NONE) hm = lmw::ballot((uint32_t)lane < t.cr.n && pid_peer(t.cr.id) == peer && sp_has(t.cr.id, t.cr.len, x));
-    if (hm) { R = t.cr; p = sd_find_leaf(t, t.cache_leaf); }
+    if (hm) { R = t.cr; p = t.cache_p; }
     else {
       uint32_t lf = lmw::first(t.loc[eb + c]);
       if (lf >= t.n_leaf) { c++; continue; }          // not an element of this container (malformed target): ignored
@@ -444,7 +447,7 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
 }
 
 // K9 (span-granular): one wave per document.  Dynamic LDS: [dir_cap] word A, [dir_cap] word B, then 3 × pmax.
-LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate_span(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {

@@ -63,6 +63,10 @@ LM_KERNEL void k_selftest(uint32_t* out, uint32_t rounds) {
     uint32_t c = (uint32_t)lmw::popc64(m & ((2ull << lane) - 1));
     uint32_t dref = lmw::scan_incl_add_shfl(v & 1);
     bad += c != dref ? 1u : 0u;
+    // whole-wave shifts on the DPP crossbar vs the LDS permute (lanes below the distance are don't-care)
+    uint32_t s1 = lmw::shift_up(x, 1), s2 = lmw::shift_up(x, 2), r1 = lmw::shfl_up(x, 1), r2 = lmw::shfl_up(x, 2);
+    bad += (lane >= 1 && s1 != r1) ? 1u : 0u;
+    bad += (lane >= 2 && s2 != r2) ? 1u : 0u;
   }
   bad = lmw::reduce_add(bad);
   if (lane == 0) out[lmw::bid()] = bad;

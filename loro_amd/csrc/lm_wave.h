@@ -267,11 +267,19 @@ LM_DEV uint32_t scan_incl_add(uint32_t v) {
 #else
 LM_DEV uint32_t scan_incl_add(uint32_t v) { return scan_incl_add_shfl(v); }
 #endif
-LM_DEV uint32_t reduce_add(uint32_t v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
-  return v;
+#ifndef LM_EMU
+// lane i receives lane i-d (d = 1 or 2) across the whole wave64 through the DPP crossbar (wave_shr:1, one or two VALU
+// ops) instead of an LDS permute; lanes below d keep their own value
+LM_DEV uint32_t shift_up(uint32_t v, int d) {
+  uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+  if (d == 2) t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x138, 0xf, 0xf, false);
+  return t;
 }
+#else
+LM_DEV uint32_t shift_up(uint32_t v, int d) { return shfl_up(v, d); }
+#endif
+// wave sum: the DPP prefix scan's last lane (six VALU ops + one readlane instead of six dependent LDS swizzles)
+LM_DEV uint32_t reduce_add(uint32_t v) { return bcast(scan_incl_add(v), 63); }
 LM_DEV uint32_t reduce_max(uint32_t v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { uint32_t t = shfl_xor(v, m); v = t > v ? t : v; }
