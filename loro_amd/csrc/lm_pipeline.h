@@ -269,7 +269,9 @@ struct Engine {
     // 4. per-doc pool sizing on the host (one small round trip)
     h_doc.resize(n_docs);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
-    const bool span = getenv("LM_SPAN") && atoi(getenv("LM_SPAN")) != 0;   // span-granular integrate kernel (lm_k_integrate_span.h)
+    // integrate kernel: span-granular leaves (lm_k_integrate_span.h) by default; LM_SPAN=0 selects the element-granular
+    // kernel (lm_k_integrate.h), kept as the second implementation the parity suites also run
+    const bool span = !(getenv("LM_SPAN") && atoi(getenv("LM_SPAN")) == 0);
     d.span = span ? 1u : 0u;
     uint64_t elem = 0, leaves = 0, vvh = 0, ht = 0;
     uint32_t dir_cap = 64, dir_opt = 64, pmax = 2;
@@ -396,7 +398,7 @@ struct Engine {
       }
     }
 #endif
-    lmbe::toc("k_integrate", times, profiling);
+    lmbe::toc(span ? "k_integrate_span" : "k_integrate", times, profiling);
     // 6. emit in one pass into worst-case slabs (every input byte renders to at most 6 output bytes), then compact
     {
       std::vector<uint64_t> slab_off(n_docs + 1, 0), vslab_off(n_docs + 1, 0);

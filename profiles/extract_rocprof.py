@@ -28,13 +28,15 @@ def main():
         q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
         for name, n, avg in c.execute(q, (cn,)):
             out["kernels"].setdefault(name, {})[cn + "_KiB_per_launch"] = round(avg, 1)
-    k = out["kernels"].get("k_integrate", {})
+    dom = "k_integrate_span" if "k_integrate_span" in out["kernels"] else "k_integrate"   # the integrate kernel that ran
+    out["dominant_kernel"] = dom
+    k = out["kernels"].get(dom, {})
     if "FETCH_SIZE_KiB_per_launch" in k and "WRITE_SIZE_KiB_per_launch" in k:
         raw = (k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024
         cor = (2 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024
-        out["k_integrate_hbm_bytes_per_launch_raw"] = int(raw)
+        out["hbm_bytes_per_launch_raw"] = int(raw)
         out["hbm_bytes_per_launch"] = int(cor)
-        out["note"] = "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 for k_integrate (gfx950 FETCH_SIZE correction); raw = uncorrected"
+        out["note"] = "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 for the integrate kernel (gfx950 FETCH_SIZE correction); raw = uncorrected"
     json.dump(out, open(f"profiles/{tag}_pmc_integrate.json", "w"), indent=1, sort_keys=True)
     open(f"profiles/{tag}_kernel_stats.md", "w").write(
         f"# rocprofv3 --kernel-trace --stats — bench.py --steps 3 --warmup 1 (configs[1], 10k docs, 1 MI355X)\n\n" + "\n".join(lines) + "\n")

@@ -60,9 +60,10 @@ def test_trace_shaped_documents_both_import_orders():
         assert got[k][1] == got[k + 1][1] and got[k][2] == got[k + 1][2]
 
 
-def test_optimistic_directory_overflow_is_retried():
+def test_optimistic_directory_overflow_is_retried(monkeypatch):
     """Sequential appends leave every leaf half full (the worst case the optimistic LDS directory does not cover):
     the document must be re-run with the worst-case directory and still match the oracle."""
+    monkeypatch.setenv("LM_SPAN", "0")   # the element-granular kernel's directory sizing
     from loro_amd import wire
     from loro_amd._cabi import Context
     r = wire.Replica(77)
@@ -290,6 +291,7 @@ def test_retry_launch_keeps_map_containers(monkeypatch):
     of a document whose Text overflowed the optimistic directory vanished from the JSON."""
     from loro_amd._cabi import Context
     monkeypatch.setenv("LM_DIR_OPT_MAX", "4")
+    monkeypatch.setenv("LM_SPAN", "0")
     docs = _cases.cfg4_docs(3, first=1016, n_steps=400) + _cases.fuzz_docs(6, base=100, steps=120)
     want = _oracle.merge_batch(docs)
     with Context(_emu.binding()) as c:
@@ -298,10 +300,12 @@ def test_retry_launch_keeps_map_containers(monkeypatch):
     assert got == want
 
 
-def test_span_granular_kernel(monkeypatch):
-    """The experimental span-granular integrate kernel (LM_SPAN=1, lm_k_integrate_span.h) on the edge cases, random
-    concurrent sessions, nested containers, checkouts (incl. cuts through op runs) and a trace-shaped document."""
-    monkeypatch.setenv("LM_SPAN", "1")
+@pytest.mark.parametrize("span", ["1", "0"])
+def test_both_integrate_kernels(monkeypatch, span):
+    """Both integrate kernels — span-granular (default, lm_k_integrate_span.h) and element-granular (LM_SPAN=0,
+    lm_k_integrate.h) — on the edge cases, random concurrent sessions, nested containers, checkouts (incl. cuts through op
+    runs) and a trace-shaped document."""
+    monkeypatch.setenv("LM_SPAN", span)
     names, docs = _cases.edge_case_docs()
     _check(docs, names)
     _check(_cases.fuzz_docs(16, base=300, steps=80) + _nested_docs(8, first=7300, n_peers=3, n_steps=120) + _cases.trace_docs(3000, n_docs=1))

@@ -227,11 +227,12 @@ def test_two_contexts_in_flight(engine):
     assert rb[:40] == want_b and rb[40:80] == want_b
 
 
-def test_span_granular_kernel(engine, monkeypatch):
-    """LM_SPAN=1: the experimental span-granular integrate kernel on the GPU — configs[1]-shaped documents, mixed
-    containers with DAG merges, nested containers, checkouts."""
+@pytest.mark.parametrize("span", ["1", "0"])
+def test_both_integrate_kernels(engine, monkeypatch, span):
+    """The span-granular (default) and the element-granular (LM_SPAN=0) integrate kernels on the GPU — configs[1]-shaped
+    documents, mixed containers with DAG merges, nested containers, checkouts."""
     import test_emu_parity
-    monkeypatch.setenv("LM_SPAN", "1")
+    monkeypatch.setenv("LM_SPAN", span)
     tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
     docs = [tpl.stamp(d) for d in range(300)]
     got = engine.merge_batch(docs)
