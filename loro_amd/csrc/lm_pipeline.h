@@ -275,7 +275,9 @@ struct Engine {
     d.span = span ? 1u : 0u;
     uint64_t elem = 0, leaves = 0, vvh = 0, ht = 0;
     uint32_t dir_cap = 64, dir_opt = 64, pmax = 2;
-    static const uint32_t DIR_CAP_MAX = 36000;  // (36000 + 2·MAX_PEERS)·4 B stays inside the 160 KiB LDS of a CU
+    // directory entries that fit the 160 KiB LDS of a CU next to 3·MAX_PEERS words: one word per entry in the
+    // element-granular kernel, two in the span-granular one
+    const uint32_t DIR_CAP_MAX = span ? 18000u : 36000u;
     std::vector<uint64_t> h_ht0(n_docs);
     std::vector<uint32_t> h_ht_cap(n_docs);
     for (uint32_t i = 0; i < n_docs; i++) {
