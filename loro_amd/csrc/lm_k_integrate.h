@@ -51,6 +51,7 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   uint32_t* loc;                  // doc element → leaf
   const uint32_t* ebase;          // LDS: element base per peer
   const uint32_t* cur;            // LDS: the tracker's version per peer at the head of the node being replayed
+  const uint32_t* end;            // LDS: version being rendered per peer (no element exists at or beyond it)
   uint32_t* dir;                  // LDS leaf directory in document order
   uint8_t* lchunk;                // HBM: leaf → chunk (= owning lane) of its directory entry (kept out of LDS for occupancy)
   uint32_t n_dir, dir_cap, CH, inv_CH;    // lane c owns directory entries [c*CH, (c+1)*CH); CH is odd (bank-conflict free)
@@ -461,6 +462,7 @@ enum { UPD_SET_FUT = 0, UPD_CLR_FUT = 1, UPD_DEL_INC = 2, UPD_DEL_DEC = 3 };
 LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int mode) {
   int lane = lmw::lane();
   uint32_t eb = t.ebase[peer];
+  if (c1 > t.end[peer]) c1 = t.end[peer];   // a damaged target range cannot make the walk longer than the peer's history
   for (uint32_t cb = c0; cb < c1 && !t.err; cb += 64) {
     lmw::wave_sync();
     uint32_t c = cb + (uint32_t)lane;
@@ -643,6 +645,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
   t.loc = d.loc + elem0;
   t.ebase = s_ebase;
   t.cur = s_cur;
+  t.end = s_end;
   t.dir = s_dir;
   t.lchunk = d.lf_chunk + m.leaf0;
   t.dir_cap = dir_cap;

@@ -27,6 +27,7 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   uint32_t* loc;                  // doc element → leaf
   const uint32_t* ebase;          // LDS: element base per peer
   const uint32_t* cur;            // LDS: tracker version per peer at the head of the node being replayed
+  const uint32_t* end;            // LDS: version being rendered per peer (no element exists at or beyond it)
   uint32_t* da;                   // LDS directory, word A per leaf in document order
   uint32_t* db;                   // LDS directory, word B (active length)
   uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
@@ -356,6 +357,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
 LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int mode) {
   int lane = lmw::lane();
   uint32_t eb = t.ebase[peer];
+  if (c1 > t.end[peer]) c1 = t.end[peer];   // a damaged target range cannot make the walk longer than the peer's history
   uint32_t c = c0;
   for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
     lmw::wave_sync();
@@ -482,7 +484,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
   Ts t;
   t.it = d.it + (uint64_t)m.leaf0 * SP_REC;
   t.loc = d.loc + elem0;
-  t.ebase = s_ebase; t.cur = s_cur; t.da = s_da; t.db = s_db;
+  t.ebase = s_ebase; t.cur = s_cur; t.end = s_end; t.da = s_da; t.db = s_db;
   t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0;
   uint32_t dir_used = 0;
   if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
