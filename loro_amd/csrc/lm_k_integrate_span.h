@@ -346,6 +346,23 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     if (t.err) return;
   }
   nw.ol = origin_left; nw.orr = origin_right;
+  // run merging (FugueSpan::is_mergeable, fugue_span.rs:281-300): the new run continues the item right before the
+  // insertion point — next id of the same peer, origin_left = that item's last element, same origin_right, same (clean)
+  // status — so the item just grows.  Keystroke-per-change histories stay run-granular this way.
+  if (ins_p == p && idx > 0 && ins_idx == idx) {
+    uint32_t pv = idx - 1;
+    uint32_t v_id = lmw::bcast(R.id, (int)pv), v_len = lmw::bcast(R.len, (int)pv), v_or = lmw::bcast(R.orr, (int)pv), v_st = lmw::bcast(R.st, (int)pv);
+    if (v_st == 0 && v_id + v_len == pid0 && pid_peer(v_id) == pid_peer(pid0) && origin_left == pid0 - 1 && v_or == origin_right) {
+      lmw::wave_sync();
+      uint32_t a = lmw::first(t.da[p]);
+      uint32_t L = sa_leaf(a);
+      if ((uint32_t)lane == pv) { R.len = v_len + len; t.it[(uint64_t)L * SP_REC + 64 + lane] = R.len; }
+      t.cache_leaf = L; t.cache_p = p; t.cr = R;
+      sp_set_loc(t, pid0, len, L);
+      sd_set(t, p, a, lmw::first(t.db[p]) + len);
+      return;
+    }
+  }
   SpanRegs D;
   if (ins_p == p) D = R;
   else if (r_p != NONE && ins_p == r_p) D = RR;
