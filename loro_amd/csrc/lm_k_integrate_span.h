@@ -35,6 +35,9 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   uint32_t cache_p;               // its directory position (kept in step with directory inserts)
   SpanRegs cr;
   int32_t err;
+#ifdef LM_PROF
+  uint64_t prof[PF_N];
+#endif
 };
 
 LM_DEV uint32_t ts_g(const Ts& t, uint32_t pid) { return t.ebase[pid_peer(pid)] + pid_ctr(pid); }
@@ -203,6 +206,8 @@ LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const
 // ---- insert (Fugue integrate, crdt_rope.rs:63-247) of run [pid0, pid0+len) at active position pos
 LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   int lane = lmw::lane();
+  PROF_T0();
+  PROF_CNT(t, PF_NINS, 1);
   if (pos > t.tot_active) pos = t.tot_active;
   uint32_t p = 0, idx = 0, origin_left = NONE;
   SpanRegs R;
@@ -233,11 +238,15 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       if ((uint32_t)lane == slot) R.len = off;
       nw.ol = origin_left; nw.orr = sid + off;
       idx = slot + 1;
+      PROF_ADD(t, PF_FIND);
       sp_insert_items(t, p, R, idx, nw, rt, 2, slot, true, false);
+      PROF_ADD(t, PF_PLACE);
+      PROF_CNT(t, PF_NHIT, 1);
       return;
     }
     idx = slot + 1;
   }
+  PROF_ADD(t, PF_FIND);
   // origin_right = first non-future item at/after the cursor; items before it are "in between"
   uint32_t origin_right = NONE, r_ol = NONE, r_p = NONE, r_slot = 0;
   bool between = false;
@@ -267,6 +276,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     }
     if (r_p != NONE) { origin_right = lmw::bcast(RR.id, (int)r_slot); r_ol = lmw::bcast(RR.ol, (int)r_slot); }
   }
+  PROF_ADD(t, PF_ORIGHT);
   uint32_t ins_p = p, ins_idx = idx;
   if (between) {
     // sibling scan over the future ITEMS between the cursor and origin_right (crdt_rope.rs:156-237); the elements inside a
@@ -345,6 +355,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     }
     if (t.err) return;
   }
+  PROF_ADD(t, PF_BETWEEN);
   nw.ol = origin_left; nw.orr = origin_right;
   // run merging (FugueSpan::is_mergeable, fugue_span.rs:281-300): the new run continues the item right before the
   // insertion point — next id of the same peer, origin_left = that item's last element, same origin_right, same (clean)
@@ -360,6 +371,8 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       t.cache_leaf = L; t.cache_p = p; t.cr = R;
       sp_set_loc(t, pid0, len, L);
       sd_set(t, p, a, lmw::first(t.db[p]) + len);
+      PROF_ADD(t, PF_PLACE);
+      PROF_CNT(t, PF_NDHIT, 1);
       return;
     }
   }
@@ -368,6 +381,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   else if (r_p != NONE && ins_p == r_p) D = RR;
   else { lmw::wave_sync(); uint32_t a = lmw::first(t.da[ins_p]); D = sp_load(t, sa_leaf(a), sa_n(a)); }
   sp_insert_item(t, ins_p, D, ins_idx, nw, D.n, true);
+  PROF_ADD(t, PF_PLACE);
 }
 
 // ---- status update of the elements with ids [c0,c1) of `peer` (crdt_rope.rs:345-381 by id): walk run by run
@@ -383,14 +397,22 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     SpanRegs R;
     uint64_t hm = 0;
     if (t.cache_leaf != NONE) hm = lmw::ballot((uint32_t)lane < t.cr.n && pid_peer(t.cr.id) == peer && sp_has(t.cr.id, t.cr.len, x));
+    bool partial = false;   // R holds only id / len / status (origins are fetched if the run has to be cut)
     if (hm) { R = t.cr; p = t.cache_p; }
     else {
       uint32_t lf = lmw::first(t.loc[eb + c]);
       if (lf >= t.n_leaf) { c++; continue; }          // not an element of this container (malformed target): ignored
+      // the three arrays a status change needs are requested for all 64 slots right away; the directory lookup (LDS)
+      // runs while they are in flight, and the item count then masks the unused slots
+      const uint32_t* rec = t.it + (uint64_t)lf * SP_REC;
+      uint32_t xid = rec[lane], xln = rec[64 + lane], xst = rec[256 + lane];
       p = sd_find_leaf(t, lf);
       if (p == NONE) { c++; continue; }                // leaf of another container of the same document
-      R = sp_load(t, lf, sa_n(lmw::first(t.da[p])));
-      hm = lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
+      R.n = sa_n(lmw::first(t.da[p]));
+      bool in = (uint32_t)lane < R.n;
+      R.id = in ? xid : NONE; R.len = in ? xln : 0u; R.st = in ? xst : ST_FUT; R.ol = NONE; R.orr = NONE;
+      partial = true;
+      hm = lmw::ballot(in && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
       if (!hm) { c++; continue; }
     }
     if (p == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
@@ -413,6 +435,12 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       sd_refresh(t, p, L, R);
     } else {
       // the run is cut at the range's ends and the affected part gets the new status: one rewrite of the leaf
+      if (partial) {
+        const uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+        bool in = (uint32_t)lane < R.n;
+        R.ol = in ? rec[128 + lane] : NONE; R.orr = in ? rec[192 + lane] : NONE;
+        orr0 = lmw::bcast(R.orr, (int)slot);
+      }
       SpanItem A, B;
       uint32_t cnt, idx = slot + 1;
       if (s_off > 0) {
@@ -503,6 +531,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
   t.loc = d.loc + elem0;
   t.ebase = s_ebase; t.cur = s_cur; t.end = s_end; t.da = s_da; t.db = s_db;
   t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0;
+#ifdef LM_PROF
+  for (int i = 0; i < PF_N; i++) t.prof[i] = 0;
+  uint64_t pf_begin = lmw::clock();
+#endif
   uint32_t dir_used = 0;
   if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
   for (uint32_t cidx = 0; cidx < m.n_cont && !t.err; cidx++) {
@@ -531,6 +563,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
         const uint32_t* op_w = (const uint32_t*)op_ro;
         uint32_t nx = (lane < 8 && n_rows) ? op_w[(uint64_t)ch.op0 * 8 + (uint32_t)lane] : 0u;
         for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
+          PROF_T0();
           OpRow r;
           r.cidx_kind = lmw::bcast(nx, 0); r.prop = (int32_t)lmw::bcast(nx, 1); r.len = lmw::bcast(nx, 2); r.ctr = lmw::bcast(nx, 3);
           r.a0 = lmw::bcast(nx, 4); r.a1 = lmw::bcast(nx, 5); r.a2 = (int32_t)lmw::bcast(nx, 6); r.chg = lmw::bcast(nx, 7);
@@ -552,7 +585,9 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
             lmw::block_sync();
             for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = vv[p];
             lmw::block_sync();
+            PROF_ADD(t, PF_CHECKOUT);
           }
+          PROF_ADD(t, PF_ROW);
           if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
             ts_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
           } else if (kind == OK_DEL) {
@@ -561,6 +596,8 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
             if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
             else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
             ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
+            PROF_ADD(t, PF_DELETE);
+            PROF_CNT(t, PF_NDEL, 1);
           } else if (kind == OK_STYLE_START) {
             ts_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
           } else if (kind == OK_STYLE_END) {
@@ -595,6 +632,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
     if (t.err == ST_RETRY) lmw::atomic_add(retry_count, 1u);
   }
   if (lane == 0) d.doc[doc].pad0 = dir_used;
+#ifdef LM_PROF
+  t.prof[PF_TOTAL] = lmw::clock() - pf_begin;
+  if (lane == 0) for (int i = 0; i < PF_N; i++) d.prof[(uint64_t)doc * PF_N + i] = t.prof[i];
+#endif
 }
 
 }  // namespace lm
