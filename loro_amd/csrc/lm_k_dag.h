@@ -91,6 +91,7 @@ LM_KERNEL void k_doc_tables(Dev d) {
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.peer_uniq[m.praw0 + mid] < v) lo = mid + 1; else hi = mid; }
     d.peer_map[m.praw0 + i] = lo;
   }
+  lmw::block_sync();   // peer_map (written lane-parallel above) is read below by every lane for child container ids
   // ---- containers
   uint32_t C = 0;
   bool cont_overflow = false;
