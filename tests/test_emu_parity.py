@@ -314,3 +314,23 @@ def test_both_integrate_kernels(monkeypatch, span):
     got = _emu.merge_batch(cd, cf)
     for g, w in zip(got, want):
         assert (g == w) if w[0] == 0 else (g[0] == w[0])
+
+
+def test_keystroke_per_change_histories_stay_run_granular():
+    """Real-time typing sends one change per keystroke: the span-granular kernel merges the runs back
+    (FugueSpan::is_mergeable), so 3,000 keystrokes need a handful of leaves, not one item per character."""
+    from loro_amd import wire
+    from loro_amd._cabi import Context
+    import _fuzz
+    docs = [_fuzz.blobs_of(_fuzz.random_session(8800 + s, n_peers=2, n_steps=400, kinds=("text",), sync_prob=0.03, max_ins=1, commit_prob=1.0))
+            for s in range(4)]
+    r = wire.Replica(5)
+    for i in range(3000):
+        r.text_insert("text", i, "abcdefghij"[i % 10]); r.commit()
+    docs.append([r.export()])
+    want = _oracle.merge_batch(docs)
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        leaves_used = c.sizing()[0]
+    assert got == want
+    assert leaves_used <= 16, leaves_used      # 3,000 sequential keystrokes = one run
