@@ -493,6 +493,37 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
   }
 }
 
+#ifdef LM_EMU_CHECK
+// debug-only (kernel-logic harness built with -DLM_EMU_CHECK): the directory against the leaves and loc[] against both
+inline bool ts_check(Ts& t, const char* what, uint32_t row) {
+  bool ok = true;
+  lmw::wave_sync();
+  if (lmw::lane() == 0) {
+    uint32_t tot = 0;
+    for (uint32_t q = 0; q < t.n_dir && ok; q++) {
+      uint32_t a = t.da[q], L = sa_leaf(a), n = sa_n(a), act = 0;
+      bool nf = false;
+      const uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+      for (uint32_t i = 0; i < n; i++) {
+        uint32_t id0 = rec[i], ln = rec[64 + i], st = rec[256 + i];
+        if (ln == 0) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u item %u has length 0\n", what, row, q, L, i); ok = false; }
+        if (st_active(st)) act += ln;
+        nf |= !(st & ST_FUT);
+        for (uint32_t k = 0; k < ln; k++)
+          if (t.loc[ts_g(t, id0 + k)] != L) { fprintf(stderr, "CHECK %s row=%u: loc of %u:%u is %u, item lives in leaf %u\n", what, row, id0 >> 24, (id0 & 0xffffff) + k, t.loc[ts_g(t, id0 + k)], L); ok = false; break; }
+      }
+      if (act != t.db[q] || nf != sa_nf(a)) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u active %u (cached %u) nf %d (cached %d)\n", what, row, q, L, act, t.db[q], (int)nf, (int)sa_nf(a)); ok = false; }
+      tot += act;
+    }
+    if (ok && tot != t.tot_active) { fprintf(stderr, "CHECK %s row=%u: total active %u, cached %u\n", what, row, tot, t.tot_active); ok = false; }
+  }
+  return lmw::any(!ok) ? false : true;
+}
+#define TS_CHECK(what, row) do { if (!t.err && !ts_check(t, what, row)) t.err = ST_INTERNAL; } while (0)
+#else
+#define TS_CHECK(what, row) do {} while (0)
+#endif
+
 // K9 (span-granular): one wave per document.  Dynamic LDS: [dir_cap] word A, [dir_cap] word B, then 3 × pmax.
 LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
@@ -586,10 +617,12 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
             for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = vv[p];
             lmw::block_sync();
             PROF_ADD(t, PF_CHECKOUT);
+            TS_CHECK("checkout", row);
           }
           PROF_ADD(t, PF_ROW);
           if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
             ts_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
+            TS_CHECK("insert", row);
           } else if (kind == OK_DEL) {
             uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
             uint32_t t0, t1;
@@ -598,6 +631,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
             ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
             PROF_ADD(t, PF_DELETE);
             PROF_CNT(t, PF_NDEL, 1);
+            TS_CHECK("delete", row);
           } else if (kind == OK_STYLE_START) {
             ts_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
           } else if (kind == OK_STYLE_END) {
