@@ -1,4 +1,4 @@
-// Integrate stage, span-granular variant (selected with LM_SPAN=1 until it replaces lm_k_integrate.h).
+// Integrate stage, span-granular kernel — the default (LM_SPAN=0 selects the element-granular lm_k_integrate.h).
 // Same replay as lm_k_integrate.h — one wavefront per document, Event-Graph-Walker over every Text / List container —
 // but a leaf slot holds a RUN of elements (the reference's FugueSpan, container/richtext/fugue_span.rs:191-279):
 //   id0 (peer:8 | counter:24), len, origin_left (of the first element), origin_right (shared), status (shared);
