@@ -134,8 +134,9 @@ class Context:
         return st, jl, vl, pe
 
     def sizing(self):
-        """(max leaves used, max leaf capacity, max elements, documents re-run with the worst-case directory)"""
-        out = (ctypes.c_uint32 * 4)()
+        """(max leaves used, max leaf capacity, max elements, documents re-run with the worst-case directory,
+        documents whose JSON overflowed the optimistic output slab and was re-rendered at its exact size)"""
+        out = (ctypes.c_uint32 * 5)()
         f = getattr(self.b.lib, [k for k in ("lm_sizing", "lmemu_sizing") if hasattr(self.b.lib, k)][0])
         f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         f(self.h, out)

@@ -22,10 +22,12 @@ struct lm_ctx_impl {
   std::string async_err;
   bool in_flight = false;
 
-  lm_ctx_impl() {
+  int device = 0;                  // HIP device of this context: every engine (stream, buffers) is created on it
+
+  explicit lm_ctx_impl(int dev) : device(dev) {
     if (const char* e = getenv("LM_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= (int)LM_MAX_PARTS) want_parts = (uint32_t)v; }
     if (const char* e = getenv("LM_PART_MIN_DOCS")) { int v = atoi(e); if (v >= 1) part_min_docs = (uint32_t)v; }
-    parts.emplace_back(new lm::Engine());
+    parts.emplace_back(new lm::Engine(device));
     first = {0, 0};
   }
   ~lm_ctx_impl() { if (runner.joinable()) runner.join(); }
@@ -46,7 +48,7 @@ struct lm_ctx_impl {
       if (acc * np >= total * first.size() && i + 1 < n) first.push_back((uint32_t)i + 1);
     }
     first.push_back((uint32_t)n);
-    while (parts.size() < n_parts()) parts.emplace_back(new lm::Engine());
+    while (parts.size() < n_parts()) parts.emplace_back(new lm::Engine(device));
     for (uint32_t p = 0; p < n_parts(); p++) parts[p]->stage(docs + first[p], first[p + 1] - first[p]);
   }
   void run() {
@@ -87,7 +89,7 @@ typedef struct lm_run_stats_c { uint64_t n_docs, n_blobs, in_bytes, out_bytes, d
 
 void* LM_API(create)(int device) {
   if (!lmbe::init(device)) return nullptr;
-  try { return new lm_ctx_impl(); } catch (const std::exception&) { return nullptr; }
+  try { return new lm_ctx_impl(device); } catch (const std::exception&) { return nullptr; }
 }
 void LM_API(destroy)(void* c) { delete (lm_ctx_impl*)c; }
 const char* LM_API(last_error)(void* c) { return c ? ((lm_ctx_impl*)c)->err.c_str() : "no context (HIP device unavailable)"; }
@@ -174,11 +176,12 @@ int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   return 0;
 }
 // sizing diagnostics of the last run: max over documents of (leaves used, leaf capacity, elements)
-int LM_API(sizing)(void* c, uint32_t* out3) {  // out3[3] = documents re-run with the worst-case directory
+int LM_API(sizing)(void* c, uint32_t* out3) {  // out3[3] = documents re-run with the worst-case directory, out3[4] = documents re-rendered at their exact size
   auto* x = (lm_ctx_impl*)c;
-  out3[0] = out3[1] = out3[2] = out3[3] = 0;
+  out3[0] = out3[1] = out3[2] = out3[3] = out3[4] = 0;
   for (uint32_t p = 0; p < x->n_parts(); p++) {
     out3[3] += x->parts[p]->last_retries;
+    out3[4] += x->parts[p]->last_reemits;
     for (auto& m : x->parts[p]->h_doc) { if (m.pad0 > out3[0]) out3[0] = m.pad0; if (m.leaf_cap > out3[1]) out3[1] = m.leaf_cap; if (m.n_elems > out3[2]) out3[2] = m.n_elems; }
   }
   return 0;

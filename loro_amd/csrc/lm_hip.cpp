@@ -16,13 +16,13 @@ namespace lmbe {
 // sub-batches of one lm_ctx, or several lm_ctx) can be driven from different host threads and overlap on the device.
 struct StreamCtx {
   hipStream_t s = nullptr;
+  int device = 0;                        // the HIP device this stream (and every buffer of its engine) lives on
   std::vector<hipEvent_t> ev;            // pairs (start, stop), one pair per timed stage of a run
   std::vector<const char*> names;        // stages recorded since the last flush
   bool open = false;
 };
 static thread_local StreamCtx* cur = nullptr;
 static std::atomic<uint64_t> g_alloc{0};
-static int g_device = -1;
 
 #define LM_HIP_CHECK(x)                                                                      \
   do {                                                                                       \
@@ -33,13 +33,12 @@ static int g_device = -1;
 inline bool init(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return false;
-  if (hipSetDevice(device) != hipSuccess) return false;
-  g_device = device;
-  return true;
+  return hipSetDevice(device) == hipSuccess;
 }
-inline StreamCtx* stream_create() {
-  (void)hipSetDevice(g_device);
+inline StreamCtx* stream_create(int device) {
+  if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
   StreamCtx* c = new StreamCtx();
+  c->device = device;
   if (hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) != hipSuccess) { delete c; throw std::runtime_error("hipStreamCreate failed"); }
   return c;
 }
@@ -51,7 +50,7 @@ inline void stream_destroy(StreamCtx* c) {
   delete c;
 }
 // bind the calling host thread to a stream context (HIP's current device is per host thread)
-inline void bind(StreamCtx* c) { (void)hipSetDevice(g_device); cur = c; }
+inline void bind(StreamCtx* c) { (void)hipSetDevice(c->device); cur = c; }
 inline void* dalloc(size_t n) {
   void* p = nullptr;
   if (hipMalloc(&p, n) != hipSuccess) return nullptr;

@@ -145,6 +145,7 @@ LM_KERNEL void k_frame_fill(Dev d) {
     bd.doc = d.blob_doc[b];
     uint64_t cs = rd_uleb(q), cl = rd_uleb(q), ls = rd_uleb(q), ll = rd_uleb(q), nc = rd_uleb(q);
     bd.status = ST_OK;
+    bd.flags = 0; bd.pad = 0;
     if (cs > 0x7fffffffull || cl > 0x7fffffffull || ls > 0xffffffffull || ll > 0xffffffffull || nc > 0x7fffffffull || nc == 0)
       bd.status = ST_DECODE_ERROR;
     if (cs + cl > MAX_COUNTER) bd.status = bd.status ? bd.status : ST_UNSUPPORTED;
@@ -228,9 +229,10 @@ LM_KERNEL void k_block_count(Dev d) {
 }
 
 // skip one nested LoroValue (docs/encoding.md §10.1); iterative with an explicit frame stack.
-// `unsupported` is raised for shapes the device emitter does not render (containers of other kinds, containers below
-// the accepted depth).  A child container (tag 9 + kind Map/List/Text) is accepted down to nesting depth `cdepth`: 0 for a Map
-// value, 1 for the items of a List insert; -1 nowhere.
+// `unsupported` is raised for shapes the device emitter does not render (a container below the accepted depth).  A child
+// container (tag 9 + kind byte) is accepted down to nesting depth `cdepth`: 0 for a Map value, 1 for the items of a List
+// insert; -1 nowhere.  Children of a kind outside Map / List / Text are accepted here: they render as null and flag the
+// document DF_SOFT_UNSUPPORTED when met by the emitter (or when one of their ops is applied).
 LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
   uint32_t f_cnt[16];
   uint32_t f_map = 0;  // bit i: frame i is a map (each item is preceded by a key index)
@@ -263,7 +265,7 @@ LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
         in_map = tag == 8;
         break;
       }
-      case 9: { uint32_t ck = rd_u8(r); if (sp > cdepth || ck > CK_TEXT) unsupported = true; break; }
+      case 9: { uint32_t ck = rd_u8(r); if (ck > CK_COUNTER) { r.bad = true; return; } if (sp > cdepth) unsupported = true; break; }
       default: r.bad = true; return;
     }
   }
@@ -400,7 +402,7 @@ LM_KERNEL void k_block_decode(Dev d) {
       w[1] = (uint32_t)pidx;
       w[2] = (uint32_t)koc;
       w[3] = bi;
-      if (kind > CK_TEXT) unsupported = true;
+      if (kind > CK_COUNTER) st = st ? st : ST_DECODE_ERROR;   // ContainerType::try_from_u8 fails (loro-common/src/lib.rs:748-793)
     }
     if (k.bad) st = st ? st : ST_DECODE_ERROR;
   }
@@ -462,7 +464,8 @@ LM_KERNEL void k_block_decode(Dev d) {
             (void)rd_u8(t);
             r.a0 = (uint32_t)rd_uleb(t);
           }
-          skip_loro_value(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && ckind == CK_LIST ? 1 : -1));
+          // (values of containers outside the device scope are never rendered: any shape is accepted)
+          skip_loro_value(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && ckind == CK_LIST ? 1 : (ckind > CK_TEXT ? 16 : -1)));
           break;
         }
         case 12: {

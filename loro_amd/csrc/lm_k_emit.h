@@ -34,13 +34,24 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
   if (t >= n_ops) return;
   OpRow r = d.op[t];
   uint32_t kind = (r.cidx_kind >> 16) & 0xff;
-  if (kind != OK_MAP_SET && kind != OK_MAP_DEL) return;
+  if (kind != OK_MAP_SET && kind != OK_MAP_DEL && kind != OK_OTHER) return;
   if (!d.chg_flag[r.chg]) return;
   uint32_t blk = d.op_blk[t];
   uint32_t doc = d.blk[blk].doc;
   const DocMeta& m = d.doc[doc];
   if (status_fatal(m.status)) return;
   const ChangeRow& ch = d.chg[r.chg];
+  if (kind == OK_OTHER) {
+    // an applied op of a container outside the device scope (Tree / MovableList / Counter): the container is known to
+    // the state store (it renders as null) and the document is reported LM_UNSUPPORTED together with its JSON
+    if (r.ctr + r.len <= ch.ctr + d.chg_skip[r.chg]) return;
+    uint32_t ci = r.cidx_kind & 0xffff;
+    if ((d.cont[m.cid0 + ci].kind_root & 0xff) > CK_TEXT) {
+      d.cont[m.cid0 + ci].touched = 1;
+      lmw::atomic_or(&d.doc[doc].flags, DF_SOFT_UNSUPPORTED);
+    }
+    return;
+  }
   if (r.ctr < ch.ctr + d.chg_skip[r.chg]) return;  // already-known prefix of a sliced change
   uint32_t cap = d.ht_cap[doc];
   if (cap == 0) { LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }
@@ -86,21 +97,22 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
 // ------------------------------------------------------------------------------------------------ sink
 struct Sink {
   uint8_t* out;       // nullptr in the sizing pass
-  uint64_t pos;       // wave-uniform
+  uint64_t pos;       // wave-uniform; keeps counting past `cap`, so the exact size is known even when the slab was too small
+  uint64_t cap;       // bytes available at `out`: nothing is ever written at or beyond it
 };
 LM_DEV void sink_byte(Sink& s, uint8_t b) {
-  if (s.out && lmw::lane() == 0) s.out[s.pos] = b;
+  if (s.out && s.pos < s.cap && lmw::lane() == 0) s.out[s.pos] = b;
   s.pos++;
 }
 LM_DEV void sink_lit(Sink& s, const char* lit, uint32_t n) {
-  if (s.out && lmw::lane() == 0) for (uint32_t i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)lit[i];
+  if (s.out && s.pos + n <= s.cap && lmw::lane() == 0) for (uint32_t i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)lit[i];
   s.pos += n;
 }
 // each lane contributes `n` (<= 8) bytes packed little-endian in `bytes`; lanes are concatenated in lane order
 LM_DEV void sink_lanes(Sink& s, uint64_t bytes, uint32_t n) {
   uint32_t inc = lmw::scan_incl_add(n);
   uint32_t tot = lmw::bcast(inc, 63);
-  if (s.out) {
+  if (s.out && s.pos + tot <= s.cap) {
     uint64_t at = s.pos + inc - n;
     for (uint32_t i = 0; i < n; i++) s.out[at + i] = (uint8_t)(bytes >> (8 * i));
   }
@@ -144,7 +156,7 @@ LM_DEV void sink_i64(Sink& s, int64_t v) {
   uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
   do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
   if (v < 0) buf[n++] = '-';
-  if (s.out && lmw::lane() == 0) for (int i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)buf[n - 1 - i];
+  if (s.out && s.pos + (uint32_t)n <= s.cap && lmw::lane() == 0) for (int i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)buf[n - 1 - i];
   s.pos += (uint32_t)n;
 }
 // one unicode scalar of a Text container → escaped UTF-8 (anchors contribute nothing)
@@ -247,7 +259,7 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err, const Dev& d, uint32_t vb, 
         if (lane == 0) s_f64[8] = (uint32_t)f64_json(bits, (char*)s_f64, s_big);
         lmw::block_sync();
         uint32_t n = s_f64[8];
-        if (s.out && lane == 0) for (uint32_t i = 0; i < n; i++) s.out[s.pos + i] = ((const uint8_t*)s_f64)[i];
+        if (s.out && s.pos + n <= s.cap && lane == 0) for (uint32_t i = 0; i < n; i++) s.out[s.pos + i] = ((const uint8_t*)s_f64)[i];
         s.pos += n;
         break;
       }
@@ -300,8 +312,11 @@ static constexpr uint32_t EMIT_MAX_DEPTH = 16;   // nesting depth of child conta
 // K11: one wave per doc — JSON of the deep value (mode 0: size only, mode 1: write) and the VV bytes.
 // Two instantiations share this body: documents made of Text containers only (the streaming pipeline, few registers,
 // five waves per SIMD) and everything else (List / Map rendering, child containers, map-typed values, f64).
+// `pass` 0 renders every document into its optimistic slab [out_off[doc], out_off[doc+1]); a document whose JSON does not fit
+// is left flagged DF_REEMIT with its exact size in out_len.  `pass` 1 re-renders only those documents (the host has moved
+// their slabs to exactly-sized ones).
 template <bool TEXT_ONLY>
-LM_DEV void emit_doc(Dev d, int mode) {
+LM_DEV void emit_doc(Dev d, int mode, int pass) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   LM_SHARED(uint32_t, s_order, MAX_ROOTS);
@@ -313,8 +328,10 @@ LM_DEV void emit_doc(Dev d, int mode) {
     if (!failed) for (uint32_t c0 = (uint32_t)lane; c0 < C; c0 += 64) other |= (d.cont[m.cid0 + c0].kind_root & 0xff) != CK_TEXT;
     if (TEXT_ONLY == lmw::any(other)) return;   // failed documents are closed by the text-only instantiation
   }
-  if (failed) { if (lane == 0) { d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; } return; }
+  if (failed) { if (lane == 0 && pass == 0) { d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; } return; }
+  if (pass != 0 && !(m.flags & DF_REEMIT)) return;
   int32_t err = 0;
+  bool soft = false;   // met a child container of a kind outside the device scope that never received an op
   // ---- root containers that received an applied op, ordered bytewise by name
   LM_SHARED(uint32_t, s_root, MAX_ROOTS);
   uint32_t n_roots = 0;
@@ -355,6 +372,7 @@ LM_DEV void emit_doc(Dev d, int mode) {
   Sink s;
   s.out = mode ? d.out + d.out_off[doc] : nullptr;
   s.pos = 0;
+  s.cap = d.out_off[doc + 1] - d.out_off[doc];
   // Containers nest: a Map value or a List item may be a child container (LoroValue::Container — on the wire only
   // the kind; its id is the id of the op / list element that created it, docs/encoding.md:967-1003, state.rs:1550-1616).
   // Rendering is therefore a small stack machine; a frame = (container, resume position).
@@ -380,7 +398,7 @@ LM_DEV void emit_doc(Dev d, int mode) {
     if (ckind == CK_TEXT) sink_lit(s, "\"\"", 2);
     else if (ckind == CK_LIST) sink_lit(s, "[]", 2);
     else if (ckind == CK_MAP) sink_lit(s, "{}", 2);
-    else err = ST_UNSUPPORTED;
+    else { sink_lit(s, "null", 4); soft = true; }   // Tree / MovableList / Counter child: outside the device scope
   };
   const uint32_t ht_capd = d.ht_cap[doc];
   const unsigned long long* keys = d.ht_key + d.ht0[doc];
@@ -617,10 +635,11 @@ LM_DEV void emit_doc(Dev d, int mode) {
   {
     uint32_t P = m.n_peers;
     uint8_t* vo = mode ? d.vv_out + d.vv_off[doc] : nullptr;
+    const uint64_t vcap = d.vv_off[doc + 1] - d.vv_off[doc];   // 16 bytes per peer + 16: a true bound (10 + 5 bytes per entry)
     uint32_t cntp = 0;
     for (uint32_t p = 0; p < P; p++) if (d.peer_end[m.praw0 + p] > 0) cntp++;
     auto put_uleb = [&](uint64_t v) {
-      do { uint8_t b = v & 0x7f; v >>= 7; if (v) b |= 0x80; if (vo && lane == 0) vo[vvn] = b; vvn++; } while (v);
+      do { uint8_t b = v & 0x7f; v >>= 7; if (v) b |= 0x80; if (vo && lane == 0 && vvn < vcap) vo[vvn] = b; vvn++; } while (v);
     };
     put_uleb(cntp);
     for (uint32_t p = 0; p < P; p++) {
@@ -630,25 +649,30 @@ LM_DEV void emit_doc(Dev d, int mode) {
       put_uleb((uint64_t)e << 1);  // zigzag of a non-negative i32
     }
   }
+  if (s.pos > 0xfffffff0ull) err = ST_UNSUPPORTED;   // a document's JSON is addressed with 32 bits
   if (lane == 0) {
-    if (err) { d.doc[doc].status = err; d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; }
-    else { d.doc[doc].out_len = (uint32_t)s.pos; d.doc[doc].vv_len = vvn; }
+    if (err) { d.doc[doc].status = err; d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; d.doc[doc].flags = m.flags & ~DF_REEMIT; }
+    else {
+      d.doc[doc].out_len = (uint32_t)s.pos; d.doc[doc].vv_len = vvn;
+      uint32_t f = (m.flags & ~DF_REEMIT) | (soft ? DF_SOFT_UNSUPPORTED : 0u) | ((mode && s.pos > s.cap) ? DF_REEMIT : 0u);
+      if (f != m.flags) d.doc[doc].flags = f;
+    }
   }
 }
 
-LM_KERNEL void k_emit_text(Dev d, int mode) { emit_doc<true>(d, mode); }
-LM_KERNEL void k_emit_any(Dev d, int mode) { emit_doc<false>(d, mode); }
+LM_KERNEL void k_emit_text(Dev d, int mode, int pass) { emit_doc<true>(d, mode, pass); }
+LM_KERNEL void k_emit_any(Dev d, int mode, int pass) { emit_doc<false>(d, mode, pass); }
 
 // K12: one wave per doc — copy the rendered JSON / VV from the worst-case slabs into the compact result buffers.
 // All four offset tables are 16-byte aligned, so the copy runs on 16-byte vectors.
-LM_KERNEL void k_compact(Dev d, const uint64_t* slab_off, const uint64_t* vv_slab_off, const uint8_t* slab, const uint8_t* vv_slab) {
+LM_KERNEL void k_compact(Dev d, const uint64_t* src_addr, const uint64_t* vv_slab_off, const uint8_t* vv_slab) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   const DocMeta& m = d.doc[doc];
   if (status_fatal(m.status)) return;
   struct V16 { uint32_t x, y, z, w; };
   {
-    const V16* src = (const V16*)(slab + slab_off[doc]);
+    const V16* src = (const V16*)(uintptr_t)src_addr[doc];
     V16* dst = (V16*)(d.out + d.out_off[doc]);
     uint32_t n = (m.out_len + 15) / 16;
     for (uint32_t i = (uint32_t)lane; i < n; i += 64) dst[i] = src[i];

@@ -57,7 +57,7 @@ struct Engine {
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
-  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off;
+  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off, b_slab2, b_slab2_off;
   uint64_t payload_bytes = 0;   // Σ json_len + Σ vv_len of the last run (without alignment padding)
   std::vector<uint64_t> h_prof;
   // results
@@ -71,10 +71,10 @@ struct Engine {
   bool profiling = false;
   std::string last_error;
   uint64_t device_bytes = 0;
-  uint32_t last_retries = 0;
+  uint32_t last_retries = 0, last_reemits = 0;
   lmbe::StreamCtx* sc = nullptr;   // this engine's HIP stream + timing events
 
-  Engine() { sc = lmbe::stream_create(); }
+  explicit Engine(int device) { sc = lmbe::stream_create(device); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
   ~Engine() { release_all(); lmbe::stream_destroy(sc); }
@@ -85,7 +85,7 @@ struct Engine {
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
-                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_out, &b_out_off,
+                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
   }
@@ -346,7 +346,7 @@ struct Engine {
     if (NB) LM_LAUNCH(k_elem_fill, NB, 64, d);
     lmbe::toc("k_elem_fill", times, profiling);
     lmbe::tic(profiling);
-    if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
+    if (NO) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
     lmbe::toc("k_map_lww", times, profiling);
     lmbe::tic(profiling);
     dir_cap = (dir_cap + 3) & ~3u;
@@ -401,14 +401,18 @@ struct Engine {
     }
 #endif
     lmbe::toc(span ? "k_integrate_span" : "k_integrate", times, profiling);
-    // 6. emit in one pass into worst-case slabs (every input byte renders to at most 6 output bytes), then compact
+    // 6. emit in one pass into optimistic slabs (2 output bytes per input byte: the JSON of a text document is shorter than
+    // its blobs), then compact.  The emitter never writes beyond a slab: a document whose JSON is longer (map-typed values
+    // re-render their keys, child maps repeat them) comes back flagged DF_REEMIT with its exact size and is rendered again
+    // into an exactly-sized slab.
+    std::vector<uint64_t> slab_off(n_docs + 1, 0), vslab_off(n_docs + 1, 0);
     {
-      std::vector<uint64_t> slab_off(n_docs + 1, 0), vslab_off(n_docs + 1, 0);
       for (uint32_t i = 0; i < n_docs; i++) {
         uint64_t in_b = 0;
         for (uint32_t b = h_doc_blob[i]; b < h_doc_blob[i + 1]; b++) in_b += h_blob_len[b];
         bool ok = h_doc[i].status == ST_OK;
-        uint64_t cap = ok ? 6 * in_b + 64ull * h_doc[i].n_cont + 64 : 0;
+        uint64_t cap = ok ? 2 * in_b + 64ull * h_doc[i].n_cont + 256 : 0;
+        if (const char* e = getenv("LM_SLAB_CAP")) cap = ok ? (uint64_t)atoll(e) : 0;   // tests: force the re-emit pass
         uint64_t vcap = ok ? 16ull * h_doc[i].n_peers + 16 : 0;
         slab_off[i + 1] = slab_off[i] + ((cap + 15) & ~15ull);
         vslab_off[i + 1] = vslab_off[i] + ((vcap + 15) & ~15ull);
@@ -421,10 +425,38 @@ struct Engine {
       d.vv_out = b_vslab.as<uint8_t>(); d.vv_off = b_vslab_off.as<uint64_t>();
     }
     lmbe::tic(profiling);
-    LM_LAUNCH(k_emit_text, n_docs, 64, d, 1);
-    LM_LAUNCH(k_emit_any, n_docs, 64, d, 1);
+    LM_LAUNCH(k_emit_text, n_docs, 64, d, 1, 0);
+    LM_LAUNCH(k_emit_any, n_docs, 64, d, 1, 0);
     lmbe::toc("k_emit", times, profiling);
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+    std::vector<uint64_t> src_addr(n_docs + 1, 0);   // absolute device address of every document's rendered JSON
+    for (uint32_t i = 0; i < n_docs; i++) src_addr[i] = (uint64_t)(uintptr_t)b_slab.p + slab_off[i];
+    last_reemits = 0;
+    for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK && (h_doc[i].flags & DF_REEMIT)) last_reemits++;
+    if (last_reemits) {
+      // second slab set: the overflowed documents at their exact sizes, the others keep an empty range (they are skipped)
+      std::vector<uint64_t> off2(n_docs + 1, 0);
+      for (uint32_t i = 0; i < n_docs; i++) {
+        bool re = h_doc[i].status == ST_OK && (h_doc[i].flags & DF_REEMIT);
+        off2[i + 1] = off2[i] + (re ? ((uint64_t)h_doc[i].out_len + 15) & ~15ull : 0);
+      }
+      b_slab2.ensure(off2[n_docs] + 64); b_slab2_off.ensure((size_t)(n_docs + 1) * 8);
+      lmbe::h2d(b_slab2_off.p, off2.data(), (size_t)(n_docs + 1) * 8);
+      d.out = b_slab2.as<uint8_t>(); d.out_off = b_slab2_off.as<uint64_t>();
+      LM_LAUNCH(k_emit_text, n_docs, 64, d, 1, 1);
+      LM_LAUNCH(k_emit_any, n_docs, 64, d, 1, 1);
+      // splice: documents rendered in the second pass are compacted from the second slab
+      std::vector<DocMeta> h2(n_docs);
+      lmbe::d2h(h2.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+      for (uint32_t i = 0; i < n_docs; i++) {
+        bool re = h_doc[i].status == ST_OK && (h_doc[i].flags & DF_REEMIT);
+        if (re && (h2[i].status != ST_OK || (h2[i].flags & DF_REEMIT) || h2[i].out_len != h_doc[i].out_len)) h2[i].status = h2[i].status != ST_OK ? h2[i].status : ST_INTERNAL;
+      }
+      for (uint32_t i = 0; i < n_docs; i++) if (h2[i].status != h_doc[i].status) lmbe::h2d(&d.doc[i].status, &h2[i].status, 4);
+      for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK && (h_doc[i].flags & DF_REEMIT)) src_addr[i] = (uint64_t)(uintptr_t)b_slab2.p + off2[i];
+      h_doc = h2;
+    }
+    lmbe::h2d(b_slab_off.p, src_addr.data(), (size_t)n_docs * 8);   // the slab offsets are no longer needed: reuse as k_compact's source table
     h_out_off.assign(n_docs + 1, 0);
     h_vv_off.assign(n_docs + 1, 0);
     for (uint32_t i = 0; i < n_docs; i++) {
@@ -439,14 +471,12 @@ struct Engine {
     lmbe::h2d(b_out_off.p, h_out_off.data(), (size_t)(n_docs + 1) * 8);
     lmbe::h2d(b_vv_off.p, h_vv_off.data(), (size_t)(n_docs + 1) * 8);
     {
-      const uint64_t* so = b_slab_off.as<uint64_t>();
       const uint64_t* vo = b_vslab_off.as<uint64_t>();
-      const uint8_t* sl = b_slab.as<uint8_t>();
       const uint8_t* vs = b_vslab.as<uint8_t>();
       d.out = b_out.as<uint8_t>(); d.out_off = b_out_off.as<uint64_t>();
       d.vv_out = b_vv_out.as<uint8_t>(); d.vv_off = b_vv_off.as<uint64_t>();
       lmbe::tic(profiling);
-      LM_LAUNCH(k_compact, n_docs, 64, d, so, vo, sl, vs);
+      LM_LAUNCH(k_compact, n_docs, 64, d, (const uint64_t*)b_slab_off.as<uint64_t>(), vo, vs);
       lmbe::toc("k_compact", times, profiling);
     }
     payload_bytes = 0;
@@ -460,6 +490,8 @@ struct Engine {
       DocResult& r = results[i];
       r.status = h_doc[i].status;
       bool ok = r.status == ST_OK;
+      // out-of-scope containers met: everything in scope is rendered (they appear as null) and the document is flagged
+      if (ok && (h_doc[i].flags & DF_SOFT_UNSUPPORTED)) r.status = ST_UNSUPPORTED;
       r.json_off = h_out_off[i]; r.json_len = ok ? h_doc[i].out_len : 0;
       r.vv_off = h_vv_off[i]; r.vv_len = ok ? h_doc[i].vv_len : 0;
       r.pending = ok ? (((uint64_t)h_doc[i].pending_hi << 32) | h_doc[i].pending_lo) : 0;

@@ -40,6 +40,8 @@ struct BlockDesc {           // one per change block; owned by one lane during d
   uint32_t sec_rel[SEC_N], sec_len[SEC_N];
   uint32_t counter_start, counter_len, lamport_start, lamport_len, n_changes;
   int32_t status;
+  uint32_t flags;            // DF_* bits raised while decoding this block
+  uint32_t pad;
 };
 // per-block row counts; scanned component-wise to get table offsets
 struct BlockCounts { uint32_t n_chg, n_dep, n_op, n_key, n_cid, n_peer; };
@@ -94,7 +96,15 @@ struct DocMeta {             // per document, filled progressively
   uint32_t vvh0_lo, vvh0_hi; // vv_head rows (n_nodes × n_peers)
   uint32_t out_len;          // JSON bytes
   uint32_t vv_len;           // VV bytes
-  uint32_t pad0, pad1;
+  uint32_t pad0;             // directory entries used by the integrate stage (sizing diagnostics)
+  uint32_t flags;            // DF_* bits
+};
+
+// DocMeta.flags / BlockDesc.flags
+enum : uint32_t {
+  DF_SOFT_UNSUPPORTED = 1u,  // the document holds containers outside the device scope (Tree / MovableList / Counter): they render as
+                             // null, everything else is rendered, and the document is reported LM_UNSUPPORTED *with* its JSON
+  DF_REEMIT = 2u,            // the rendered JSON did not fit the optimistic output slab: re-rendered at its exact size
 };
 
 }  // namespace lm

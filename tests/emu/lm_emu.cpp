@@ -15,7 +15,7 @@ static uint64_t g_alloc = 0;
 static std::chrono::steady_clock::time_point g_t0;
 inline bool init(int) { return true; }
 struct StreamCtx { int unused = 0; };
-inline StreamCtx* stream_create() { return new StreamCtx(); }
+inline StreamCtx* stream_create(int) { return new StreamCtx(); }
 inline void stream_destroy(StreamCtx* c) { delete c; }
 inline void bind(StreamCtx*) {}
 inline void* dalloc(size_t n) { g_alloc += n; void* p = malloc(n ? n : 1); memset(p, 0xA5, n); return p; }  // poisoned: kernels must not rely on fresh memory

@@ -334,3 +334,81 @@ def test_keystroke_per_change_histories_stay_run_granular():
         leaves_used = c.sizing()[0]
     assert got == want
     assert leaves_used <= 16, leaves_used      # 3,000 sequential keystrokes = one run
+
+
+def test_json_longer_than_the_optimistic_slab_is_rerendered():
+    """Map-typed values reference their keys by index, so `{"someLongerFieldNameHere":null}` costs 4 input bytes and
+    renders 36; child maps repeat keys too.  The emitter must never write beyond a document's slab: such a document
+    is re-rendered at its exact size and its neighbours in the batch are untouched (lm_pipeline.h slab cap)."""
+    from loro_amd import wire
+    from loro_amd._cabi import Context
+    big = wire.Replica(5)
+    big.list_insert("l", 0, [{"someLongerFieldNameHere": None}] * 3000)
+    big.commit()
+    kids = wire.Replica(6)
+    for i in range(40):
+        c = kids.map_set_container("root", "child%02d" % i, wire.KIND_MAP)
+        for k in ("aRatherLongKeyThatEveryChildRepeats", "anotherLongKeySharedByAllTheChildren"):
+            kids.map_set(c, k, i)
+    kids.commit()
+    small = _cases.fuzz_docs(3, base=8100)
+    docs = [small[0], [big.export()], small[1], [kids.export()], small[2]]
+    want = _oracle.merge_batch(docs)
+    assert len(want[1][1]) > 6 * len(docs[1][0])          # beyond even the old 6x bound
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        sizing = c.sizing()
+    assert got == want
+    assert sizing[4] >= 1, f"expected a re-render, sizing={sizing}"
+
+
+def test_forced_rerender_of_every_document(monkeypatch):
+    """LM_SLAB_CAP=16: every document overflows its slab in the first emit pass and goes through the exact-size pass."""
+    from loro_amd._cabi import Context
+    monkeypatch.setenv("LM_SLAB_CAP", "16")
+    names, docs = _cases.edge_case_docs()
+    docs = docs + _cases.fuzz_docs(6, base=8200) + _nested_docs(4, n_peers=3, n_steps=120)
+    want = _oracle.merge_batch(docs)
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        assert c.sizing()[4] >= 10
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert (g == w) if w[0] in (0, 4) and g[0] == w[0] and g[1] else (g[0] == w[0]), i
+
+
+def _fixture_docs_and_check():
+    """(docs, check(got)): the reference fixtures that hold out-of-scope containers next to in-scope ones."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_fixtures.json")))
+    b = {k: bytes.fromhex(v) for k, v in fx["blobs"].items()}
+    docs = [[b["updates.blob"]], [b["updates.ts.blob"]], [b["runtime-updates.ts.blob"]],
+            [b["concurrent-base.ts.blob"], b["concurrent-left.ts.blob"], b["concurrent-right.ts.blob"]],
+            [b["concurrent-base.ts.blob"], b["concurrent-right.ts.blob"], b["concurrent-left.ts.blob"]]]
+
+    def check(got):
+        want = _oracle.merge_batch(docs)
+        assert got == want
+        assert all(g[0] == 4 and g[1] for g in got)
+        deep = fx["json"]["snapshot.deep.json"]
+        for g in got[:2]:
+            v = json.loads(g[1])
+            assert v["list"] == deep["list"] and v["text"] == deep["text"]
+            for k, x in deep["map"].items():
+                if k not in ("child_mlist", "child_tree"):
+                    assert v["map"][k] == x, k
+        rt = fx["json"]["runtime.expected.json"]
+        v = json.loads(got[2][1])
+        assert v["list"] == rt["list"] and v["text"] == rt["text"] and all(v["map"][k] == rt["map"][k] for k in ("answer", "child", "nested"))
+        cc = fx["json"]["concurrent.expected.json"]
+        for g in got[3:]:
+            v = json.loads(g[1])
+            assert all(v[k] == cc[k] for k in ("list", "text", "map"))
+    return docs, check
+
+
+def test_reference_fixtures_with_out_of_scope_containers_render_the_rest():
+    """Rust-written `updates.blob` (and the TS-written fixtures) hold MovableList / Tree / Counter containers: the device
+    path renders every in-scope key, shows the out-of-scope containers as null and reports LM_UNSUPPORTED *with* the JSON —
+    compared key by key with the oracle and with the reference's expected deep JSON (loro_js_interop.rs:42-126)."""
+    docs, check = _fixture_docs_and_check()
+    check(_emu.merge_batch(docs))

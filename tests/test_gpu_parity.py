@@ -44,9 +44,12 @@ def test_reference_fixture_blobs(engine):
     docs = [[b["fugue-left.ts.blob"], b["fugue-right.ts.blob"]], [b["fugue-right.ts.blob"], b["fugue-left.ts.blob"]]]
     got = _same(engine, docs)
     assert got[0][1] == b'{"text":"Hello World!"}' and got[1][1] == got[0][1]
-    # fixtures with containers outside the device scope must be flagged, not guessed
-    for name in ("updates.blob", "runtime-updates.ts.blob"):   # Tree / MovableList / Counter containers inside
-        assert engine.merge_batch([[b[name]]])[0][0] == 4
+    # fixtures with containers outside the device scope (Tree / MovableList / Counter): flagged LM_UNSUPPORTED, the in-scope
+    # keys rendered and compared with the oracle and the reference's expected deep JSON — this is the Rust-written
+    # `updates.blob` going through the HIP decoder (DeltaRle run form, real DeltaOfDelta ranges)
+    import test_emu_parity
+    fdocs, check = test_emu_parity._fixture_docs_and_check()
+    check(engine.merge_batch(fdocs))
     got = _same(engine, [[b["concurrent-base.ts.blob"]]])        # List + Text only: fully in scope
     assert got[0][1] == b'{"list":["base"],"text":"x"}'
 
@@ -166,6 +169,24 @@ def test_child_containers(engine):
     got = engine.merge_batch(docs)
     for i, g in enumerate(got):
         assert g == want[i % len(base)], i
+
+
+def test_json_longer_than_the_optimistic_slab(engine, monkeypatch):
+    """The emitter never writes beyond a document's slab; overflowing documents are re-rendered at their exact size."""
+    big = wire.Replica(5)
+    big.list_insert("l", 0, [{"someLongerFieldNameHere": None}] * 3000)
+    big.commit()
+    small = _cases.fuzz_docs(64, base=8100)
+    docs = []
+    for i, s_ in enumerate(small):
+        docs.append(s_)
+        if i % 8 == 0:
+            docs.append([big.export()])
+    assert engine.merge_batch(docs) == _oracle.merge_batch(docs, threads=8)
+    assert engine.sizing()[4] >= 8
+    monkeypatch.setenv("LM_SLAB_CAP", "16")       # every document through the exact-size pass
+    assert engine.merge_batch(docs) == _oracle.merge_batch(docs, threads=8)
+    assert engine.sizing()[4] == len(docs)
 
 
 def test_container_limit_is_reported(engine):
