@@ -233,8 +233,7 @@ LM_KERNEL void k_block_count(Dev d) {
 // container (tag 9 + kind byte) is accepted down to nesting depth `cdepth`: 0 for a Map value, 1 for the items of a List
 // insert; -1 nowhere.  Children of a kind outside Map / List / Text are accepted here: they render as null and flag the
 // document DF_SOFT_UNSUPPORTED when met by the emitter (or when one of their ops is applied).
-LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
-  uint32_t f_cnt[16];
+LM_DEV void skip_loro_value_fs(Rd& r, bool& unsupported, int cdepth, uint32_t* f_cnt) {   // f_cnt: 16 words of frame stack
   uint32_t f_map = 0;  // bit i: frame i is a map (each item is preceded by a key index)
   int sp = 0;
   uint32_t cnt = 1;
@@ -270,6 +269,10 @@ LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
     }
   }
   r.bad = true;
+}
+LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
+  uint32_t f_cnt[16];
+  skip_loro_value_fs(r, unsupported, cdepth, f_cnt);
 }
 
 // K4: one lane per block — full decode into the row tables (block-local indices; K6 remaps them).
@@ -543,3 +546,5 @@ LM_KERNEL void k_block_decode(Dev d) {
 }
 
 }  // namespace lm
+
+#include "lm_k_decode_wave.h"

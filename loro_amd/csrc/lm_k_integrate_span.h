@@ -36,7 +36,7 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   SpanRegs cr;
   int32_t err;
 #ifdef LM_PROF
-  uint64_t prof[PF_N];
+  mutable uint64_t prof[PF_N];
 #endif
 };
 
@@ -48,6 +48,7 @@ LM_DEV SpanRegs sp_load(const Ts& t, uint32_t L, uint32_t n) {
   int lane = lmw::lane();
   lmw::wave_sync();
   if (L == t.cache_leaf) return t.cr;
+  PROF_CNT(t, PF_NEXTRA, 1);   // leaf fetched from HBM
   SpanRegs r;
   r.n = n;
   bool in = (uint32_t)lane < n;
@@ -290,6 +291,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       uint32_t limit = (origin_right != NONE && cp == r_p) ? r_slot : C.n;
       for (uint32_t h = ci; h < limit && !stop && !t.err; h++) {
         uint32_t o_id = lmw::bcast(C.id, (int)h), o_ol = lmw::bcast(C.ol, (int)h), o_or = lmw::bcast(C.orr, (int)h);
+        PROF_CNT(t, PF_NHEAD, 1);   // in-between items examined by the sibling scan
         if (o_ol != origin_left) {
           // is o_ol one of the in-between elements already passed?  (inside an item at a position in [cursor, (cp,h)))
           bool visited = false;
@@ -401,6 +403,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     if (hm) { R = t.cr; p = t.cache_p; }
     else {
       uint32_t lf = lmw::first(t.loc[eb + c]);
+      PROF_CNT(t, 15, 1);   // status updates that went through loc[] (the target was not in the cached leaf)
       if (lf >= t.n_leaf) { c++; continue; }          // not an element of this container (malformed target): ignored
       // the three arrays a status change needs are requested for all 64 slots right away; the directory lookup (LDS)
       // runs while they are in flight, and the item count then masks the unused slots

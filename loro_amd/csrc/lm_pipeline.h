@@ -255,7 +255,16 @@ struct Engine {
     lmbe::dmemset(b_chg_skip.p, 0, (size_t)(NC + 1) * 4);
     lmbe::dmemset(b_chg_lamport.p, 0, (size_t)(NC + 1) * 4);
     lmbe::tic(profiling);
-    if (NB) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
+    // one wave per group of DEC_G blocks, staged through LDS (lm_k_decode_wave.h); LM_DECODE=0 selects the one-lane-per-block
+    // decoder (kept as the second, independently structured implementation the parity suites also run)
+    if (NB) {
+      if (getenv("LM_DECODE") && atoi(getenv("LM_DECODE")) == 0) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
+      else {
+        uint32_t slot_cap = 2048;   // LDS bytes per block for everything before its value payloads
+        if (const char* e = getenv("LM_DEC_SLOT")) slot_cap = ((uint32_t)atoi(e) + 15u) & ~15u;
+        LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_G * 16 * 4 + DEC_G * DEC_KINDS, d, slot_cap);
+      }
+    }
     lmbe::toc("k_block_decode", times, profiling);
     lmbe::tic(profiling);
     LM_LAUNCH(k_doc_ranges, cdiv(n_docs, 64), 64, d);

@@ -412,3 +412,26 @@ def test_reference_fixtures_with_out_of_scope_containers_render_the_rest():
     compared key by key with the oracle and with the reference's expected deep JSON (loro_js_interop.rs:42-126)."""
     docs, check = _fixture_docs_and_check()
     check(_emu.merge_batch(docs))
+
+
+@pytest.mark.parametrize("variant", ["wave", "wave-unstaged", "lane"])
+def test_block_decoders_agree(monkeypatch, variant):
+    """The wave-per-block-group decoder (default; LDS-staged, lane = block x column), the same kernel with slots too
+    small to stage anything (every parser reads HBM) and the one-lane-per-block decoder (LM_DECODE=0) must all give the
+    oracle's results — including WHICH error a damaged block is rejected with."""
+    if variant == "wave-unstaged":
+        monkeypatch.setenv("LM_DEC_SLOT", "16")
+    if variant == "lane":
+        monkeypatch.setenv("LM_DECODE", "0")
+    names, docs = _cases.edge_case_docs()
+    _check(docs, names)
+    _check(_cases.fuzz_docs(16, base=9300) + _cases.cfg4_docs(3, first=1200, n_steps=300) + _nested_docs(4, n_peers=3, n_steps=150))
+    docs, check = _fixture_docs_and_check()
+    check(_emu.merge_batch(docs))
+    bad = _cases.corrupted_docs(120, seed=11)
+    got = _emu.merge_batch(bad)
+    monkeypatch.delenv("LM_DEC_SLOT", raising=False)
+    monkeypatch.setenv("LM_DECODE", "0")
+    ref = _emu.merge_batch(bad)          # the sequential decoder's verdicts
+    assert [g[0] for g in got] == [x[0] for x in ref]
+    assert got == ref

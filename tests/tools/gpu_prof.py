@@ -8,9 +8,12 @@ so = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspat
 b = Binding(so, "lm_")
 b.lib.lm_prof_sum.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
 n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+for kv in sys.argv[2:]:
+    k, _, v = kv.partition('=')
+    os.environ[k] = v
 tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
 docs = [tpl.stamp(d) for d in range(n_docs)]
-names = ["row", "find", "leaf", "oright", "between", "place", "delete", "checkout", "n_ins", "n_del", "n_extra_leaf", "n_heads", "total", "n_ins_cache_hit", "n_upd_cache_hit", "slot15"]
+names = ["row", "find", "leaf", "oright", "between", "place", "delete", "checkout", "n_ins", "n_del", "n_leaf_loads", "n_between_items", "total", "n_ins_inside_run", "n_ins_merged", "n_upd_via_loc"]
 with Context(b, 0) as e:
     print("selftest mismatches:", b.selftest(e.h))
     e.stage(docs)
