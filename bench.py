@@ -37,35 +37,73 @@ def build_docs(n_docs, first_doc, n_base, n_branch, commit_every, seed):
     return tpl, [tpl.stamp(first_doc + d) for d in range(n_docs)]
 
 
-def cpu_baseline(docs, sample, cores):
+_CPU_DOCS = None   # set before the workers fork: they read their slice copy-on-write
+
+
+def _cpu_worker(w, lo, hi, reps, barrier, q):
+    """One single-threaded oracle process: merges its slice of the benchmark documents `reps` times."""
+    import _oracle
+    packed = _oracle.pack(_CPU_DOCS[lo:hi])
+    _oracle.merge_batch(None, threads=1, packed=packed)            # warm: library paged in, heap grown
+    barrier.wait()
+    t0 = time.monotonic()
+    ok = True
+    for _ in range(reps):
+        res = _oracle.merge_batch(None, threads=1, packed=packed)
+        ok = ok and all(r[0] == 0 for r in res)
+    q.put((w, (hi - lo) * reps, t0, time.monotonic(), ok))
+
+
+def _cpu_procs(docs, procs, per_proc, reps):
+    """docs/s of `procs` independent single-threaded oracle processes (one address space each: no shared heap, no mmap
+    lock), all released by one barrier; throughput = merges done / (last finish - first start)."""
+    import multiprocessing as mp
+    global _CPU_DOCS
+    _CPU_DOCS = docs
+    ctx = mp.get_context("fork")
+    barrier, q = ctx.Barrier(procs), ctx.Queue()
+    ps = []
+    for w in range(procs):
+        lo = (w * per_proc) % max(1, len(docs) - per_proc + 1)
+        ps.append(ctx.Process(target=_cpu_worker, args=(w, lo, lo + per_proc, reps, barrier, q)))
+    for p_ in ps:
+        p_.start()
+    out = [q.get() for _ in ps]
+    for p_ in ps:
+        p_.join()
+    assert all(o[4] for o in out)
+    n = sum(o[1] for o in out)
+    return n / (max(o[3] for o in out) - min(o[2] for o in out)), n
+
+
+def cpu_baseline(docs, sample, cores, target_s=8.0):
     """The CPU restatement of the reference algorithm (oracle/, kind "port") timed on this box's host cores on a
     bounded sample of the same workload.  Reported next to the GPU number; never the thing measured above.
-    The best of {all hardware threads, 1/2, 1/4, 1/8 of them} after a warm run (heap already faulted in) is reported:
-    on the 256-thread measurement box the port scales to ≈32 threads and loses throughput beyond (allocator / page-fault
-    contention), so the best count, not the largest, is the fair baseline."""
+    Documents are independent, so the port is run the way a CPU deployment would scale it: one single-threaded process
+    per core (round 1 used threads in one process and stopped scaling at 32 of 256 hardware threads: shared glibc heap
+    and mmap lock).  Measured at 1 process, at half and at all of the hardware threads; the best is `value`."""
     import _oracle
     sample_docs = docs[:sample]
-    packed = _oracle.pack(sample_docs)
-    best = None
-    res = None
-    for threads in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
-        _oracle.merge_batch(None, threads=threads, packed=packed)          # warm
-        t = time.perf_counter()
-        res = _oracle.merge_batch(None, threads=threads, packed=packed)
-        dt = time.perf_counter() - t
-        if best is None or dt < best[0]:
-            best = (dt, threads)
-    dt, threads = best
-    one = _oracle.pack(sample_docs[: min(32, len(sample_docs))])
-    _oracle.merge_batch(None, threads=1, packed=one)
+    one = _oracle.pack(sample_docs[:16])
+    res = _oracle.merge_batch(None, threads=1, packed=one)           # warm + the results bench.py cross-checks
     t1 = time.perf_counter()
     _oracle.merge_batch(None, threads=1, packed=one)
-    dt1 = (time.perf_counter() - t1) / min(32, len(sample_docs))
+    per_doc = (time.perf_counter() - t1) / 16
     assert all(r[0] == 0 for r in res)
+    per_proc = 16
+    reps = max(1, int(target_s / (per_doc * per_proc)))
+    runs = {}
+    for procs in sorted({1, max(1, cores // 2), cores}):
+        rate, n = _cpu_procs(sample_docs, procs, per_proc, reps if procs > 1 else max(1, reps // 2))
+        runs[procs] = (rate, n)
+    best = max(runs, key=lambda k: runs[k][0])
     return {
-        "value": round(len(sample_docs) / dt, 1), "unit": "docs/s", "cores": threads, "kind": "port",
-        "sample": f"{len(sample_docs)} of the benchmark documents (same blobs), oracle/liblorooracle.so, {threads} threads "
-                  f"(of {cores} hardware threads), {dt:.2f} s wall after a warm run; single thread {1.0 / dt1:.1f} docs/s",
+        "value": round(runs[best][0], 1), "unit": "docs/s", "cores": best, "kind": "port",
+        "sample": f"{runs[best][1]} merges of the benchmark documents (same blobs): {best} single-threaded processes of "
+                  f"oracle/liblorooracle.so x {per_proc} documents x {reps} passes, released together; "
+                  + "; ".join(f"{k} proc: {v[0]:.0f} docs/s" for k, v in sorted(runs.items()))
+                  + f" ({cores} hardware threads on the box)",
+        "scaling": {str(k): round(v[0], 1) for k, v in sorted(runs.items())},
     }, res
 
 
@@ -106,6 +144,10 @@ def main():
 
     tpl, docs = build_docs(args.docs, rank * args.docs, args.base_ops, args.branch_ops, args.commit_every, seed=0)
     doc_ids = list(range(rank * args.docs, (rank + 1) * args.docs))
+    # CPU baseline first (rank 0 at N=1 only): its worker processes are forked before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, _ = cpu_baseline(docs, min(args.cpu_sample, len(docs)), os.cpu_count() or 1)
     engs = [loro_amd.MergeEngine(local_rank) for _ in range(max(1, args.inflight))]
     for e in engs:
         e.stage(docs)                     # blobs → HBM (outside the timed region); every context holds the batch
@@ -202,11 +244,11 @@ def main():
         got = eng.fetch()
         for e in engs[1:]:
             assert e.fetch() == got, "contexts disagree"
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            threads = os.cpu_count() or 1
-            cpu, want = cpu_baseline(docs, min(args.cpu_sample, len(docs)), threads)
-            assert got[: len(want)] == want, "device results differ from the CPU oracle"
+        if world == 1:
+            import _oracle
+            n_chk = min(256, len(docs))
+            want = _oracle.merge_batch(docs[:n_chk], threads=min(32, os.cpu_count() or 1))
+            assert got[:n_chk] == want, "device results differ from the CPU oracle"
         n_total = args.docs * world
         line = {
             "metric": "merged docs/sec (batch of N docs x M remote ops)",
