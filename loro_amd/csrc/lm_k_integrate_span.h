@@ -33,6 +33,8 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
   uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); write-through
   uint32_t cache_p;               // its directory position (kept in step with directory inserts)
+  uint32_t cache_pre;             // active elements in front of the cached leaf, NONE when not known: an edit at a position
+                                  // inside the cached leaf then needs no directory search at all
   SpanRegs cr;
   int32_t err;
 #ifdef LM_PROF
@@ -61,7 +63,7 @@ LM_DEV SpanRegs sp_load(const Ts& t, uint32_t L, uint32_t n) {
   return r;
 }
 // store lanes [from, R.n) of leaf L and make it the cached leaf
-LM_DEV void sp_store(Ts& t, uint32_t L, const SpanRegs& R, uint32_t from, uint32_t p) {
+LM_DEV void sp_store(Ts& t, uint32_t L, const SpanRegs& R, uint32_t from, uint32_t p, uint32_t pre) {
   int lane = lmw::lane();
   if ((uint32_t)lane < R.n && (uint32_t)lane >= from) {
     uint32_t* rec = t.it + (uint64_t)L * SP_REC;
@@ -69,6 +71,7 @@ LM_DEV void sp_store(Ts& t, uint32_t L, const SpanRegs& R, uint32_t from, uint32
   }
   t.cache_leaf = L;
   t.cache_p = p;
+  t.cache_pre = pre;
   t.cr = R;
 }
 LM_DEV uint32_t sp_alen(const SpanRegs& R) { return ((uint32_t)lmw::lane() < R.n && st_active(R.st)) ? R.len : 0u; }
@@ -148,7 +151,7 @@ LM_DEV void sd_refresh(Ts& t, uint32_t p, uint32_t L, const SpanRegs& R) {   // 
 // (loc[] must be written); a part of a split run only needs loc[] when it lands in another leaf.  On return (p, idx)
 // address item A and R holds its leaf.
 LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& A, const SpanItem& B, uint32_t cnt,
-                            uint32_t dirty_from, bool newA, bool newB) {
+                            uint32_t dirty_from, bool newA, bool newB, uint32_t pre) {   // pre: active elements before leaf p (NONE = unknown)
   int lane = lmw::lane();
   lmw::wave_sync();
   uint32_t L = sa_leaf(lmw::first(t.da[p]));
@@ -168,18 +171,19 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
     for (uint32_t j = 0; j < nu; j++) sp_set_loc(t, lmw::bcast(U.id, (int)j), lmw::bcast(U.len, (int)j), NL);
     if (idx > 32 || (idx == 32 && dirty_from >= 32)) {
       // the edit goes to the upper half: the lower half only needs its modified lanes stored
-      sp_store(t, L, Lo, dirty_from < 32 ? dirty_from : 32, p);
+      sp_store(t, L, Lo, dirty_from < 32 ? dirty_from : 32, p, pre);
       sd_refresh(t, p, L, Lo);
+      if (pre != NONE) pre += lmw::first(t.db[p]);   // the new leaf starts behind the lower half
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
       if (t.err) return;
-      sp_store(t, NL, U, 0, p + 1);
+      sp_store(t, NL, U, 0, p + 1, pre);
       p = p + 1; idx -= 32; R = U; L = NL;
       dirty_from = 0;
       moved = true;
     } else {
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
       if (t.err) return;
-      sp_store(t, NL, U, 0, p + 1);
+      sp_store(t, NL, U, 0, p + 1, NONE);
       R = Lo;
       if (dirty_from > 32) dirty_from = 32;
     }
@@ -194,14 +198,14 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
   if ((uint32_t)lane == idx) { N.id = A.id; N.len = A.len; N.ol = A.ol; N.orr = A.orr; N.st = A.st; }
   if (cnt == 2 && (uint32_t)lane == idx + 1) { N.id = B.id; N.len = B.len; N.ol = B.ol; N.orr = B.orr; N.st = B.st; }
   if ((uint32_t)lane >= N.n) { N.id = NONE; N.len = 0; N.ol = NONE; N.orr = NONE; N.st = ST_FUT; }
-  sp_store(t, L, N, dirty_from < idx ? dirty_from : idx, p);
+  sp_store(t, L, N, dirty_from < idx ? dirty_from : idx, p, pre);
   if (newA || moved) sp_set_loc(t, A.id, A.len, L);
   if (cnt == 2 && (newB || moved)) sp_set_loc(t, B.id, B.len, L);
   sd_refresh(t, p, L, N);
   R = N;
 }
-LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& it, uint32_t dirty_from, bool new_elems) {
-  sp_insert_items(t, p, R, idx, it, it, 1, dirty_from, new_elems, false);
+LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& it, uint32_t dirty_from, bool new_elems, uint32_t pre) {
+  sp_insert_items(t, p, R, idx, it, it, 1, dirty_from, new_elems, false, pre);
 }
 
 // ---- insert (Fugue integrate, crdt_rope.rs:63-247) of run [pid0, pid0+len) at active position pos
@@ -210,7 +214,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   PROF_T0();
   PROF_CNT(t, PF_NINS, 1);
   if (pos > t.tot_active) pos = t.tot_active;
-  uint32_t p = 0, idx = 0, origin_left = NONE;
+  uint32_t p = 0, idx = 0, origin_left = NONE, pre_p = 0;
   SpanRegs R;
   SpanItem nw;
   nw.id = pid0; nw.len = len; nw.st = 0;
@@ -218,8 +222,12 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     R = sp_load(t, sa_leaf(lmw::first(t.da[0])), sa_n(lmw::first(t.da[0])));
   } else {
     uint32_t k = pos;
-    p = sd_find_kth(t, k);
+    lmw::wave_sync();
+    if (t.cache_leaf != NONE && t.cache_pre != NONE && pos > t.cache_pre && pos - t.cache_pre <= lmw::first(t.db[t.cache_p])) {
+      p = t.cache_p; k = pos - t.cache_pre;        // the position lies inside the cached leaf: no directory search
+    } else p = sd_find_kth(t, k);
     if (p == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    pre_p = pos - k;
     lmw::wave_sync();
     uint32_t a = lmw::first(t.da[p]);
     R = sp_load(t, sa_leaf(a), sa_n(a));
@@ -240,7 +248,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       nw.ol = origin_left; nw.orr = sid + off;
       idx = slot + 1;
       PROF_ADD(t, PF_FIND);
-      sp_insert_items(t, p, R, idx, nw, rt, 2, slot, true, false);
+      sp_insert_items(t, p, R, idx, nw, rt, 2, slot, true, false, pre_p);
       PROF_ADD(t, PF_PLACE);
       PROF_CNT(t, PF_NHIT, 1);
       return;
@@ -289,7 +297,22 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     SpanRegs C = R;
     for (uint32_t guard = 0; guard <= t.n_dir && !t.err && !stop; guard++) {
       uint32_t limit = (origin_right != NONE && cp == r_p) ? r_slot : C.n;
+      // continuation items: origin_left = last element of the item right before them in this leaf, which the scan has
+      // already passed (a run cut by deletes or by an insertion stays a chain of such items).  They are visited
+      // non-siblings by construction — one ballot finds them all, and the scan hops over whole chains
+      uint64_t contm;
+      {
+        uint32_t prev_last = lmw::shift_up(C.id + C.len - 1, 1);
+        contm = lmw::ballot((uint32_t)lane > ci && (uint32_t)lane < limit && C.ol == prev_last);
+      }
       for (uint32_t h = ci; h < limit && !stop && !t.err; h++) {
+        if ((contm >> h) & 1) {
+          uint64_t rest = ~contm >> h;
+          uint32_t e = rest ? h + (uint32_t)lmw::ffs64(rest) : limit;   // first item at/after h that is not a continuation (bits at and beyond `limit` are clear)
+          if (!scanning) { ins_p = cp; ins_idx = e; }
+          h = e - 1;
+          continue;
+        }
         uint32_t o_id = lmw::bcast(C.id, (int)h), o_ol = lmw::bcast(C.ol, (int)h), o_or = lmw::bcast(C.orr, (int)h);
         PROF_CNT(t, PF_NHEAD, 1);   // in-between items examined by the sibling scan
         if (o_ol != origin_left) {
@@ -370,7 +393,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       uint32_t a = lmw::first(t.da[p]);
       uint32_t L = sa_leaf(a);
       if ((uint32_t)lane == pv) { R.len = v_len + len; t.it[(uint64_t)L * SP_REC + 64 + lane] = R.len; }
-      t.cache_leaf = L; t.cache_p = p; t.cr = R;
+      t.cache_leaf = L; t.cache_p = p; t.cache_pre = pre_p; t.cr = R;
       sp_set_loc(t, pid0, len, L);
       sd_set(t, p, a, lmw::first(t.db[p]) + len);
       PROF_ADD(t, PF_PLACE);
@@ -382,12 +405,14 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   if (ins_p == p) D = R;
   else if (r_p != NONE && ins_p == r_p) D = RR;
   else { lmw::wave_sync(); uint32_t a = lmw::first(t.da[ins_p]); D = sp_load(t, sa_leaf(a), sa_n(a)); }
-  sp_insert_item(t, ins_p, D, ins_idx, nw, D.n, true);
+  sp_insert_item(t, ins_p, D, ins_idx, nw, D.n, true, ins_p == p ? pre_p : NONE);
   PROF_ADD(t, PF_PLACE);
 }
 
 // ---- status update of the elements with ids [c0,c1) of `peer` (crdt_rope.rs:345-381 by id): walk run by run
-LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int mode) {
+// hint_k != 0: the first target is the hint_k-th active element (1-based) of the tracker's current version — a delete row
+// carries its position — so the leaf is found through the LDS directory and only verified by id; loc[] is the fallback
+LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int mode, uint32_t hint_k = 0) {
   int lane = lmw::lane();
   uint32_t eb = t.ebase[peer];
   if (c1 > t.end[peer]) c1 = t.end[peer];   // a damaged target range cannot make the walk longer than the peer's history
@@ -399,22 +424,35 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     SpanRegs R;
     uint64_t hm = 0;
     if (t.cache_leaf != NONE) hm = lmw::ballot((uint32_t)lane < t.cr.n && pid_peer(t.cr.id) == peer && sp_has(t.cr.id, t.cr.len, x));
-    bool partial = false;   // R holds only id / len / status (origins are fetched if the run has to be cut)
     if (hm) { R = t.cr; p = t.cache_p; }
-    else {
+    else if (hint_k && c == c0 && hint_k <= t.tot_active) {
+      uint32_t k = hint_k;
+      lmw::wave_sync();
+      if (t.cache_leaf != NONE && t.cache_pre != NONE && hint_k > t.cache_pre && hint_k - t.cache_pre <= lmw::first(t.db[t.cache_p])) { p = t.cache_p; k = hint_k - t.cache_pre; }
+      else p = sd_find_kth(t, k);
+      if (p != NONE) {
+        lmw::wave_sync();
+        uint32_t a = lmw::first(t.da[p]);
+        R = sp_load(t, sa_leaf(a), sa_n(a));
+        hm = lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
+        if (hm) { t.cache_leaf = sa_leaf(a); t.cache_p = p; t.cache_pre = hint_k - k; t.cr = R; }
+      }
+    }
+    if (!hm) {
       uint32_t lf = lmw::first(t.loc[eb + c]);
       PROF_CNT(t, 15, 1);   // status updates that went through loc[] (the target was not in the cached leaf)
       if (lf >= t.n_leaf) { c++; continue; }          // not an element of this container (malformed target): ignored
-      // the three arrays a status change needs are requested for all 64 slots right away; the directory lookup (LDS)
-      // runs while they are in flight, and the item count then masks the unused slots
+      // all five arrays are requested for all 64 slots right away; the directory lookup (LDS) runs while they are in
+      // flight, and the item count then masks the unused slots.  The leaf becomes the cached leaf: a delete run arrives
+      // as one row per contiguous id span, and the following rows address its neighbours
       const uint32_t* rec = t.it + (uint64_t)lf * SP_REC;
-      uint32_t xid = rec[lane], xln = rec[64 + lane], xst = rec[256 + lane];
+      uint32_t xid = rec[lane], xln = rec[64 + lane], xol = rec[128 + lane], xor_ = rec[192 + lane], xst = rec[256 + lane];
       p = sd_find_leaf(t, lf);
       if (p == NONE) { c++; continue; }                // leaf of another container of the same document
       R.n = sa_n(lmw::first(t.da[p]));
       bool in = (uint32_t)lane < R.n;
-      R.id = in ? xid : NONE; R.len = in ? xln : 0u; R.st = in ? xst : ST_FUT; R.ol = NONE; R.orr = NONE;
-      partial = true;
+      R.id = in ? xid : NONE; R.len = in ? xln : 0u; R.ol = in ? xol : NONE; R.orr = in ? xor_ : NONE; R.st = in ? xst : ST_FUT;
+      t.cache_leaf = lf; t.cache_p = p; t.cache_pre = NONE; t.cr = R;
       hm = lmw::ballot(in && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
       if (!hm) { c++; continue; }
     }
@@ -434,16 +472,10 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     if (s_off == 0 && tail == 0) {
       // the whole run: one status word
       if ((uint32_t)lane == slot) { R.st = st1; t.it[(uint64_t)L * SP_REC + 256 + lane] = st1; }
-      if (L == t.cache_leaf) t.cr.st = R.st;
+      t.cr.st = R.st;   // (R is the cached leaf: either it was, or the lookup above made it so)
       sd_refresh(t, p, L, R);
     } else {
       // the run is cut at the range's ends and the affected part gets the new status: one rewrite of the leaf
-      if (partial) {
-        const uint32_t* rec = t.it + (uint64_t)L * SP_REC;
-        bool in = (uint32_t)lane < R.n;
-        R.ol = in ? rec[128 + lane] : NONE; R.orr = in ? rec[192 + lane] : NONE;
-        orr0 = lmw::bcast(R.orr, (int)slot);
-      }
       SpanItem A, B;
       uint32_t cnt, idx = slot + 1;
       if (s_off > 0) {
@@ -457,7 +489,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
         B = A;
         cnt = 1;
       }
-      sp_insert_items(t, p, R, idx, A, B, cnt, slot, false, false);
+      sp_insert_items(t, p, R, idx, A, B, cnt, slot, false, false, t.cache_pre);
       if (t.err) return;
     }
     c = endc;
@@ -519,6 +551,12 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
       tot += act;
     }
     if (ok && tot != t.tot_active) { fprintf(stderr, "CHECK %s row=%u: total active %u, cached %u\n", what, row, tot, t.tot_active); ok = false; }
+    if (ok && t.cache_leaf != NONE) {
+      if (t.cache_p >= t.n_dir || sa_leaf(t.da[t.cache_p]) != t.cache_leaf) { fprintf(stderr, "CHECK %s row=%u: cached leaf %u is not at directory position %u\n", what, row, t.cache_leaf, t.cache_p); ok = false; }
+      uint32_t pre = 0;
+      for (uint32_t q = 0; q < t.cache_p && q < t.n_dir; q++) pre += t.db[q];
+      if (ok && t.cache_pre != NONE && pre != t.cache_pre) { fprintf(stderr, "CHECK %s row=%u: %u active elements before the cached leaf, cached prefix %u\n", what, row, pre, t.cache_pre); ok = false; }
+    }
   }
   return lmw::any(!ok) ? false : true;
 }
@@ -578,7 +616,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
     uint32_t L0 = t.n_leaf++;
     lmw::block_sync();
     if (lane == 0) { s_da[0] = sa_make(L0, 0, false); s_db[0] = 0; }
-    t.n_dir = 1; t.tot_active = 0; t.cache_leaf = NONE;
+    t.n_dir = 1; t.tot_active = 0; t.cache_leaf = NONE; t.cache_pre = NONE;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
     lmw::block_sync();
     bool touched = false;
@@ -631,7 +669,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
             uint32_t t0, t1;
             if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
             else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
-            ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
+            // unsliced row: its position addresses the leftmost target (forward: prop; backward: prop + 1 - len)
+            uint32_t hint = 0;
+            if (a == 0 && b == r.len && Ln == r.len && r.prop >= 0) { if (r.a2 > 0) hint = (uint32_t)r.prop + 1; else if ((uint32_t)r.prop + 1 >= Ln) hint = (uint32_t)r.prop + 2 - Ln; }
+            ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC, hint);
             PROF_ADD(t, PF_DELETE);
             PROF_CNT(t, PF_NDEL, 1);
             TS_CHECK("delete", row);
