@@ -31,11 +31,13 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   uint32_t* da;                   // LDS directory, word A per leaf in document order
   uint32_t* db;                   // LDS directory, word B (active length)
   uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
-  uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); write-through
+  uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); WRITE-BACK: `cr` is the truth, HBM is updated by sp_flush
   uint32_t cache_p;               // its directory position (kept in step with directory inserts)
   uint32_t cache_pre;             // active elements in front of the cached leaf, NONE when not known: an edit at a position
                                   // inside the cached leaf then needs no directory search at all
   SpanRegs cr;
+  bool dirty;                     // `cr` differs from the leaf record in HBM
+  uint64_t loc_dirty;             // lanes of `cr` whose items entered the leaf since the last flush: their loc[] entries are pending
   int32_t err;
 #ifdef LM_PROF
   mutable uint64_t prof[PF_N];
@@ -62,17 +64,13 @@ LM_DEV SpanRegs sp_load(const Ts& t, uint32_t L, uint32_t n) {
   r.st = in ? rec[256 + lane] : ST_FUT;
   return r;
 }
-// store lanes [from, R.n) of leaf L and make it the cached leaf
-LM_DEV void sp_store(Ts& t, uint32_t L, const SpanRegs& R, uint32_t from, uint32_t p, uint32_t pre) {
+// leaf record L in HBM := R
+LM_DEV void sp_write(Ts& t, uint32_t L, const SpanRegs& R) {
   int lane = lmw::lane();
-  if ((uint32_t)lane < R.n && (uint32_t)lane >= from) {
+  if ((uint32_t)lane < R.n) {
     uint32_t* rec = t.it + (uint64_t)L * SP_REC;
     rec[lane] = R.id; rec[64 + lane] = R.len; rec[128 + lane] = R.ol; rec[192 + lane] = R.orr; rec[256 + lane] = R.st;
   }
-  t.cache_leaf = L;
-  t.cache_p = p;
-  t.cache_pre = pre;
-  t.cr = R;
 }
 LM_DEV uint32_t sp_alen(const SpanRegs& R) { return ((uint32_t)lmw::lane() < R.n && st_active(R.st)) ? R.len : 0u; }
 LM_DEV bool sp_nf(const SpanRegs& R) { return lmw::ballot((uint32_t)lmw::lane() < R.n && !(R.st & ST_FUT)) != 0; }
@@ -80,6 +78,26 @@ LM_DEV bool sp_nf(const SpanRegs& R) { return lmw::ballot((uint32_t)lmw::lane() 
 LM_DEV void sp_set_loc(Ts& t, uint32_t id0, uint32_t len, uint32_t L) {
   uint32_t g = ts_g(t, id0);
   for (uint32_t k = (uint32_t)lmw::lane(); k < len; k += 64) t.loc[g + k] = L;
+}
+
+LM_DEV void sp_set_loc_mask(Ts& t, const SpanRegs& R, uint64_t m, uint32_t L) {
+  while (m) {
+    int j = lmw::ffs64(m);
+    m &= m - 1;
+    sp_set_loc(t, lmw::bcast(R.id, j), lmw::bcast(R.len, j), L);
+  }
+}
+// The cached leaf is write-back: an edit that stays inside it issues NO global store (on gfx9-class hardware stores share
+// the load counter, so a store per edit makes the next op-row fetch wait a full write round trip).  HBM and loc[] catch up
+// when another leaf takes the cache, before a sibling scan (which reads loc[] and other leaves) and at the end of the replay.
+LM_DEV void sp_flush(Ts& t) {
+  if (t.cache_leaf == NONE) return;
+  if (t.dirty) { sp_write(t, t.cache_leaf, t.cr); t.dirty = false; }
+  if (t.loc_dirty) { sp_set_loc_mask(t, t.cr, t.loc_dirty, t.cache_leaf); t.loc_dirty = 0; }
+}
+// leaf L becomes the cached leaf (its registers are set by the caller); another cached leaf is written back first
+LM_DEV void sp_take(Ts& t, uint32_t L) {
+  if (t.cache_leaf != L) { sp_flush(t); t.cache_leaf = L; t.dirty = false; t.loc_dirty = 0; }
 }
 
 // ---- directory (LDS, a few hundred entries: linear, 64 per step)
@@ -145,16 +163,42 @@ LM_DEV void sd_refresh(Ts& t, uint32_t p, uint32_t L, const SpanRegs& R) {   // 
 }
 
 // ---- leaf edits
-// Insert `cnt` (1 or 2) items — A, then B — as items idx, idx+1 of the leaf at directory position p (registers R): ONE
-// rewrite of the leaf per edit.  A leaf without room is split first (lower half keeps 32 items).  `dirty_from` = lowest
-// lane of R the caller modified in registers (R.n if none).  newA / newB: the item's elements are new to the container
-// (loc[] must be written); a part of a split run only needs loc[] when it lands in another leaf.  On return (p, idx)
-// address item A and R holds its leaf.
+// lanes >= idx move up by cnt (1 or 2) and items A (, B) drop in at idx (, idx+1); the leaf has room
+LM_DEV SpanRegs sp_shift_in(const SpanRegs& R, uint32_t idx, const SpanItem& A, const SpanItem& B, uint32_t cnt) {
+  int lane = lmw::lane();
+  SpanRegs N;
+  N.n = R.n + cnt;
+  int sh_d = (int)cnt;
+  uint32_t pid = lmw::shift_up(R.id, sh_d), pln = lmw::shift_up(R.len, sh_d), pol = lmw::shift_up(R.ol, sh_d), por = lmw::shift_up(R.orr, sh_d), pst = lmw::shift_up(R.st, sh_d);
+  bool sh = (uint32_t)lane >= idx + cnt;
+  N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
+  if ((uint32_t)lane == idx) { N.id = A.id; N.len = A.len; N.ol = A.ol; N.orr = A.orr; N.st = A.st; }
+  if (cnt == 2 && (uint32_t)lane == idx + 1) { N.id = B.id; N.len = B.len; N.ol = B.ol; N.orr = B.orr; N.st = B.st; }
+  if ((uint32_t)lane >= N.n) { N.id = NONE; N.len = 0; N.ol = NONE; N.orr = NONE; N.st = ST_FUT; }
+  return N;
+}
+// the pending-loc[] lane mask follows the same shift.  setA / setB: the item's loc[] must be (re)written.  A part cut off an
+// item comes from the item at lane idx-1: if that item's loc[] is still pending, so is the part's
+LM_DEV uint64_t sp_locbits_in(uint64_t lm, uint32_t idx, uint32_t cnt, bool setA, bool setB) {
+  uint64_t low = idx ? (~0ull >> (64 - idx)) : 0ull;   // idx <= 63 (the leaf had room for cnt more items)
+  bool inh = idx > 0 && ((lm >> (idx - 1)) & 1);
+  lm = (lm & low) | ((lm & ~low) << cnt);
+  if (setA || inh) lm |= 1ull << idx;
+  if (cnt == 2 && (setB || inh)) lm |= 1ull << (idx + 1);
+  return lm;
+}
+// Insert `cnt` (1 or 2) items — A, then B — as items idx, idx+1 of the leaf at directory position p (registers R, which
+// may carry edits the caller made in registers): the leaf becomes the cached leaf and nothing is stored.  A leaf without
+// room is split first (lower half keeps 32 items); the half that does not hold the edit is written to HBM.  newA / newB:
+// the item's elements are new to the container (loc[] must be written); a part of a split run only needs loc[] when it
+// lands in another leaf.  On return (p, idx) address item A and R holds its leaf.
 LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& A, const SpanItem& B, uint32_t cnt,
-                            uint32_t dirty_from, bool newA, bool newB, uint32_t pre) {   // pre: active elements before leaf p (NONE = unknown)
+                            bool newA, bool newB, uint32_t pre) {   // pre: active elements before leaf p (NONE = unknown)
   int lane = lmw::lane();
   lmw::wave_sync();
   uint32_t L = sa_leaf(lmw::first(t.da[p]));
+  sp_take(t, L);
+  uint64_t lm = t.loc_dirty;
   bool moved = false;   // the items end up in a leaf other than L
   if (R.n + cnt > 64) {
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
@@ -168,44 +212,91 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
     SpanRegs Lo = R;
     Lo.n = 32;
     if (lane >= 32) { Lo.id = NONE; Lo.len = 0; Lo.ol = NONE; Lo.orr = NONE; Lo.st = ST_FUT; }
-    for (uint32_t j = 0; j < nu; j++) sp_set_loc(t, lmw::bcast(U.id, (int)j), lmw::bcast(U.len, (int)j), NL);
-    if (idx > 32 || (idx == 32 && dirty_from >= 32)) {
-      // the edit goes to the upper half: the lower half only needs its modified lanes stored
-      sp_store(t, L, Lo, dirty_from < 32 ? dirty_from : 32, p, pre);
+    if (idx >= 32) {
+      // the edit goes to the upper half, which becomes the cached leaf; the lower half is written out
+      sp_write(t, L, Lo);
+      sp_set_loc_mask(t, Lo, lm & 0xffffffffull, L);
       sd_refresh(t, p, L, Lo);
       if (pre != NONE) pre += lmw::first(t.db[p]);   // the new leaf starts behind the lower half
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
-      if (t.err) return;
-      sp_store(t, NL, U, 0, p + 1, pre);
+      if (t.err) { t.cache_leaf = NONE; t.dirty = false; t.loc_dirty = 0; return; }
       p = p + 1; idx -= 32; R = U; L = NL;
-      dirty_from = 0;
+      t.cache_leaf = NL;
+      lm = nu >= 64 ? ~0ull : ((1ull << nu) - 1);   // every item of the upper half moved: loc[] := NL at the next flush
       moved = true;
     } else {
+      sp_write(t, NL, U);
+      sp_set_loc_mask(t, U, nu >= 64 ? ~0ull : ((1ull << nu) - 1), NL);
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
-      if (t.err) return;
-      sp_store(t, NL, U, 0, p + 1, NONE);
+      if (t.err) { t.cache_leaf = NONE; t.dirty = false; t.loc_dirty = 0; return; }
       R = Lo;
-      if (dirty_from > 32) dirty_from = 32;
+      lm &= 0xffffffffull;
     }
   }
-  // shift lanes >= idx up by cnt and drop the items in
-  SpanRegs N;
-  N.n = R.n + cnt;
-  int sh_d = (int)cnt;
-  uint32_t pid = lmw::shift_up(R.id, sh_d), pln = lmw::shift_up(R.len, sh_d), pol = lmw::shift_up(R.ol, sh_d), por = lmw::shift_up(R.orr, sh_d), pst = lmw::shift_up(R.st, sh_d);
-  bool sh = (uint32_t)lane >= idx + cnt;
-  N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
-  if ((uint32_t)lane == idx) { N.id = A.id; N.len = A.len; N.ol = A.ol; N.orr = A.orr; N.st = A.st; }
-  if (cnt == 2 && (uint32_t)lane == idx + 1) { N.id = B.id; N.len = B.len; N.ol = B.ol; N.orr = B.orr; N.st = B.st; }
-  if ((uint32_t)lane >= N.n) { N.id = NONE; N.len = 0; N.ol = NONE; N.orr = NONE; N.st = ST_FUT; }
-  sp_store(t, L, N, dirty_from < idx ? dirty_from : idx, p, pre);
-  if (newA || moved) sp_set_loc(t, A.id, A.len, L);
-  if (cnt == 2 && (newB || moved)) sp_set_loc(t, B.id, B.len, L);
+  SpanRegs N = sp_shift_in(R, idx, A, B, cnt);
+  lm = sp_locbits_in(lm, idx, cnt, newA || moved, newB || moved);
+  t.cache_p = p; t.cache_pre = pre; t.cr = N; t.dirty = true; t.loc_dirty = lm;
   sd_refresh(t, p, L, N);
   R = N;
 }
-LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& it, uint32_t dirty_from, bool new_elems, uint32_t pre) {
-  sp_insert_items(t, p, R, idx, it, it, 1, dirty_from, new_elems, false, pre);
+LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const SpanItem& it, bool new_elems, uint32_t pre) {
+  sp_insert_items(t, p, R, idx, it, it, 1, new_elems, false, pre);
+}
+
+// ---- the common insert, instruction-lean (the kernel is issue-bound: one wave alone needs half the time of a full machine):
+// the cursor lies inside the cached leaf, which has room, and origin_right is the very next item (or the cursor is
+// inside an active run) — no directory search, no leaf traffic, no sibling scan; the directory entry is patched in place.
+// Returns false without touching anything when the general path is needed.
+LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
+  if (t.cache_leaf == NONE || t.cache_pre == NONE || pos <= t.cache_pre || t.cr.n > 62) return false;
+  int lane = lmw::lane();
+  uint32_t p = t.cache_p, k = pos - t.cache_pre;
+  lmw::wave_sync();
+  if (k > lmw::first(t.db[p])) return false;
+  uint32_t n = t.cr.n;
+  uint32_t al = sp_alen(t.cr);
+  uint32_t inc = lmw::scan_incl_add(al);
+  uint64_t hit = lmw::ballot(al != 0 && inc >= k);
+  if (!hit) return false;
+  uint32_t slot = (uint32_t)lmw::ffs64(hit), idx = slot + 1;
+  uint32_t sln = lmw::bcast(al, (int)slot), sid = lmw::bcast(t.cr.id, (int)slot);
+  uint32_t off = k - (lmw::bcast(inc, (int)slot) - sln);   // 1..sln: cursor right after element off-1 of the run
+  uint32_t v_or = lmw::bcast(t.cr.orr, (int)slot), v_st = lmw::bcast(t.cr.st, (int)slot);
+  SpanItem A, B;
+  A.id = pid0; A.len = len; A.ol = sid + off - 1; A.st = 0;
+  uint32_t cnt;
+  if (off < sln) {
+    // inside an active run: cut, the new run goes between the halves
+    A.orr = sid + off;
+    B.id = sid + off; B.len = sln - off; B.ol = sid + off - 1; B.orr = v_or; B.st = v_st;
+    if ((uint32_t)lane == slot) t.cr.len = off;
+    cnt = 2;
+  } else {
+    uint64_t nf = lmw::ballot((uint32_t)lane >= idx && (uint32_t)lane < n && !(t.cr.st & ST_FUT));
+    if (!nf || (uint32_t)lmw::ffs64(nf) != idx) return false;   // origin_right in another leaf, or future items in between
+    A.orr = lmw::bcast(t.cr.id, (int)idx);
+    if (v_st == 0 && sid + sln == pid0 && pid_peer(sid) == pid_peer(pid0) && v_or == A.orr) {
+      // run merging (FugueSpan::is_mergeable): the item grows
+      if ((uint32_t)lane == slot) t.cr.len = sln + len;
+      t.loc_dirty |= 1ull << slot;
+      t.dirty = true;
+      if (lane == 0) lmw::lds_add(&t.db[p], len);
+      t.tot_active += len;
+      lmw::wave_sync();
+      PROF_CNT(t, PF_NDHIT, 1);
+      return true;
+    }
+    B = A;
+    cnt = 1;
+  }
+  t.cr = sp_shift_in(t.cr, idx, A, B, cnt);
+  t.loc_dirty = sp_locbits_in(t.loc_dirty, idx, cnt, true, false);
+  t.dirty = true;
+  if (lane == 0) { t.da[p] = sa_make(t.cache_leaf, n + cnt, true); lmw::lds_add(&t.db[p], len); }
+  t.tot_active += len;
+  lmw::wave_sync();
+  if (cnt == 2) PROF_CNT(t, PF_NHIT, 1);
+  return true;
 }
 
 // ---- insert (Fugue integrate, crdt_rope.rs:63-247) of run [pid0, pid0+len) at active position pos
@@ -214,6 +305,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   PROF_T0();
   PROF_CNT(t, PF_NINS, 1);
   if (pos > t.tot_active) pos = t.tot_active;
+  if (ts_insert_fast(t, pos, pid0, len)) { PROF_ADD(t, PF_PLACE); PROF_CNT(t, PF_LEAF, 1u << 20); return; }
   uint32_t p = 0, idx = 0, origin_left = NONE, pre_p = 0;
   SpanRegs R;
   SpanItem nw;
@@ -248,7 +340,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       nw.ol = origin_left; nw.orr = sid + off;
       idx = slot + 1;
       PROF_ADD(t, PF_FIND);
-      sp_insert_items(t, p, R, idx, nw, rt, 2, slot, true, false, pre_p);
+      sp_insert_items(t, p, R, idx, nw, rt, 2, true, false, pre_p);
       PROF_ADD(t, PF_PLACE);
       PROF_CNT(t, PF_NHIT, 1);
       return;
@@ -288,6 +380,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   PROF_ADD(t, PF_ORIGHT);
   uint32_t ins_p = p, ins_idx = idx;
   if (between) {
+    sp_flush(t);   // the scan reads loc[] and other leaves from HBM
     // sibling scan over the future ITEMS between the cursor and origin_right (crdt_rope.rs:156-237); the elements inside a
     // run are continuations by construction, so every item is examined exactly once through its first element
     bool parent_right = origin_right != NONE && r_ol == origin_left;
@@ -392,9 +485,10 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       lmw::wave_sync();
       uint32_t a = lmw::first(t.da[p]);
       uint32_t L = sa_leaf(a);
-      if ((uint32_t)lane == pv) { R.len = v_len + len; t.it[(uint64_t)L * SP_REC + 64 + lane] = R.len; }
-      t.cache_leaf = L; t.cache_p = p; t.cache_pre = pre_p; t.cr = R;
-      sp_set_loc(t, pid0, len, L);
+      sp_take(t, L);
+      if ((uint32_t)lane == pv) R.len = v_len + len;
+      t.cache_p = p; t.cache_pre = pre_p; t.cr = R; t.dirty = true;
+      t.loc_dirty |= 1ull << pv;   // (the whole item's loc[] is rewritten at the flush — the appended elements are what is new)
       sd_set(t, p, a, lmw::first(t.db[p]) + len);
       PROF_ADD(t, PF_PLACE);
       PROF_CNT(t, PF_NDHIT, 1);
@@ -405,8 +499,59 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   if (ins_p == p) D = R;
   else if (r_p != NONE && ins_p == r_p) D = RR;
   else { lmw::wave_sync(); uint32_t a = lmw::first(t.da[ins_p]); D = sp_load(t, sa_leaf(a), sa_n(a)); }
-  sp_insert_item(t, ins_p, D, ins_idx, nw, D.n, true, ins_p == p ? pre_p : NONE);
+  sp_insert_item(t, ins_p, D, ins_idx, nw, true, ins_p == p ? pre_p : NONE);
   PROF_ADD(t, PF_PLACE);
+}
+
+// ---- the common status update, instruction-lean: the run holding element (peer, c) sits in the cached leaf, which has room
+// for a cut; the run (or its part inside [c, c1)) gets the new status, c advances.  false = general path.
+LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int mode) {
+  if (t.cache_leaf == NONE || t.cr.n > 62) return false;
+  int lane = lmw::lane();
+  uint32_t x = pid_make(peer, c);
+  uint64_t hm = lmw::ballot((uint32_t)lane < t.cr.n && pid_peer(t.cr.id) == peer && sp_has(t.cr.id, t.cr.len, x));
+  if (!hm) return false;
+  uint32_t slot = (uint32_t)lmw::ffs64(hm);
+  uint32_t id0 = lmw::bcast(t.cr.id, (int)slot), ln = lmw::bcast(t.cr.len, (int)slot);
+  uint32_t st0 = lmw::bcast(t.cr.st, (int)slot), st1 = st0;
+  if (mode == UPD_SET_FUT) st1 |= ST_FUT;
+  else if (mode == UPD_CLR_FUT) st1 &= ~ST_FUT;
+  else if (mode == UPD_DEL_INC) st1 = (st1 + ST_DEL1) | ST_EVER;
+  else if (st1 & ST_DELMASK) st1 -= ST_DEL1;
+  uint32_t s_off = x - id0;
+  uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
+  uint32_t tail = pid_ctr(id0) + ln - endc, mid = endc - c;
+  uint32_t n = t.cr.n;
+  if (s_off == 0 && tail == 0) {
+    if ((uint32_t)lane == slot) t.cr.st = st1;
+  } else {
+    uint32_t orr0 = lmw::bcast(t.cr.orr, (int)slot);
+    SpanItem A, B;
+    uint32_t cnt;
+    if (s_off > 0) {
+      if ((uint32_t)lane == slot) t.cr.len = s_off;
+      A.id = x; A.len = mid; A.ol = x - 1; A.orr = orr0; A.st = st1;
+      B.id = pid_make(peer, endc); B.len = tail; B.ol = B.id - 1; B.orr = orr0; B.st = st0;
+      cnt = tail ? 2u : 1u;
+    } else {
+      if ((uint32_t)lane == slot) { t.cr.len = mid; t.cr.st = st1; }
+      A.id = pid_make(peer, endc); A.len = tail; A.ol = A.id - 1; A.orr = orr0; A.st = st0;
+      B = A;
+      cnt = 1;
+    }
+    t.cr = sp_shift_in(t.cr, slot + 1, A, B, cnt);
+    t.loc_dirty = sp_locbits_in(t.loc_dirty, slot + 1, cnt, false, false);
+    n += cnt;
+  }
+  t.dirty = true;
+  uint32_t d_act = (st_active(st1) ? mid : 0u) - (st_active(st0) ? mid : 0u);
+  bool nf = sp_nf(t.cr);
+  lmw::wave_sync();
+  if (lane == 0) { t.da[t.cache_p] = sa_make(t.cache_leaf, n, nf); if (d_act) lmw::lds_add(&t.db[t.cache_p], d_act); }
+  t.tot_active += d_act;
+  lmw::wave_sync();
+  c = endc;
+  return true;
 }
 
 // ---- status update of the elements with ids [c0,c1) of `peer` (crdt_rope.rs:345-381 by id): walk run by run
@@ -419,6 +564,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   uint32_t c = c0;
   for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
     lmw::wave_sync();
+    if (ts_update_fast(t, peer, c, c1, mode)) { PROF_CNT(t, PF_LEAF, 1); continue; }
     uint32_t x = pid_make(peer, c);
     uint32_t p;
     SpanRegs R;
@@ -435,13 +581,13 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
         uint32_t a = lmw::first(t.da[p]);
         R = sp_load(t, sa_leaf(a), sa_n(a));
         hm = lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
-        if (hm) { t.cache_leaf = sa_leaf(a); t.cache_p = p; t.cache_pre = hint_k - k; t.cr = R; }
+        if (hm) { sp_take(t, sa_leaf(a)); t.cache_p = p; t.cache_pre = hint_k - k; t.cr = R; }
       }
     }
     if (!hm) {
       uint32_t lf = lmw::first(t.loc[eb + c]);
       PROF_CNT(t, 15, 1);   // status updates that went through loc[] (the target was not in the cached leaf)
-      if (lf >= t.n_leaf) { c++; continue; }          // not an element of this container (malformed target): ignored
+      if (lf >= t.n_leaf || lf == t.cache_leaf) { c++; continue; }   // not an element of this container (malformed target): ignored
       // all five arrays are requested for all 64 slots right away; the directory lookup (LDS) runs while they are in
       // flight, and the item count then masks the unused slots.  The leaf becomes the cached leaf: a delete run arrives
       // as one row per contiguous id span, and the following rows address its neighbours
@@ -452,7 +598,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       R.n = sa_n(lmw::first(t.da[p]));
       bool in = (uint32_t)lane < R.n;
       R.id = in ? xid : NONE; R.len = in ? xln : 0u; R.ol = in ? xol : NONE; R.orr = in ? xor_ : NONE; R.st = in ? xst : ST_FUT;
-      t.cache_leaf = lf; t.cache_p = p; t.cache_pre = NONE; t.cr = R;
+      sp_take(t, lf); t.cache_p = p; t.cache_pre = NONE; t.cr = R;
       hm = lmw::ballot(in && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
       if (!hm) { c++; continue; }
     }
@@ -471,8 +617,8 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     uint32_t L = sa_leaf(lmw::first(t.da[p]));
     if (s_off == 0 && tail == 0) {
       // the whole run: one status word
-      if ((uint32_t)lane == slot) { R.st = st1; t.it[(uint64_t)L * SP_REC + 256 + lane] = st1; }
-      t.cr.st = R.st;   // (R is the cached leaf: either it was, or the lookup above made it so)
+      if ((uint32_t)lane == slot) R.st = st1;
+      t.cr.st = R.st; t.dirty = true;   // (R is the cached leaf: either it was, or the lookup above made it so)
       sd_refresh(t, p, L, R);
     } else {
       // the run is cut at the range's ends and the affected part gets the new status: one rewrite of the leaf
@@ -489,11 +635,34 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
         B = A;
         cnt = 1;
       }
-      sp_insert_items(t, p, R, idx, A, B, cnt, slot, false, false, t.cache_pre);
+      sp_insert_items(t, p, R, idx, A, B, cnt, false, false, t.cache_pre);
       if (t.err) return;
     }
     c = endc;
   }
+}
+
+// ---- op rows are read eight at a time: one 256-byte wave load per window (lane = dword of the window), and the next
+// window is requested while the current one is consumed.  (A lone wave replaying configs[1] took 2 µs per op row — one
+// dependent HBM round trip for the row itself — before this.)
+struct RowWin { uint32_t base, lim, cur, nxt; };
+LM_DEV uint32_t rw_load(const uint32_t* op_w, uint32_t base, uint32_t lim) {
+  uint32_t lane = (uint32_t)lmw::lane();
+  return base + (lane >> 3) < lim ? op_w[(uint64_t)base * 8 + lane] : 0u;
+}
+LM_DEV void rw_open(RowWin& w, const uint32_t* op_w, uint32_t first, uint32_t lim) {   // rows [first, lim) will be read in ascending order
+  w.base = first; w.lim = lim;
+  w.cur = rw_load(op_w, first, lim);
+  w.nxt = rw_load(op_w, first + 8, lim);
+}
+LM_DEV OpRow rw_get(RowWin& w, const uint32_t* op_w, uint32_t row) {
+  if (row >= w.base + 16) rw_open(w, op_w, row, w.lim);
+  else if (row >= w.base + 8) { w.base += 8; w.cur = w.nxt; w.nxt = rw_load(op_w, w.base + 8, w.lim); }
+  int j = (int)(row - w.base) * 8;
+  OpRow r;
+  r.cidx_kind = lmw::bcast(w.cur, j); r.prop = (int32_t)lmw::bcast(w.cur, j + 1); r.len = lmw::bcast(w.cur, j + 2); r.ctr = lmw::bcast(w.cur, j + 3);
+  r.a0 = lmw::bcast(w.cur, j + 4); r.a1 = lmw::bcast(w.cur, j + 5); r.a2 = (int32_t)lmw::bcast(w.cur, j + 6); r.chg = lmw::bcast(w.cur, j + 7);
+  return r;
 }
 
 // retreat (dir < 0) / forward (dir > 0) every op of `peer` with id in [c0,c1) that belongs to container `cidx`
@@ -508,8 +677,10 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
     if (!((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1)) continue;
     uint32_t lo = ch.op0, hr = ch.op0 + ch.n_op;
     while (lo < hr) { uint32_t mid = (lo + hr) >> 1; if (d.op[mid].ctr + d.op[mid].len <= c0) lo = mid + 1; else hr = mid; }
+    RowWin w;
+    rw_open(w, (const uint32_t*)d.op, lo, ch.op0 + ch.n_op);
     for (uint32_t row = lo; row < ch.op0 + ch.n_op && !t.err; row++) {
-      const OpRow r = d.op[row];
+      const OpRow r = rw_get(w, (const uint32_t*)d.op, row);
       if (r.ctr >= c1) break;
       if ((r.cidx_kind & 0xffff) != cidx) continue;
       uint32_t kind = (r.cidx_kind >> 16) & 0xff;
@@ -532,6 +703,7 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
 // debug-only (kernel-logic harness built with -DLM_EMU_CHECK): the directory against the leaves and loc[] against both
 inline bool ts_check(Ts& t, const char* what, uint32_t row) {
   bool ok = true;
+  sp_flush(t);   // the checker reads HBM
   lmw::wave_sync();
   if (lmw::lane() == 0) {
     uint32_t tot = 0;
@@ -616,7 +788,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
     uint32_t L0 = t.n_leaf++;
     lmw::block_sync();
     if (lane == 0) { s_da[0] = sa_make(L0, 0, false); s_db[0] = 0; }
-    t.n_dir = 1; t.tot_active = 0; t.cache_leaf = NONE; t.cache_pre = NONE;
+    t.n_dir = 1; t.tot_active = 0; t.cache_leaf = NONE; t.cache_pre = NONE; t.dirty = false; t.loc_dirty = 0;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
     lmw::block_sync();
     bool touched = false;
@@ -633,13 +805,11 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
         uint32_t pe = s_end[node_peer];
         uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
         const uint32_t* op_w = (const uint32_t*)op_ro;
-        uint32_t nx = (lane < 8 && n_rows) ? op_w[(uint64_t)ch.op0 * 8 + (uint32_t)lane] : 0u;
+        RowWin w;
+        rw_open(w, op_w, ch.op0, ch.op0 + n_rows);
         for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
-          OpRow r;
-          r.cidx_kind = lmw::bcast(nx, 0); r.prop = (int32_t)lmw::bcast(nx, 1); r.len = lmw::bcast(nx, 2); r.ctr = lmw::bcast(nx, 3);
-          r.a0 = lmw::bcast(nx, 4); r.a1 = lmw::bcast(nx, 5); r.a2 = (int32_t)lmw::bcast(nx, 6); r.chg = lmw::bcast(nx, 7);
-          if (row + 1 < ch.op0 + n_rows) nx = lane < 8 ? op_w[(uint64_t)(row + 1) * 8 + (uint32_t)lane] : 0u;
+          const OpRow r = rw_get(w, op_w, row);
           if ((r.cidx_kind & 0xffff) != cidx) continue;
           if (r.ctr + r.len <= skip_to) continue;
           uint32_t kind = (r.cidx_kind >> 16) & 0xff;
@@ -694,6 +864,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
       }
       lmw::block_sync();
     }
+    sp_flush(t);
     lmw::block_sync();
     if (dir_used + t.n_dir > m.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     for (uint32_t i = (uint32_t)lane; i < t.n_dir; i += 64) d.dir_out[m.leaf0 + dir_used + i] = s_da[i];

@@ -264,3 +264,50 @@ def test_both_integrate_kernels(engine, monkeypatch, span):
     want = _oracle.merge_batch(cd, threads=8, frontiers=cf)
     for g, w in zip(engine.merge_batch(cd, cf), want):
         assert (g == w) if w[0] == 0 else (g[0] == w[0])
+
+
+def _gen_cfg5(args):
+    d, n = args
+    return workload.cfg5_doc(d, n_ops=n, turn=1000, n_checkouts=16)
+
+
+def _gen_cfg3(args):
+    d, combined = args
+    return workload.cfg3_doc(d, n_peers=16, n_writes=10000, n_keys=1024, combined=combined)
+
+
+def test_config3_full_size_16_peers_10k_writes(engine):
+    """BASELINE.json configs[2] at its stated size: 16 concurrent peers x 10,000 writes on 1,024 keys per document
+    (160k Map ops), variant 3a = one combined blob, variant 3b = 16 per-peer blobs; 8 distinct documents, each
+    variant bit-exact against the oracle and both variants equal."""
+    import multiprocessing
+    with multiprocessing.get_context("fork").Pool(8) as pool:
+        docs = pool.map(_gen_cfg3, [(d, c) for d in range(8) for c in (True, False)])
+    assert len(docs[0]) == 1 and len(docs[1]) == 16
+    want = _oracle.merge_batch(docs, threads=8)
+    got = engine.merge_batch(docs)
+    assert all(w[0] == 0 for w in want)
+    assert got == want
+    for k in range(0, len(docs), 2):
+        assert got[k][1] == got[k + 1][1] and got[k][2] == got[k + 1][2]
+        assert len(json.loads(got[k][1])["map"]) == 1024
+    assert len({g[1] for g in got}) == 8
+
+
+def test_config5_full_size_1m_op_documents_with_16_checkouts(engine):
+    """BASELINE.json configs[4] at its stated size: 1M-op deep-history rich-text documents (two peers alternating every
+    1k trace actions, ~1 % bold marks), each rendered at 16 random versions plus the latest one; 8 distinct documents
+    (136 renderings) bit-exact against the oracle."""
+    import multiprocessing
+    with multiprocessing.get_context("fork").Pool(8) as pool:
+        gens = pool.map(_gen_cfg5, [(d, 1000000) for d in range(8)])
+    docs, fronts = [], []
+    for blobs, fr in gens:
+        assert len(fr) == 16
+        docs += [blobs] * (len(fr) + 1)
+        fronts += fr + [None]
+    want = _oracle.merge_batch(docs, threads=16, frontiers=fronts)
+    got = engine.merge_batch(docs, fronts)
+    assert all(w[0] == 0 for w in want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, (i, g[0], w[0], len(g[1]), len(w[1]))
