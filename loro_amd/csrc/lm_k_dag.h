@@ -461,6 +461,8 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
   }
   lmw::block_sync();  // every lane has read peer_end before it is rewritten
   if (ferr) { if (lane == 0) LM_SETERR(d.doc[doc].status, ferr); return; }
+  for (uint32_t p = (uint32_t)lane; p < P; p += 64) d.peer_end_all[m.praw0 + p] = d.peer_end[m.praw0 + p];
+  lmw::block_sync();
   for (uint32_t p0 = 0; p0 < P; p0 += 64) {
     uint32_t p = p0 + (uint32_t)lane, acc = 0;
     Rd r = rd_make(d.front + f0, f1 - f0);

@@ -94,6 +94,66 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
   LM_SETERR(d.doc[doc].status, ST_INTERNAL);
 }
 
+// K9b: documents rendered at a checked-out version only, one wave per document, after the integrate stage.
+// The reference's state store holds a root Text / List once a diff for it was not empty (diff_calc.rs:299, state.rs:1365):
+// importing the batch is ONE diff from the empty version to the latest one (LoroDoc::import_batch, loro.rs:1432-1523) —
+// not empty iff something is visible at the LATEST version — and the checkout a second one, latest → version.  The
+// integrate stage replayed only the version's causal closure (it set `touched` when something is visible there), so
+// "visible at the latest version" is decided here from the op rows alone: an applied element is visible at the latest
+// version iff no applied delete row targets it.  loc[] is free at this point and serves as the mark array.
+LM_KERNEL void k_seq_alive_latest(Dev d) {
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  if (d.front_off[doc + 1] == d.front_off[doc]) return;
+  const DocMeta m = d.doc[doc];
+  if (status_fatal(m.status)) return;
+  bool need = false;
+  for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {
+    const ContRow o = d.cont[m.cid0 + c];
+    uint32_t ck = o.kind_root & 0xff;
+    if ((ck == CK_TEXT || ck == CK_LIST) && (o.kind_root & 0x100) && !o.touched) need = true;
+  }
+  if (!lmw::any(need)) return;
+  static constexpr uint32_t MARK = 0xFFFFFFFEu;
+  uint32_t* loc = d.loc + (((uint64_t)m.elem0_hi << 32) | m.elem0_lo);
+  for (uint32_t i = (uint32_t)lane; i < m.atoms; i += 64) loc[i] = NONE;
+  lmw::mem_fence();
+  lmw::block_sync();
+  for (int pass = 0; pass < 2; pass++) {
+    for (uint32_t ci = 0; ci < m.n_valid_chg; ci++) {
+      uint32_t crow = d.chg_sorted[m.chg0 + ci];
+      const ChangeRow ch = d.chg[crow];
+      uint32_t lo = ch.ctr + d.chg_skip[crow], hi = d.peer_end_all[m.praw0 + ch.peer];
+      for (uint32_t r0 = 0; r0 < ch.n_op; r0 += 64) {
+        uint32_t ri = r0 + (uint32_t)lane;
+        if (ri >= ch.n_op) continue;
+        const OpRow r = d.op[ch.op0 + ri];
+        uint32_t cidx = r.cidx_kind & 0xffff, kind = (r.cidx_kind >> 16) & 0xff;
+        if (cidx >= m.n_cont) continue;
+        uint32_t ck = d.cont[m.cid0 + cidx].kind_root & 0xff;
+        if (ck != CK_TEXT && ck != CK_LIST) continue;
+        uint32_t a = lo > r.ctr ? lo - r.ctr : 0, b = hi < r.ctr + r.len ? (hi > r.ctr ? hi - r.ctr : 0) : r.len;
+        if (a >= b) continue;
+        if (pass == 0 && kind == OK_DEL) {
+          uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2), t0, t1;
+          if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; } else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
+          if (r.a0 >= m.n_peers) continue;
+          uint32_t ext = d.peer_ext[m.praw0 + r.a0], eb = d.elem_base[m.praw0 + r.a0];
+          if (t1 > ext) t1 = ext;
+          for (uint32_t c = t0; c < t1; c++) loc[eb + c] = MARK;
+        } else if (pass == 1 && (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END)) {
+          if (d.cont[m.cid0 + cidx].touched) continue;
+          uint32_t eb = d.elem_base[m.praw0 + ch.peer];
+          for (uint32_t c = r.ctr + a; c < r.ctr + b; c++)
+            if (loc[eb + c] != MARK) { d.cont[m.cid0 + cidx].touched = 1; break; }
+        }
+      }
+    }
+    lmw::mem_fence();
+    lmw::block_sync();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ sink
 struct Sink {
   uint8_t* out;       // nullptr in the sizing pass

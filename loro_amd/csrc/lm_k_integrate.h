@@ -754,10 +754,17 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
     lmw::block_sync();
     if (dir_used + t.n_dir > m.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     for (uint32_t i = (uint32_t)lane; i < t.n_dir; i += 64) d.dir_out[m.leaf0 + dir_used + i] = s_dir[i];
+    // the state store holds a root sequence once something is visible in it (diff_calc.rs:299): any element never deleted
+    bool alive = false;
+    for (uint32_t q = 0; q < t.n_dir && touched; q++) {
+      uint32_t e = s_dir[q];
+      uint32_t st = (uint32_t)lane < de_n(e) ? t.it[(uint64_t)de_leaf(e) * 256 + 192 + lane] : ST_EVER;
+      if (lmw::ballot(!(st & ST_EVER))) { alive = true; break; }
+    }
     if (lane == 0) {
       d.cont_root0[m.cid0 + cidx] = dir_used;
       d.cont_nroot[m.cid0 + cidx] = t.n_dir;
-      if (touched) d.cont[m.cid0 + cidx].touched = 1;
+      if (alive) d.cont[m.cid0 + cidx].touched = 1;
     }
     dir_used += t.n_dir;
     lmw::block_sync();

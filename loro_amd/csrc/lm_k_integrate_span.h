@@ -31,6 +31,7 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   uint32_t* da;                   // LDS directory, word A per leaf in document order
   uint32_t* db;                   // LDS directory, word B (active length)
   uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
+  uint32_t n_alive;               // elements inserted and never deleted by a replayed op = visible at the rendered version
   uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); WRITE-BACK: `cr` is the truth, HBM is updated by sp_flush
   uint32_t cache_p;               // its directory position (kept in step with directory inserts)
   uint32_t cache_pre;             // active elements in front of the cached leaf, NONE when not known: an edit at a position
@@ -305,6 +306,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   PROF_T0();
   PROF_CNT(t, PF_NINS, 1);
   if (pos > t.tot_active) pos = t.tot_active;
+  t.n_alive += len;
   if (ts_insert_fast(t, pos, pid0, len)) { PROF_ADD(t, PF_PLACE); PROF_CNT(t, PF_LEAF, 1u << 20); return; }
   uint32_t p = 0, idx = 0, origin_left = NONE, pre_p = 0;
   SpanRegs R;
@@ -522,6 +524,7 @@ LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int m
   uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
   uint32_t tail = pid_ctr(id0) + ln - endc, mid = endc - c;
   uint32_t n = t.cr.n;
+  if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= mid;
   if (s_off == 0 && tail == 0) {
     if ((uint32_t)lane == slot) t.cr.st = st1;
   } else {
@@ -613,6 +616,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     uint32_t s_off = x - id0;                                   // elements of the run before the range
     uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
     uint32_t tail = pid_ctr(id0) + ln - endc;                   // elements of the run beyond the range
+    if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= endc - c;
     lmw::wave_sync();
     uint32_t L = sa_leaf(lmw::first(t.da[p]));
     if (s_off == 0 && tail == 0) {
@@ -788,7 +792,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
     uint32_t L0 = t.n_leaf++;
     lmw::block_sync();
     if (lane == 0) { s_da[0] = sa_make(L0, 0, false); s_db[0] = 0; }
-    t.n_dir = 1; t.tot_active = 0; t.cache_leaf = NONE; t.cache_pre = NONE; t.dirty = false; t.loc_dirty = 0;
+    t.n_dir = 1; t.tot_active = 0; t.n_alive = 0; t.cache_leaf = NONE; t.cache_pre = NONE; t.dirty = false; t.loc_dirty = 0;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
     lmw::block_sync();
     bool touched = false;
@@ -871,7 +875,9 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
     if (lane == 0) {
       d.cont_root0[m.cid0 + cidx] = dir_used;
       d.cont_nroot[m.cid0 + cidx] = t.n_dir;
-      if (touched) d.cont[m.cid0 + cidx].touched = 1;
+      // the state store holds a root sequence once something is visible in it (diff_calc.rs:299: a container state is
+      // created by a non-empty diff; from the empty version the diff is empty exactly when nothing is visible)
+      if (touched && t.n_alive > 0) d.cont[m.cid0 + cidx].touched = 1;
     }
     dir_used += t.n_dir;
     lmw::block_sync();

@@ -50,7 +50,7 @@ struct Engine {
   DBuf b_blob_status, b_blob_nblk, b_blob_blk0, b_tile, b_tot;
   DBuf b_blk, b_bcnt, b_boff;
   DBuf b_chg, b_dep_peer, b_dep_ctr, b_op, b_op_val, b_op_blk, b_key_off, b_key_len, b_cid_raw, b_cid_map, b_peer_raw, b_peer_map;
-  DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
+  DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
   DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
   DBuf b_cp, b_loc;
@@ -81,7 +81,7 @@ struct Engine {
   void release_all() {
     DBuf* all[] = {&b_front, &b_front_off, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
-                   &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_elem_base,
+                   &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
@@ -226,7 +226,7 @@ struct Engine {
     b_peer_raw.ensure((size_t)(NP + 1) * 8); b_peer_map.ensure((size_t)(NP + 1) * 4);
     b_doc.ensure((size_t)n_docs * sizeof(DocMeta));
     b_peer_uniq.ensure((size_t)(NP + 1) * 8);
-    for (DBuf* b : {&b_peer_end, &b_peer_ext, &b_elem_base, &b_peer_chg0, &b_peer_chg1}) b->ensure((size_t)(NP + 1) * 4);
+    for (DBuf* b : {&b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base, &b_peer_chg0, &b_peer_chg1}) b->ensure((size_t)(NP + 1) * 4);
     b_cont.ensure((size_t)(NCID + 1) * sizeof(ContRow));
     for (DBuf* b : {&b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first, &b_node_last, &b_node_order, &b_chg_node,
                     &b_node_done, &b_node_lam})
@@ -240,7 +240,7 @@ struct Engine {
     d.cid_raw = b_cid_raw.as<uint32_t>(); d.cid_map = b_cid_map.as<uint32_t>();
     d.peer_raw = b_peer_raw.as<uint64_t>(); d.peer_map = b_peer_map.as<uint32_t>();
     d.doc = b_doc.as<DocMeta>(); d.peer_uniq = b_peer_uniq.as<uint64_t>();
-    d.peer_end = b_peer_end.as<uint32_t>(); d.peer_ext = b_peer_ext.as<uint32_t>(); d.elem_base = b_elem_base.as<uint32_t>();
+    d.peer_end = b_peer_end.as<uint32_t>(); d.peer_ext = b_peer_ext.as<uint32_t>(); d.peer_end_all = b_peer_end_all.as<uint32_t>(); d.elem_base = b_elem_base.as<uint32_t>();
     d.peer_chg0 = b_peer_chg0.as<uint32_t>(); d.peer_chg1 = b_peer_chg1.as<uint32_t>();
     d.cont = b_cont.as<ContRow>();
     d.chg_sorted = b_chg_sorted.as<uint32_t>(); d.chg_lamport = b_chg_lamport.as<uint32_t>();
@@ -387,6 +387,7 @@ struct Engine {
       }
     }
     last_retries = n_retry;
+    if (h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only
 #ifdef LM_EMU_TRACE
     if (getenv("LM_EMU_DUMP")) {  // kernel-logic harness only: leaves of document 0 in document order
       lmbe::d2h(h_doc.data(), b_doc.p, (size_t)n_docs * sizeof(DocMeta));

@@ -52,6 +52,7 @@ LM_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }  // 
 // executes each instruction for all lanes at once, so this is only a scheduling fence here; the fiber
 // emulation needs a real rendezvous.
 LM_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+LM_DEV void mem_fence() { __threadfence(); }   // global stores of this wave are visible to later loads of any lane
 LM_DEV uint64_t clock() { return __builtin_readcyclecounter(); }
 }  // namespace lmw
 
@@ -230,6 +231,7 @@ inline uint64_t atomic_cas64(unsigned long long* p, uint64_t cmp, uint64_t v) { 
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 inline void wave_sync() { (void)emu_exchange(0); }
+inline void mem_fence() {}
 inline uint64_t clock() { return 0; }
 }  // namespace lmw
 #endif

@@ -155,4 +155,60 @@ int lo_json_f64(double v, char* out) {
   memcpy(out, t.data(), t.size());
   return (int)t.size();
 }
+
+// ---- DAG queries (lo_dag.hpp) on a caller-built DAG: nodes (peer, counter, len, lamport, deps[dep_off[i]..dep_off[i+1]))
+static std::vector<DagNodeT> nodes_from(uint32_t n, const uint64_t* peers, const int32_t* ctrs, const int32_t* lens, const uint32_t* lamports,
+                                        const uint32_t* dep_off, const uint64_t* dep_peers, const int32_t* dep_ctrs) {
+  std::vector<DagNodeT> nodes(n);
+  for (uint32_t i = 0; i < n; i++) {
+    nodes[i].id = ID{peers[i], ctrs[i]}; nodes[i].len = lens[i]; nodes[i].lamport = lamports[i];
+    for (uint32_t k = dep_off[i]; k < dep_off[i + 1]; k++) nodes[i].deps.push_back(ID{dep_peers[k], dep_ctrs[k]});
+  }
+  return nodes;
+}
+// returns the DiffMode (0 Checkout, 1 Import, 2 ImportGreaterUpdates, 3 Linear) or -1; the LCA frontiers go to out_*
+int32_t lo_dag_lca(uint32_t n, const uint64_t* peers, const int32_t* ctrs, const int32_t* lens, const uint32_t* lamports,
+                   const uint32_t* dep_off, const uint64_t* dep_peers, const int32_t* dep_ctrs,
+                   uint32_t n_left, const uint64_t* lp, const int32_t* lc, uint32_t n_right, const uint64_t* rp, const int32_t* rc,
+                   uint64_t* out_peers, int32_t* out_ctrs, uint32_t* out_n) {
+  try {
+    std::vector<DagNodeT> nodes = nodes_from(n, peers, ctrs, lens, lamports, dep_off, dep_peers, dep_ctrs);
+    DagGet get = [&nodes](ID id) -> const DagNodeT* {
+      for (const DagNodeT& x : nodes) if (x.contains(id)) return &x;
+      return nullptr;
+    };
+    Frontiers l, r;
+    for (uint32_t i = 0; i < n_left; i++) l.push_back(ID{lp[i], lc[i]});
+    for (uint32_t i = 0; i < n_right; i++) r.push_back(ID{rp[i], rc[i]});
+    auto res = find_common_ancestor(get, l, r);
+    *out_n = (uint32_t)res.first.size();
+    for (size_t i = 0; i < res.first.size(); i++) { out_peers[i] = res.first[i].peer; out_ctrs[i] = res.first[i].counter; }
+    return (int32_t)res.second;
+  } catch (...) {
+    return -1;
+  }
+}
+// brute force (dag.rs:955-985): every id that is an ancestor of, or equal to, one of the given ids
+int64_t lo_dag_ancestors(uint32_t n, const uint64_t* peers, const int32_t* ctrs, const int32_t* lens, const uint32_t* lamports,
+                         const uint32_t* dep_off, const uint64_t* dep_peers, const int32_t* dep_ctrs,
+                         uint32_t n_ids, const uint64_t* ip, const int32_t* ic, uint64_t* out_peers, int32_t* out_ctrs, uint64_t cap) {
+  std::vector<DagNodeT> nodes = nodes_from(n, peers, ctrs, lens, lamports, dep_off, dep_peers, dep_ctrs);
+  std::set<std::pair<PeerID, Counter>> ans;
+  for (uint32_t i = 0; i < n_ids; i++) collect_ancestors(nodes, ID{ip[i], ic[i]}, ans);
+  uint64_t k = 0;
+  for (auto& x : ans) { if (k < cap) { out_peers[k] = x.first; out_ctrs[k] = x.second; } k++; }
+  return (int64_t)k;
+}
+// DiffMode of each LoroDoc::import when the blobs are imported one after another into an attached, empty document
+int32_t lo_import_modes(const uint8_t* data, const uint64_t* blob_off, uint32_t n_blobs, int32_t* modes) {
+  try {
+    Doc d;
+    for (uint32_t b = 0; b < n_blobs; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    auto ms = d.import_modes();
+    for (size_t i = 0; i < ms.size() && i < n_blobs; i++) modes[i] = (int32_t)ms[i].second;
+    return 0;
+  } catch (...) {
+    return -1;
+  }
+}
 }

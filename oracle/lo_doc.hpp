@@ -28,6 +28,7 @@
 #include <charconv>
 #include "lo_codec.hpp"
 #include "lo_tracker.hpp"
+#include "lo_dag.hpp"
 
 namespace lo {
 
@@ -108,6 +109,19 @@ struct Doc {
   std::map<uint32_t, std::unique_ptr<SeqState>> seqs;
   std::map<uint32_t, std::map<std::string, MapEntry>> maps;
   std::set<uint32_t> touched;  // containers that received at least one applied op
+  // Root containers the state store holds (diff_calc.rs:299 `if !diff.is_empty() || bring_back`, state.rs:621-849): a
+  // container state is created by the first import / checkout step whose diff for it is not empty.  The batch is
+  // imported like LoroDoc::import_batch (loro.rs:1432-1523): every blob goes into the OpLog while the document is
+  // detached, then ONE diff from the empty version to the latest one is applied (one blob: LoroDoc::import, same
+  // versions); a checkout is a second diff latest → version.  From the empty version a sequence diff (tracker.diff,
+  // crdt_rope.rs:396-451; Linear mode: the composed DeltaRope, whose fully deleted inserts are dropped —
+  // delta_item.rs:353-363) is empty exactly when nothing is visible at the target; a Map diff lists every key with an
+  // op (deleted ones too, diff_calc.rs:553-605), so a Map exists once it was written.
+  std::set<uint32_t> seq_exists;
+  // Frontiers of the OpLog (version/frontiers.rs:233 update_frontiers_on_new_change) and the import steps taken
+  std::vector<ID> oplog_frontiers;
+  struct ImportStep { Frontiers from_f, to_f; VV from_vv, to_vv; };
+  std::vector<ImportStep> steps;
   // optional checkout (LoroDoc::checkout, loro.rs:1625-1760): the state is rendered at `frontiers` instead of the
   // latest version; the OpLog (and so the set of root containers the state store knows) stays the imported one
   bool has_target = false;
@@ -233,6 +247,17 @@ struct Doc {
     for (Op& o : c2.ops) o.container = reg(c2.cids[o.container]);
     c2.cids.clear();
     vv[c2.id.peer] = c2.ctr_end();
+    {
+      Frontiers nf;
+      for (const ID& f : oplog_frontiers) {
+        bool dep = f.peer == c2.id.peer;
+        for (const ID& d : c2.deps) if (id_eq(d, f)) dep = true;
+        if (!dep) nf.push_back(f);
+      }
+      nf.push_back(ID{c2.id.peer, c2.ctr_end() - 1});
+      fr_norm(nf);
+      oplog_frontiers.swap(nf);
+    }
     changes[c2.id.peer].push_back(std::move(c2));
     return 0;
   }
@@ -240,6 +265,8 @@ struct Doc {
     std::vector<Change> decoded;
     decode_updates_blob(blob, len, decoded);
     materialized = false;
+    ImportStep step;
+    step.from_f = oplog_frontiers; step.from_vv = vv;
     // receiver-VV filter happens per change in try_apply (drop / slice); application order = lamport order
     std::stable_sort(decoded.begin(), decoded.end(), [](const Change& a, const Change& b) { return a.lamport < b.lamport; });
     for (auto& c : decoded)
@@ -254,6 +281,45 @@ struct Doc {
       }
       pending.swap(still);
     }
+    step.to_f = oplog_frontiers; step.to_vv = vv;
+    steps.push_back(std::move(step));
+  }
+  // ---- the DAG as the import path sees it: runs of one peer's changes linked only by self-dependency
+  // (AppDagNode, loro_dag.rs:302-367,995-1019)
+  std::vector<DagNodeT> dag_nodes() const {
+    std::vector<DagNodeT> out;
+    for (auto& kv : changes) {
+      auto& v = kv.second;
+      for (size_t i = 0; i < v.size(); i++) {
+        bool cont = i > 0 && v[i].deps.size() == 1 && v[i].deps[0].peer == kv.first && v[i].deps[0].counter == v[i].id.counter - 1 &&
+                    v[i].lamport == v[i - 1].lamport + (Lamport)v[i - 1].len;
+        if (cont) out.back().len += v[i].len;
+        else { DagNodeT n; n.id = v[i].id; n.len = v[i].len; n.lamport = v[i].lamport; n.deps = v[i].deps; out.push_back(n); }
+      }
+    }
+    return out;
+  }
+  // DiffMode of every import() taken so far, as LoroDoc::import computes it for an attached document
+  // (oplog.rs:591-615: find_common_ancestor(from, to); Checkout becomes Import when `to` is strictly greater)
+  std::vector<std::pair<Frontiers, DiffMode>> import_modes() const {
+    std::vector<DagNodeT> nodes = dag_nodes();
+    DagGet get = [&nodes](ID id) -> const DagNodeT* {
+      for (const DagNodeT& n : nodes) if (n.contains(id)) return &n;
+      return nullptr;
+    };
+    std::vector<std::pair<Frontiers, DiffMode>> out;
+    for (const ImportStep& st : steps) {
+      if (st.from_vv == st.to_vv) { out.push_back({st.from_f, DM_LINEAR}); continue; }   // diff_calc.rs:150-152
+      auto r = find_common_ancestor(get, st.from_f, st.to_f);
+      if (r.second == DM_CHECKOUT) {
+        bool ge = true, gt = false;
+        for (auto& kv : st.from_vv) { auto it = st.to_vv.find(kv.first); Counter t = it == st.to_vv.end() ? 0 : it->second; if (t < kv.second) ge = false; }
+        for (auto& kv : st.to_vv) { auto it = st.from_vv.find(kv.first); Counter f = it == st.from_vv.end() ? 0 : it->second; if (kv.second > f) gt = true; }
+        if (ge && gt) r.second = DM_IMPORT;
+      }
+      out.push_back(r);
+    }
+    return out;
   }
   uint64_t pending_atoms() const {
     uint64_t n = 0;
@@ -412,7 +478,16 @@ struct Doc {
         Tracker::bump(cur, ch.id.peer, ch.ctr_end());
       }
     }
-    for (auto& kv : seqs) kv.second->tr.checkout(target);   // tracker.rs:354-461: ops outside the version become future / un-deleted
+    // the state store's containers: step 1 = diff(∅ → latest), step 2 (checkout) = diff(latest → version)
+    seq_exists.clear();
+    for (auto& kv : seqs) {
+      kv.second->tr.checkout(vv);
+      if (kv.second->tr.active_len() > 0) seq_exists.insert(kv.first);
+    }
+    for (auto& kv : seqs) {
+      kv.second->tr.checkout(target);   // tracker.rs:354-461: ops outside the version become future / un-deleted
+      if (kv.second->tr.active_len() > 0) seq_exists.insert(kv.first);
+    }
     materialized = true;
   }
 
@@ -467,6 +542,7 @@ struct Doc {
     std::map<std::string, uint32_t> roots;
     for (uint32_t i = 0; i < containers.size(); i++) {
       if (!containers[i].root || !touched.count(i)) continue;
+      if ((containers[i].kind == CK_TEXT || containers[i].kind == CK_LIST) && !seq_exists.count(i)) continue;
       if (roots.count(containers[i].name)) fail(ST_UNSUPPORTED, "two root containers share a name");
       roots[containers[i].name] = i;
     }

@@ -86,6 +86,49 @@ def edge_case_docs():
     return names, docs
 
 
+def container_existence_cases():
+    """(name, blobs, encoded frontiers or None, expected JSON) — which root containers the reference's state store holds
+    (diff_calc.rs:299 `!diff.is_empty() || bring_back`, state.rs:1352-1391): the batch is imported like import_batch
+    (loro.rs:1432-1523: one diff empty → latest), a checkout is a second diff latest → version.  A root Text / List
+    gets a state when something is visible at the latest version or at the checked-out one; a root Map as soon as a key
+    was written (a deleted key is still an entry of the diff, diff_calc.rs:553-605)."""
+    out = []
+    a = wire.Replica(1)
+    a.text_insert("text", 0, "ab"); a.list_insert("list", 0, [1, 2]); a.map_set("map", "k", 1); a.commit(); v1 = list(a.frontiers)
+    first = a.export()
+    a.text_delete("text", 0, 2); a.list_delete("list", 0, 2); a.map_delete("map", "k"); a.commit(); v2 = list(a.frontiers)
+    one = a.export()
+    two = [first, a.export({1: a.changes[1][0].ctr_end})]
+    out.append(("inserted and fully deleted, one blob", [one], None, b'{"map":{}}'))
+    out.append(("inserted and fully deleted, two blobs", two, None, b'{"map":{}}'))
+    out.append(("…checked out where it was visible", [one], wire.encode_frontiers(v1), b'{"list":[1,2],"map":{"k":1},"text":"ab"}'))
+    out.append(("…checked out at the latest (empty) version", [one], wire.encode_frontiers(v2), b'{"map":{}}'))
+    out.append(("…checked out at the empty version", [one], wire.encode_frontiers([]), b'{"map":{}}'))
+    a.text_insert("text", 0, "c"); a.commit()
+    three = [a.export()]
+    out.append(("visible again at the latest version", three, None, b'{"map":{},"text":"c"}'))
+    out.append(("…checked out where it was empty: the state exists", three, wire.encode_frontiers(v2), b'{"map":{},"text":""}'))
+    out.append(("…checked out at the empty version", three, wire.encode_frontiers([]), b'{"map":{},"text":""}'))
+    # more deleted than inserted (two peers delete the same run concurrently) and still something visible at the latest version
+    p, q, r = wire.Replica(11), wire.Replica(12), wire.Replica(13)
+    p.text_insert("text", 0, "abc"); p.commit(); vp = list(p.frontiers)
+    for x in (q, r):
+        x.merge_from(p)
+        x.set_visible("text", wire.KIND_TEXT, _oracle.visible_ids([p.export()], "text", wire.KIND_TEXT))
+        x.text_delete("text", 0, 2); x.commit()
+    q.merge_from(r)
+    both = [q.export()]
+    out.append(("overlapping concurrent deletes", both, None, b'{"text":"c"}'))
+    out.append(("…checked out before the insert", both, wire.encode_frontiers([]), b'{"text":""}'))
+    q.set_visible("text", wire.KIND_TEXT, _oracle.visible_ids(both, "text", wire.KIND_TEXT))
+    q.text_delete("text", 0, 1); q.commit()
+    gone = [q.export()]
+    out.append(("…and the rest deleted later", gone, None, b'{}'))
+    out.append(("…checked out before the insert", gone, wire.encode_frontiers([]), b'{}'))
+    out.append(("…checked out at the insert", gone, wire.encode_frontiers(vp), b'{"text":"abc"}'))
+    return out
+
+
 def fuzz_docs(n, base=0, steps=40, peers=None, **kw):
     docs = []
     for seed in range(base, base + n):

@@ -104,3 +104,70 @@ def visible_ids(blobs, name, kind):
         n = L.lo_visible_ids2(data.ctypes.data, off.ctypes.data, len(blobs), None, name.peer, name.counter, kind, peers.ctypes.data, ctrs.ctypes.data, cap)
     assert n >= 0
     return list(zip(peers[:n].tolist(), ctrs[:n].tolist()))
+
+
+# ---- DAG queries (oracle/lo_dag.hpp).  A test DAG is a list of nodes (peer, counter, len, lamport, [(peer, counter) deps]).
+MODES = {0: "Checkout", 1: "Import", 2: "ImportGreaterUpdates", 3: "Linear"}
+
+
+def _dag_arrays(nodes):
+    peers = np.array([n[0] for n in nodes], dtype=np.uint64)
+    ctrs = np.array([n[1] for n in nodes], dtype=np.int32)
+    lens = np.array([n[2] for n in nodes], dtype=np.int32)
+    lams = np.array([n[3] for n in nodes], dtype=np.uint32)
+    off = np.zeros(len(nodes) + 1, dtype=np.uint32)
+    dp, dc = [], []
+    for i, n in enumerate(nodes):
+        for (p, c) in n[4]:
+            dp.append(p); dc.append(c)
+        off[i + 1] = len(dp)
+    return peers, ctrs, lens, lams, off, np.array(dp + [0], dtype=np.uint64), np.array(dc + [0], dtype=np.int32)
+
+
+def _ids(ids):
+    return np.array([p for p, _ in ids] + [0], dtype=np.uint64), np.array([c for _, c in ids] + [0], dtype=np.int32)
+
+
+def dag_lca(nodes, left, right):
+    """find_common_ancestor(left, right) → (sorted LCA frontiers, DiffMode name)  (dag.rs:318-332,487-765)"""
+    L = lib()
+    a = _dag_arrays(nodes)
+    lp, lc = _ids(left)
+    rp, rc = _ids(right)
+    op = np.zeros(64 + len(nodes) * 4, dtype=np.uint64)
+    oc = np.zeros(64 + len(nodes) * 4, dtype=np.int32)
+    on = ctypes.c_uint32(0)
+    L.lo_dag_lca.restype = ctypes.c_int32
+    m = L.lo_dag_lca(ctypes.c_uint32(len(nodes)), *[ctypes.c_void_p(x.ctypes.data) for x in a],
+                     ctypes.c_uint32(len(left)), ctypes.c_void_p(lp.ctypes.data), ctypes.c_void_p(lc.ctypes.data),
+                     ctypes.c_uint32(len(right)), ctypes.c_void_p(rp.ctypes.data), ctypes.c_void_p(rc.ctypes.data),
+                     ctypes.c_void_p(op.ctypes.data), ctypes.c_void_p(oc.ctypes.data), ctypes.byref(on))
+    assert m >= 0
+    return sorted(zip(op[:on.value].tolist(), oc[:on.value].tolist())), MODES[m]
+
+
+def dag_ancestors(nodes, ids):
+    """brute force: the set of ids that are ancestors of (or equal to) one of `ids`  (dag.rs:955-985)"""
+    L = lib()
+    a = _dag_arrays(nodes)
+    ip, ic = _ids(ids)
+    cap = sum(n[2] for n in nodes) + 8
+    op = np.zeros(cap, dtype=np.uint64)
+    oc = np.zeros(cap, dtype=np.int32)
+    L.lo_dag_ancestors.restype = ctypes.c_int64
+    n = L.lo_dag_ancestors(ctypes.c_uint32(len(nodes)), *[ctypes.c_void_p(x.ctypes.data) for x in a],
+                           ctypes.c_uint32(len(ids)), ctypes.c_void_p(ip.ctypes.data), ctypes.c_void_p(ic.ctypes.data),
+                           ctypes.c_void_p(op.ctypes.data), ctypes.c_void_p(oc.ctypes.data), ctypes.c_uint64(cap))
+    assert 0 <= n <= cap
+    return set(zip(op[:n].tolist(), oc[:n].tolist()))
+
+
+def import_modes(blobs):
+    """DiffMode of each LoroDoc::import when the blobs are imported one after another (oplog.rs:591-615)"""
+    L = lib()
+    data, off, _ = pack([list(blobs)])
+    modes = np.full(len(blobs), -1, dtype=np.int32)
+    L.lo_import_modes.restype = ctypes.c_int32
+    rc = L.lo_import_modes(ctypes.c_void_p(data.ctypes.data), ctypes.c_void_p(off.ctypes.data), ctypes.c_uint32(len(blobs)), ctypes.c_void_p(modes.ctypes.data))
+    assert rc == 0
+    return [MODES[int(m)] for m in modes]

@@ -130,6 +130,19 @@ def test_checkout_known_answers_and_random_versions(engine):
         assert (g == w) if w[0] == 0 else (g[0] == w[0]), (i, g[:3], w[:3])
 
 
+def test_root_containers_the_state_store_holds(engine):
+    """diff_calc.rs:299 / state.rs:1352-1391: a root Text / List is part of the value only when some diff for it was not
+    empty — inserted-and-deleted content in one blob or in two, checkouts before / at / after the content existed."""
+    cases = _cases.container_existence_cases()
+    docs = [c[1] for c in cases]
+    fronts = [c[2] for c in cases]
+    want = _oracle.merge_batch(docs, frontiers=fronts)
+    got = engine.merge_batch(docs, fronts)
+    for c, w, g in zip(cases, want, got):
+        assert w[0] == 0 and w[1] == c[3], (c[0], w[1])
+        assert g == w, (c[0], g[:2], w[:2])
+
+
 def test_config5_checkouts(engine):
     """configs[4] shape: 2 peers alternating every 1k trace actions, ~1 % bold marks, 16 versions per document."""
     docs, fronts = [], []

@@ -48,7 +48,11 @@ def test_rust_updates_fixture_matches_deep_json(name):
     want = FX["json"]["snapshot.deep.json"]
     st, v, vv, pend = deep([BLOB[name]])
     assert pend == 0
-    assert v["list"] == want["list"] and v["text"] == want["text"]
+    # snapshot.deep.json is the deep value of a SNAPSHOT import (its state section carries every container state of the
+    # exporting document, `imports_typescript_reencoded_snapshot`); for the updates blobs the reference only asserts
+    # Rust-bytes == TS-bytes.  "list" and "text" end empty in this history, so an UPDATES import creates no state for
+    # them (diff_calc.rs:299, state.rs:1365): absent here, empty there.
+    assert v.get("list", []) == want["list"] == [] and v.get("text", "") == want["text"] == ""
     for k, x in want["map"].items():
         if k in ("child_mlist", "child_tree"):  # MovableList / Tree children: out of scope
             continue
@@ -269,7 +273,7 @@ def test_tracker_known_answers_through_checkout():
     rev = _two_peer_delete_doc(True)
     assert json.loads(_at(rev, [(2, 4)])[1]) == {"text": "abcde"}
     assert json.loads(_at(rev, [(1, 9)])[1]) == {"text": "abcdefghij"}
-    assert json.loads(_at(rev, [(2, 9)])[1]) == {"text": ""}
+    assert json.loads(_at(rev, [(2, 9)])[1]) == {}   # nothing visible at the latest version nor here: the root never got a state (diff_calc.rs:299)
     fwd = _two_peer_delete_doc(False)
     assert json.loads(_at(fwd, [(2, 3)])[1]) == {"text": "efghij"}
     assert _at(fwd, [(2, 3)])[2] == wire.encode_vv({1: 10, 2: 4})
