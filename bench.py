@@ -28,6 +28,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+_T0 = time.time()
+
+
+def note(msg):
+    """progress on stderr (the JSON line on stdout stays the only stdout output)"""
+    print("[bench %6.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ≈6300 GB/s achievable
 
 
@@ -76,13 +84,45 @@ def _cpu_procs(docs, procs, per_proc, reps):
     return n / (max(o[3] for o in out) - min(o[2] for o in out)), n
 
 
-def cpu_baseline(docs, sample, cores, target_s=8.0):
+def host_cores():
+    """(cores this process may use, hardware threads of the box, why): the container's cgroup CPU quota and affinity mask
+    bound what a CPU deployment on this box could use from here."""
+    hw = os.cpu_count() or 1
+    n, why = hw, "all hardware threads"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, why = aff, f"affinity mask of {aff} CPUs"
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != "max":
+                lim = max(1, int(int(q) / int(per)))
+                if lim < n:
+                    n, why = lim, f"cgroup cpu.max = {q} {per} ({lim} CPUs)"
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and q // per < n:
+            n, why = max(1, q // per), f"cgroup cfs quota {q}/{per}"
+    except Exception:
+        pass
+    return n, hw, why
+
+
+def cpu_baseline(docs, sample, target_s=6.0):
     """The CPU restatement of the reference algorithm (oracle/, kind "port") timed on this box's host cores on a
     bounded sample of the same workload.  Reported next to the GPU number; never the thing measured above.
     Documents are independent, so the port is run the way a CPU deployment would scale it: one single-threaded process
-    per core (round 1 used threads in one process and stopped scaling at 32 of 256 hardware threads: shared glibc heap
-    and mmap lock).  Measured at 1 process, at half and at all of the hardware threads; the best is `value`."""
+    per core (threads in one process stop scaling early: shared glibc heap and mmap lock).  The box shows 256 hardware
+    threads but the container's cgroup grants a fraction of them (cpu.max): more processes than that are throttled, not
+    faster — measured at 1 process, at half and at all of the CPUs the container may use; the best is `value`."""
     import _oracle
+    cores, hw, why = host_cores()
     sample_docs = docs[:sample]
     one = _oracle.pack(sample_docs[:16])
     res = _oracle.merge_batch(None, threads=1, packed=one)           # warm + the results bench.py cross-checks
@@ -97,14 +137,154 @@ def cpu_baseline(docs, sample, cores, target_s=8.0):
         rate, n = _cpu_procs(sample_docs, procs, per_proc, reps if procs > 1 else max(1, reps // 2))
         runs[procs] = (rate, n)
     best = max(runs, key=lambda k: runs[k][0])
+    one_rate = runs[1][0]
     return {
         "value": round(runs[best][0], 1), "unit": "docs/s", "cores": best, "kind": "port",
         "sample": f"{runs[best][1]} merges of the benchmark documents (same blobs): {best} single-threaded processes of "
                   f"oracle/liblorooracle.so x {per_proc} documents x {reps} passes, released together; "
                   + "; ".join(f"{k} proc: {v[0]:.0f} docs/s" for k, v in sorted(runs.items()))
-                  + f" ({cores} hardware threads on the box)",
+                  + f" (the box has {hw} hardware threads; this container may use {cores}: {why})",
         "scaling": {str(k): round(v[0], 1) for k, v in sorted(runs.items())},
+        "cores_available": cores, "hardware_threads": hw,
+        "linear_extrapolation_to_physical_cores": {"cores": hw // 2, "value": round(one_rate * (hw // 2), 1),
+                                                   "note": "1-process rate x physical cores: an upper bound for this port on the whole box, not a measurement"},
     }, res
+
+
+class StepLoop:
+    """The serving loop of one rank: `inflight` contexts hold their batch in HBM and alternate; finishing a step = wait for
+    the device pipeline, read the per-document summary (status, pending, lengths + the xxh64 of the JSON computed ON THE
+    DEVICE — no JSON crosses PCIe) and, with more than one rank, all-gather it (the single exchange step).
+    tests/test_dist.py drives this same class under gloo with the kernel-logic harness standing in for the GPU."""
+
+    def __init__(self, engs, doc_ids, world, dev):
+        self.engs, self.doc_ids, self.world, self.dev = engs, doc_ids, world, dev
+        self.busy = [False] * len(engs)
+        self.timing = {"on": False, "k": {}}
+
+    def finish(self, k):
+        from loro_amd import dist as lmdist
+        e = self.engs[k]
+        e.wait()
+        self.busy[k] = False
+        if self.timing["on"]:
+            for name, ms in e.kernel_times():       # HIP events of this step, recorded without host syncs
+                self.timing["k"].setdefault(name, []).append(ms)
+        st, jl, vl, pe = e.result_meta()
+        local = lmdist.summarize_device(self.doc_ids, st, pe, jl, vl, e.result_hashes())
+        if self.world > 1:
+            return lmdist.all_gather_summaries(local, device=self.dev)
+        return local
+
+    def run_steps(self, n):
+        """n steps; step i runs on context i % inflight, which is first drained of its previous step"""
+        out = None
+        for i in range(n):
+            k = i % len(self.engs)
+            if self.busy[k]:
+                out = self.finish(k)
+            self.engs[k].run_async()            # device pipeline of one batch; returns at once
+            self.busy[k] = True
+        for j in range(len(self.engs)):         # drain in launch order
+            k = (n + j) % len(self.engs)
+            if self.busy[k]:
+                out = self.finish(k)
+        return out
+
+
+def end_to_end(engs, docs, steps):
+    """PCIe-inclusive rate of the same workload: every step stages the blobs from host memory (lm_stage: host → pinned
+    → HBM), runs the pipeline and fetches JSON + VV back (lm_fetch), two contexts alternating so that one batch's copies
+    overlap the other's kernels.  The lm_doc_in array is built once; the timed region holds only C-ABI calls."""
+    from loro_amd._cabi import Context
+    packed = Context._pack(docs)
+    t_stage = t_fetch = 0.0
+    for e in engs:
+        e.stage_packed(packed); e.run(); e.fetch()                 # warm: staging buffers, pools
+    busy = [False] * len(engs)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        k = i % len(engs)
+        if busy[k]:
+            engs[k].wait()
+            t = time.perf_counter(); engs[k].fetch_raw(); t_fetch += time.perf_counter() - t
+        t = time.perf_counter(); engs[k].stage_packed(packed); t_stage += time.perf_counter() - t
+        engs[k].run_async()
+        busy[k] = True
+    for j in range(len(engs)):
+        k = (steps + j) % len(engs)
+        if busy[k]:
+            engs[k].wait()
+            t = time.perf_counter(); engs[k].fetch_raw(); t_fetch += time.perf_counter() - t
+    dt = time.perf_counter() - t0
+    st = engs[0].stats()
+    return {"value": round(len(docs) * steps / dt, 1), "unit": "docs/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+            "host_to_device_bytes_per_step": int(st.in_bytes), "device_to_host_bytes_per_step": int(st.out_bytes),
+            "lm_stage_ms": round(t_stage / steps * 1e3, 2), "lm_fetch_ms": round(t_fetch / steps * 1e3, 2),
+            "what": "lm_stage (pageable host blobs -> pinned -> HBM) + lm_run + lm_fetch (JSON + VV -> host) per step, "
+                    f"{len(engs)} contexts alternating"}
+
+
+def _gen(args):
+    kind, d = args
+    from loro_amd import workload
+    if kind == "cfg3a":
+        return workload.cfg3_doc(d, combined=True), None
+    if kind == "cfg3b":
+        return workload.cfg3_doc(d, combined=False), None
+    if kind == "cfg5":
+        return workload.cfg5_doc(d, n_ops=1000000, turn=1000, n_checkouts=16)
+    raise ValueError(kind)
+
+
+def other_configs(device, cores):
+    """The other BASELINE.json configs on one GPU, each checked against the oracle on its distinct documents before it
+    is timed (one context, runs strictly one after the other, inputs resident in HBM): docs/s and the algorithmic
+    bytes (blobs in + JSON + VV out) per second as a fraction of the HBM peak."""
+    import multiprocessing as mp
+    import loro_amd, _oracle, _cases
+    from loro_amd import workload
+    out = {}
+    with mp.get_context("fork").Pool(min(24, cores)) as pool:
+        g3 = pool.map_async(_gen, [("cfg3a", d) for d in range(8)] + [("cfg3b", d) for d in range(8)])
+        g5 = pool.map_async(_gen, [("cfg5", d) for d in range(4)])
+        cfg1 = [workload.cfg1_doc(d) for d in range(100)]
+        cfg4_base = _cases.cfg4_docs(96)
+        g3, g5 = g3.get(), g5.get()
+    note("other configs: documents generated")
+
+    def run(name, docs, fronts, distinct, desc, reps=3):
+        want = _oracle.merge_batch(docs[:distinct], threads=min(32, cores), frontiers=None if fronts is None else fronts[:distinct])
+        with loro_amd.MergeEngine(device) as e:
+            e.stage(docs, fronts)
+            e.run()
+            got = e.fetch()
+            assert all(got[i] == want[i % distinct] for i in range(len(docs))), f"{name}: device results differ from the CPU oracle"
+            best = 1e9
+            for _ in range(reps):
+                t = time.perf_counter(); e.run(); best = min(best, time.perf_counter() - t)
+            st = e.stats()
+        alg = float(st.in_bytes + st.out_bytes)
+        note(f"other configs: {name} done")
+        out[name] = {"docs": len(docs), "distinct_docs": distinct, "docs_per_s": round(len(docs) / best, 1), "ms_per_batch": round(best * 1e3, 2),
+                     "algorithmic_bytes": int(alg), "algorithmic_GBps": round(alg / best / 1e9, 2), "frac_of_hbm_peak": round(alg / best / 1e9 / HBM_PEAK_GBS, 5),
+                     "parity": f"all {len(docs)} results equal to the oracle's", "workload": desc}
+
+    run("configs[0]", cfg1, None, 100, "100 docs x 2 peers x 1,000 sequential inserts, 2 blobs/doc")
+    d3 = [g[0] for g in g3]
+    run("configs[2]", [d3[i % 16] for i in range(2048)], None, 16,
+        "LWW Map, 16 peers x 10,000 writes on 1,024 keys per doc (160k ops/doc); 2,048 docs (of the config's 10,000): 8 distinct "
+        "histories x {one combined blob, 16 per-peer blobs}")
+    run("configs[3]", [cfg4_base[i % 96] for i in range(12500)], None, 96,
+        "mixed List/Map/Text roots, 4 peers x ~1k ops with pairwise syncs; 12,500 docs = one GPU's share of the config's 100k over 8")
+    docs5, fr5 = [], []
+    for blobs, fr in g5:
+        docs5 += [blobs] * len(fr); fr5 += fr
+    n5 = len(docs5)
+    run("configs[4]", [docs5[i % n5] for i in range(1024)], [fr5[i % n5] for i in range(1024)], n5,
+        "1M-op rich-text documents (2 peers alternating every 1k trace actions, ~1% marks), 16 checkouts each: 1,024 renderings = "
+        "64 documents x 16 versions (of the config's 1,000 documents); every rendering replays its version from the empty one", reps=2)
+    return out
 
 
 def main():
@@ -118,6 +298,8 @@ def main():
     ap.add_argument("--commit-every", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE configs (N=1 only; ~2 min)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive measurement (N=1 only)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="contexts in flight per GPU (double buffering: one batch's decode stages run beside the other's integrate "
                          "kernels); every step is still one full pipeline pass over one context's batch")
@@ -144,48 +326,21 @@ def main():
 
     tpl, docs = build_docs(args.docs, rank * args.docs, args.base_ops, args.branch_ops, args.commit_every, seed=0)
     doc_ids = list(range(rank * args.docs, (rank + 1) * args.docs))
+    note("documents built")
     # CPU baseline first (rank 0 at N=1 only): its worker processes are forked before this process touches the GPU
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, _ = cpu_baseline(docs, min(args.cpu_sample, len(docs)), os.cpu_count() or 1)
+        cpu, _ = cpu_baseline(docs, min(args.cpu_sample, len(docs)))
+    note("cpu baseline done" if cpu else "no cpu baseline")
     engs = [loro_amd.MergeEngine(local_rank) for _ in range(max(1, args.inflight))]
     for e in engs:
         e.stage(docs)                     # blobs → HBM (outside the timed region); every context holds the batch
         e.run()                           # first run of a context allocates its work pools (≈47 GB): part of set-up
     eng = engs[0]
-    busy = [False] * len(engs)
+    loop = StepLoop(engs, doc_ids, world, dev)
+    run_steps, timing = loop.run_steps, loop.timing
 
-    def finish(k):
-        """complete the step in flight on context k: wait for the device pipeline, read the per-document summary and
-        (multi-GPU) exchange it"""
-        engs[k].wait()
-        busy[k] = False
-        if timing["on"]:
-            for name, ms in engs[k].kernel_times():       # HIP events of this step, recorded without host syncs
-                timing["k"].setdefault(name, []).append(ms)
-        st, jl, vl, pe = engs[k].result_meta()
-        if world > 1:
-            local = np.stack([np.asarray(doc_ids, dtype=np.int64), st.astype(np.int64), pe.astype(np.int64),
-                              jl.astype(np.int64), vl.astype(np.int64), np.zeros(len(st), dtype=np.int64)], axis=1)
-            return lmdist.all_gather_summaries(local, device=dev)
-        return st
-
-    def run_steps(n):
-        """n steps; step i runs on context i % inflight, which is first drained of its previous step"""
-        out = None
-        for i in range(n):
-            k = i % len(engs)
-            if busy[k]:
-                out = finish(k)
-            engs[k].run_async()            # device pipeline of one batch; returns at once
-            busy[k] = True
-        for j in range(len(engs)):         # drain in launch order
-            k = (n + j) % len(engs)
-            if busy[k]:
-                out = finish(k)
-        return out
-
-    timing = {"on": False, "k": {}}
+    note("contexts staged")
     run_steps(args.warmup)
     for e in engs:
         e.set_profiling(2)                 # stage events on the engine streams, streams overlapped as in production
@@ -205,6 +360,7 @@ def main():
     dt = float(tmax.item())
 
     timing["on"] = False
+    note("timed steps done")
     for e in engs:
         e.set_profiling(0)
     # ---- everything below is outside the timed region
@@ -230,13 +386,18 @@ def main():
     alg_bytes = float(stats.in_bytes + stats.out_bytes)  # Σ blob bytes in + JSON + VV bytes out
     alg_per_launch = alg_bytes / n_streams                # one launch of the dominant kernel covers 1/n_streams of the batch
     achieved = alg_per_launch / (kavg[dom] * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_integrate.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM traffic of the dominant kernel cannot be read inside this process: it comes from separate rocprofv3 --pmc passes
+    # of this same command (profiles/collect.sh), committed per round; the newest one is quoted and named
+    traffic, traffic_src = None, None
+    for tag in ("r02", "r01"):
+        pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_integrate.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic_src = f"profiles/{tag}_pmc_integrate.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
+                break
+            except Exception:
+                traffic = None
 
     line = None
     if rank == 0:
@@ -273,7 +434,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg_per_launch), "launches_per_step": n_streams, "kernel_ms": round(kavg[dom], 3),
                 "kernel_ms_alone": round(kalone.get(dom, 0.0), 3),
                 "frac_alone": round(alg_per_launch / (kalone[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kalone.get(dom) else None,
@@ -284,8 +445,23 @@ def main():
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
+            line["gpu_over_cpu"] = {"measured_on_available_cores": round(line["value"] / cpu["value"], 2),
+                                    "vs_linear_extrapolation_to_physical_cores": round(line["value"] / cpu["linear_extrapolation_to_physical_cores"]["value"], 2)}
+        table = out
+        assert table.shape[0] == n_total and (table[:, 1] == 0).all() and (table[:, 5] != 0).all()
+        import xxhash
+        hashes = np.ascontiguousarray(table[:, 5]).view(np.uint64)
+        for i in (0, len(got) // 2, len(got) - 1):   # the summary's content word is the hash of what lm_fetch returns
+            assert int(hashes[i]) == xxhash.xxh64(got[i][1]).intdigest(), "device xxh64 differs from the fetched JSON's"
+        note("parity + summary checked")
+        if world == 1 and not args.no_end_to_end:
+            line["end_to_end"] = end_to_end(engs, docs, max(4, args.steps // 2))
+            note("end-to-end done")
     for e in engs:
         e.close()
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        line["other_configs"] = other_configs(local_rank, host_cores()[0])
+        note("other configs done")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -88,6 +88,9 @@ int lm_wait(lm_ctx* ctx);
 /* Per-document metadata of the last lm_run (arrays of n_docs entries, any may be NULL) without copying the
  * rendered bytes back: what a sharded deployment all-gathers as the merged-state summary. */
 int lm_result_meta(lm_ctx* ctx, int32_t* status, uint64_t* json_len, uint64_t* vv_len, uint64_t* pending_ops);
+/* xxh64 (seed 0) of every document's JSON (n_docs entries; 0 for a failed document), computed on the device: the content
+ * word of the merged-state summary — ranks compare merged states without moving the JSON. */
+int lm_result_hashes(lm_ctx* ctx, uint64_t* json_xxh64);
 
 /* Wave-primitive self test on the device (DPP scan, ballot ranks); returns the number of mismatches. */
 int lm_selftest(lm_ctx* ctx);

@@ -18,7 +18,7 @@ class RunStats(ctypes.Structure):
                 ("device_bytes_allocated", ctypes.c_uint64), ("n_kernels", ctypes.c_uint32)]
 
 
-SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "n_streams", "run_async", "wait"]
+SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait"]
 
 
 class Binding:
@@ -40,6 +40,8 @@ class Binding:
         self.set_profiling = g("set_profiling"); self.set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self.result_meta = g("result_meta"); self.result_meta.restype = ctypes.c_int
         self.result_meta.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.result_hashes = g("result_hashes"); self.result_hashes.restype = ctypes.c_int
+        self.result_hashes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.selftest = g("selftest"); self.selftest.restype = ctypes.c_int; self.selftest.argtypes = [ctypes.c_void_p]
         self.n_streams = g("n_streams"); self.n_streams.restype = ctypes.c_int; self.n_streams.argtypes = [ctypes.c_void_p]
         self.kernel_time = g("kernel_time"); self.kernel_time.restype = ctypes.c_int
@@ -87,7 +89,7 @@ class Context:
                 keep.append(f)
                 arr[i].checkout_frontiers = f
                 arr[i].checkout_len = len(f)
-        return arr, keep
+        return arr, (n, keep)
 
     def stage(self, docs, frontiers=None):
         """docs: list of lists of update blobs.  frontiers: optional list (one per document) of None or encoded
@@ -97,6 +99,13 @@ class Context:
         if self.b.stage(self.h, arr, self.n) != 0:
             raise RuntimeError(self.b.last_error(self.h).decode())
         del keep  # the engine copied the blobs into its staging buffer
+
+    def stage_packed(self, packed):
+        """lm_stage on an lm_doc_in array prepared once with Context._pack (bench.py: the host-side call alone)"""
+        arr, keep = packed
+        self.n = len(keep) if not isinstance(keep, tuple) else keep[0]
+        if self.b.stage(self.h, arr, self.n) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
 
     def run(self):
         if self.b.run(self.h) != 0:
@@ -108,6 +117,13 @@ class Context:
 
     def wait(self):
         if self.b.wait(self.h) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+
+    def fetch_raw(self):
+        """lm_fetch alone (JSON + VV copied to host memory owned by the library), without building Python objects"""
+        if getattr(self, "_outs", None) is None or len(self._outs) < max(self.n, 1):
+            self._outs = (DocOut * max(self.n, 1))()
+        if self.b.fetch(self.h, self._outs) != 0:
             raise RuntimeError(self.b.last_error(self.h).decode())
 
     def fetch(self):
@@ -132,6 +148,14 @@ class Context:
         if self.b.result_meta(self.h, st.ctypes.data, jl.ctypes.data, vl.ctypes.data, pe.ctypes.data) != 0:
             raise RuntimeError(self.b.last_error(self.h).decode())
         return st, jl, vl, pe
+
+    def result_hashes(self):
+        """xxh64 (seed 0) of every document's JSON, computed on the device by the last run (u64[n]; 0 = failed document)"""
+        import numpy as np
+        h = np.zeros(self.n, dtype=np.uint64)
+        if self.b.result_hashes(self.h, h.ctypes.data) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        return h
 
     def sizing(self):
         """(max leaves used, max leaf capacity, max elements, documents re-run with the worst-case directory,

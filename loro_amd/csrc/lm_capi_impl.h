@@ -49,7 +49,15 @@ struct lm_ctx_impl {
     }
     first.push_back((uint32_t)n);
     while (parts.size() < n_parts()) parts.emplace_back(new lm::Engine(device));
-    for (uint32_t p = 0; p < n_parts(); p++) parts[p]->stage(docs + first[p], first[p + 1] - first[p]);
+    // every part gathers and uploads its share on its own host thread and stream
+    uint32_t np2 = n_parts();
+    std::vector<std::string> errs(np2);
+    auto body = [&](uint32_t p) { try { parts[p]->stage(docs + first[p], first[p + 1] - first[p]); } catch (const std::exception& e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "error"; } };
+    std::vector<std::thread> th;
+    for (uint32_t p = 1; p < np2; p++) th.emplace_back(body, p);
+    body(0);
+    for (auto& t : th) t.join();
+    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
   }
   void run() {
     uint32_t np = n_parts();
@@ -163,6 +171,13 @@ int LM_API(result_meta)(void* c, int32_t* status, uint64_t* json_len, uint64_t* 
     if (vv_len) vv_len[i] = r.vv_len;
     if (pending) pending[i] = r.pending;
   });
+  return 0;
+}
+// xxh64 (seed 0) of every document's JSON, computed on the device by the last lm_run (0 for failed documents)
+int LM_API(result_hashes)(void* c, uint64_t* json_xxh64) {
+  auto* x = (lm_ctx_impl*)c;
+  if (!x->ran) { x->err = "lm_result_hashes before lm_run"; return -1; }
+  x->for_docs([&](uint32_t i, lm::Engine&, const lm::DocResult& r) { json_xxh64[i] = r.json_xxh64; });
   return 0;
 }
 int LM_API(get_stats)(void* c, lm_run_stats_c* s) {

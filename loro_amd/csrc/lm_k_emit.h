@@ -745,4 +745,41 @@ LM_KERNEL void k_compact(Dev d, const uint64_t* src_addr, const uint64_t* vv_sla
   }
 }
 
+// K12: xxh64 (seed 0) of every document's rendered JSON, one wave per document — the content word of the merged-state
+// summary a sharded deployment all-gathers, so ranks can compare states without moving the JSON.
+// The four accumulators of the 32-byte stripe loop live in lanes 0..3 (each reads its own 8 bytes of a stripe).
+LM_DEV uint64_t xx_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+LM_KERNEL void k_hash_json(Dev d, uint64_t* out_hash) {
+  static constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull,
+                            P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  const DocMeta& m = d.doc[doc];
+  if (status_fatal(m.status)) { if (lane == 0) out_hash[doc] = 0; return; }
+  const uint8_t* p = d.out + d.out_off[doc];   // 16-byte aligned
+  uint64_t len = m.out_len, h;
+  uint64_t n_str = len / 32;
+  if (n_str) {
+    uint64_t v = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0ull : 0ull - P1;
+    if (lane < 4) {
+      const uint64_t* q = (const uint64_t*)p + lane;
+#pragma unroll 8
+      for (uint64_t s = 0; s < n_str; s++) v = xx_rotl(v + q[s * 4] * P2, 31) * P1;
+    }
+    uint64_t v1 = lmw::shfl64(v, 0), v2 = lmw::shfl64(v, 1), v3 = lmw::shfl64(v, 2), v4 = lmw::shfl64(v, 3);
+    h = xx_rotl(v1, 1) + xx_rotl(v2, 7) + xx_rotl(v3, 12) + xx_rotl(v4, 18);
+    h = (h ^ (xx_rotl(v1 * P2, 31) * P1)) * P1 + P4;
+    h = (h ^ (xx_rotl(v2 * P2, 31) * P1)) * P1 + P4;
+    h = (h ^ (xx_rotl(v3 * P2, 31) * P1)) * P1 + P4;
+    h = (h ^ (xx_rotl(v4 * P2, 31) * P1)) * P1 + P4;
+  } else h = P5;
+  h += len;
+  uint64_t i = n_str * 32;
+  for (; i + 8 <= len; i += 8) { uint64_t k = *(const uint64_t*)(p + i); h ^= xx_rotl(k * P2, 31) * P1; h = xx_rotl(h, 27) * P1 + P4; }
+  if (i + 4 <= len) { h ^= (uint64_t)(*(const uint32_t*)(p + i)) * P1; h = xx_rotl(h, 23) * P2 + P3; i += 4; }
+  for (; i < len; i++) { h ^= (uint64_t)p[i] * P5; h = xx_rotl(h, 11) * P1; }
+  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+  if (lane == 0) out_hash[doc] = h;
+}
+
 }  // namespace lm

@@ -6,6 +6,8 @@
 //   lmbe::dalloc/dfree/dmemset/h2d/d2h/sync/halloc/hfree, lmbe::tic()/toc(name) and the macro
 //   LM_LAUNCH(kernel, grid, block, args...).
 #pragma once
+#include <thread>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
@@ -35,6 +37,7 @@ struct DBuf {  // grow-only device buffer
 struct DocResult {
   int32_t status;
   uint64_t json_off, json_len, vv_off, vv_len, pending;
+  uint64_t json_xxh64;   // xxh64 (seed 0) of the JSON bytes, computed on the device (0 for failed documents)
 };
 
 struct KernelTime { std::string name; double ms; };
@@ -57,9 +60,9 @@ struct Engine {
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
-  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off, b_slab2, b_slab2_off;
+  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_hash, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off, b_slab2, b_slab2_off;
   uint64_t payload_bytes = 0;   // Σ json_len + Σ vv_len of the last run (without alignment padding)
-  std::vector<uint64_t> h_prof;
+  std::vector<uint64_t> h_prof, h_hash;
   // results
   std::vector<DocMeta> h_doc;
   std::vector<DocResult> results;
@@ -77,7 +80,9 @@ struct Engine {
   explicit Engine(int device) { sc = lmbe::stream_create(device); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
-  ~Engine() { release_all(); lmbe::stream_destroy(sc); }
+  uint8_t* h_stage = nullptr;      // pinned staging buffer of lm_stage (grow-only)
+  size_t h_stage_cap = 0;
+  ~Engine() { release_all(); if (h_stage) lmbe::hfree(h_stage); lmbe::stream_destroy(sc); }
   void release_all() {
     DBuf* all[] = {&b_front, &b_front_off, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
@@ -85,7 +90,7 @@ struct Engine {
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
-                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
+                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
   }
@@ -117,15 +122,54 @@ struct Engine {
       }
     h_blob_off[nb] = off;
     data_bytes = off + 64;
-    uint8_t* host = (uint8_t*)lmbe::halloc(data_bytes);
-    if (!host) throw std::runtime_error("host staging allocation failed");
-    memset(host, 0, data_bytes);
-    b = 0;
-    for (size_t i = 0; i < nd; i++)
-      for (size_t k = 0; k < docs[i].n; k++, b++) memcpy(host + h_blob_off[b], docs[i].blobs[k], docs[i].lens[k]);
+    // Pinned staging buffer, kept across batches (pinning a fresh gigabyte per batch cost more than the copy).  The
+    // blobs are gathered into it by a few worker threads in ≈16 MB chunks of destination, and every chunk is handed
+    // to the copy engine as soon as it is complete: the gather of chunk c+1 runs beside the DMA of chunk c.
+    if (data_bytes > h_stage_cap) {
+      if (h_stage) lmbe::hfree(h_stage);
+      h_stage_cap = data_bytes + data_bytes / 4 + 4096;
+      h_stage = (uint8_t*)lmbe::halloc(h_stage_cap);
+      if (!h_stage) { h_stage_cap = 0; throw std::runtime_error("host staging allocation failed"); }
+    }
     b_data.ensure(data_bytes);
-    lmbe::h2d(b_data.p, host, data_bytes);
-    lmbe::hfree(host);
+    {
+      uint8_t* host = h_stage;
+      std::vector<const uint8_t*> src(nb);
+      b = 0;
+      for (size_t i = 0; i < nd; i++) for (size_t k = 0; k < docs[i].n; k++, b++) src[b] = docs[i].blobs[k];
+      std::vector<size_t> cut{0};           // chunk c = blobs [cut[c], cut[c+1])
+      const uint64_t CHUNK = 16ull << 20;
+      for (size_t j = 0; j < nb; j++) if (h_blob_off[j + 1] - h_blob_off[cut.back()] >= CHUNK && j + 1 < nb) cut.push_back(j + 1);
+      cut.push_back(nb);
+      size_t nc = cut.size() - 1;
+      std::vector<std::atomic<int>> done(nc);
+      for (auto& x : done) x.store(0);
+      std::atomic<size_t> next(0);
+      auto gather = [&]() {
+        for (;;) {
+          size_t c = next.fetch_add(1);
+          if (c >= nc) return;
+          for (size_t j = cut[c]; j < cut[c + 1]; j++) {
+            uint64_t o = h_blob_off[j], l = h_blob_len[j], pad = h_blob_off[j + 1] - o - l;
+            memcpy(host + o, src[j], l);
+            if (pad) memset(host + o + l, 0, pad);
+          }
+          done[c].store(1, std::memory_order_release);
+        }
+      };
+      size_t nt = nc < 2 ? 0 : (nc < 6 ? nc - 1 : 6);
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < nt; t++) th.emplace_back(gather);
+      if (!nt) gather();
+      memset(host + off, 0, 64);
+      for (size_t c = 0; c < nc; c++) {
+        while (!done[c].load(std::memory_order_acquire)) std::this_thread::yield();
+        uint64_t o0 = h_blob_off[cut[c]], o1 = c + 1 == nc ? data_bytes : h_blob_off[cut[c + 1]];
+        lmbe::h2d_async((uint8_t*)b_data.p + o0, host + o0, o1 - o0);
+      }
+      for (auto& t : th) t.join();
+      if (!nb) lmbe::h2d_async(b_data.p, host, data_bytes);
+    }
     b_blob_off.ensure((nb + 1) * 8); lmbe::h2d(b_blob_off.p, h_blob_off.data(), (nb + 1) * 8);
     b_blob_len.ensure(nb * 4 + 4); if (nb) lmbe::h2d(b_blob_len.p, h_blob_len.data(), nb * 4);
     b_doc_blob.ensure((nd + 1) * 4); lmbe::h2d(b_doc_blob.p, h_doc_blob.data(), (nd + 1) * 4);
@@ -488,6 +532,10 @@ struct Engine {
       lmbe::tic(profiling);
       LM_LAUNCH(k_compact, n_docs, 64, d, (const uint64_t*)b_slab_off.as<uint64_t>(), vo, vs);
       lmbe::toc("k_compact", times, profiling);
+      b_hash.ensure((size_t)n_docs * 8 + 8);
+      LM_LAUNCH(k_hash_json, n_docs, 64, d, b_hash.as<uint64_t>());
+      h_hash.resize(n_docs);
+      lmbe::d2h(h_hash.data(), b_hash.p, (size_t)n_docs * 8);
     }
     payload_bytes = 0;
     for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) payload_bytes += (uint64_t)h_doc[i].out_len + h_doc[i].vv_len;
@@ -505,6 +553,7 @@ struct Engine {
       r.json_off = h_out_off[i]; r.json_len = ok ? h_doc[i].out_len : 0;
       r.vv_off = h_vv_off[i]; r.vv_len = ok ? h_doc[i].vv_len : 0;
       r.pending = ok ? (((uint64_t)h_doc[i].pending_hi << 32) | h_doc[i].pending_lo) : 0;
+      r.json_xxh64 = ok ? h_hash[i] : 0;
     }
     lmbe::flush_times(times);
     ran = true;

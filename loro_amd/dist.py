@@ -5,23 +5,36 @@ ROCm; gloo in the CPU tests) of a fixed-size per-document summary so that every 
 table; the JSON itself stays with the owning rank."""
 from __future__ import annotations
 
-import zlib
 from typing import List, Sequence, Tuple
 
 import numpy as np
 
-SUMMARY_WORDS = 6  # doc index, status, pending ops, json length, vv length, crc32(json)
+SUMMARY_WORDS = 6  # doc index, status, pending ops, json length, vv length, xxh64(json) (SURVEY.md §8e)
 
 
 def owned_docs(n_docs: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_docs, world))
 
 
-def summarize(doc_ids: Sequence[int], results: Sequence[Tuple[int, bytes, bytes, int]]) -> np.ndarray:
+def summarize_device(doc_ids: Sequence[int], status, pending, json_len, vv_len, json_xxh64) -> np.ndarray:
+    """The per-document summary table from what the engine returns WITHOUT fetching the JSON: lm_result_meta +
+    lm_result_hashes (the hash is computed on the device, k_hash_json)."""
     out = np.zeros((len(doc_ids), SUMMARY_WORDS), dtype=np.int64)
-    for i, (d, (st, js, vv, pend)) in enumerate(zip(doc_ids, results)):
-        out[i] = (d, st, pend, len(js), len(vv), zlib.crc32(js))
+    out[:, 0] = np.asarray(doc_ids, dtype=np.int64)
+    out[:, 1] = np.asarray(status, dtype=np.int64)
+    out[:, 2] = np.asarray(pending, dtype=np.uint64).astype(np.int64)
+    out[:, 3] = np.asarray(json_len, dtype=np.uint64).astype(np.int64)
+    out[:, 4] = np.asarray(vv_len, dtype=np.uint64).astype(np.int64)
+    out[:, 5] = np.asarray(json_xxh64, dtype=np.uint64).view(np.int64)
     return out
+
+
+def summarize(doc_ids: Sequence[int], results: Sequence[Tuple[int, bytes, bytes, int]]) -> np.ndarray:
+    """Same table from fetched results (host-side xxh64): what summarize_device must agree with."""
+    import xxhash
+    hashes = np.array([xxhash.xxh64(js).intdigest() if st in (0, 4) and js else 0 for st, js, _, _ in results], dtype=np.uint64)
+    return summarize_device(doc_ids, [r[0] for r in results], [r[3] for r in results], [len(r[1]) for r in results],
+                            [len(r[2]) for r in results], hashes)
 
 
 def all_gather_summaries(local: np.ndarray, device=None):

@@ -22,6 +22,7 @@ inline void* dalloc(size_t n) { g_alloc += n; void* p = malloc(n ? n : 1); memse
 inline void dfree(void* p) { free(p); }
 inline void dmemset(void* p, int v, size_t n) { memset(p, v, n); }
 inline void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
+inline void h2d_async(void* d, const void* h, size_t n) { memcpy(d, h, n); }
 inline void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
 inline void sync() {}
 inline void* halloc(size_t n) { return malloc(n ? n : 1); }

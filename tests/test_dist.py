@@ -45,3 +45,45 @@ def test_ownership_partitions_documents():
     for n, w in ((10, 2), (7, 4), (3, 8)):
         owned = [lmdist.owned_docs(n, r, w) for r in range(w)]
         assert sorted(d for o in owned for d in o) == list(range(n))
+
+
+def _bench_worker(rank, world, port, per_rank, out_dir):
+    """bench.py's serving loop (StepLoop: contexts in flight, device-side summary incl. the xxh64 of the JSON, the single
+    all-gather) with the kernel-logic harness standing in for the GPU and gloo for RCCL."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench, _emu
+    from loro_amd._cabi import Context
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    docs = _cases.fuzz_docs(per_rank * world)[rank * per_rank:(rank + 1) * per_rank]
+    doc_ids = list(range(rank * per_rank, (rank + 1) * per_rank))
+    engs = [Context(_emu.binding()) for _ in range(2)]
+    for e in engs:
+        e.stage(docs)
+        e.run()
+    loop = bench.StepLoop(engs, doc_ids, world, None)
+    loop.run_steps(1)
+    table = loop.run_steps(3)
+    np.save(os.path.join(out_dir, f"bench_table{rank}.npy"), table)
+    for e in engs:
+        e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_loop_two_ranks(tmp_path):
+    world, per_rank = 2, 5
+    _emu_binding_is_built()
+    mp.spawn(_bench_worker, args=(world, _free_port(), per_rank, str(tmp_path)), nprocs=world, join=True)
+    docs = _cases.fuzz_docs(per_rank * world)
+    ref = lmdist.summarize(list(range(per_rank * world)), _oracle.merge_batch(docs))   # host-side xxh64 of the oracle's JSON
+    for r in range(world):
+        t = np.load(os.path.join(str(tmp_path), f"bench_table{r}.npy"))
+        assert t.shape == ref.shape and (t == ref).all(), f"rank {r}: gathered summary differs (device-side hash included)"
+
+
+def _emu_binding_is_built():
+    import _emu
+    _emu.binding()   # compile once in the parent, not concurrently in both ranks

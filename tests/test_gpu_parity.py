@@ -324,3 +324,22 @@ def test_config5_full_size_1m_op_documents_with_16_checkouts(engine):
     assert all(w[0] == 0 for w in want)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g == w, (i, g[0], w[0], len(g[1]), len(w[1]))
+
+
+def test_device_side_xxh64_of_the_json(engine):
+    """lm_result_hashes: the content word of the all-gathered summary is computed on the device and must
+    be the xxh64 (seed 0) of exactly the bytes lm_fetch returns — short values, every tail length, 50 KB texts."""
+    import xxhash
+    docs = _cases.fuzz_docs(64) + [workload.Cfg2Template(3000, 1500, seed=3, commit_every=10, fuse=True).stamp(d) for d in range(8)]
+    names, edge = _cases.edge_case_docs()
+    docs += edge
+    got = engine.merge_batch(docs)
+    hashes = engine.result_hashes()
+    seen = set()
+    for (st, js, _, _), h in zip(got, hashes.tolist()):
+        if st in (0, 4) and js:
+            assert h == xxhash.xxh64(js).intdigest()
+            seen.add(len(js) % 32)
+        else:
+            assert h == 0
+    assert len(seen) > 16
