@@ -169,8 +169,9 @@ LM_DEV SpanRegs sp_shift_in(const SpanRegs& R, uint32_t idx, const SpanItem& A, 
   int lane = lmw::lane();
   SpanRegs N;
   N.n = R.n + cnt;
-  int sh_d = (int)cnt;
-  uint32_t pid = lmw::shift_up(R.id, sh_d), pln = lmw::shift_up(R.len, sh_d), pol = lmw::shift_up(R.ol, sh_d), por = lmw::shift_up(R.orr, sh_d), pst = lmw::shift_up(R.st, sh_d);
+  uint32_t pid, pln, pol, por, pst;
+  if (cnt == 2) { pid = lmw::shift_up(R.id, 2); pln = lmw::shift_up(R.len, 2); pol = lmw::shift_up(R.ol, 2); por = lmw::shift_up(R.orr, 2); pst = lmw::shift_up(R.st, 2); }
+  else { pid = lmw::shift_up(R.id, 1); pln = lmw::shift_up(R.len, 1); pol = lmw::shift_up(R.ol, 1); por = lmw::shift_up(R.orr, 1); pst = lmw::shift_up(R.st, 1); }
   bool sh = (uint32_t)lane >= idx + cnt;
   N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
   if ((uint32_t)lane == idx) { N.id = A.id; N.len = A.len; N.ol = A.ol; N.orr = A.orr; N.st = A.st; }
@@ -562,9 +563,12 @@ LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int m
 // carries its position — so the leaf is found through the LDS directory and only verified by id; loc[] is the fallback
 LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int mode, uint32_t hint_k = 0) {
   int lane = lmw::lane();
+  uint32_t c = c0;
+  // items only hold applied elements, so the in-leaf path needs neither the peer's element base nor its end (two LDS round trips)
+  while (c < c1 && ts_update_fast(t, peer, c, c1, mode)) { PROF_CNT(t, PF_LEAF, 1); }
+  if (c >= c1) return;
   uint32_t eb = t.ebase[peer];
   if (c1 > t.end[peer]) c1 = t.end[peer];   // a damaged target range cannot make the walk longer than the peer's history
-  uint32_t c = c0;
   for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
     lmw::wave_sync();
     if (ts_update_fast(t, peer, c, c1, mode)) { PROF_CNT(t, PF_LEAF, 1); continue; }
@@ -660,7 +664,7 @@ LM_DEV void rw_open(RowWin& w, const uint32_t* op_w, uint32_t first, uint32_t li
   w.nxt = rw_load(op_w, first + 8, lim);
 }
 LM_DEV OpRow rw_get(RowWin& w, const uint32_t* op_w, uint32_t row) {
-  if (row >= w.base + 16) rw_open(w, op_w, row, w.lim);
+  if (row >= w.base + 16 || row < w.base) rw_open(w, op_w, row, w.lim);
   else if (row >= w.base + 8) { w.base += 8; w.cur = w.nxt; w.nxt = rw_load(op_w, w.base + 8, w.lim); }
   int j = (int)(row - w.base) * 8;
   OpRow r;
@@ -802,15 +806,15 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
       const uint32_t* vv = vvh_ro + vvh0 + (uint64_t)n * P;
       uint32_t node_peer = chg_ro[sorted_ro[m.chg0 + first]].peer;
       bool checked_out = false;
+      const uint32_t* op_w = (const uint32_t*)op_ro;
+      RowWin w;
+      w.base = NONE - 64; w.lim = m.op0 + m.n_op; w.cur = 0; w.nxt = 0;   // opened by the first row; stays open across the node's changes
       for (uint32_t ci = first; ci <= last && !t.err; ci++) {
         uint32_t crow = sorted_ro[m.chg0 + ci];
         const ChangeRow ch = chg_ro[crow];
         uint32_t skip_to = ch.ctr + skip_ro[crow];
         uint32_t pe = s_end[node_peer];
         uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
-        const uint32_t* op_w = (const uint32_t*)op_ro;
-        RowWin w;
-        rw_open(w, op_w, ch.op0, ch.op0 + n_rows);
         for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
           const OpRow r = rw_get(w, op_w, row);

@@ -257,16 +257,15 @@ LM_DEV uint32_t scan_incl_add_shfl(uint32_t v) {
 #ifndef LM_EMU
 // wave64 inclusive prefix sum on the DPP crossbar: row_shr 1/2/4/8 inside each 16-lane row, then
 // row_bcast:15 and row_bcast:31 to carry the row totals (six VALU ops instead of six LDS round trips).
+// A lane without a source (row_shr past the row start, a row masked out of a row_bcast) receives `old` = 0, so every step
+// is an unconditional add — no lane predicates to keep in (or reload into) SGPR pairs.
 LM_DEV uint32_t scan_incl_add(uint32_t v) {
-  int l = lane();
-  int rl = l & 15;
-  uint32_t t;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); if (rl >= 1) v += t;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); if (rl >= 2) v += t;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); if (rl >= 4) v += t;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); if (rl >= 8) v += t;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xf, 0xf, false); if ((l & 31) >= 16) v += t;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xf, 0xf, false); if (l >= 32) v += t;
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
   return v;
 }
 #else

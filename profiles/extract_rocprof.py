@@ -5,9 +5,9 @@
 
 The three databases come from three separate runs of the SAME command, as the HBM section of
 /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass):
-  rocprofv3 --kernel-trace --stats -d ... -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
-  rocprofv3 --pmc FETCH_SIZE      -d ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  rocprofv3 --pmc WRITE_SIZE      -d ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  rocprofv3 --kernel-trace --stats -d ... -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-end-to-end
+  rocprofv3 --pmc FETCH_SIZE      -d ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-end-to-end
+  rocprofv3 --pmc WRITE_SIZE      -d ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-end-to-end
 FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction from the guide: FETCH_SIZE under-reports wide coalesced
 reads by 2x; the corrected figure doubles it (other access widths are uncalibrated — both figures are kept).
 """
