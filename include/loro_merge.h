@@ -35,12 +35,21 @@ enum {
   LM_DECODE_ERROR = 1,       /* LoroError::DecodeError */
   LM_CHECKSUM_MISMATCH = 2,  /* LoroError::DecodeChecksumMismatchError */
   LM_DATA_CORRUPTION = 3,    /* LoroError::DecodeDataCorruptionError */
-  LM_UNSUPPORTED = 4,        /* outside the device path's scope: Tree / MovableList / Counter containers,
-                              * snapshot blobs, > 256 containers or > 255 peers per document */
+  LM_UNSUPPORTED = 4,        /* outside the device path's scope — see "Limits" below */
   LM_INTERNAL = 5,
   LM_FRONTIERS_NOT_FOUND = 6 /* LoroError::FrontiersNotFound: a checkout id the imported history does not hold */
 };
 
+/* Limits of the device path.  A document beyond one of them is reported LM_UNSUPPORTED — never a guessed value — and
+ * does not disturb the other documents of the batch (tests: `documented_limits_are_reported_not_guessed`, emu + GPU):
+ *   - container kinds: Map, List, Text (root or child).  A document that also holds Tree / MovableList / Counter
+ *     containers is rendered with those as null and reported LM_UNSUPPORTED *together with* its JSON and VV;
+ *   - blobs: EncodeMode::FastUpdates (mode 4); snapshots (mode 3) are not ingested;
+ *   - per document: <= 255 peers, <= 256 containers of which <= 64 roots, container nesting <= 16, counters < 2^24 per
+ *     peer (element ids are packed peer:8 | counter:24), < 2^24 Map op rows, <= 18,000 tracker leaves per sequence
+ *     replay (~190k op runs; the 1M-op documents of BASELINE configs[4] use ~1,200), JSON < 4 GiB, a blob < 4 GiB;
+ *   - two root containers with the same name but different kinds; a StyleEnd op that does not directly follow its
+ *     StyleStart (every writer emits them as a pair).  */
 typedef struct lm_ctx lm_ctx;
 
 typedef struct lm_doc_in {
@@ -91,6 +100,18 @@ int lm_result_meta(lm_ctx* ctx, int32_t* status, uint64_t* json_len, uint64_t* v
 /* xxh64 (seed 0) of every document's JSON (n_docs entries; 0 for a failed document), computed on the device: the content
  * word of the merged-state summary — ranks compare merged states without moving the JSON. */
 int lm_result_hashes(lm_ctx* ctx, uint64_t* json_xxh64);
+
+/* ---- Export / encode side (host only, no device needed): the inverse of the decode stage.
+ * lm_block_tables = the tables of ONE change block — the changes of one peer, counter-contiguous — exactly what the decode
+ * stage extracts from a block (crates/loro-internal/src/oplog/change_store/block_encode.rs:535-706); lm_encode_block writes
+ * the bytes the reference's encode_block (block_encode.rs:137-278, block_meta_encode.rs:13-88) writes for them, and
+ * lm_encode_updates frames encoded blocks into a FastUpdates blob (encoding.rs:440-473, fast_snapshot.rs:346-360).  Value
+ * payloads and the position arena are opaque sections: their bytes are carried as given.  Outputs are malloc'ed; release
+ * them with lm_free_bytes.  Returns 0, or -1 on malformed tables. */
+#include "loro_block_tables.h"   /* lm_block_tables */
+int lm_encode_block(const lm_block_tables* tables, uint8_t** out, size_t* out_len);
+int lm_encode_updates(const uint8_t* const* blocks, const size_t* block_lens, size_t n_blocks, uint8_t** out, size_t* out_len);
+void lm_free_bytes(uint8_t* p);
 
 /* Wave-primitive self test on the device (DPP scan, ballot ranks); returns the number of mismatches. */
 int lm_selftest(lm_ctx* ctx);

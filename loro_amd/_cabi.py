@@ -18,7 +18,8 @@ class RunStats(ctypes.Structure):
                 ("device_bytes_allocated", ctypes.c_uint64), ("n_kernels", ctypes.c_uint32)]
 
 
-SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait"]
+SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
+           "encode_block", "encode_updates", "free_bytes"]
 
 
 class Binding:
@@ -40,12 +41,30 @@ class Binding:
         self.set_profiling = g("set_profiling"); self.set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self.result_meta = g("result_meta"); self.result_meta.restype = ctypes.c_int
         self.result_meta.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        # export / encode side (host only)
+        self.encode_block = g("encode_block"); self.encode_block.restype = ctypes.c_int
+        self.encode_block.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        self.encode_updates = g("encode_updates"); self.encode_updates.restype = ctypes.c_int
+        self.encode_updates.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        self.free_bytes = g("free_bytes"); self.free_bytes.argtypes = [ctypes.c_void_p]
         self.result_hashes = g("result_hashes"); self.result_hashes.restype = ctypes.c_int
         self.result_hashes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.selftest = g("selftest"); self.selftest.restype = ctypes.c_int; self.selftest.argtypes = [ctypes.c_void_p]
         self.n_streams = g("n_streams"); self.n_streams.restype = ctypes.c_int; self.n_streams.argtypes = [ctypes.c_void_p]
         self.kernel_time = g("kernel_time"); self.kernel_time.restype = ctypes.c_int
         self.kernel_time.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double)]
+
+
+def frame_updates(binding, blocks):
+    """lm_encode_updates: encoded change blocks → one FastUpdates blob (envelope + checksum)."""
+    ptrs = (ctypes.c_char_p * max(1, len(blocks)))(*blocks)
+    lens = (ctypes.c_size_t * max(1, len(blocks)))(*[len(b) for b in blocks])
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    if binding.encode_updates(ptrs, lens, len(blocks), ctypes.byref(out), ctypes.byref(n)) != 0:
+        raise RuntimeError("lm_encode_updates failed")
+    b = ctypes.string_at(out.value, n.value)
+    binding.free_bytes(out)
+    return b
 
 
 class Context:

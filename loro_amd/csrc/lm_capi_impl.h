@@ -4,6 +4,7 @@
 #include <memory>
 #include <thread>
 #include "lm_pipeline.h"
+#include "lm_encode.h"
 
 // One lm_ctx drives up to LM_MAX_PARTS engines, each on its own HIP stream over a contiguous range of the batch's
 // documents.  lm_run launches the parts from separate host threads so the kernels of one part (latency-bound
@@ -180,6 +181,32 @@ int LM_API(result_hashes)(void* c, uint64_t* json_xxh64) {
   x->for_docs([&](uint32_t i, lm::Engine&, const lm::DocResult& r) { json_xxh64[i] = r.json_xxh64; });
   return 0;
 }
+// ---- export / encode side (host only): lm_encode.h
+int LM_API(encode_block)(const lm_block_tables* t, uint8_t** out, size_t* out_len) {
+  try {
+    lmenc::Bytes b = lmenc::encode_block(*t);
+    *out = (uint8_t*)malloc(b.size() ? b.size() : 1);
+    if (!*out) return -1;
+    memcpy(*out, b.data(), b.size());
+    *out_len = b.size();
+    return 0;
+  } catch (...) {
+    return -1;
+  }
+}
+int LM_API(encode_updates)(const uint8_t* const* blocks, const size_t* lens, size_t n, uint8_t** out, size_t* out_len) {
+  try {
+    lmenc::Bytes b = lmenc::encode_updates(blocks, lens, n);
+    *out = (uint8_t*)malloc(b.size());
+    if (!*out) return -1;
+    memcpy(*out, b.data(), b.size());
+    *out_len = b.size();
+    return 0;
+  } catch (...) {
+    return -1;
+  }
+}
+void LM_API(free_bytes)(uint8_t* p) { free(p); }
 int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   auto* x = (lm_ctx_impl*)c;
   s->n_docs = x->n_docs; s->n_blobs = 0; s->in_bytes = 0; s->out_bytes = 0;

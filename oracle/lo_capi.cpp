@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  C entry points for ctypes (tests/, bench.py cpu_baseline, smoke()).
 // Never linked into or loaded by the product library (loro_amd/csrc).
 #include <thread>
+#include <memory>
 #include <atomic>
 #include <cstdlib>
 #include <malloc.h>
@@ -211,4 +212,31 @@ int32_t lo_import_modes(const uint8_t* data, const uint64_t* blob_off, uint32_t 
     return -1;
   }
 }
+
+// ---- raw block tables of a FastUpdates blob, for the product's encode side (tests/test_encode_roundtrip.py)
+struct RawBlob { std::vector<std::unique_ptr<RawBlock>> blocks; std::vector<std::pair<size_t, size_t>> span; };   // span: (offset, len) of each block in the blob
+void* lo_blocks_open(const uint8_t* blob, uint64_t len) {
+  try {
+    if (len < 22 || memcmp(blob, "loro", 4) != 0) return nullptr;
+    RawBlob* rb = new RawBlob();
+    Reader r(blob + 22, (size_t)len - 22);
+    while (!r.eof()) {
+      uint64_t bl = r.uleb();
+      if (bl == 0 || bl > r.remaining()) { delete rb; return nullptr; }
+      Reader blk(r.p, (size_t)bl);
+      rb->span.push_back({(size_t)(r.p - blob), (size_t)bl});
+      r.p += bl;
+      std::vector<Change> tmp;
+      rb->blocks.emplace_back(new RawBlock());
+      decode_block(blk, tmp, rb->blocks.back().get());
+    }
+    return rb;
+  } catch (...) {
+    return nullptr;
+  }
+}
+uint32_t lo_blocks_count(void* h) { return (uint32_t)((RawBlob*)h)->blocks.size(); }
+const lm_block_tables* lo_blocks_tables(void* h, uint32_t i) { return &((RawBlob*)h)->blocks[i]->t; }
+void lo_blocks_span(void* h, uint32_t i, uint64_t* off, uint64_t* len) { *off = ((RawBlob*)h)->span[i].first; *len = ((RawBlob*)h)->span[i].second; }
+void lo_blocks_close(void* h) { delete (RawBlob*)h; }
 }

@@ -17,6 +17,7 @@
 // by the Rust-written fixture loro-js/tests/fixtures/rust/updates.blob):
 //   serde_columnar 0.3.14 (BoolRle/AnyRle/DeltaRle/DeltaOfDelta), postcard 1.1.3, xxhash-rust 0.8.15.
 #pragma once
+#include "../include/loro_block_tables.h"
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -459,7 +460,38 @@ struct BlockCtx {
 
 inline void skip_future_value(Reader& r) { (void)r.bytes(); }
 
-inline void decode_block(Reader blk, std::vector<Change>& out) {
+// The tables of one block exactly as the wire holds them (test infrastructure for the product's encode side:
+// tests/test_encode_roundtrip.py hands them to lm_encode_block through the C ABI and expects the block's own bytes back).
+struct RawBlock {
+  std::vector<uint64_t> peers;
+  std::vector<uint32_t> change_len, dep_count, dep_peer_idx, lamport, msg_len, cid_peer_idx, op_container, op_len, del_peer_idx;
+  std::vector<uint8_t> dep_on_self, msgs, cid_is_root, cid_kind, op_value_type, positions, values;
+  std::vector<int32_t> dep_counter, cid_key_or_counter, op_prop, del_counter;
+  std::vector<int64_t> timestamp, del_len;
+  std::vector<std::string> keys;
+  std::vector<const uint8_t*> key_ptr;
+  std::vector<size_t> key_len;
+  lm_block_tables t;
+  void finish() {
+    key_ptr.clear(); key_len.clear();
+    for (auto& k : keys) { key_ptr.push_back((const uint8_t*)k.data()); key_len.push_back(k.size()); }
+    t.peers = peers.data(); t.n_peers = peers.size();
+    t.change_len = change_len.data(); t.dep_on_self = dep_on_self.data(); t.dep_count = dep_count.data();
+    t.dep_peer_idx = dep_peer_idx.data(); t.dep_counter = dep_counter.data(); t.n_deps = dep_peer_idx.size();
+    t.lamport = lamport.data(); t.timestamp = timestamp.data();
+    t.msg_len = msg_len.data(); t.msgs = msgs.data(); t.msgs_len = msgs.size();
+    t.cid_is_root = cid_is_root.data(); t.cid_kind = cid_kind.data(); t.cid_peer_idx = cid_peer_idx.data();
+    t.cid_key_or_counter = cid_key_or_counter.data(); t.n_cids = cid_kind.size();
+    t.keys = key_ptr.data(); t.key_lens = key_len.data(); t.n_keys = keys.size();
+    t.positions = positions.data(); t.positions_len = positions.size();
+    t.op_container = op_container.data(); t.op_prop = op_prop.data(); t.op_value_type = op_value_type.data(); t.op_len = op_len.data();
+    t.n_ops = op_len.size();
+    t.del_peer_idx = del_peer_idx.data(); t.del_counter = del_counter.data(); t.del_len = del_len.data(); t.n_dels = del_len.size();
+    t.values = values.data(); t.values_len = values.size();
+  }
+};
+
+inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = nullptr) {
   // postcard EncodedBlock (block_encode.rs:94-119)
   uint64_t counter_start = blk.uleb(), counter_len = blk.uleb(), lamport_start = blk.uleb(),
            lamport_len = blk.uleb(), n_changes = blk.uleb();
@@ -468,7 +500,12 @@ inline void decode_block(Reader blk, std::vector<Change>& out) {
     fail(ST_DECODE_ERROR, "block scalar out of range");
   Reader header = blk.bytes(), change_meta = blk.bytes(), cids_b = blk.bytes(), keys_b = blk.bytes(),
          positions = blk.bytes(), ops_b = blk.bytes(), del_b = blk.bytes(), values_b = blk.bytes();
-  (void)positions;
+  if (raw) {
+    raw->t.counter_start = (uint32_t)counter_start; raw->t.counter_len = (uint32_t)counter_len; raw->t.lamport_start = (uint32_t)lamport_start;
+    raw->t.lamport_len = (uint32_t)lamport_len; raw->t.n_changes = (uint32_t)n_changes;
+    raw->positions.assign(positions.p, positions.p + positions.remaining());
+    raw->values.assign(values_b.p, values_b.p + values_b.remaining());
+  }
   if (n_changes == 0) fail(ST_DECODE_ERROR, "empty change block");
   size_t N = (size_t)n_changes;
   BlockCtx ctx;
@@ -511,6 +548,15 @@ inline void decode_block(Reader blk, std::vector<Change>& out) {
     for (auto l : lengths) { counters.push_back(last); last += l; if (last > INT32_MAX) fail(ST_DECODE_ERROR, "counter overflow"); }
     counters.push_back((int64_t)counter_start + (int64_t)counter_len);
   }
+  if (raw) {
+    raw->peers = ctx.peers;
+    for (auto l : lengths) raw->change_len.push_back((uint32_t)l);
+    raw->dep_on_self = dep_self;
+    for (auto x : deps_len) raw->dep_count.push_back((uint32_t)x);
+    for (auto x : dep_peers) raw->dep_peer_idx.push_back((uint32_t)x);
+    for (auto x : dep_counters) raw->dep_counter.push_back((int32_t)x);
+    for (auto x : lamports) raw->lamport.push_back((uint32_t)x);
+  }
   size_t base = out.size();
   {
     size_t di = 0;
@@ -537,12 +583,18 @@ inline void decode_block(Reader blk, std::vector<Change>& out) {
     uint64_t tot = 0;
     for (auto l : msg_lens) tot += l;
     if (tot > change_meta.remaining()) fail(ST_DATA_CORRUPTION, "commit message bytes");
+    if (raw) {
+      raw->timestamp = ts;
+      for (auto l : msg_lens) raw->msg_len.push_back((uint32_t)l);
+      raw->msgs.assign(change_meta.p, change_meta.p + change_meta.remaining());
+    }
   }
   // ---- keys (block_encode.rs:280-305)
   while (!keys_b.eof()) {
     Reader k = keys_b.bytes();
     ctx.keys.emplace_back((const char*)k.p, k.remaining());
   }
+  if (raw) raw->keys = ctx.keys;
   // ---- cids (arena.rs:39-105)
   {
     uint64_t n = cids_b.eof() ? 0 : cids_b.uleb();
@@ -553,6 +605,7 @@ inline void decode_block(Reader blk, std::vector<Change>& out) {
       uint8_t kind = cids_b.u8();
       uint64_t peer_idx = cids_b.uleb();
       int64_t koc = cids_b.zigzag();
+      if (raw) { raw->cid_is_root.push_back(is_root); raw->cid_kind.push_back(kind); raw->cid_peer_idx.push_back((uint32_t)peer_idx); raw->cid_key_or_counter.push_back((int32_t)koc); }
       ContainerID c;
       c.kind = kind;
       if (is_root) {
@@ -595,6 +648,14 @@ inline void decode_block(Reader blk, std::vector<Change>& out) {
     del_counter = decode_delta_rle(del_b.bytes());
     del_len = decode_delta_rle(del_b.bytes());
     if (del_counter.size() != del_peer.size() || del_len.size() != del_peer.size()) fail(ST_DECODE_ERROR, "delete column mismatch");
+  }
+  if (raw) {
+    for (size_t i = 0; i < col_container.size(); i++) {
+      raw->op_container.push_back((uint32_t)col_container[i]); raw->op_prop.push_back((int32_t)col_prop[i]);
+      raw->op_value_type.push_back(col_vt[i]); raw->op_len.push_back((uint32_t)col_len[i]);
+    }
+    for (size_t i = 0; i < del_peer.size(); i++) { raw->del_peer_idx.push_back((uint32_t)del_peer[i]); raw->del_counter.push_back((int32_t)del_counter[i]); raw->del_len.push_back(del_len[i]); }
+    raw->finish();
   }
   size_t del_i = 0;
   // ---- row walk (block_encode.rs:651-704)

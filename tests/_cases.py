@@ -129,6 +129,41 @@ def container_existence_cases():
     return out
 
 
+def limit_docs():
+    """(name, blobs): one document beyond each documented limit of the device path (include/loro_merge.h, "Limits"); each
+    must come back LM_UNSUPPORTED (4), never a guessed value, and must not disturb its neighbours in the batch."""
+    out = []
+    r = wire.Replica(11)
+    for i in range(300):
+        c = r.map_set_container("root", "k%d" % i, wire.KIND_MAP)
+        r.map_set(c, "v", i)
+    r.commit()
+    out.append(("more than 256 containers", [r.export()]))
+    out.append(("more than 255 peers", [b for p in range(1, 258) for b in [_one_key(p)]]))
+    r = wire.Replica(12)
+    for i in range(65):
+        r.map_set("root%d" % i, "k", i)
+    r.commit()
+    out.append(("more than 64 root containers", [r.export()]))
+    r = wire.Replica(13)
+    c = "root"
+    for i in range(18):
+        c = r.map_set_container(c, "down", wire.KIND_MAP)
+    r.map_set(c, "bottom", 1); r.commit()
+    out.append(("nesting deeper than 16", [r.export()]))
+    r = wire.Replica(14)
+    r.next_counter = (1 << 24) - 2
+    r.text_insert("text", 0, "abcd"); r.commit()
+    out.append(("counters beyond 2^24", [r.export()]))
+    return out
+
+
+def _one_key(p):
+    r = wire.Replica(p)
+    r.map_set("root", "k%d" % p, p); r.commit()
+    return r.export()
+
+
 def fuzz_docs(n, base=0, steps=40, peers=None, **kw):
     docs = []
     for seed in range(base, base + n):

@@ -4,6 +4,7 @@ GPU parity tests proper are in test_gpu_parity.py (-m gpu)."""
 import pytest
 
 import _oracle, _emu, _cases
+from loro_amd import wire
 
 
 DEVICE_SCOPE_GAPS = set()   # every edge-case document is rendered by the device path
@@ -154,6 +155,18 @@ def test_checkout_versions():
         else:
             assert g[0] == w[0], (i, g[0], w[0])
     assert n_ok > 60
+
+
+def test_documented_limits_are_reported_not_guessed():
+    lim = _cases.limit_docs()
+    good = wire.Replica(99); good.map_set("root", "a", 1); good.commit()
+    docs = []
+    for _, blobs in lim:
+        docs += [blobs, [good.export()]]
+    got = _emu.merge_batch(docs)
+    for i, (name, _) in enumerate(lim):
+        assert got[2 * i][0] == 4, (name, got[2 * i][:2])
+        assert got[2 * i + 1][:2] == (0, b'{"root":{"a":1}}'), name
 
 
 def test_root_containers_the_state_store_holds():

@@ -130,6 +130,20 @@ def test_checkout_known_answers_and_random_versions(engine):
         assert (g == w) if w[0] == 0 else (g[0] == w[0]), (i, g[:3], w[:3])
 
 
+def test_documented_limits_are_reported_not_guessed(engine):
+    """include/loro_merge.h "Limits": > 256 containers, > 255 peers, > 64 roots, nesting > 16, counters >= 2^24 — each is
+    LM_UNSUPPORTED for that document only."""
+    lim = _cases.limit_docs()
+    good = wire.Replica(99); good.map_set("root", "a", 1); good.commit()
+    docs = []
+    for _, blobs in lim:
+        docs += [blobs, [good.export()]]
+    got = engine.merge_batch(docs)
+    for i, (name, _) in enumerate(lim):
+        assert got[2 * i][0] == 4, (name, got[2 * i][:2])
+        assert got[2 * i + 1][:2] == (0, b'{"root":{"a":1}}'), name
+
+
 def test_root_containers_the_state_store_holds(engine):
     """diff_calc.rs:299 / state.rs:1352-1391: a root Text / List is part of the value only when some diff for it was not
     empty — inserted-and-deleted content in one blob or in two, checkouts before / at / after the content existed."""
