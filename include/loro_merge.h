@@ -3,7 +3,8 @@
  * Drop-in boundary for Loro's import → diff_calc → state path.  The reference has no FFI on this path
  * (SURVEY.md §8b); the boundary therefore sits at the byte interface the Rust host already owns:
  *
- *   input   exactly what `LoroDoc::export(ExportMode::Updates{..})` produces and `LoroDoc::import()` consumes
+ *   input   exactly what `LoroDoc::export(ExportMode::Updates{..})` (or ExportMode::Snapshot, see "Limits") produces and
+ *           `LoroDoc::import()` consumes
  *           (crates/loro/src/lib.rs:710,1306; crates/loro-internal/src/encoding.rs:334-373,399-405;
  *           docs/encoding.md §2,§6-10).  The blobs of one document are imported in order, like
  *           `LoroDoc::import_batch` (crates/loro-internal/src/loro.rs:1432-1523), into an empty document.
@@ -44,7 +45,11 @@ enum {
  * does not disturb the other documents of the batch (tests: `documented_limits_are_reported_not_guessed`, emu + GPU):
  *   - container kinds: Map, List, Text (root or child).  A document that also holds Tree / MovableList / Counter
  *     containers is rendered with those as null and reported LM_UNSUPPORTED *together with* its JSON and VV;
- *   - blobs: EncodeMode::FastUpdates (mode 4); snapshots (mode 3) are not ingested;
+ *   - blobs: EncodeMode::FastUpdates (mode 4) and FastSnapshot (mode 3).  A snapshot is ingested through its ChangeStore
+ *     section, the path LoroDoc::import takes for a document that is not empty (fast_snapshot.rs:326-344): the history is
+ *     replayed, the state sections are not read — so a root container that is EMPTY at the snapshot's version is absent
+ *     from the value, where direct initialisation of an empty document from the state section keeps it.  Shallow
+ *     snapshots (history trimmed below a shallow root) are LM_UNSUPPORTED;
  *   - per document: <= 255 peers, <= 256 containers of which <= 64 roots, container nesting <= 16, counters < 2^24 per
  *     peer (element ids are packed peer:8 | counter:24), < 2^24 Map op rows, <= 18,000 tracker leaves per sequence
  *     replay (~190k op runs; the 1M-op documents of BASELINE configs[4] use ~1,200), JSON < 4 GiB, a blob < 4 GiB;

@@ -16,6 +16,7 @@
 #include <stdexcept>
 #include "lm_k_scan.h"
 #include "lm_k_emit.h"
+#include "lm_snapshot.h"
 
 namespace lm {
 
@@ -111,14 +112,36 @@ struct Engine {
     uint64_t off = 0;
     in_bytes = 0;
     size_t b = 0;
+    // FastSnapshot blobs (mode 3) are turned into the FastUpdates framing of their ChangeStore here, on the host
+    // (lm_snapshot.h); everything behind this point only ever sees mode 4.  A shallow snapshot stays as it is (the device
+    // reports LM_UNSUPPORTED for mode 3); a damaged one becomes a stub that fails the way its damage would.
+    std::vector<const uint8_t*> bsrc(nb);
+    std::vector<size_t> blen(nb);
+    std::vector<std::vector<uint8_t>> conv;
+    static const uint8_t stub_decode[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xff, 0xff};
+    static const uint8_t stub_checksum[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4};
     for (size_t i = 0; i < nd; i++)
       for (size_t k = 0; k < docs[i].n; k++, b++) {
-        if (docs[i].lens[k] > 0xfffffff0ull) throw std::runtime_error("blob larger than 4 GiB");
+        const uint8_t* p = docs[i].blobs[k];
+        size_t l = docs[i].lens[k];
+        if (l >= 22 && memcmp(p, "loro", 4) == 0 && p[20] == 0 && p[21] == 3) {
+          std::vector<uint8_t> o;
+          int st = lmsnap::snapshot_to_updates(p, l, o);
+          if (st == lmsnap::SN_OK) { conv.push_back(std::move(o)); p = conv.back().data(); l = conv.back().size(); }
+          else if (st == lmsnap::SN_CHECKSUM) { p = stub_checksum; l = 22; }
+          else if (st == lmsnap::SN_DECODE) { p = stub_decode; l = 22; }
+        }
+        bsrc[b] = p; blen[b] = l;
+      }
+    b = 0;
+    for (size_t i = 0; i < nd; i++)
+      for (size_t k = 0; k < docs[i].n; k++, b++) {
+        if (blen[b] > 0xfffffff0ull) throw std::runtime_error("blob larger than 4 GiB");
         h_blob_off[b] = off;
-        h_blob_len[b] = (uint32_t)docs[i].lens[k];
+        h_blob_len[b] = (uint32_t)blen[b];
         h_blob_doc[b] = (uint32_t)i;
-        in_bytes += docs[i].lens[k];
-        off += (docs[i].lens[k] + 15) & ~(uint64_t)15;
+        in_bytes += blen[b];
+        off += (blen[b] + 15) & ~(uint64_t)15;
       }
     h_blob_off[nb] = off;
     data_bytes = off + 64;
@@ -134,9 +157,7 @@ struct Engine {
     b_data.ensure(data_bytes);
     {
       uint8_t* host = h_stage;
-      std::vector<const uint8_t*> src(nb);
-      b = 0;
-      for (size_t i = 0; i < nd; i++) for (size_t k = 0; k < docs[i].n; k++, b++) src[b] = docs[i].blobs[k];
+      const std::vector<const uint8_t*>& src = bsrc;
       std::vector<size_t> cut{0};           // chunk c = blobs [cut[c], cut[c+1])
       const uint64_t CHUNK = 16ull << 20;
       for (size_t j = 0; j < nb; j++) if (h_blob_off[j + 1] - h_blob_off[cut.back()] >= CHUNK && j + 1 < nb) cut.push_back(j + 1);

@@ -19,7 +19,8 @@ def edge_case_docs():
     add("checksum mismatch", [bytes(bad)])
     add("bad magic", [b"lor0" + good[4:]])
     add("truncated", [good[:10]])
-    add("snapshot mode", [wire.envelope(b"\x00" * 12, mode=3)])
+    # a FastSnapshot whose third (shallow-root state) section is not empty: history below the root is gone → unsupported
+    add("shallow snapshot", [wire.envelope(b"\x00" * 8 + b"\x01\x00\x00\x00" + b"E", mode=3)])
     add("good next to bad docs", [good])
     # pending: second export without the first
     a.text_insert("text", 2, "cd"); a.commit()
@@ -127,6 +128,36 @@ def container_existence_cases():
     out.append(("…checked out before the insert", gone, wire.encode_frontiers([]), b'{}'))
     out.append(("…checked out at the insert", gone, wire.encode_frontiers(vp), b'{"text":"abc"}'))
     return out
+
+
+def snapshot_cases():
+    """(docs, check(got)): FastSnapshot (mode 3) ingest through the ChangeStore (lm_snapshot.h).  The oracle does not read
+    snapshots, so these are pinned on the reference fixtures alone: `snapshot.blob` (Rust-written, LZ4-framed SSTable blocks)
+    and `snapshot.ts.blob` hold the history of `updates.blob`, `runtime-snapshot.ts.blob` that of `runtime-updates.ts.blob`
+    (crates/loro/tests/loro_js_interop.rs:58-90) — the value must be the updates import's, and its in-scope, non-empty keys
+    the ones of snapshot.deep.json."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_fixtures.json")))
+    b = {k: bytes.fromhex(v) for k, v in fx["blobs"].items()}
+    flipped = bytearray(b["snapshot.blob"]); flipped[300] ^= 0x40
+    docs = [[b["snapshot.blob"]], [b["updates.blob"]], [b["snapshot.ts.blob"]], [b["runtime-snapshot.ts.blob"]], [b["runtime-updates.ts.blob"]],
+            [b["shallow.ts.blob"]], [bytes(flipped)], [b["snapshot.blob"][:200]], [b["snapshot.blob"], b["updates.blob"], b["snapshot.ts.blob"]],
+            [b["fugue-left.ts.blob"], b["fugue-right.ts.blob"]]]
+
+    def check(got):
+        snap, upd, snap_ts, rsnap, rupd, shallow, bad_sum, cut, both, plain = got
+        assert snap[0] == upd[0] == 4 and snap[1] and snap[1:] == upd[1:] and snap_ts[1:] == upd[1:]      # out-of-scope containers ride along as null
+        assert rsnap == rupd
+        deep = fx["json"]["snapshot.deep.json"]
+        v = json.loads(snap[1])
+        for k, x in deep["map"].items():
+            if k not in ("child_mlist", "child_tree"):
+                assert v["map"][k] == x, k
+        assert shallow[0] == 4 and not shallow[1]             # history below a shallow root is gone: not replayable
+        assert bad_sum[0] == 2 and cut[0] in (1, 2)           # checksum mismatch / truncated
+        assert both[1:] == upd[1:]                            # the same history three times over
+        assert plain[:2] == (0, b'{"text":"Hello World!"}')
+    return docs, check
 
 
 def limit_docs():

@@ -12,7 +12,9 @@ SRC = "/root/reference/loro-js/tests/fixtures/rust"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_fixtures.json")
 
 BLOBS = ["updates.blob", "updates.ts.blob", "concurrent-base.ts.blob", "concurrent-left.ts.blob",
-         "concurrent-right.ts.blob", "fugue-left.ts.blob", "fugue-right.ts.blob", "runtime-updates.ts.blob"]
+         "concurrent-right.ts.blob", "fugue-left.ts.blob", "fugue-right.ts.blob", "runtime-updates.ts.blob",
+         # FastSnapshot (mode 3) fixtures: the same histories as updates.blob / runtime-updates.ts.blob, and a shallow one
+         "snapshot.blob", "snapshot.ts.blob", "runtime-snapshot.ts.blob", "shallow.ts.blob"]
 JSONS = ["snapshot.deep.json", "concurrent.expected.json", "runtime.expected.json", "meta.json"]
 
 

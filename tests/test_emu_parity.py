@@ -31,7 +31,7 @@ def test_edge_cases():
     by = dict(zip(names, got))
     assert by["no blobs"][:2] == (0, b"{}")
     assert by["checksum mismatch"][0] == 2 and by["bad magic"][0] == 1 and by["truncated"][0] == 1
-    assert by["snapshot mode"][0] == 4
+    assert by["shallow snapshot"][0] == 4
     assert by["good next to bad docs"][:2] == (0, b'{"text":"ab"}')
     assert by["pending only"][1] == b"{}" and by["pending only"][3] == 2
     assert by["pending resolved later"][1] == b'{"text":"abcd"}'
@@ -155,6 +155,11 @@ def test_checkout_versions():
         else:
             assert g[0] == w[0], (i, g[0], w[0])
     assert n_ok > 60
+
+
+def test_snapshot_blobs_are_ingested_through_their_change_store():
+    docs, check = _cases.snapshot_cases()
+    check(_emu.merge_batch(docs))
 
 
 def test_documented_limits_are_reported_not_guessed():

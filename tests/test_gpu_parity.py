@@ -58,7 +58,7 @@ def test_edge_cases(engine):
     names, docs = _cases.edge_case_docs()
     got = _same(engine, docs, names)
     by = dict(zip(names, got))
-    assert by["checksum mismatch"][0] == 2 and by["bad magic"][0] == 1 and by["snapshot mode"][0] == 4
+    assert by["checksum mismatch"][0] == 2 and by["bad magic"][0] == 1 and by["shallow snapshot"][0] == 4
     assert by["good next to bad docs"][:2] == (0, b'{"text":"ab"}')      # a bad document never fails the batch
     assert by["pending only"][3] == 2 and by["pending resolved later"][1] == b'{"text":"abcd"}'
 
@@ -128,6 +128,11 @@ def test_checkout_known_answers_and_random_versions(engine):
     assert [g[0] for g in got[:13]] == [0] * 7 + [6, 6, 6, 1, 1, 0]
     for i, (g, w) in enumerate(zip(got, want)):
         assert (g == w) if w[0] == 0 else (g[0] == w[0]), (i, g[:3], w[:3])
+
+
+def test_snapshot_blobs_are_ingested_through_their_change_store(engine):
+    docs, check = _cases.snapshot_cases()
+    check(engine.merge_batch(docs))
 
 
 def test_documented_limits_are_reported_not_guessed(engine):
