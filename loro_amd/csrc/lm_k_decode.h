@@ -47,6 +47,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* peer_map;  // raw peer row → doc peer idx
   // per doc
   DocMeta* doc;
+  const uint32_t* doc_order;   // integrate stage: workgroup → document, longest (most op rows) first
   uint64_t* peer_uniq;   // [praw0 + i], i < n_peers, ascending
   uint32_t* peer_end;    // applied (exclusive) counter end == final VV; lowered to the checkout version by k_dag_b
   uint32_t* peer_ext;    // contiguous covered end

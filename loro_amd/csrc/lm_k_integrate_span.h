@@ -750,7 +750,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(5) void k_integrate_span(Dev d, DevDag g, uint32_t d
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {
-  uint32_t doc = (uint32_t)lmw::bid();
+  uint32_t doc = d.doc_order[(uint32_t)lmw::bid()];
   int lane = lmw::lane();
   LM_DYN_SHARED(uint32_t, s_mem);
   uint32_t* s_da = s_mem;

@@ -6,6 +6,7 @@
 //   lmbe::dalloc/dfree/dmemset/h2d/d2h/sync/halloc/hfree, lmbe::tic()/toc(name) and the macro
 //   LM_LAUNCH(kernel, grid, block, args...).
 #pragma once
+#include <algorithm>
 #include <thread>
 #include <atomic>
 #include <cstdint>
@@ -61,7 +62,7 @@ struct Engine {
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
-  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_hash, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off, b_slab2, b_slab2_off;
+  DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_hash, b_order, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off, b_slab2, b_slab2_off;
   uint64_t payload_bytes = 0;   // Σ json_len + Σ vv_len of the last run (without alignment padding)
   std::vector<uint64_t> h_prof, h_hash;
   // results
@@ -91,7 +92,7 @@ struct Engine {
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
-                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
+                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
   }
@@ -385,6 +386,16 @@ struct Engine {
       ht += cap;
     }
     if (dir_cap > DIR_CAP_MAX) dir_cap = DIR_CAP_MAX;  // larger documents are reported LM_UNSUPPORTED by k_integrate
+    // longest first: workgroups are dispatched in index order, so the integrate stage takes its documents by descending op
+    // rows — a batch of mixed sizes does not end with a few long replays that started in the last round
+    {
+      std::vector<uint32_t> order(n_docs);
+      for (uint32_t i = 0; i < n_docs; i++) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h_doc[a].n_op > h_doc[b].n_op; });
+      b_order.ensure((size_t)n_docs * 4 + 4);
+      lmbe::h2d(b_order.p, order.data(), (size_t)n_docs * 4);
+      d.doc_order = b_order.as<uint32_t>();
+    }
     lmbe::h2d(d.doc, h_doc.data(), (size_t)n_docs * sizeof(DocMeta));
     b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
     b_it.ensure((leaves + 1) * (span ? (size_t)SP_REC : 256) * 4);
