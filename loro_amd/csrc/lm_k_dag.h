@@ -494,6 +494,13 @@ LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint64_t nbytes, uint
     uint64_t i = c + (uint64_t)lane;
     uint32_t b = i < nbytes ? s[i] : 0x80u;
     bool last_chunk = c + 61 >= nbytes;
+    bool mine = i < nbytes && (last_chunk || lane < 61);   // this lane's byte belongs to this step
+    if (!lmw::ballot(mine && b >= 0x80)) {
+      // an all-ASCII step: byte = scalar, no lane permutes
+      if (mine && n + (uint32_t)lane < len) d.cp[e0 + n + (uint32_t)lane] = b;
+      n += (uint32_t)lmw::popc64(lmw::ballot(mine));
+      continue;
+    }
     bool lead = i < nbytes && (b & 0xC0) != 0x80 && (last_chunk || lane < 61);
     uint32_t b1 = lmw::shfl(b, (lane + 1) & 63), b2 = lmw::shfl(b, (lane + 2) & 63), b3 = lmw::shfl(b, (lane + 3) & 63);
     uint64_t lm_ = lmw::ballot(lead);
@@ -562,6 +569,17 @@ LM_KERNEL void k_elem_fill(Dev d) {
         const uint8_t* s = v.p;
         uint32_t n = 0;
         for (uint32_t i = 0; i < (uint32_t)nbytes;) {
+          if (i + 4 <= (uint32_t)nbytes) {
+            // four ASCII bytes at once: the loads go out together and four scalars are stored (the pipeline is issue bound —
+            // one byte per trip cost ≈25 instructions per character)
+            uint32_t q0 = s[i], q1 = s[i + 1], q2 = s[i + 2], q3 = s[i + 3];
+            if (((q0 | q1 | q2 | q3) & 0x80) == 0) {
+              if (n + 3 < r.len) { d.cp[e0 + n] = q0; d.cp[e0 + n + 1] = q1; d.cp[e0 + n + 2] = q2; d.cp[e0 + n + 3] = q3; }
+              else { if (n < r.len) d.cp[e0 + n] = q0; if (n + 1 < r.len) d.cp[e0 + n + 1] = q1; if (n + 2 < r.len) d.cp[e0 + n + 2] = q2; }
+              n += 4; i += 4;
+              continue;
+            }
+          }
           uint32_t b = s[i], cpv, extra;
           if (b < 0x80) { cpv = b; extra = 0; }
           else if ((b & 0xE0) == 0xC0) { cpv = b & 0x1F; extra = 1; }
