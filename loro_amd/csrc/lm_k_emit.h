@@ -506,13 +506,21 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
           for (uint32_t e0 = 0; e0 < total; e0 += 64) {
             uint32_t e = e0 + (uint32_t)lane;
             uint64_t bytes = 0;
-            uint32_t nb = 0;
+            uint32_t nb = 0, cpv = 0x20;
             if (e < total) {
               uint32_t lo = 0, hi = 63;                    // first run whose running length exceeds e
               while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_inc[mid] > e) hi = mid; else lo = mid + 1; }
               uint32_t gi = s_g0[lo] + e;                  // 32-bit wrap-around arithmetic: g0 may be "negative"
-              cp_bytes(d.cp[elem0 + gi], bytes, nb);
+              cpv = d.cp[elem0 + gi];
             }
+            // a step of plain ASCII (nothing to escape): scalar = byte, lane = output position — no scan, no byte loop
+            if (!lmw::ballot(cpv < 0x20 || cpv >= 0x80 || cpv == '"' || cpv == '\\')) {
+              uint32_t cnt = total - e0 < 64 ? total - e0 : 64;
+              if (s.out && s.pos + cnt <= s.cap && e < total) s.out[s.pos + (uint32_t)lane] = (uint8_t)cpv;
+              s.pos += cnt;
+              continue;
+            }
+            if (e < total) cp_bytes(cpv, bytes, nb);
             sink_lanes(s, bytes, nb);
           }
         }
