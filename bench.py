@@ -17,6 +17,14 @@ step is still one complete pipeline pass over 10,000 documents; all K steps are 
     python bench.py                       # N=1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+The JSON line carries, beside the contract fields: `roofline` (dominant kernel: algorithmic bytes per launch over its
+HIP-event duration in the timed region and alone; `traffic` from the committed rocprofv3 --pmc passes, named in
+`traffic_source`), `cpu_baseline` (the oracle — a CPU restatement of the reference path, kind "port" — as one
+single-threaded process per core the container's cgroup grants, with the 1-core and half-cores points), and at N=1:
+`end_to_end` (every step stages the blobs from host memory and fetches JSON + VV back: PCIe-inclusive) and
+`other_configs` (BASELINE configs[0], [2], [3], [4] and a heterogeneous configs[1] batch, each checked against the
+oracle before it is timed).  `--no-cpu-baseline --no-end-to-end --no-other-configs` leaves the timed steps only.
 """
 import argparse
 import json
