@@ -30,7 +30,7 @@ inline bool lz4_block(const uint8_t* p, size_t n, std::vector<uint8_t>& out, siz
     uint8_t tok = p[i++];
     size_t lit = tok >> 4;
     if (lit == 15) { uint8_t e; do { if (i >= n) return false; e = p[i++]; lit += e; } while (e == 255); }
-    if (lit > n - i) return false;
+    if (lit > n - i || out.size() - base + lit > (4u << 20)) return false;
     out.insert(out.end(), p + i, p + i + lit);
     i += lit;
     if (i >= n) return true;   // the last sequence has literals only
@@ -40,7 +40,7 @@ inline bool lz4_block(const uint8_t* p, size_t n, std::vector<uint8_t>& out, siz
     size_t ml = 4 + (tok & 15);
     if ((tok & 15) == 15) { uint8_t e; do { if (i >= n) return false; e = p[i++]; ml += e; } while (e == 255); }
     if (off == 0 || off > out.size() - base) return false;
-    if (ml > (64u << 20)) return false;
+    if (ml > (4u << 20) || out.size() - base + ml > (4u << 20)) return false;   // an LZ4 data block decodes to at most 4 MiB (BD 0x70)
     size_t s = out.size() - off;
     for (size_t k = 0; k < ml; k++) out.push_back(out[s + k]);   // may overlap its own output
   }
@@ -62,6 +62,7 @@ inline bool lz4_frame(const uint8_t* p, size_t n, std::vector<uint8_t>& out) {
     uint32_t info = rd32(p + i);
     i += 4;
     if (info == 0) break;
+    if (out.size() > (256u << 20)) return false;   // an SSTable block body is a few KiB; a frame that expands beyond this is not one of ours
     size_t len = info & 0x7fffffffu;
     if (len > n - i) return false;
     if (info & 0x80000000u) out.insert(out.end(), p + i, p + i + len);
