@@ -45,11 +45,12 @@ enum {
  * does not disturb the other documents of the batch (tests: `documented_limits_are_reported_not_guessed`, emu + GPU):
  *   - container kinds: Map, List, Text (root or child).  A document that also holds Tree / MovableList / Counter
  *     containers is rendered with those as null and reported LM_UNSUPPORTED *together with* its JSON and VV;
- *   - blobs: EncodeMode::FastUpdates (mode 4) and FastSnapshot (mode 3).  A snapshot is ingested through its ChangeStore
- *     section, the path LoroDoc::import takes for a document that is not empty (fast_snapshot.rs:326-344): the history is
- *     replayed, the state sections are not read — so a root container that is EMPTY at the snapshot's version is absent
- *     from the value, where direct initialisation of an empty document from the state section keeps it.  Shallow
- *     snapshots (history trimmed below a shallow root) are LM_UNSUPPORTED;
+ *   - blobs: EncodeMode::FastUpdates (mode 4) and FastSnapshot (mode 3).  A snapshot is ingested on the host in front of
+ *     the device path: its history from the ChangeStore section (replayed like updates, fast_snapshot.rs:326-344), the set
+ *     of root containers from the keys of its state section (an empty document initialises its state store from that
+ *     section, fast_snapshot.rs:168-258, so a root in which nothing is visible is still part of the value); the state
+ *     VALUES are not read.  The first snapshot among a document's blobs plays that role (import_batch imports snapshots
+ *     first).  Shallow snapshots (history trimmed below a shallow root) are LM_UNSUPPORTED;
  *   - per document: <= 255 peers, <= 256 containers of which <= 64 roots, container nesting <= 16, counters < 2^24 per
  *     peer (element ids are packed peer:8 | counter:24), < 2^24 Map op rows, <= 18,000 tracker leaves per sequence
  *     replay (~190k op runs; the 1M-op documents of BASELINE configs[4] use ~1,200), JSON < 4 GiB, a blob < 4 GiB;

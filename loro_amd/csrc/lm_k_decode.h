@@ -22,6 +22,8 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t span;              // 1: leaves hold runs (lm_k_integrate_span.h, SP_REC dwords per leaf), 0: one element per slot
   const uint8_t* front;       // optional checkout frontiers (postcard Vec<ID>), front_off[n_docs+1]; empty range = latest
   const uint64_t* front_off;
+  const uint8_t* froot;       // per document: root containers its first snapshot's state section holds ([kind, uleb len, name]*)
+  const uint64_t* froot_off;
   // per blob
   int32_t* blob_status;
   uint32_t* blob_nblk;

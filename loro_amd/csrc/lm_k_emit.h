@@ -154,6 +154,35 @@ LM_KERNEL void k_seq_alive_latest(Dev d) {
   }
 }
 
+// K9c: documents whose first blob was a snapshot.  An empty reference document initialises its state store from the
+// snapshot's state section (fast_snapshot.rs:168-258), so every root container that section holds is part of the value —
+// also one in which nothing is visible.  lm_stage passed the section's root keys; one wave per document marks them.
+LM_KERNEL void k_state_roots(Dev d) {
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  uint64_t f0 = d.froot_off[doc], f1 = d.froot_off[doc + 1];
+  if (f1 == f0) return;
+  const DocMeta m = d.doc[doc];
+  if (status_fatal(m.status)) return;
+  Rd r = rd_make(d.froot + f0, f1 - f0);
+  while (r.p < r.end && !r.bad) {
+    uint32_t kind = rd_u8(r);
+    uint64_t nl = rd_uleb(r);
+    if (r.bad || nl > rd_left(r)) break;
+    const uint8_t* name = r.p;
+    r.p += nl;
+    for (uint32_t c0 = 0; c0 < m.n_cont; c0 += 64) {
+      uint32_t c = c0 + (uint32_t)lane;
+      if (c >= m.n_cont) continue;
+      const ContRow o = d.cont[m.cid0 + c];
+      if ((o.kind_root & 0x100) && (o.kind_root & 0xff) == kind && o.name_len == nl && bytes_eq(d.data + o.name_off, name, (uint32_t)nl)) {
+        d.cont[m.cid0 + c].touched = 1;
+        if (kind > CK_TEXT) lmw::atomic_or(&d.doc[doc].flags, DF_SOFT_UNSUPPORTED);   // renders as null: the document is flagged
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ sink
 struct Sink {
   uint8_t* out;       // nullptr in the sizing pass

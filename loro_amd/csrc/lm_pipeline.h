@@ -48,9 +48,9 @@ struct Engine {
   // staged input
   uint32_t n_docs = 0, n_blobs = 0;
   uint64_t data_bytes = 0, in_bytes = 0;
-  std::vector<uint64_t> h_blob_off, h_front_off;
+  std::vector<uint64_t> h_blob_off, h_front_off, h_froot_off;
   std::vector<uint32_t> h_blob_len, h_doc_blob, h_blob_doc;
-  DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc, b_front, b_front_off;
+  DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc, b_front, b_front_off, b_froot, b_froot_off;
   // work buffers
   DBuf b_blob_status, b_blob_nblk, b_blob_blk0, b_tile, b_tot;
   DBuf b_blk, b_bcnt, b_boff;
@@ -86,7 +86,7 @@ struct Engine {
   size_t h_stage_cap = 0;
   ~Engine() { release_all(); if (h_stage) lmbe::hfree(h_stage); lmbe::stream_destroy(sc); }
   void release_all() {
-    DBuf* all[] = {&b_front, &b_front_off, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
+    DBuf* all[] = {&b_front, &b_front_off, &b_froot, &b_froot_off, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
@@ -119,21 +119,30 @@ struct Engine {
     std::vector<const uint8_t*> bsrc(nb);
     std::vector<size_t> blen(nb);
     std::vector<std::vector<uint8_t>> conv;
+    std::vector<uint8_t> froot;                 // per document: root containers of its first snapshot's state section
+    h_froot_off.assign(nd + 1, 0);
     static const uint8_t stub_decode[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xff, 0xff};
     static const uint8_t stub_checksum[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4};
     for (size_t i = 0; i < nd; i++)
       for (size_t k = 0; k < docs[i].n; k++, b++) {
         const uint8_t* p = docs[i].blobs[k];
         size_t l = docs[i].lens[k];
+        if (k == 0) h_froot_off[i] = froot.size();
         if (l >= 22 && memcmp(p, "loro", 4) == 0 && p[20] == 0 && p[21] == 3) {
-          std::vector<uint8_t> o;
-          int st = lmsnap::snapshot_to_updates(p, l, o);
-          if (st == lmsnap::SN_OK) { conv.push_back(std::move(o)); p = conv.back().data(); l = conv.back().size(); }
+          std::vector<uint8_t> o, roots;
+          bool first_snapshot = froot.size() == h_froot_off[i];
+          int st = lmsnap::snapshot_to_updates(p, l, o, first_snapshot ? &roots : nullptr);
+          if (st == lmsnap::SN_OK) { conv.push_back(std::move(o)); p = conv.back().data(); l = conv.back().size(); froot.insert(froot.end(), roots.begin(), roots.end()); }
           else if (st == lmsnap::SN_CHECKSUM) { p = stub_checksum; l = 22; }
           else if (st == lmsnap::SN_DECODE) { p = stub_decode; l = 22; }
         }
         bsrc[b] = p; blen[b] = l;
       }
+    for (size_t i = 0; i < nd; i++) if (docs[i].n == 0) h_froot_off[i] = froot.size();
+    h_froot_off[nd] = froot.size();
+    for (size_t i = nd; i-- > 0;) if (h_froot_off[i] > h_froot_off[i + 1]) h_froot_off[i] = h_froot_off[i + 1];
+    b_froot.ensure(froot.size() + 16); if (!froot.empty()) lmbe::h2d(b_froot.p, froot.data(), froot.size());
+    b_froot_off.ensure((nd + 1) * 8); lmbe::h2d(b_froot_off.p, h_froot_off.data(), (nd + 1) * 8);
     b = 0;
     for (size_t i = 0; i < nd; i++)
       for (size_t k = 0; k < docs[i].n; k++, b++) {
@@ -246,6 +255,7 @@ struct Engine {
     memset(&d, 0, sizeof d);
     d.data = b_data.as<uint8_t>();
     d.front = b_front.as<uint8_t>(); d.front_off = b_front_off.as<uint64_t>();
+    d.froot = b_froot.as<uint8_t>(); d.froot_off = b_froot_off.as<uint64_t>();
     d.blob_off = b_blob_off.as<uint64_t>();
     d.blob_len = b_blob_len.as<uint32_t>();
     d.doc_blob = b_doc_blob.as<uint32_t>();
@@ -464,6 +474,7 @@ struct Engine {
     }
     last_retries = n_retry;
     if (h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only
+    if (h_froot_off.size() > n_docs && h_froot_off[n_docs] > 0) LM_LAUNCH(k_state_roots, n_docs, 64, d);        // documents initialised from a snapshot only
 #ifdef LM_EMU_TRACE
     if (getenv("LM_EMU_DUMP")) {  // kernel-logic harness only: leaves of document 0 in document order
       lmbe::d2h(h_doc.data(), b_doc.p, (size_t)n_docs * sizeof(DocMeta));

@@ -135,7 +135,11 @@ inline bool sstable_for_each(const uint8_t* p, size_t n, F&& f) {
 }
 
 // a mode-3 blob → a FastUpdates blob holding its ChangeStore's change blocks (in key order: peer, counter)
-inline int snapshot_to_updates(const uint8_t* blob, size_t len, std::vector<uint8_t>& out) {
+// `roots` (optional) receives the root containers of the state section as [kind u8, uleb name_len, name]* — the keys of
+// the state SSTable (docs/encoding-container-states.md §1.1: root key = kind | 0x80, uleb len, name).  An empty document
+// importing the snapshot initialises its state store from that section (fast_snapshot.rs:168-258), so these roots are
+// part of the value even when nothing is visible in them.
+inline int snapshot_to_updates(const uint8_t* blob, size_t len, std::vector<uint8_t>& out, std::vector<uint8_t>* roots = nullptr) {
   if (len < 22 || memcmp(blob, "loro", 4) != 0) return SN_DECODE;
   if (blob[20] != 0 || blob[21] != 3) return SN_DECODE;
   if (lmenc::xxh32(blob + 20, len - 20, 0x4F524F4Cu) != rd32(blob + 16)) return SN_CHECKSUM;
@@ -161,6 +165,19 @@ inline int snapshot_to_updates(const uint8_t* blob, size_t len, std::vector<uint
   });
   if (!ok) return SN_DECODE;
   if (shallow_keys) return SN_UNSUPPORTED;
+  if (roots) {
+    roots->clear();
+    bool ok2 = sstable_for_each(sec[1], sl[1], [&](const uint8_t* k, size_t kl, const uint8_t*, size_t) {
+      if (kl < 2 || !(k[0] & 0x80)) return;
+      size_t i = 1, nl = 0, sh = 0;
+      for (;;) { if (i >= kl || sh > 28) return; uint8_t c = k[i++]; nl |= (size_t)(c & 0x7f) << sh; sh += 7; if (!(c & 0x80)) break; }
+      if (nl != kl - i) return;
+      roots->push_back(k[0] & 0x7f);
+      lmenc::put_uleb(*roots, nl);
+      roots->insert(roots->end(), k + i, k + kl);
+    });
+    if (!ok2) return SN_DECODE;
+  }
   std::vector<const uint8_t*> ptrs;
   std::vector<size_t> lens;
   for (auto& b : blocks) { ptrs.push_back(b.data()); lens.push_back(b.size()); }

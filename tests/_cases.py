@@ -131,11 +131,11 @@ def container_existence_cases():
 
 
 def snapshot_cases():
-    """(docs, check(got)): FastSnapshot (mode 3) ingest through the ChangeStore (lm_snapshot.h).  The oracle does not read
-    snapshots, so these are pinned on the reference fixtures alone: `snapshot.blob` (Rust-written, LZ4-framed SSTable blocks)
-    and `snapshot.ts.blob` hold the history of `updates.blob`, `runtime-snapshot.ts.blob` that of `runtime-updates.ts.blob`
-    (crates/loro/tests/loro_js_interop.rs:58-90) — the value must be the updates import's, and its in-scope, non-empty keys
-    the ones of snapshot.deep.json."""
+    """(docs, check(got)): FastSnapshot (mode 3) ingest (lm_snapshot.h): the history from the ChangeStore section, the set
+    of root containers from the state section.  The oracle does not read snapshots, so these are pinned on the reference
+    fixtures alone: `snapshot.blob` (Rust-written, LZ4-framed SSTable blocks) and `snapshot.ts.blob` hold the history of
+    `updates.blob`, `runtime-snapshot.ts.blob` that of `runtime-updates.ts.blob` (crates/loro/tests/loro_js_interop.rs:58-90):
+    the in-scope values must be those of snapshot.deep.json / the updates import, the ROOTS those of snapshot.deep.json."""
     import json, os
     fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_fixtures.json")))
     b = {k: bytes.fromhex(v) for k, v in fx["blobs"].items()}
@@ -146,16 +146,22 @@ def snapshot_cases():
 
     def check(got):
         snap, upd, snap_ts, rsnap, rupd, shallow, bad_sum, cut, both, plain = got
-        assert snap[0] == upd[0] == 4 and snap[1] and snap[1:] == upd[1:] and snap_ts[1:] == upd[1:]      # out-of-scope containers ride along as null
-        assert rsnap == rupd
+        assert snap[0] == upd[0] == 4 and snap[1] and snap_ts[1:] == snap[1:] and snap[2] == upd[2]   # out-of-scope containers ride along as null
+        assert rsnap[2] == rupd[2]
         deep = fx["json"]["snapshot.deep.json"]
-        v = json.loads(snap[1])
+        v, u = json.loads(snap[1]), json.loads(upd[1])
+        # an empty document takes its state store from the snapshot's state section: every root of snapshot.deep.json is there,
+        # "list" too, in which nothing is visible (an UPDATES import of the same history has no state for it)
+        assert sorted(v) == sorted(deep) and v["list"] == deep["list"] == [] and v["text"] == deep["text"] == "" and "list" not in u
+        assert {k: x for k, x in v.items() if k != "list"} == u
         for k, x in deep["map"].items():
             if k not in ("child_mlist", "child_tree"):
                 assert v["map"][k] == x, k
+        rv, ru = json.loads(rsnap[1]), json.loads(rupd[1])
+        assert all(rv[k] == ru[k] for k in ru) and sorted(k for k in rv if ":$" not in k) == sorted(fx["json"]["runtime.expected.json"])
         assert shallow[0] == 4 and not shallow[1]             # history below a shallow root is gone: not replayable
         assert bad_sum[0] == 2 and cut[0] in (1, 2)           # checksum mismatch / truncated
-        assert both[1:] == upd[1:]                            # the same history three times over
+        assert both[1:] == snap[1:]                           # the same history three times over, one of them a snapshot
         assert plain[:2] == (0, b'{"text":"Hello World!"}')
     return docs, check
 
