@@ -250,6 +250,46 @@ LM_DEV uint32_t xxh32_lane(const uint8_t* p, uint64_t len, uint32_t seed) {
   return h;
 }
 
+// xxHash32 of one LARGE buffer by a whole wave: 1 KB (64 stripes) per step is loaded with coalesced dword loads, then lanes
+// 0..3 — the four accumulators — consume their words stripe by stripe through lane permutes; the rest (< 1 KB) and the
+// finalisation are done redundantly by every lane.  (One lane per blob streams a 2.4 MB blob at one 16-byte load per
+// instruction per lane: 12 ms for a configs[2] document; this takes ≈2.)  `p` must be 4-byte aligned; wave-uniform arguments.
+LM_DEV uint32_t xxh32_wave(const uint8_t* p, uint64_t len, uint32_t seed) {
+  const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, P4 = 0x27D4EB2Fu, P5 = 0x165667B1u;
+  if (len < 1024) return xxh32_lane(p, len, seed);
+  int lane = lmw::lane();
+  const uint8_t* end = p + len;
+  const uint32_t* w = (const uint32_t*)p;
+  uint32_t v = lane == 0 ? seed + P1 + P2 : lane == 1 ? seed + P2 : lane == 2 ? seed : seed - P1;   // lanes >= 4 compute along, unused
+  int src0 = lane & 3;
+  while ((const uint8_t*)(w + 256) <= end) {
+    uint32_t x0 = w[lane], x1 = w[64 + lane], x2 = w[128 + lane], x3 = w[192 + lane];
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_++) v = rotl32(v + lmw::shfl(x0, (s_ * 4 + src0) & 63) * P2, 13) * P1;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_++) v = rotl32(v + lmw::shfl(x1, (s_ * 4 + src0) & 63) * P2, 13) * P1;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_++) v = rotl32(v + lmw::shfl(x2, (s_ * 4 + src0) & 63) * P2, 13) * P1;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_++) v = rotl32(v + lmw::shfl(x3, (s_ * 4 + src0) & 63) * P2, 13) * P1;
+    w += 256;
+  }
+  uint32_t v1 = lmw::bcast(v, 0), v2 = lmw::bcast(v, 1), v3 = lmw::bcast(v, 2), v4 = lmw::bcast(v, 3);
+  const uint8_t* q = (const uint8_t*)w;
+  while (q + 16 <= end) {
+    const uint32_t* u = (const uint32_t*)q;
+    v1 = rotl32(v1 + u[0] * P2, 13) * P1; v2 = rotl32(v2 + u[1] * P2, 13) * P1;
+    v3 = rotl32(v3 + u[2] * P2, 13) * P1; v4 = rotl32(v4 + u[3] * P2, 13) * P1;
+    q += 16;
+  }
+  uint32_t h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+  h += (uint32_t)len;
+  while (q + 4 <= end) { h = rotl32(h + ld32le(q) * P3, 17) * P4; q += 4; }
+  while (q < end) { h = rotl32(h + (*q) * P5, 11) * P1; q++; }
+  h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+  return h;
+}
+
 // packed element id helpers
 LM_DEV uint32_t pid_make(uint32_t peer, uint32_t ctr) { return (peer << 24) | ctr; }
 LM_DEV uint32_t pid_peer(uint32_t pid) { return pid >> 24; }

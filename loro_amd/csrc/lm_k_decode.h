@@ -26,6 +26,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   const uint64_t* froot_off;
   // per blob
   int32_t* blob_status;
+  uint32_t* blob_hash;        // xxh32 of the large blobs (k_hash_big_blobs)
   uint32_t* blob_nblk;
   uint32_t* blob_blk0;
   uint32_t* blob_doc;
@@ -96,6 +97,18 @@ enum { BC_CHG = 0, BC_DEP, BC_OP, BC_KEY, BC_CID, BC_PEER, BC_MAPOP, BC_ATOMS };
 static constexpr uint32_t VIS_CAP = 1024;
 
 // -------------------------------------------------------------------------------------------------
+static constexpr uint64_t BIG_BLOB = 32768;   // blobs from this size on are hashed by a whole wave
+// K0: one wave per large blob (listed by the host, which knows the blob lengths) — the envelope checksum
+LM_KERNEL void k_hash_big_blobs(Dev d, const uint32_t* big, uint32_t n_big) {
+  uint32_t i = (uint32_t)lmw::bid();
+  if (i >= n_big) return;
+  uint32_t b = big[i];
+  const uint8_t* p = d.data + d.blob_off[b];
+  uint64_t len = d.blob_len[b];
+  uint32_t h = len >= 22 ? xxh32_wave(p + 20, len - 20, 0x4f524f4cu) : 0u;
+  if (lmw::lane() == 0) d.blob_hash[b] = h;
+}
+
 // K1: one lane per blob — envelope, xxh32, block count.
 LM_KERNEL void k_frame_count(Dev d) {
   uint32_t b = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
@@ -112,7 +125,9 @@ LM_KERNEL void k_frame_count(Dev d) {
     else if (mode != 4) st = ST_DECODE_ERROR;
     else {
       uint32_t expect = ld32le(p + 16);
-      if (xxh32_lane(p + 20, len - 20, 0x4f524f4cu) != expect) st = ST_CHECKSUM_MISMATCH;
+      // large blobs were hashed by a wave each (k_hash_big_blobs); the others by this lane
+      uint32_t h = len >= BIG_BLOB ? d.blob_hash[b] : xxh32_lane(p + 20, len - 20, 0x4f524f4cu);
+      if (h != expect) st = ST_CHECKSUM_MISMATCH;
       else {
         Rd r = rd_make(p + 22, len - 22);
         while (r.p < r.end && !r.bad) {

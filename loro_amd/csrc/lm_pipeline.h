@@ -50,7 +50,7 @@ struct Engine {
   uint64_t data_bytes = 0, in_bytes = 0;
   std::vector<uint64_t> h_blob_off, h_front_off, h_froot_off;
   std::vector<uint32_t> h_blob_len, h_doc_blob, h_blob_doc;
-  DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc, b_front, b_front_off, b_froot, b_froot_off;
+  DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc, b_front, b_front_off, b_froot, b_froot_off, b_blob_hash, b_big;
   // work buffers
   DBuf b_blob_status, b_blob_nblk, b_blob_blk0, b_tile, b_tot;
   DBuf b_blk, b_bcnt, b_boff;
@@ -86,7 +86,7 @@ struct Engine {
   size_t h_stage_cap = 0;
   ~Engine() { release_all(); if (h_stage) lmbe::hfree(h_stage); lmbe::stream_destroy(sc); }
   void release_all() {
-    DBuf* all[] = {&b_front, &b_front_off, &b_froot, &b_froot_off, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
+    DBuf* all[] = {&b_front, &b_front_off, &b_froot, &b_froot_off, &b_blob_hash, &b_big, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
@@ -272,6 +272,17 @@ struct Engine {
     d.blob_blk0 = b_blob_blk0.as<uint32_t>();
     d.blob_doc = b_blob_doc.as<uint32_t>();
     lmbe::tic(profiling);
+    {
+      std::vector<uint32_t> big;
+      for (uint32_t i = 0; i < n_blobs; i++) if (h_blob_len[i] >= BIG_BLOB) big.push_back(i);
+      b_blob_hash.ensure((size_t)n_blobs * 4 + 4);
+      d.blob_hash = b_blob_hash.as<uint32_t>();
+      if (!big.empty()) {
+        b_big.ensure(big.size() * 4);
+        lmbe::h2d(b_big.p, big.data(), big.size() * 4);
+        LM_LAUNCH(k_hash_big_blobs, (uint32_t)big.size(), 64, d, (const uint32_t*)b_big.as<uint32_t>(), (uint32_t)big.size());
+      }
+    }
     if (n_blobs) LM_LAUNCH(k_frame_count, cdiv(n_blobs, 64), 64, d);
     lmbe::toc("k_frame_count", times, profiling);
     scan(d.blob_nblk, d.blob_blk0, n_blobs, 1);
