@@ -81,6 +81,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   // map LWW
   unsigned long long* ht_key;   // per doc open-addressing table
   unsigned long long* ht_best;
+  unsigned long long* ht_pfx;   // per slot: first eight key bytes (big endian), filled by the emit stage for its key sort
   uint64_t* ht0;                // per doc first slot; ht_cap per doc
   uint32_t* ht_cap;
   uint32_t* ht_list;            // per doc [ht0, ht0+cap): lower half = slots claimed (one per distinct key), upper half = sort scratch

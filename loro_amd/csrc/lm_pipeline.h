@@ -61,7 +61,7 @@ struct Engine {
   DBuf b_cp, b_loc;
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
-  DBuf b_ht_key, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
+  DBuf b_ht_key, b_ht_pfx, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
   DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_hash, b_order, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off, b_slab2, b_slab2_off;
   uint64_t payload_bytes = 0;   // Σ json_len + Σ vv_len of the last run (without alignment padding)
   std::vector<uint64_t> h_prof, h_hash;
@@ -92,7 +92,7 @@ struct Engine {
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
-                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
+                   &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off};
     for (DBuf* b : all) b->release();
   }
@@ -426,7 +426,7 @@ struct Engine {
     b_prof.ensure((size_t)n_docs * 16 * 8);
     d.prof = b_prof.as<unsigned long long>();
     lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
-    b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 8);   // per doc 2·cap entries: claimed slots [0, cap/2) + sort scratch
+    b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_pfx.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 8);   // per doc 2·cap entries: claimed slots [0, cap/2) + sort scratch
     b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4); b_ht_cnt.ensure((size_t)n_docs * 4 + 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
@@ -435,7 +435,7 @@ struct Engine {
     d.dir_out = b_dir_out.as<uint32_t>();
     d.lf_chunk = b_lf_chunk.as<uint8_t>();
     d.vvh = b_vvh.as<uint32_t>();
-    d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>();
+    d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>(); d.ht_pfx = b_ht_pfx.as<unsigned long long>();
     d.ht0 = b_ht0.as<uint64_t>(); d.ht_cap = b_ht_cap.as<uint32_t>();
     d.ht_list = b_ht_list.as<uint32_t>(); d.ht_cnt = b_ht_cnt.as<uint32_t>();
     lmbe::dmemset(b_ht_cnt.p, 0, (size_t)n_docs * 4 + 4);

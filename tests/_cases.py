@@ -81,6 +81,13 @@ def edge_case_docs():
     u2.list_insert("list", 0, [{"q": 1, "p": [{"b": 2, "a": 1}]}, "tail"]); u2.commit()
     u3 = wire.Replica(53); u3.map_set("map", "other", {"k2": 2, "k1": 1}); u3.commit()
     add("nested map value", [u2.export(), u3.export()])
+    # map keys that tie on their first eight bytes (the emit stage sorts by an 8-byte prefix and reads the strings on a tie)
+    u4 = wire.Replica(55)
+    for i, k in enumerate(["abcdefgh1", "abcdefgh0", "abcdefgh", "abcdefg", "ab", "a", "", "a\x00", "a\x00b", "abcdefgh\x00", "abcdefghij", "b",
+                           "\u00e9t\u00e9", "\u00e9", "zzzzzzzzzzzzzzzz", "zzzzzzzzzzzzzzzy", "zzzzzzzz"]):
+        u4.map_set("map", k, i)
+    u4.commit()
+    add("map keys with common prefixes", [u4.export()])
     # still outside the device scope: flagged, never guessed
     t = wire.Replica(54); t.map_set_container("map", "tree", 3); t.commit()
     add("tree child container", [t.export()])
