@@ -109,7 +109,37 @@ LM_DEV uint32_t rle_next_u8(RleCur& c) {
 LM_DEV int64_t rle_next_delta(RleCur& c) {  // DeltaRle: running sum of i128 deltas
   if (c.rem == 0) { if (!rle_head(c)) return c.val; if (c.run) c.runv = rd_zigzag128(c.r); }
   c.rem--;
-  c.val += c.run ? c.runv : rd_zigzag128(c.r);
+  if (__builtin_add_overflow(c.val, c.run ? c.runv : rd_zigzag128(c.r), &c.val)) c.r.bad = true;   // the reference sums in i128 and fails the narrowing
+  return c.val;
+}
+// The three cursors above as ONE code path selected by a per-lane `mode` (0 = Rle<u8>, 1 = Rle<uvar>, 2 = DeltaRle), so lanes
+// that own different columns do not diverge (k_block_decode_wave).  Same results and the same `bad` latching as
+// rle_next_u8 / rle_next_uvar / rle_next_delta.
+LM_DEV int64_t rd_any(Rd& r, uint32_t mode) {
+  uint64_t lo = 0, hi = 0;
+  uint32_t lim = mode == 0 ? 1u : (mode == 1 ? 10u : 19u);
+  bool term = false;
+  for (uint32_t i = 0; i < lim; i++) {
+    uint32_t b = rd_u8(r);
+    uint64_t part = mode == 0 ? b : (b & 0x7f);
+    uint32_t sh = 7 * i;
+    if (sh < 64) { lo |= part << sh; if (sh > 57) hi |= part >> (64 - sh); }
+    else hi |= part << (sh - 64);
+    if (mode == 0 || !(b & 0x80)) { term = true; break; }
+  }
+  if (!term) { r.bad = true; return mode == 1 ? (int64_t)lo : 0; }
+  if (mode != 2) return (int64_t)lo;
+  if (hi > 1) { r.bad = true; return 0; }   // a delta beyond i64
+  uint64_t mag = (lo >> 1) | (hi << 63);
+  return (int64_t)mag ^ -(int64_t)(lo & 1);
+}
+LM_DEV int64_t rle_next_any(RleCur& c, uint32_t mode) {   // the run value lives in runv for every mode; val is the delta sum
+  bool need = !c.run;
+  if (c.rem == 0) { if (!rle_head(c)) return mode == 2 ? c.val : 0; need = true; }
+  c.rem--;
+  if (need) c.runv = rd_any(c.r, mode);
+  if (mode != 2) return c.runv;
+  if (__builtin_add_overflow(c.val, c.runv, &c.val)) c.r.bad = true;   // the reference sums in i128 and fails the narrowing
   return c.val;
 }
 // number of values in a whole AnyRle payload whose literals are single bytes (Rle<u8>)
@@ -188,8 +218,8 @@ LM_DEV int64_t dod_next(DodCur& c) {
   else if (dod_bits(c, 1) == 0) dd = (int64_t)dod_bits(c, 12) - 2047;
   else if (dod_bits(c, 1) == 0) dd = (int64_t)dod_bits(c, 21) - 1048575;
   else dd = (int64_t)dod_bits(c, 64);
-  c.delta += dd;
-  c.prev += c.delta;
+  c.delta = (int64_t)((uint64_t)c.delta + (uint64_t)dd);      // wrapping, like the release-mode Rust reader (damaged input only)
+  c.prev = (int64_t)((uint64_t)c.prev + (uint64_t)c.delta);
   return c.prev;
 }
 // after taking `n` values: validate the used-bits byte and advance the byte reader past the stream

@@ -8,10 +8,14 @@
 //  * lane = (block b = lane / 8, role r = lane % 8).  Roles 0-3 own the four EncodedOp columns (container_index
 //    DeltaRle, prop DeltaRle, value_type Rle<u8>, len Rle<u32>; block_encode.rs:417-428), roles 4-6 the three
 //    EncodedDeleteStartId columns (outdated_encode_reordered.rs:480-489), role 7 walks the value payloads
-//    (encoding/value.rs) and assembles the 32-byte OpRow.  All column lanes run the SAME AnyRle cursor code on their own
-//    byte range, so one pass of the row loop advances 7 columns x 8 blocks; the row's fields meet in role 7 through
-//    lane permutes.  Header, change meta, keys and container ids (small, sequential by format) are parsed by role 0 of
-//    every block before the row loop.
+//    (encoding/value.rs).  Rows are decoded eight at a time in phases that keep the active lanes on ONE code path:
+//    every column lane runs the same mode-selected AnyRle cursor (rle_next_any) and the same table-driven range check
+//    on its own byte range — first the op columns for the 8 rows, then the delete-start columns once per DeleteSeq row
+//    of the chunk; the walker then passes over the 8 payloads; finally lane = (block, row) maps each row (decode_op)
+//    and stores the 32-byte OpRow, 64 rows per store.  Fields meet through two small LDS tables (s_x, s_w), not lane
+//    permutes.  (The first version ran all seven roles' code for every single row — 3.3x the instructions.)
+//    Header, change meta, keys and container ids (small, sequential by format) are parsed by role 0 of every block
+//    before the row loop.
 //  * nothing lives in scratch: the nested-value frame stack of role 7 is in LDS.
 // A block whose head exceeds the slot (thousands of changes or keys) is decoded by the same code straight from HBM.
 // Reference: decode_block block_encode.rs:535-706, decode_changes_header block_meta_encode.rs:90-242,
@@ -21,6 +25,9 @@
 namespace lm {
 
 static constexpr uint32_t DEC_G = 8;            // blocks per wave
+static constexpr uint32_t DEC_R = 8;            // rows per chunk (one lane per row in the assembly phase)
+static constexpr uint32_t DEC_WW = 6;           // words the walker hands over per row: value offset lo/hi, aux, flags, counter, change
+static constexpr uint32_t DEC_LDS_FIXED = DEC_G * 16 * 4 + DEC_G * DEC_R * 8 * 4 + DEC_G * DEC_R * DEC_WW * 4;   // frame stacks + s_x + s_w
 static constexpr uint32_t DEC_KINDS = 32;       // container kinds of a block cached in LDS (more: read back from cid_raw)
 // error bookkeeping of the row loop: the earliest row wins, then the role order of the sequential decoder
 LM_DEV void dec_err(uint32_t& key, uint32_t row, uint32_t prio, int32_t code) {
@@ -33,9 +40,11 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
   uint32_t g0 = (uint32_t)lmw::bid() * DEC_G;
   uint32_t b = (uint32_t)lane >> 3, r = (uint32_t)lane & 7;
   uint32_t bi = g0 + b;
-  LM_DYN_SHARED(uint32_t, s_mem);   // DEC_G slots of slot_cap staged bytes | DEC_G x 16 frame-stack words | DEC_G x DEC_KINDS kind bytes
+  LM_DYN_SHARED(uint32_t, s_mem);   // DEC_G slots of slot_cap staged bytes | DEC_G x 16 frame-stack words | s_x | s_w | DEC_G x DEC_KINDS kind bytes
   uint32_t* s_fs = s_mem + DEC_G * (slot_cap / 4);
-  uint8_t* s_kinds = (uint8_t*)(s_fs + DEC_G * 16);
+  uint32_t* s_x = s_fs + DEC_G * 16;                  // DEC_G x DEC_R rows x 8 column words
+  uint32_t* s_w = s_x + DEC_G * DEC_R * 8;            // DEC_G x DEC_R rows x DEC_WW walker words
+  uint8_t* s_kinds = (uint8_t*)(s_w + DEC_G * DEC_R * DEC_WW);
   bool have = bi < d.n_blocks;
   // only the scalar fields of the descriptor stay in registers; section extents are read where a section is opened
   struct { uint64_t base; uint32_t counter_start, counter_len, n_changes; } bd = {0, 0, 0, 0};
@@ -200,7 +209,7 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
     }
   }
   lmw::block_sync();   // kinds (LDS) and the change rows (HBM, read back by role 7 of the same block) are in place
-  // ---- column cursors
+  // ---- column cursors (roles 0-6) and the per-role parameters that let ONE code path decode all seven columns
   RleCur col = rle_make(rd_make(blk_p, 0));
   bool has_del = false;
   uint32_t errk = 0xffffffffu;   // earliest row error of this lane
@@ -220,6 +229,21 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
     }
     col = rle_make(mine);
   }
+  // value domain of each column: [v_lo, v_lo + v_span) (v_nz: zero is invalid too); a value outside it records the
+  // row error (v_prio orders the findings of one row like the sequential decoder) and is replaced by v_repl
+  uint32_t mode = r == 2 ? 0u : (r == 3 ? 1u : 2u);        // Rle<u8> | Rle<u32> | DeltaRle
+  int64_t v_lo = 0, v_repl = 0;
+  uint64_t v_span = 256;
+  uint32_t v_prio = 0, v_mask = 0xffffffffu;
+  int32_t v_code = ST_DATA_CORRUPTION;
+  bool v_nz = false;
+  if (r == 0) { v_span = n_cids; v_prio = 0; }                                                       // container_index
+  else if (r == 1) { v_lo = INT32_MIN; v_span = 1ull << 32; v_prio = 1; v_code = ST_DECODE_ERROR; }    // prop
+  else if (r == 2) { v_mask = 0x7f; }                                                                 // value_type
+  else if (r == 3) { v_span = (uint64_t)MAX_COUNTER + 1; v_repl = MAX_COUNTER; v_prio = 5; v_code = ST_UNSUPPORTED; }   // len
+  else if (r == 4) { v_span = n_peers; v_prio = 6; }                                                  // delete start: peer_idx
+  else if (r == 5) { v_span = MAX_COUNTER; v_prio = 8; }                                              //   counter
+  else if (r == 6) { v_lo = -(int64_t)MAX_COUNTER; v_span = 2ull * MAX_COUNTER + 1; v_nz = true; v_repl = 1; v_prio = 7; }   //   signed len
   // ---- role 7: value walker + row→change bookkeeping
   Rd v = rd_make(blk_p, 0);
   uint64_t counter = bd.counter_start;
@@ -232,88 +256,122 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
     d.chg[chg0].op0 = op0;
   }
   uint32_t max_rows = lmw::reduce_max(ok ? n_ops : 0u);
-  int base_lane = lane & ~7;
-  for (uint32_t row = 0; row < max_rows; row++) {
-    bool act = ok && row < n_ops;
-    // 1. the four op columns advance
-    uint32_t x = 0;
-    if (act && r < 4) {
-      if (r == 2) x = rle_next_u8(col) & 0x7f;
-      else if (r == 3) { uint64_t l = rle_next_uvar(col); if (l > MAX_COUNTER) { dec_err(errk, row, 5, ST_UNSUPPORTED); l = MAX_COUNTER; } x = (uint32_t)l; }
-      else {
-        int64_t w = rle_next_delta(col);
-        if (r == 0) { if (w < 0 || (uint64_t)w >= n_cids) { dec_err(errk, row, 0, ST_DATA_CORRUPTION); w = 0; } }
-        else if (w < INT32_MIN || w > INT32_MAX) { dec_err(errk, row, 1, ST_DECODE_ERROR); w = 0; }
-        x = (uint32_t)w;
+  // Rows are decoded DEC_R = 8 at a time in four phases that each keep the lanes on one code path:
+  //   A  lane = (block, column): the four op columns advance 8 rows, then the three delete-start columns advance once
+  //      per DeleteSeq row of the chunk; values land in s_x[block][row][column]
+  //   W  lane = (block, role 7): the value walker passes over the 8 payloads (sequential by format) → s_w[block][row]
+  //   B  lane = (block, row): decode_op mapping, the 32-byte OpRow and its side tables, 64 rows per store
+  uint32_t* sx = s_x + (size_t)b * (DEC_R * 8);       // this block's rows: 8 words each (columns 0-6, word 7 = container kind)
+  uint32_t* sw = s_w + (size_t)b * (DEC_R * DEC_WW);
+  for (uint32_t c0 = 0; c0 < max_rows; c0 += DEC_R) {
+    // A1. op columns
+    for (uint32_t k = 0; k < DEC_R; k++) {
+      uint32_t row = c0 + k;
+      if (ok && row < n_ops && r < 4) {
+        int64_t w = rle_next_any(col, mode);
+        if ((uint64_t)(w - v_lo) >= v_span) { dec_err(errk, row, v_prio, v_code); w = v_repl; }
+        sx[k * 8 + r] = (uint32_t)w & v_mask;
       }
     }
-    uint32_t ci = lmw::shfl(x, base_lane), prop = lmw::shfl(x, base_lane + 1), vt = lmw::shfl(x, base_lane + 2), len = lmw::shfl(x, base_lane + 3);
+    lmw::wave_sync();
+    // T. lane = (block, row r): which rows are DeleteSeq ops of a sequence container
+    uint32_t row = c0 + r;
+    bool act = ok && row < n_ops;
+    uint32_t ci = 0, prop = 0, vt = 0, len = 0;
+    if (act) { ci = sx[r * 8]; prop = sx[r * 8 + 1]; vt = sx[r * 8 + 2]; len = sx[r * 8 + 3]; }
     uint32_t ckind = 0xff;
     if (act && n_cids) ckind = ci < DEC_KINDS ? s_kinds[b * DEC_KINDS + ci] : (d.cid_raw[(uint64_t)(cid0 + ci) * 4] & 0xff);
-    // 2. delete-start columns advance on DeleteSeq rows of sequence containers
     bool take_del = act && vt == 9 && (ckind == CK_TEXT || ckind == CK_LIST || ckind == CK_MOVABLE);
-    uint32_t y = 0;
-    if (take_del && has_del && r >= 4 && r < 7) {
-      int64_t w = rle_next_delta(col);
-      if (r == 4) { if (w < 0 || (uint64_t)w >= n_peers) { dec_err(errk, row, 6, ST_DATA_CORRUPTION); w = 0; } }
-      else if (r == 5) { if (w < 0 || w >= (int64_t)MAX_COUNTER) { dec_err(errk, row, 8, ST_DATA_CORRUPTION); w = 0; } }
-      else if (w == 0 || w > (int64_t)MAX_COUNTER || w < -(int64_t)MAX_COUNTER) { dec_err(errk, row, 7, ST_DATA_CORRUPTION); w = 1; }
-      if (col.r.bad) dec_err(errk, row, 9, ST_DATA_CORRUPTION);
-      y = (uint32_t)w;
+    if (act) sx[r * 8 + 7] = ckind;
+    uint64_t tdm = lmw::ballot(take_del && has_del);
+    // A2. delete-start columns: one value per DeleteSeq row, in row order
+    uint32_t todo = (r >= 4 && r < 7) ? (uint32_t)(tdm >> (b * 8)) & 0xffu : 0u;
+    while (lmw::any(todo != 0)) {
+      if (todo) {
+        uint32_t k = (uint32_t)__builtin_ctz(todo);
+        todo &= todo - 1;
+        int64_t w = rle_next_any(col, 2);
+        if ((uint64_t)(w - v_lo) >= v_span || (v_nz && w == 0)) { dec_err(errk, c0 + k, v_prio, v_code); w = v_repl; }
+        if (col.r.bad) dec_err(errk, c0 + k, 9, ST_DATA_CORRUPTION);
+        sx[k * 8 + r] = (uint32_t)w;
+      }
     }
-    uint32_t dpeer = lmw::shfl(y, base_lane + 4), dctr = lmw::shfl(y, base_lane + 5), dlen = lmw::shfl(y, base_lane + 6);
-    // 3. role 7: value payload (docs/encoding.md §10), decode_op mapping, the 32-byte row
-    if (act && r == 7) {
+    lmw::wave_sync();
+    // W. role 7: value payloads (docs/encoding.md §10) and the row → change bookkeeping
+    if (ok && r == 7) {
+      uint32_t* fs = s_fs + b * 16;
+      for (uint32_t k = 0; k < DEC_R && c0 + k < n_ops; k++) {
+        uint32_t wvt = sx[k * 8 + 2], wlen = sx[k * 8 + 3], wkind = sx[k * 8 + 7];
+        uint64_t val_at = (uint64_t)(v.p - d.data);
+        uint32_t aux = 0, flags = 0;   // aux: element count of a list value | mark length; flags bit 0: the value is a list
+        switch (wvt) {
+          case 0: case 1: case 2: case 8: case 9: break;
+          case 3: (void)rd_sleb(v); break;
+          case 4: rd_skip(v, 8); break;
+          case 5: case 6: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
+          case 7: (void)rd_uleb(v); break;
+          case 10: (void)rd_sleb(v); break;
+          case 11: {
+            bool is_list_value = v.p < v.end && *v.p == 7;
+            if (is_list_value) { Rd t = v; (void)rd_u8(t); aux = (uint32_t)rd_uleb(t); flags = 1; }
+            // (values of containers outside the device scope are never rendered: any shape is accepted)
+            skip_loro_value_fs(v, unsupported, wkind == CK_MAP ? 0 : (is_list_value && wkind == CK_LIST ? 1 : (wkind > CK_TEXT ? 16 : -1)), fs);
+            break;
+          }
+          case 12: {
+            (void)rd_u8(v);
+            aux = (uint32_t)rd_uleb(v);
+            uint64_t key_idx = rd_uleb(v);
+            if (key_idx >= n_keys) dec_err(errk, c0 + k, 2, ST_DATA_CORRUPTION);
+            bool u = false;
+            skip_loro_value_fs(v, u, -1, fs);
+            break;
+          }
+          case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
+          case 14: (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v); break;
+          case 15: { (void)rd_uleb(v); (void)rd_uleb(v); bool u = false; skip_loro_value_fs(v, u, -1, fs); break; }
+          case 16: {
+            (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v);
+            uint32_t isn = rd_u8(v);
+            if (!isn) { (void)rd_uleb(v); (void)rd_uleb(v); }
+            break;
+          }
+          default: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
+        }
+        uint32_t* o = sw + k * DEC_WW;
+        o[0] = (uint32_t)val_at; o[1] = (uint32_t)(val_at >> 32); o[2] = aux; o[3] = flags;
+        o[4] = (uint32_t)counter; o[5] = chg0 + change_index;
+        counter += wlen;
+        if (counter > MAX_COUNTER) { dec_err(errk, c0 + k, 10, ST_UNSUPPORTED); counter = MAX_COUNTER; }
+        if (change_index >= N) { dec_err(errk, c0 + k, 11, ST_DATA_CORRUPTION); change_index = N - 1; }
+        rows_in_change++;
+        if (counter >= next_boundary && change_index + 1 < N) {
+          d.chg[chg0 + change_index].n_op = rows_in_change;
+          rows_in_change = 0;
+          change_index++;
+          d.chg[chg0 + change_index].op0 = op0 + c0 + k + 1;
+          next_boundary = change_index + 1 < N ? d.chg[chg0 + change_index + 1].ctr : (uint64_t)bd.counter_start + bd.counter_len;
+        }
+      }
+    }
+    lmw::wave_sync();
+    // B. lane = (block, row): decode_op mapping (outdated_encode_reordered.rs:215-476) and the row itself
+    if (act) {
+      const uint32_t* o = sw + r * DEC_WW;
+      uint32_t aux = o[2];
+      bool is_list_value = (o[3] & 1) != 0;
       OpRow orow;
       orow.cidx_kind = ci;  // block-local until k_remap
       orow.prop = (int32_t)prop;
       orow.len = len;
-      orow.ctr = (uint32_t)counter;
-      orow.a0 = 0; orow.a1 = 0; orow.a2 = 0;
-      orow.chg = chg0 + change_index;
-      uint64_t val_at = (uint64_t)(v.p - d.data);
-      uint32_t kind = OK_OTHER, mark_len = 0;
-      bool is_list_value = false;
-      uint32_t* fs = s_fs + b * 16;
-      switch (vt) {
-        case 0: case 1: case 2: case 8: case 9: break;
-        case 3: (void)rd_sleb(v); break;
-        case 4: rd_skip(v, 8); break;
-        case 5: case 6: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
-        case 7: (void)rd_uleb(v); break;
-        case 10: (void)rd_sleb(v); break;
-        case 11: {
-          is_list_value = v.p < v.end && *v.p == 7;
-          if (is_list_value) { Rd t = v; (void)rd_u8(t); orow.a0 = (uint32_t)rd_uleb(t); }
-          // (values of containers outside the device scope are never rendered: any shape is accepted)
-          skip_loro_value_fs(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && ckind == CK_LIST ? 1 : (ckind > CK_TEXT ? 16 : -1)), fs);
-          break;
-        }
-        case 12: {
-          (void)rd_u8(v);
-          mark_len = (uint32_t)rd_uleb(v);
-          uint64_t key_idx = rd_uleb(v);
-          if (key_idx >= n_keys) dec_err(errk, row, 2, ST_DATA_CORRUPTION);
-          bool u = false;
-          skip_loro_value_fs(v, u, -1, fs);
-          break;
-        }
-        case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
-        case 14: (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v); break;
-        case 15: { (void)rd_uleb(v); (void)rd_uleb(v); bool u = false; skip_loro_value_fs(v, u, -1, fs); break; }
-        case 16: {
-          (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v);
-          uint32_t isn = rd_u8(v);
-          if (!isn) { (void)rd_uleb(v); (void)rd_uleb(v); }
-          break;
-        }
-        default: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
-      }
-      // decode_op mapping (outdated_encode_reordered.rs:215-476)
+      orow.ctr = o[4];
+      orow.a0 = (vt == 11 && is_list_value) ? aux : 0u; orow.a1 = 0; orow.a2 = 0;
+      orow.chg = o[5];
+      uint32_t kind = OK_OTHER;
       if (ckind == CK_TEXT) {
         if (vt == 5) kind = OK_TEXT_INS;
         else if (vt == 9) kind = OK_DEL;
-        else if (vt == 12) { kind = OK_STYLE_START; orow.a0 = mark_len; }
+        else if (vt == 12) { kind = OK_STYLE_START; orow.a0 = aux; }
         else if (vt == 0) kind = OK_STYLE_END;
         else dec_err(errk, row, 3, ST_DATA_CORRUPTION);
       } else if (ckind == CK_MAP) {
@@ -328,24 +386,14 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
       }
       if (take_del) {
         if (!has_del) dec_err(errk, row, 4, ST_DATA_CORRUPTION);
-        else { orow.a0 = dpeer; orow.a1 = dctr; orow.a2 = (int32_t)dlen; }
+        else { orow.a0 = sx[r * 8 + 4]; orow.a1 = sx[r * 8 + 5]; orow.a2 = (int32_t)sx[r * 8 + 6]; }
       }
       orow.cidx_kind |= kind << 16;
       d.op[op0 + row] = orow;
-      d.op_val[op0 + row] = val_at;
+      d.op_val[op0 + row] = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
       d.op_blk[op0 + row] = bi;
-      counter += len;
-      if (counter > MAX_COUNTER) { dec_err(errk, row, 10, ST_UNSUPPORTED); counter = MAX_COUNTER; }
-      if (change_index >= N) { dec_err(errk, row, 11, ST_DATA_CORRUPTION); change_index = N - 1; }
-      rows_in_change++;
-      if (counter >= next_boundary && change_index + 1 < N) {
-        d.chg[chg0 + change_index].n_op = rows_in_change;
-        rows_in_change = 0;
-        change_index++;
-        d.chg[chg0 + change_index].op0 = op0 + row + 1;
-        next_boundary = change_index + 1 < N ? d.chg[chg0 + change_index + 1].ctr : (uint64_t)bd.counter_start + bd.counter_len;
-      }
     }
+    lmw::wave_sync();   // the next chunk overwrites s_x / s_w
   }
   // ---- close the block: remaining change rows, the reader flags, the block status
   uint32_t tail = 0;   // low-priority findings (bit 0: a reader ran off its column, bit 1: counter does not add up, bit 2: unsupported shape)

@@ -349,7 +349,7 @@ struct Engine {
       else {
         uint32_t slot_cap = 1280;   // LDS bytes per block for everything before its value payloads (per 5k configs[1] documents: 512 5.4 ms, 1024 4.5, 1280 4.2, 1536 4.9, 2048 5.7 — occupancy against the share of heads that fit; larger heads are read from HBM)
         if (const char* e = getenv("LM_DEC_SLOT")) slot_cap = ((uint32_t)atoi(e) + 15u) & ~15u;
-        LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_G * 16 * 4 + DEC_G * DEC_KINDS, d, slot_cap);
+        LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_cap);
       }
     }
     lmbe::toc("k_block_decode", times, profiling);

@@ -229,11 +229,13 @@ inline std::vector<int64_t> decode_delta_rle(Reader r) {
   int64_t cur = 0;
   while (!r.eof())
     any_rle_segment(r, (size_t)1 << 31, cnt, [&](bool run, size_t len) {
+      // (the reference sums in i128 and fails when narrowing to the column type; no in-scope column exceeds i64)
+      auto add = [&](int64_t d) { if (__builtin_add_overflow(cur, d, &cur)) fail(ST_DECODE_ERROR, "DeltaRle sum beyond i64"); out.push_back(cur); };
       if (run) {
         int64_t d = r.zigzag128_as_i64();
-        for (size_t i = 0; i < len; i++) { cur += d; out.push_back(cur); }
+        for (size_t i = 0; i < len; i++) add(d);
       } else
-        for (size_t i = 0; i < len; i++) { cur += r.zigzag128_as_i64(); out.push_back(cur); }
+        for (size_t i = 0; i < len; i++) add(r.zigzag128_as_i64());
     });
   return out;
 }
@@ -278,8 +280,8 @@ inline std::vector<int64_t> take_delta_of_delta(Reader& r, size_t n) {
   out.push_back(first);
   int64_t prev = first, delta = 0;
   while (out.size() < n) {
-    delta += dod_value(b);
-    prev += delta;
+    delta = (int64_t)((uint64_t)delta + (uint64_t)dod_value(b));   // wrapping, like the release-mode Rust reader (damaged input only)
+    prev = (int64_t)((uint64_t)prev + (uint64_t)delta);
     out.push_back(prev);
   }
   if (n == 1) {
@@ -756,6 +758,11 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
         break;
       default: op.kind = OP_OTHER; break;
     }
+    // canonical invariant (docs/encoding.md §10.6): an insert's content spans exactly the atoms its `len` column entry
+    // claims.  The Rust reader does not check this; slicing such an op (Sliceable, below in lo_doc.hpp) would index past
+    // its content, so the restatement rejects it here — the device does the same where it fills elements (k_elem_fill).
+    if (op.kind == OP_TEXT_INSERT && op.cps.size() != (size_t)col_len[row]) fail(ST_DATA_CORRUPTION, "text insert len");
+    if (op.kind == OP_LIST_INSERT && op.values.size() != (size_t)col_len[row]) fail(ST_DATA_CORRUPTION, "list insert len");
     if (change_index >= N) fail(ST_DATA_CORRUPTION, "op beyond last change");
     Change& ch = out[base + change_index];
     // ops carry a per-change cid table index until the Doc registers containers

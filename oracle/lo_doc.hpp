@@ -502,6 +502,9 @@ struct Doc {
         for (Span* sp = it->second->tr.head; sp; sp = sp->next)
           if (sp->active())
             for (int32_t k = 0; k < sp->len; k++) {
+              // a visible span without content: a delete of ids no insert ever produced left its placeholder behind
+              // (damaged input only; what the Rust state would hold for it is undefined)
+              if ((uint64_t)sp->content + (uint32_t)k >= it->second->cps.size()) fail(ST_DATA_CORRUPTION, "visible span without content");
               uint32_t cp = it->second->cps[sp->content + (uint32_t)k];
               if (cp != 0xFFFFFFFFu) cp_to_utf8(cp, s);
             }
@@ -516,6 +519,7 @@ struct Doc {
             for (int32_t k = 0; k < sp->len; k++) {
               if (!first) out.push_back(',');
               first = false;
+              if ((uint64_t)sp->content + (uint32_t)k >= it->second->values.size()) fail(ST_DATA_CORRUPTION, "visible span without content");
               json_value(*this, it->second->values[sp->content + (uint32_t)k], out, depth + 1);
             }
       out.push_back(']');

@@ -2,7 +2,7 @@
 import gzip, json, os
 import pytest
 
-import _oracle
+import _oracle, _cases
 from loro_amd import wire
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -285,3 +285,20 @@ def test_tracker_known_answers_through_checkout():
     assert len(json.loads(_oracle.merge(both)[1])["text"]) == 4
     assert json.loads(_at(both, [(1, 1)])[1]) == {"text": "ab"}
     assert json.loads(_at(both, [])[1]) == {"text": ""}
+
+
+def test_oracle_rejects_damaged_documents_without_crashing():
+    """The oracle is the checker, so it must survive anything the parity tests feed it: a damaged document (byte flips,
+    truncation, splices; checksum re-fitted) either decodes or raises a LoroError-kind status — never an out-of-bounds
+    read.  tests/golden/damaged_placeholder_span.json is the document that used to crash it (a delete of ids no insert
+    produced left a visible span without content); inserts whose content does not match their `len` column entry are
+    rejected at decode (docs/encoding.md §10.6, lo_codec.hpp)."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "damaged_placeholder_span.json")))
+    st = _oracle.merge_batch([[bytes.fromhex(h) for h in fx["blobs_hex"]]], threads=1)[0][0]
+    assert st == 3          # LM_DATA_CORRUPTION
+    for seed in (12, 21, 22):
+        docs = _cases.corrupted_docs(400, seed=seed)
+        res = _oracle.merge_batch(docs, threads=8)
+        assert {r[0] for r in res} <= {0, 1, 2, 3, 4}
+        assert any(r[0] == 0 for r in res) and any(r[0] != 0 for r in res)
