@@ -38,7 +38,8 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
                                   // inside the cached leaf then needs no directory search at all
   SpanRegs cr;
   bool dirty;                     // `cr` differs from the leaf record in HBM
-  uint64_t loc_dirty;             // lanes of `cr` whose items entered the leaf since the last flush: their loc[] entries are pending
+  uint32_t loc_pend;              // per lane: the item of `cr` in this lane entered the leaf since the last flush, its loc[] entries are pending
+                                  // (a lane flag, not a 64-bit mask: it shifts with the items on the vector unit — the kernel is scalar-issue bound)
   int32_t err;
 #ifdef LM_PROF
   mutable uint64_t prof[PF_N];
@@ -73,8 +74,13 @@ LM_DEV void sp_write(Ts& t, uint32_t L, const SpanRegs& R) {
     rec[lane] = R.id; rec[64 + lane] = R.len; rec[128 + lane] = R.ol; rec[192 + lane] = R.orr; rec[256 + lane] = R.st;
   }
 }
-LM_DEV uint32_t sp_alen(const SpanRegs& R) { return ((uint32_t)lmw::lane() < R.n && st_active(R.st)) ? R.len : 0u; }
-LM_DEV bool sp_nf(const SpanRegs& R) { return lmw::ballot((uint32_t)lmw::lane() < R.n && !(R.st & ST_FUT)) != 0; }
+// (register invariant of SpanRegs: lanes >= n hold id NONE, len 0, status ST_FUT — sp_load, sp_shift_in and the split keep it —
+// so the per-lane predicates below need no `lane < n` term)
+LM_DEV uint32_t sp_alen(const SpanRegs& R) { return st_active(R.st) ? R.len : 0u; }
+LM_DEV bool sp_nf(const SpanRegs& R) { return lmw::ballot(!(R.st & ST_FUT)) != 0; }
+// lanes whose run holds element x: ids of different peers are >= 2^24 apart and a run never crosses 2^24, so one unsigned
+// compare covers "same peer, inside the run" (and NONE / len 0 of the unused lanes never match)
+LM_DEV uint64_t sp_hit(const SpanRegs& R, uint32_t x) { return lmw::ballot(x - R.id < R.len); }
 // loc[] of every element of one item := leaf L
 LM_DEV void sp_set_loc(Ts& t, uint32_t id0, uint32_t len, uint32_t L) {
   uint32_t g = ts_g(t, id0);
@@ -94,11 +100,12 @@ LM_DEV void sp_set_loc_mask(Ts& t, const SpanRegs& R, uint64_t m, uint32_t L) {
 LM_DEV void sp_flush(Ts& t) {
   if (t.cache_leaf == NONE) return;
   if (t.dirty) { sp_write(t, t.cache_leaf, t.cr); t.dirty = false; }
-  if (t.loc_dirty) { sp_set_loc_mask(t, t.cr, t.loc_dirty, t.cache_leaf); t.loc_dirty = 0; }
+  uint64_t pend = lmw::ballot(t.loc_pend != 0);
+  if (pend) { sp_set_loc_mask(t, t.cr, pend, t.cache_leaf); t.loc_pend = 0; }
 }
 // leaf L becomes the cached leaf (its registers are set by the caller); another cached leaf is written back first
 LM_DEV void sp_take(Ts& t, uint32_t L) {
-  if (t.cache_leaf != L) { sp_flush(t); t.cache_leaf = L; t.dirty = false; t.loc_dirty = 0; }
+  if (t.cache_leaf != L) { sp_flush(t); t.cache_leaf = L; t.dirty = false; t.loc_pend = 0; }
 }
 
 // ---- directory (LDS, a few hundred entries: linear, 64 per step)
@@ -165,29 +172,27 @@ LM_DEV void sd_refresh(Ts& t, uint32_t p, uint32_t L, const SpanRegs& R) {   // 
 
 // ---- leaf edits
 // lanes >= idx move up by cnt (1 or 2) and items A (, B) drop in at idx (, idx+1); the leaf has room
-LM_DEV SpanRegs sp_shift_in(const SpanRegs& R, uint32_t idx, const SpanItem& A, const SpanItem& B, uint32_t cnt) {
-  int lane = lmw::lane();
+LM_DEV SpanRegs sp_shift_in(const SpanRegs& R, uint32_t& lp, uint32_t idx, const SpanItem& A, const SpanItem& B, uint32_t cnt, bool setA, bool setB) {
+  // items idx.. move up by cnt, A (and B) take lanes idx (idx + 1).  `lp` (the pending-loc[] lane flag) follows the same shift;
+  // setA / setB: the item's loc[] must be (re)written.  A part cut off an item comes from the item at lane idx-1: if that
+  // item's loc[] is still pending, so is the part's.  Selects only — no exec-masked blocks — and the unused lanes need no
+  // clearing: they are shifted in from unused lanes (register invariant above).
+  uint32_t lane = (uint32_t)lmw::lane();
   SpanRegs N;
   N.n = R.n + cnt;
-  uint32_t pid, pln, pol, por, pst;
-  if (cnt == 2) { pid = lmw::shift_up(R.id, 2); pln = lmw::shift_up(R.len, 2); pol = lmw::shift_up(R.ol, 2); por = lmw::shift_up(R.orr, 2); pst = lmw::shift_up(R.st, 2); }
-  else { pid = lmw::shift_up(R.id, 1); pln = lmw::shift_up(R.len, 1); pol = lmw::shift_up(R.ol, 1); por = lmw::shift_up(R.orr, 1); pst = lmw::shift_up(R.st, 1); }
-  bool sh = (uint32_t)lane >= idx + cnt;
+  uint32_t pid, pln, pol, por, pst, plp;
+  if (cnt == 2) { pid = lmw::shift_up0(R.id, 2); pln = lmw::shift_up0(R.len, 2); pol = lmw::shift_up0(R.ol, 2); por = lmw::shift_up0(R.orr, 2); pst = lmw::shift_up0(R.st, 2); plp = lmw::shift_up0(lp, 2); }
+  else { pid = lmw::shift_up0(R.id, 1); pln = lmw::shift_up0(R.len, 1); pol = lmw::shift_up0(R.ol, 1); por = lmw::shift_up0(R.orr, 1); pst = lmw::shift_up0(R.st, 1); plp = lmw::shift_up0(lp, 1); }
+  uint32_t inh = idx ? lmw::bcast(lp, (int)idx - 1) : 0u;
+  bool sh = lane >= idx + cnt, isA = lane == idx, isB = (cnt == 2) & (lane == idx + 1);
   N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
-  if ((uint32_t)lane == idx) { N.id = A.id; N.len = A.len; N.ol = A.ol; N.orr = A.orr; N.st = A.st; }
-  if (cnt == 2 && (uint32_t)lane == idx + 1) { N.id = B.id; N.len = B.len; N.ol = B.ol; N.orr = B.orr; N.st = B.st; }
-  if ((uint32_t)lane >= N.n) { N.id = NONE; N.len = 0; N.ol = NONE; N.orr = NONE; N.st = ST_FUT; }
+  uint32_t nlp = sh ? plp : lp;
+  N.id = isA ? A.id : N.id; N.len = isA ? A.len : N.len; N.ol = isA ? A.ol : N.ol; N.orr = isA ? A.orr : N.orr; N.st = isA ? A.st : N.st;
+  nlp = isA ? ((setA ? 1u : 0u) | inh) : nlp;
+  N.id = isB ? B.id : N.id; N.len = isB ? B.len : N.len; N.ol = isB ? B.ol : N.ol; N.orr = isB ? B.orr : N.orr; N.st = isB ? B.st : N.st;
+  nlp = isB ? ((setB ? 1u : 0u) | inh) : nlp;
+  lp = nlp;
   return N;
-}
-// the pending-loc[] lane mask follows the same shift.  setA / setB: the item's loc[] must be (re)written.  A part cut off an
-// item comes from the item at lane idx-1: if that item's loc[] is still pending, so is the part's
-LM_DEV uint64_t sp_locbits_in(uint64_t lm, uint32_t idx, uint32_t cnt, bool setA, bool setB) {
-  uint64_t low = idx ? (~0ull >> (64 - idx)) : 0ull;   // idx <= 63 (the leaf had room for cnt more items)
-  bool inh = idx > 0 && ((lm >> (idx - 1)) & 1);
-  lm = (lm & low) | ((lm & ~low) << cnt);
-  if (setA || inh) lm |= 1ull << idx;
-  if (cnt == 2 && (setB || inh)) lm |= 1ull << (idx + 1);
-  return lm;
 }
 // Insert `cnt` (1 or 2) items — A, then B — as items idx, idx+1 of the leaf at directory position p (registers R, which
 // may carry edits the caller made in registers): the leaf becomes the cached leaf and nothing is stored.  A leaf without
@@ -200,7 +205,7 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
   lmw::wave_sync();
   uint32_t L = sa_leaf(lmw::first(t.da[p]));
   sp_take(t, L);
-  uint64_t lm = t.loc_dirty;
+  uint32_t lp = t.loc_pend;
   bool moved = false;   // the items end up in a leaf other than L
   if (R.n + cnt > 64) {
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); return; }
@@ -217,27 +222,26 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
     if (idx >= 32) {
       // the edit goes to the upper half, which becomes the cached leaf; the lower half is written out
       sp_write(t, L, Lo);
-      sp_set_loc_mask(t, Lo, lm & 0xffffffffull, L);
+      sp_set_loc_mask(t, Lo, lmw::ballot(lp != 0) & 0xffffffffull, L);
       sd_refresh(t, p, L, Lo);
       if (pre != NONE) pre += lmw::first(t.db[p]);   // the new leaf starts behind the lower half
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
-      if (t.err) { t.cache_leaf = NONE; t.dirty = false; t.loc_dirty = 0; return; }
+      if (t.err) { t.cache_leaf = NONE; t.cr.n = 255; t.dirty = false; t.loc_pend = 0; return; }
       p = p + 1; idx -= 32; R = U; L = NL;
       t.cache_leaf = NL;
-      lm = nu >= 64 ? ~0ull : ((1ull << nu) - 1);   // every item of the upper half moved: loc[] := NL at the next flush
+      lp = (uint32_t)lane < nu ? 1u : 0u;   // every item of the upper half moved: loc[] := NL at the next flush
       moved = true;
     } else {
       sp_write(t, NL, U);
       sp_set_loc_mask(t, U, nu >= 64 ? ~0ull : ((1ull << nu) - 1), NL);
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
-      if (t.err) { t.cache_leaf = NONE; t.dirty = false; t.loc_dirty = 0; return; }
+      if (t.err) { t.cache_leaf = NONE; t.cr.n = 255; t.dirty = false; t.loc_pend = 0; return; }
       R = Lo;
-      lm &= 0xffffffffull;
+      lp = lane < 32 ? lp : 0u;
     }
   }
-  SpanRegs N = sp_shift_in(R, idx, A, B, cnt);
-  lm = sp_locbits_in(lm, idx, cnt, newA || moved, newB || moved);
-  t.cache_p = p; t.cache_pre = pre; t.cr = N; t.dirty = true; t.loc_dirty = lm;
+  SpanRegs N = sp_shift_in(R, lp, idx, A, B, cnt, newA || moved, newB || moved);
+  t.cache_p = p; t.cache_pre = pre; t.cr = N; t.dirty = true; t.loc_pend = lp;
   sd_refresh(t, p, L, N);
   R = N;
 }
@@ -250,7 +254,7 @@ LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const
 // inside an active run) — no directory search, no leaf traffic, no sibling scan; the directory entry is patched in place.
 // Returns false without touching anything when the general path is needed.
 LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
-  if (t.cache_leaf == NONE || t.cache_pre == NONE || pos <= t.cache_pre || t.cr.n > 62) return false;
+  if (t.cr.n > 62 || pos <= t.cache_pre) return false;   // no cached leaf: n = 255; unknown prefix: cache_pre = NONE
   int lane = lmw::lane();
   uint32_t p = t.cache_p, k = pos - t.cache_pre;
   lmw::wave_sync();
@@ -258,7 +262,7 @@ LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   uint32_t n = t.cr.n;
   uint32_t al = sp_alen(t.cr);
   uint32_t inc = lmw::scan_incl_add(al);
-  uint64_t hit = lmw::ballot(al != 0 && inc >= k);
+  uint64_t hit = lmw::ballot((al != 0) & (inc >= k));
   if (!hit) return false;
   uint32_t slot = (uint32_t)lmw::ffs64(hit), idx = slot + 1;
   uint32_t sln = lmw::bcast(al, (int)slot), sid = lmw::bcast(t.cr.id, (int)slot);
@@ -271,16 +275,16 @@ LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     // inside an active run: cut, the new run goes between the halves
     A.orr = sid + off;
     B.id = sid + off; B.len = sln - off; B.ol = sid + off - 1; B.orr = v_or; B.st = v_st;
-    if ((uint32_t)lane == slot) t.cr.len = off;
+    t.cr.len = (uint32_t)lane == slot ? off : t.cr.len;
     cnt = 2;
   } else {
-    uint64_t nf = lmw::ballot((uint32_t)lane >= idx && (uint32_t)lane < n && !(t.cr.st & ST_FUT));
+    uint64_t nf = lmw::ballot(((uint32_t)lane >= idx) & !(t.cr.st & ST_FUT));
     if (!nf || (uint32_t)lmw::ffs64(nf) != idx) return false;   // origin_right in another leaf, or future items in between
     A.orr = lmw::bcast(t.cr.id, (int)idx);
     if (v_st == 0 && sid + sln == pid0 && pid_peer(sid) == pid_peer(pid0) && v_or == A.orr) {
       // run merging (FugueSpan::is_mergeable): the item grows
-      if ((uint32_t)lane == slot) t.cr.len = sln + len;
-      t.loc_dirty |= 1ull << slot;
+      t.cr.len = (uint32_t)lane == slot ? sln + len : t.cr.len;
+      t.loc_pend = (uint32_t)lane == slot ? 1u : t.loc_pend;
       t.dirty = true;
       if (lane == 0) lmw::lds_add(&t.db[p], len);
       t.tot_active += len;
@@ -291,8 +295,7 @@ LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     B = A;
     cnt = 1;
   }
-  t.cr = sp_shift_in(t.cr, idx, A, B, cnt);
-  t.loc_dirty = sp_locbits_in(t.loc_dirty, idx, cnt, true, false);
+  t.cr = sp_shift_in(t.cr, t.loc_pend, idx, A, B, cnt, true, false);
   t.dirty = true;
   if (lane == 0) { t.da[p] = sa_make(t.cache_leaf, n + cnt, true); lmw::lds_add(&t.db[p], len); }
   t.tot_active += len;
@@ -328,7 +331,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     R = sp_load(t, sa_leaf(a), sa_n(a));
     uint32_t al = sp_alen(R);
     uint32_t inc = lmw::scan_incl_add(al);
-    uint64_t hit = lmw::ballot(al != 0 && inc >= k);
+    uint64_t hit = lmw::ballot((al != 0) & (inc >= k));
     if (!hit) { LM_SETERR(t.err, ST_INTERNAL); return; }
     uint32_t slot = (uint32_t)lmw::ffs64(hit);
     uint32_t off = k - (lmw::bcast(inc, (int)slot) - lmw::bcast(al, (int)slot));   // 1..len: cursor right after element off-1
@@ -491,7 +494,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       sp_take(t, L);
       if ((uint32_t)lane == pv) R.len = v_len + len;
       t.cache_p = p; t.cache_pre = pre_p; t.cr = R; t.dirty = true;
-      t.loc_dirty |= 1ull << pv;   // (the whole item's loc[] is rewritten at the flush — the appended elements are what is new)
+      t.loc_pend = (uint32_t)lane == pv ? 1u : t.loc_pend;   // (the whole item's loc[] is rewritten at the flush — the appended elements are what is new)
       sd_set(t, p, a, lmw::first(t.db[p]) + len);
       PROF_ADD(t, PF_PLACE);
       PROF_CNT(t, PF_NDHIT, 1);
@@ -509,10 +512,10 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
 // ---- the common status update, instruction-lean: the run holding element (peer, c) sits in the cached leaf, which has room
 // for a cut; the run (or its part inside [c, c1)) gets the new status, c advances.  false = general path.
 LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int mode) {
-  if (t.cache_leaf == NONE || t.cr.n > 62) return false;
+  if (t.cr.n > 62) return false;   // (no cached leaf: n = 255)
   int lane = lmw::lane();
   uint32_t x = pid_make(peer, c);
-  uint64_t hm = lmw::ballot((uint32_t)lane < t.cr.n && pid_peer(t.cr.id) == peer && sp_has(t.cr.id, t.cr.len, x));
+  uint64_t hm = sp_hit(t.cr, x);
   if (!hm) return false;
   uint32_t slot = (uint32_t)lmw::ffs64(hm);
   uint32_t id0 = lmw::bcast(t.cr.id, (int)slot), ln = lmw::bcast(t.cr.len, (int)slot);
@@ -526,25 +529,24 @@ LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int m
   uint32_t tail = pid_ctr(id0) + ln - endc, mid = endc - c;
   uint32_t n = t.cr.n;
   if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= mid;
-  if (s_off == 0 && tail == 0) {
-    if ((uint32_t)lane == slot) t.cr.st = st1;
+  if ((s_off | tail) == 0) {
+    t.cr.st = (uint32_t)lane == slot ? st1 : t.cr.st;
   } else {
     uint32_t orr0 = lmw::bcast(t.cr.orr, (int)slot);
     SpanItem A, B;
     uint32_t cnt;
     if (s_off > 0) {
-      if ((uint32_t)lane == slot) t.cr.len = s_off;
+      t.cr.len = (uint32_t)lane == slot ? s_off : t.cr.len;
       A.id = x; A.len = mid; A.ol = x - 1; A.orr = orr0; A.st = st1;
       B.id = pid_make(peer, endc); B.len = tail; B.ol = B.id - 1; B.orr = orr0; B.st = st0;
       cnt = tail ? 2u : 1u;
     } else {
-      if ((uint32_t)lane == slot) { t.cr.len = mid; t.cr.st = st1; }
+      t.cr.len = (uint32_t)lane == slot ? mid : t.cr.len; t.cr.st = (uint32_t)lane == slot ? st1 : t.cr.st;
       A.id = pid_make(peer, endc); A.len = tail; A.ol = A.id - 1; A.orr = orr0; A.st = st0;
       B = A;
       cnt = 1;
     }
-    t.cr = sp_shift_in(t.cr, slot + 1, A, B, cnt);
-    t.loc_dirty = sp_locbits_in(t.loc_dirty, slot + 1, cnt, false, false);
+    t.cr = sp_shift_in(t.cr, t.loc_pend, slot + 1, A, B, cnt, false, false);
     n += cnt;
   }
   t.dirty = true;
@@ -799,7 +801,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span(Dev d, Dev
     uint32_t L0 = t.n_leaf++;
     lmw::block_sync();
     if (lane == 0) { s_da[0] = sa_make(L0, 0, false); s_db[0] = 0; }
-    t.n_dir = 1; t.tot_active = 0; t.n_alive = 0; t.cache_leaf = NONE; t.cache_pre = NONE; t.dirty = false; t.loc_dirty = 0;
+    t.n_dir = 1; t.tot_active = 0; t.n_alive = 0; t.cache_leaf = NONE; t.cr.n = 255; t.cache_pre = NONE; t.dirty = false; t.loc_pend = 0;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
     lmw::block_sync();
     bool touched = false;

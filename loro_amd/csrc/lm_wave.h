@@ -279,8 +279,15 @@ LM_DEV uint32_t shift_up(uint32_t v, int d) {
   if (d == 2) t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x138, 0xf, 0xf, false);
   return t;
 }
+// same, but lanes below d receive 0: no tied `old` operand, so no register copy in front of the DPP move
+LM_DEV uint32_t shift_up0(uint32_t v, int d) {
+  uint32_t t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true);
+  if (d == 2) t = (uint32_t)__builtin_amdgcn_mov_dpp((int)t, 0x138, 0xf, 0xf, true);
+  return t;
+}
 #else
 LM_DEV uint32_t shift_up(uint32_t v, int d) { return shfl_up(v, d); }
+LM_DEV uint32_t shift_up0(uint32_t v, int d) { uint32_t t = shfl_up(v, d); return lane() < d ? 0u : t; }
 #endif
 // wave sum: the DPP prefix scan's last lane (six VALU ops + one readlane instead of six dependent LDS swizzles)
 LM_DEV uint32_t reduce_add(uint32_t v) { return bcast(scan_incl_add(v), 63); }
