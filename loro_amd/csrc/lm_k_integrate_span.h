@@ -81,17 +81,22 @@ LM_DEV bool sp_nf(const SpanRegs& R) { return lmw::ballot(!(R.st & ST_FUT)) != 0
 // lanes whose run holds element x: ids of different peers are >= 2^24 apart and a run never crosses 2^24, so one unsigned
 // compare covers "same peer, inside the run" (and NONE / len 0 of the unused lanes never match)
 LM_DEV uint64_t sp_hit(const SpanRegs& R, uint32_t x) { return lmw::ballot(x - R.id < R.len); }
-// loc[] of every element of one item := leaf L
-LM_DEV void sp_set_loc(Ts& t, uint32_t id0, uint32_t len, uint32_t L) {
-  uint32_t g = ts_g(t, id0);
-  for (uint32_t k = (uint32_t)lmw::lane(); k < len; k += 64) t.loc[g + k] = L;
-}
-
-LM_DEV void sp_set_loc_mask(Ts& t, const SpanRegs& R, uint64_t m, uint32_t L) {
+// loc[] := leaf L for every element of the items in the lanes with `pend` set.  The first LOC_SHORT elements of each item
+// are written by the item's own lane (one divergent loop for all items at once: an item-by-item walk cost ≈40 scalar
+// instructions per item and this kernel is scalar-issue bound); what lies beyond — long runs — is written 64 elements
+// per store by the whole wave, item by item.
+static constexpr uint32_t LOC_SHORT = 16;
+LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
+  uint32_t len = pend ? R.len : 0u;
+  uint32_t g = pend ? t.ebase[pid_peer(R.id)] + pid_ctr(R.id) : 0u;
+  uint32_t lim = len < LOC_SHORT ? len : LOC_SHORT;
+  for (uint32_t k = 0; k < lim; k++) t.loc[g + k] = L;
+  uint64_t m = lmw::ballot(len > LOC_SHORT);
   while (m) {
     int j = lmw::ffs64(m);
     m &= m - 1;
-    sp_set_loc(t, lmw::bcast(R.id, j), lmw::bcast(R.len, j), L);
+    uint32_t gj = lmw::bcast(g, j), lj = lmw::bcast(len, j);
+    for (uint32_t k = LOC_SHORT + (uint32_t)lmw::lane(); k < lj; k += 64) t.loc[gj + k] = L;
   }
 }
 // The cached leaf is write-back: an edit that stays inside it issues NO global store (on gfx9-class hardware stores share
@@ -100,8 +105,7 @@ LM_DEV void sp_set_loc_mask(Ts& t, const SpanRegs& R, uint64_t m, uint32_t L) {
 LM_DEV void sp_flush(Ts& t) {
   if (t.cache_leaf == NONE) return;
   if (t.dirty) { sp_write(t, t.cache_leaf, t.cr); t.dirty = false; }
-  uint64_t pend = lmw::ballot(t.loc_pend != 0);
-  if (pend) { sp_set_loc_mask(t, t.cr, pend, t.cache_leaf); t.loc_pend = 0; }
+  if (lmw::any(t.loc_pend != 0)) { sp_set_loc_lanes(t, t.cr, t.loc_pend != 0, t.cache_leaf); t.loc_pend = 0; }
 }
 // leaf L becomes the cached leaf (its registers are set by the caller); another cached leaf is written back first
 LM_DEV void sp_take(Ts& t, uint32_t L) {
@@ -222,7 +226,7 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
     if (idx >= 32) {
       // the edit goes to the upper half, which becomes the cached leaf; the lower half is written out
       sp_write(t, L, Lo);
-      sp_set_loc_mask(t, Lo, lmw::ballot(lp != 0) & 0xffffffffull, L);
+      sp_set_loc_lanes(t, Lo, (lp != 0) & (lane < 32), L);
       sd_refresh(t, p, L, Lo);
       if (pre != NONE) pre += lmw::first(t.db[p]);   // the new leaf starts behind the lower half
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
@@ -233,7 +237,7 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
       moved = true;
     } else {
       sp_write(t, NL, U);
-      sp_set_loc_mask(t, U, nu >= 64 ? ~0ull : ((1ull << nu) - 1), NL);
+      sp_set_loc_lanes(t, U, (uint32_t)lane < nu, NL);
       sd_insert_after(t, p, sa_make(NL, nu, sp_nf(U)), lmw::reduce_add(sp_alen(U)));
       if (t.err) { t.cache_leaf = NONE; t.cr.n = 255; t.dirty = false; t.loc_pend = 0; return; }
       R = Lo;
