@@ -363,7 +363,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   bool between = false;
   SpanRegs RR = R;
   {
-    uint64_t nf = lmw::ballot((uint32_t)lane >= idx && (uint32_t)lane < R.n && !(R.st & ST_FUT));
+    uint64_t nf = lmw::ballot(((uint32_t)lane >= idx) & !(R.st & ST_FUT));
     if (nf) {
       r_p = p; r_slot = (uint32_t)lmw::ffs64(nf);
       if (r_slot > idx) between = true;
@@ -379,7 +379,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
         if (r_p > p + 1) between = true;
         uint32_t a = lmw::first(t.da[r_p]);
         RR = sp_load(t, sa_leaf(a), sa_n(a));
-        uint64_t nf2 = lmw::ballot((uint32_t)lane < RR.n && !(RR.st & ST_FUT));
+        uint64_t nf2 = lmw::ballot(!(RR.st & ST_FUT));
         if (!nf2) { LM_SETERR(t.err, ST_INTERNAL); return; }
         r_slot = (uint32_t)lmw::ffs64(nf2);
         if (r_slot > 0) between = true;
@@ -406,7 +406,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       uint64_t contm;
       {
         uint32_t prev_last = lmw::shift_up(C.id + C.len - 1, 1);
-        contm = lmw::ballot((uint32_t)lane > ci && (uint32_t)lane < limit && C.ol == prev_last);
+        contm = lmw::ballot(((uint32_t)lane > ci) & ((uint32_t)lane < limit) & (C.ol == prev_last));
       }
       for (uint32_t h = ci; h < limit && !stop && !t.err; h++) {
         if ((contm >> h) & 1) {
@@ -421,8 +421,8 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
         if (o_ol != origin_left) {
           // is o_ol one of the in-between elements already passed?  (inside an item at a position in [cursor, (cp,h)))
           bool visited = false;
-          uint64_t here = lmw::ballot((uint32_t)lane < C.n && pid_peer(C.id) == pid_peer(o_ol) && sp_has(C.id, C.len, o_ol));
-          uint64_t in_r = cp != p ? lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == pid_peer(o_ol) && sp_has(R.id, R.len, o_ol)) : 0ull;
+          uint64_t here = sp_hit(C, o_ol);
+          uint64_t in_r = cp != p ? sp_hit(R, o_ol) : 0ull;
           if (o_ol == NONE) visited = false;
           else if (here) { uint32_t xs = (uint32_t)lmw::ffs64(here); visited = xs < h && (cp != p || xs >= idx); }
           else if (in_r) visited = (uint32_t)lmw::ffs64(in_r) >= idx;
@@ -442,9 +442,9 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
             uint32_t opr = NONE, o_p = NONE, o_s = 0;
             if (o_or != NONE) {
               uint32_t x_ol = NONE;
-              uint64_t hc = lmw::ballot((uint32_t)lane < C.n && pid_peer(C.id) == pid_peer(o_or) && sp_has(C.id, C.len, o_or));
-              uint64_t hr = (!hc && cp != p) ? lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == pid_peer(o_or) && sp_has(R.id, R.len, o_or)) : 0ull;
-              uint64_t hq = (!hc && !hr && r_p != NONE && r_p != cp && r_p != p) ? lmw::ballot((uint32_t)lane < RR.n && pid_peer(RR.id) == pid_peer(o_or) && sp_has(RR.id, RR.len, o_or)) : 0ull;
+              uint64_t hc = sp_hit(C, o_or);
+              uint64_t hr = (!hc && cp != p) ? sp_hit(R, o_or) : 0ull;
+              uint64_t hq = (!hc && !hr && r_p != NONE && r_p != cp && r_p != p) ? sp_hit(RR, o_or) : 0ull;
               if (hc) { o_s = (uint32_t)lmw::ffs64(hc); o_p = cp; x_ol = lmw::bcast(C.id, (int)o_s) == o_or ? lmw::bcast(C.ol, (int)o_s) : o_or - 1; }
               else if (hr) { o_s = (uint32_t)lmw::ffs64(hr); o_p = p; x_ol = lmw::bcast(R.id, (int)o_s) == o_or ? lmw::bcast(R.ol, (int)o_s) : o_or - 1; }
               else if (hq) { o_s = (uint32_t)lmw::ffs64(hq); o_p = r_p; x_ol = lmw::bcast(RR.id, (int)o_s) == o_or ? lmw::bcast(RR.ol, (int)o_s) : o_or - 1; }
@@ -455,7 +455,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
                 uint32_t xp = sd_find_leaf(t, xl);
                 if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
                 SpanRegs X = sp_load(t, xl, sa_n(lmw::first(t.da[xp])));
-                uint64_t xm = lmw::ballot((uint32_t)lane < X.n && pid_peer(X.id) == pid_peer(o_or) && sp_has(X.id, X.len, o_or));
+                uint64_t xm = sp_hit(X, o_or);
                 if (!xm) { LM_SETERR(t.err, ST_INTERNAL); break; }
                 o_s = (uint32_t)lmw::ffs64(xm); o_p = xp;
                 x_ol = lmw::bcast(X.id, (int)o_s) == o_or ? lmw::bcast(X.ol, (int)o_s) : o_or - 1;
@@ -582,7 +582,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     uint32_t p;
     SpanRegs R;
     uint64_t hm = 0;
-    if (t.cache_leaf != NONE) hm = lmw::ballot((uint32_t)lane < t.cr.n && pid_peer(t.cr.id) == peer && sp_has(t.cr.id, t.cr.len, x));
+    if (t.cache_leaf != NONE) hm = sp_hit(t.cr, x);
     if (hm) { R = t.cr; p = t.cache_p; }
     else if (hint_k && c == c0 && hint_k <= t.tot_active) {
       uint32_t k = hint_k;
@@ -593,7 +593,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
         lmw::wave_sync();
         uint32_t a = lmw::first(t.da[p]);
         R = sp_load(t, sa_leaf(a), sa_n(a));
-        hm = lmw::ballot((uint32_t)lane < R.n && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
+        hm = sp_hit(R, x);
         if (hm) { sp_take(t, sa_leaf(a)); t.cache_p = p; t.cache_pre = hint_k - k; t.cr = R; }
       }
     }
@@ -612,7 +612,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       bool in = (uint32_t)lane < R.n;
       R.id = in ? xid : NONE; R.len = in ? xln : 0u; R.ol = in ? xol : NONE; R.orr = in ? xor_ : NONE; R.st = in ? xst : ST_FUT;
       sp_take(t, lf); t.cache_p = p; t.cache_pre = NONE; t.cr = R;
-      hm = lmw::ballot(in && pid_peer(R.id) == peer && sp_has(R.id, R.len, x));
+      hm = sp_hit(R, x);
       if (!hm) { c++; continue; }
     }
     if (p == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
@@ -629,9 +629,9 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= endc - c;
     lmw::wave_sync();
     uint32_t L = sa_leaf(lmw::first(t.da[p]));
-    if (s_off == 0 && tail == 0) {
+    if ((s_off | tail) == 0) {
       // the whole run: one status word
-      if ((uint32_t)lane == slot) R.st = st1;
+      R.st = (uint32_t)lane == slot ? st1 : R.st;
       t.cr.st = R.st; t.dirty = true;   // (R is the cached leaf: either it was, or the lookup above made it so)
       sd_refresh(t, p, L, R);
     } else {
@@ -639,12 +639,12 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       SpanItem A, B;
       uint32_t cnt, idx = slot + 1;
       if (s_off > 0) {
-        if ((uint32_t)lane == slot) R.len = s_off;
+        R.len = (uint32_t)lane == slot ? s_off : R.len;
         A.id = x; A.len = endc - c; A.ol = x - 1; A.orr = orr0; A.st = st1;
         B.id = pid_make(peer, endc); B.len = tail; B.ol = B.id - 1; B.orr = orr0; B.st = st0;
         cnt = tail ? 2u : 1u;
       } else {
-        if ((uint32_t)lane == slot) { R.len = endc - c; R.st = st1; }
+        R.len = (uint32_t)lane == slot ? endc - c : R.len; R.st = (uint32_t)lane == slot ? st1 : R.st;
         A.id = pid_make(peer, endc); A.len = tail; A.ol = A.id - 1; A.orr = orr0; A.st = st0;
         B = A;
         cnt = 1;
@@ -670,8 +670,9 @@ LM_DEV void rw_open(RowWin& w, const uint32_t* op_w, uint32_t first, uint32_t li
   w.nxt = rw_load(op_w, first + 8, lim);
 }
 LM_DEV OpRow rw_get(RowWin& w, const uint32_t* op_w, uint32_t row) {
-  if (row >= w.base + 16 || row < w.base) rw_open(w, op_w, row, w.lim);
-  else if (row >= w.base + 8) { w.base += 8; w.cur = w.nxt; w.nxt = rw_load(op_w, w.base + 8, w.lim); }
+  uint32_t ahead = row - w.base;   // (a row below the window wraps to a huge value)
+  if (ahead >= 16) rw_open(w, op_w, row, w.lim);
+  else if (ahead >= 8) { w.base += 8; w.cur = w.nxt; w.nxt = rw_load(op_w, w.base + 8, w.lim); }
   int j = (int)(row - w.base) * 8;
   OpRow r;
   r.cidx_kind = lmw::bcast(w.cur, j); r.prop = (int32_t)lmw::bcast(w.cur, j + 1); r.len = lmw::bcast(w.cur, j + 2); r.ctr = lmw::bcast(w.cur, j + 3);
