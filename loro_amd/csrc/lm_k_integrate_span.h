@@ -101,11 +101,16 @@ LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
 }
 // The cached leaf is write-back: an edit that stays inside it issues NO global store (on gfx9-class hardware stores share
 // the load counter, so a store per edit makes the next op-row fetch wait a full write round trip).  HBM and loc[] catch up
-// when another leaf takes the cache, before a sibling scan (which reads loc[] and other leaves) and at the end of the replay.
+// when another leaf takes the cache and at the end of the replay; a sibling scan that must read loc[] writes the pending loc[]
+// entries first (sp_flush_loc).
 LM_DEV void sp_flush(Ts& t) {
   if (t.cache_leaf == NONE) return;
   if (t.dirty) { sp_write(t, t.cache_leaf, t.cr); t.dirty = false; }
   if (lmw::any(t.loc_pend != 0)) { sp_set_loc_lanes(t, t.cr, t.loc_pend != 0, t.cache_leaf); t.loc_pend = 0; }
+}
+// only the pending loc[] entries (before a loc[] read that may concern an item of the cached leaf); the leaf stays cached
+LM_DEV void sp_flush_loc(Ts& t) {
+  if (t.cache_leaf != NONE && lmw::any(t.loc_pend != 0)) { sp_set_loc_lanes(t, t.cr, t.loc_pend != 0, t.cache_leaf); t.loc_pend = 0; }
 }
 // leaf L becomes the cached leaf (its registers are set by the caller); another cached leaf is written back first
 LM_DEV void sp_take(Ts& t, uint32_t L) {
@@ -390,7 +395,8 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   PROF_ADD(t, PF_ORIGHT);
   uint32_t ins_p = p, ins_idx = idx;
   if (between) {
-    sp_flush(t);   // the scan reads loc[] and other leaves from HBM
+    // (the scan reads other leaves through sp_load, which serves the cached leaf from its registers; where it reads loc[],
+    // the cached leaf's pending entries are written first — the leaf itself stays cached across the scan)
     // sibling scan over the future ITEMS between the cursor and origin_right (crdt_rope.rs:156-237); the elements inside a
     // run are continuations by construction, so every item is examined exactly once through its first element
     bool parent_right = origin_right != NONE && r_ol == origin_left;
@@ -428,6 +434,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
           else if (in_r) visited = (uint32_t)lmw::ffs64(in_r) >= idx;
           else if (pid_ctr(o_ol) < t.cur[pid_peer(o_ol)]) visited = false;   // inside the tracker's version: not future
           else {
+            sp_flush_loc(t);
             lmw::wave_sync();
             uint32_t xl = t.loc[ts_g(t, o_ol)];
             if (xl < t.n_leaf) { uint32_t xp = sd_find_leaf(t, xl); visited = xp != NONE && xp > p && xp < cp; }
@@ -449,6 +456,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
               else if (hr) { o_s = (uint32_t)lmw::ffs64(hr); o_p = p; x_ol = lmw::bcast(R.id, (int)o_s) == o_or ? lmw::bcast(R.ol, (int)o_s) : o_or - 1; }
               else if (hq) { o_s = (uint32_t)lmw::ffs64(hq); o_p = r_p; x_ol = lmw::bcast(RR.id, (int)o_s) == o_or ? lmw::bcast(RR.ol, (int)o_s) : o_or - 1; }
               else {
+                sp_flush_loc(t);
                 lmw::wave_sync();
                 uint32_t xl = t.loc[ts_g(t, o_or)];
                 if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
