@@ -85,7 +85,10 @@ LM_DEV uint64_t sp_hit(const SpanRegs& R, uint32_t x) { return lmw::ballot(x - R
 // are written by the item's own lane (one divergent loop for all items at once: an item-by-item walk cost ≈40 scalar
 // instructions per item and this kernel is scalar-issue bound); what lies beyond — long runs — is written 64 elements
 // per store by the whole wave, item by item.
-static constexpr uint32_t LOC_SHORT = 16;
+#ifndef LM_LOC_SHORT
+#define LM_LOC_SHORT 16
+#endif
+static constexpr uint32_t LOC_SHORT = LM_LOC_SHORT;
 LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
   uint32_t len = pend ? R.len : 0u;
   uint32_t g = pend ? t.ebase[pid_peer(R.id)] + pid_ctr(R.id) : 0u;
@@ -583,9 +586,11 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   if (c >= c1) return;
   uint32_t eb = t.ebase[peer];
   if (c1 > t.end[peer]) c1 = t.end[peer];   // a damaged target range cannot make the walk longer than the peer's history
+  bool tried = true;   // the in-leaf path has just declined this very element
   for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
     lmw::wave_sync();
-    if (ts_update_fast(t, peer, c, c1, mode)) { PROF_CNT(t, PF_LEAF, 1); continue; }
+    if (!tried && ts_update_fast(t, peer, c, c1, mode)) { PROF_CNT(t, PF_LEAF, 1); continue; }
+    tried = false;
     uint32_t x = pid_make(peer, c);
     uint32_t p;
     SpanRegs R;
