@@ -291,9 +291,9 @@ LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     cnt = 2;
   } else {
     uint64_t nf = lmw::ballot(((uint32_t)lane >= idx) & !(t.cr.st & ST_FUT));
-    if (!nf || (uint32_t)lmw::ffs64(nf) != idx) return false;   // origin_right in another leaf, or future items in between
+    if (!((nf >> idx) & 1)) return false;   // origin_right in another leaf, or future items in between (nf has no bit below idx)
     A.orr = lmw::bcast(t.cr.id, (int)idx);
-    if (v_st == 0 && sid + sln == pid0 && pid_peer(sid) == pid_peer(pid0) && v_or == A.orr) {
+    if ((v_st | (sid + sln - pid0) | ((sid ^ pid0) >> 24) | (v_or ^ A.orr)) == 0) {
       // run merging (FugueSpan::is_mergeable): the item grows
       t.cr.len = (uint32_t)lane == slot ? sln + len : t.cr.len;
       t.loc_pend = (uint32_t)lane == slot ? 1u : t.loc_pend;
@@ -417,7 +417,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
         uint32_t prev_last = lmw::shift_up(C.id + C.len - 1, 1);
         contm = lmw::ballot(((uint32_t)lane > ci) & ((uint32_t)lane < limit) & (C.ol == prev_last));
       }
-      for (uint32_t h = ci; h < limit && !stop && !t.err; h++) {
+      for (uint32_t h = ci; h < limit; h++) {   // (every `stop` / error leaves through a break)
         if ((contm >> h) & 1) {
           uint64_t rest = ~contm >> h;
           uint32_t e = rest ? h + (uint32_t)lmw::ffs64(rest) : limit;   // first item at/after h that is not a continuation (bits at and beyond `limit` are clear)
