@@ -483,26 +483,28 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
   }
 }
 
-// cooperative UTF-8 → scalars of ONE long string: 61 bytes per step with coalesced loads; scalar boundaries come
-// from a ballot over the lead bytes and each lead lane assembles its scalar from the following lanes
-LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint64_t nbytes, uint64_t e0, uint32_t len) {
-  int lane = lmw::lane();
+// cooperative UTF-8 → scalars of ONE long string with coalesced loads: 64 bytes per step while the text is ASCII (byte =
+// scalar, no lane traffic), otherwise 61 — a scalar spans at most 4 bytes, so a lead byte below lane 61 has its tail loaded;
+// scalar boundaries come from a ballot over the lead bytes and each lead lane assembles its scalar from the following lanes.
+// (32-bit offsets: a value is shorter than its blob, and a blob shorter than 4 GiB.)
+LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint32_t nbytes, uint64_t e0, uint32_t len) {
+  uint32_t lane = (uint32_t)lmw::lane();
   bool bad = false;
   uint32_t n = 0;  // scalars emitted so far
-  // a scalar spans at most 4 bytes: advance 61 bytes per step so a lead byte below lane 61 has its tail loaded
-  for (uint64_t c = 0; c < nbytes; c += 61) {
-    uint64_t i = c + (uint64_t)lane;
-    uint32_t b = i < nbytes ? s[i] : 0x80u;
-    bool last_chunk = c + 61 >= nbytes;
-    bool mine = i < nbytes && (last_chunk || lane < 61);   // this lane's byte belongs to this step
-    if (!lmw::ballot(mine && b >= 0x80)) {
-      // an all-ASCII step: byte = scalar, no lane permutes
-      if (mine && n + (uint32_t)lane < len) d.cp[e0 + n + (uint32_t)lane] = b;
-      n += (uint32_t)lmw::popc64(lmw::ballot(mine));
+  for (uint32_t c = 0; c < nbytes;) {
+    uint32_t i = c + lane;
+    bool inb = i < nbytes;
+    uint32_t b = inb ? s[i] : 0u;
+    if (!lmw::ballot(b >= 0x80)) {
+      if (inb & (n + lane < len)) d.cp[e0 + n + lane] = b;
+      uint32_t took = nbytes - c < 64 ? nbytes - c : 64u;
+      n += took; c += 64;
       continue;
     }
-    bool lead = i < nbytes && (b & 0xC0) != 0x80 && (last_chunk || lane < 61);
-    uint32_t b1 = lmw::shfl(b, (lane + 1) & 63), b2 = lmw::shfl(b, (lane + 2) & 63), b3 = lmw::shfl(b, (lane + 3) & 63);
+    bool last_chunk = c + 61 >= nbytes;
+    bool mine = inb & (last_chunk | (lane < 61));   // this lane's byte belongs to this step
+    bool lead = mine & ((b & 0xC0) != 0x80);
+    uint32_t b1 = lmw::shfl(b, (int)((lane + 1) & 63)), b2 = lmw::shfl(b, (int)((lane + 2) & 63)), b3 = lmw::shfl(b, (int)((lane + 3) & 63));
     uint64_t lm_ = lmw::ballot(lead);
     uint32_t rank = (uint32_t)lmw::popc64(lm_ & ((1ull << lane) - 1));
     if (lead) {
@@ -516,10 +518,11 @@ LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint64_t nbytes, uint
       if (extra >= 1 && (b1 & 0xC0) != 0x80) bad = true;
       if (extra >= 2 && (b2 & 0xC0) != 0x80) bad = true;
       if (extra >= 3 && (b3 & 0xC0) != 0x80) bad = true;
-      if ((uint32_t)lane + extra > 63) bad = true;  // cannot happen: leads above lane 60 only exist in the last chunk
+      if (lane + extra > 63) bad = true;  // cannot happen: leads above lane 60 only exist in the last chunk
       if (n + rank < len) d.cp[e0 + n + rank] = cpv;
     }
     n += (uint32_t)lmw::popc64(lm_);
+    c += 61;
   }
   return lmw::any(bad) || n != len;
 }

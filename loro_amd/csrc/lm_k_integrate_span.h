@@ -193,8 +193,14 @@ LM_DEV SpanRegs sp_shift_in(const SpanRegs& R, uint32_t& lp, uint32_t idx, const
   SpanRegs N;
   N.n = R.n + cnt;
   uint32_t pid, pln, pol, por, pst, plp;
-  if (cnt == 2) { pid = lmw::shift_up0(R.id, 2); pln = lmw::shift_up0(R.len, 2); pol = lmw::shift_up0(R.ol, 2); por = lmw::shift_up0(R.orr, 2); pst = lmw::shift_up0(R.st, 2); plp = lmw::shift_up0(lp, 2); }
-  else { pid = lmw::shift_up0(R.id, 1); pln = lmw::shift_up0(R.len, 1); pol = lmw::shift_up0(R.ol, 1); por = lmw::shift_up0(R.orr, 1); pst = lmw::shift_up0(R.st, 1); plp = lmw::shift_up0(lp, 1); }
+  // (no branch on cnt: both shifts are computed and a select picks — vector work instead of scalar control)
+  pid = lmw::shift_up0(R.id, 1); pln = lmw::shift_up0(R.len, 1); pol = lmw::shift_up0(R.ol, 1); por = lmw::shift_up0(R.orr, 1); pst = lmw::shift_up0(R.st, 1); plp = lmw::shift_up0(lp, 1);
+  {
+    bool two = cnt == 2;
+    uint32_t q;
+    q = lmw::shift_up0(pid, 1); pid = two ? q : pid;  q = lmw::shift_up0(pln, 1); pln = two ? q : pln;  q = lmw::shift_up0(pol, 1); pol = two ? q : pol;
+    q = lmw::shift_up0(por, 1); por = two ? q : por;  q = lmw::shift_up0(pst, 1); pst = two ? q : pst;  q = lmw::shift_up0(plp, 1); plp = two ? q : plp;
+  }
   uint32_t inh = idx ? lmw::bcast(lp, (int)idx - 1) : 0u;
   bool sh = lane >= idx + cnt, isA = lane == idx, isB = (cnt == 2) & (lane == idx + 1);
   N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
