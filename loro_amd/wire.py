@@ -236,7 +236,7 @@ class ContainerValue:
 class Op:
     cid: CID
     counter: int
-    kind: str  # text_insert | delete | style_start | style_end | list_insert | map_set | map_delete
+    kind: str  # text_insert | delete | style_start | style_end | list_insert | map_set | map_delete | list_move | list_set
     pos: int = 0
     text: str = ""  # text_insert
     values: Optional[list] = None  # list_insert
@@ -246,6 +246,8 @@ class Op:
     signed_len: int = 0  # delete
     mark_len: int = 0  # style_start
     mark_info: int = 0x80
+    elem: Tuple[int, int] = (0, 0)  # list_move / list_set: the MovableList element (peer, lamport)
+    move_from: int = 0  # list_move: source position (pos = destination)
 
     @property
     def atom_len(self) -> int:
@@ -393,6 +395,14 @@ def encode_block(changes: List[Change]) -> bytes:
             elif op.kind == "map_delete":
                 col_prop.append(keys.get(op.key))
                 col_vt.append(8)
+            elif op.kind == "list_move":   # docs/encoding.md §10.5
+                col_prop.append(op.pos)
+                col_vt.append(14)
+                values += uleb(op.move_from) + uleb(peers.get(op.elem[0])) + uleb(op.elem[1])
+            elif op.kind == "list_set":
+                col_prop.append(0)
+                col_vt.append(15)
+                values += uleb(peers.get(op.elem[0])) + uleb(op.elem[1]) + _enc_value(op.value, keys)
             else:
                 raise ValueError(op.kind)
             col_len.append(op.atom_len)
@@ -687,6 +697,113 @@ class Replica:
     def map_delete(self, name: str, key: str):
         cid = self._cid(name, KIND_MAP)
         self._push(Op(cid, self._alloc(1), "map_delete", key=key))
+
+    # -- movable list (handler.rs:3528-4000; state/movable_list_state.rs).  self.seq[cid] holds the ids of the list ITEMS
+    # alive at this replica's version in op-index order — the items no element points at any more (losers of concurrent
+    # moves) included; the user addresses ELEMENTS, i.e. the items some element points at.
+    def _ml_index(self, cid: CID):
+        """item id -> element (peer, lamport), element -> id of the item it points at (greatest move by (lamport, peer),
+        else its insert) over every op this replica knows."""
+        item_elem: Dict[Tuple[int, int], Tuple[int, int]] = {}
+        best: Dict[Tuple[int, int], Tuple[int, int, Tuple[int, int]]] = {}
+
+        def visit(peer, lam0, ctr0, ops):
+            for o in ops:
+                if o.cid != cid:
+                    continue
+                lam = lam0 + (o.counter - ctr0)
+                if o.kind == "list_insert":
+                    for i in range(len(o.values)):
+                        e = (peer, lam + i)
+                        item_elem[(peer, o.counter + i)] = e
+                        cand = (lam + i, peer, (peer, o.counter + i))
+                        if e not in best or best[e][:2] < cand[:2]:
+                            best[e] = cand
+                elif o.kind == "list_move":
+                    item_elem[(peer, o.counter)] = o.elem
+                    cand = (lam, peer, (peer, o.counter))
+                    if o.elem not in best or best[o.elem][:2] < cand[:2]:
+                        best[o.elem] = cand
+
+        for p, chs in self.changes.items():
+            for c in chs:
+                visit(p, c.lamport, c.counter, c.ops)
+        if self.pending_ops:
+            first = self.pending_ops[0].counter
+            lam = 0
+            for (p, ctr) in self.frontiers:
+                lam = max(lam, self._lamport_of_id(p, ctr) + 1)
+            visit(self.peer, lam, first, self.pending_ops)
+        return item_elem, {e: b[2] for e, b in best.items()}
+
+    def mlist_elements(self, name) -> List[Tuple[int, Tuple[int, int], Tuple[int, int]]]:
+        """[(op index, item id, element)] of the items an element points at, in list order (= the user's view)."""
+        cid = self._cid(name, KIND_MOVABLE)
+        item_elem, pos = self._ml_index(cid)
+        out = []
+        for i, it in enumerate(self.seq.setdefault(cid, [])):
+            e = item_elem.get(it)
+            if e is not None and pos.get(e) == it:
+                out.append((i, it, e))
+        return out
+
+    def mlist_len(self, name) -> int:
+        return len(self.mlist_elements(name))
+
+    def _ml_op_index(self, cid: CID, elems, user_pos: int) -> int:  # convert_index(ForUser -> ForOp), movable_list_state.rs:855-876
+        return len(self.seq[cid]) if user_pos == len(elems) else elems[user_pos][0]
+
+    def mlist_insert(self, name, pos: int, values: list):
+        cid = self._cid(name, KIND_MOVABLE)
+        for k, v in enumerate(values):   # one op per value (handler.rs:3552-3585); RleVec merging fuses contiguous ones
+            elems = self.mlist_elements(cid)
+            assert 0 <= pos + k <= len(elems)
+            at = self._ml_op_index(cid, elems, pos + k)
+            c0 = self._alloc(1)
+            self._push(Op(cid, c0, "list_insert", pos=at, values=[v]))
+            self.seq[cid].insert(at, (self.peer, c0))
+
+    def mlist_insert_container(self, name, pos: int, kind: int) -> CID:
+        cid = self._cid(name, KIND_MOVABLE)
+        c0 = self.next_counter
+        self.mlist_insert(cid, pos, [ContainerValue(kind)])
+        return CID(False, kind, "", self.peer, c0)
+
+    def mlist_delete(self, name, pos: int, n: int):
+        """handler.rs:3918-3959: one single-item delete per element, positions computed up front."""
+        cid = self._cid(name, KIND_MOVABLE)
+        elems = self.mlist_elements(cid)
+        assert 0 <= pos and pos + n <= len(elems)
+        plan = [(elems[u][1], elems[u][0] - (u - pos)) for u in range(pos, pos + n)]
+        for item, at in plan:
+            assert self.seq[cid][at] == item
+            c0 = self._alloc(1)
+            self._push(Op(cid, c0, "delete", pos=at, del_id=item, signed_len=1))
+            del self.seq[cid][at]
+
+    def mlist_move(self, name, frm: int, to: int):
+        """handler.rs:3616-3665 + tracker.rs:289-347: the element's item is deleted, a new item (this op's id) inserted."""
+        cid = self._cid(name, KIND_MOVABLE)
+        if frm == to:
+            return
+        elems = self.mlist_elements(cid)
+        assert 0 <= frm < len(elems) and 0 <= to < len(elems)
+        op_from, op_to, elem = elems[frm][0], elems[to][0], elems[frm][2]
+        c0 = self._alloc(1)
+        self._push(Op(cid, c0, "list_move", pos=op_to, move_from=op_from, elem=elem))
+        del self.seq[cid][op_from]
+        self.seq[cid].insert(op_to, (self.peer, c0))
+
+    def mlist_set(self, name, index: int, value: Any):
+        cid = self._cid(name, KIND_MOVABLE)
+        elems = self.mlist_elements(cid)
+        assert 0 <= index < len(elems)
+        self._push(Op(cid, self._alloc(1), "list_set", elem=elems[index][2], value=value))
+
+    def mlist_set_container(self, name, index: int, kind: int) -> CID:
+        c0 = self.next_counter
+        self.mlist_set(name, index, ContainerValue(kind))
+        return CID(False, kind, "", self.peer, c0)
 
     # -- commit / exchange
     def commit(self, msg: Optional[str] = None):

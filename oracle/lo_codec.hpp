@@ -390,7 +390,8 @@ inline Value read_loro_value(Reader& r, const DecodeArena& a, ID id, int depth, 
 
 // ---------------------------------------------------------------- ops / changes
 enum OpKind : uint8_t {
-  OP_TEXT_INSERT, OP_SEQ_DELETE, OP_STYLE_START, OP_STYLE_END, OP_LIST_INSERT, OP_MAP_SET, OP_MAP_DELETE, OP_OTHER
+  OP_TEXT_INSERT, OP_SEQ_DELETE, OP_STYLE_START, OP_STYLE_END, OP_LIST_INSERT, OP_MAP_SET, OP_MAP_DELETE, OP_OTHER,
+  OP_LIST_MOVE, OP_LIST_SET   // MovableList (docs/encoding.md §10.5; outdated_encode_reordered.rs:388-459)
 };
 struct Op {
   uint32_t container;  // index into Doc-level container table after registration (filled by caller)
@@ -407,9 +408,13 @@ struct Op {
   uint32_t style_end = 0;
   // list insert
   std::vector<Value> values;
-  // map
+  // map (and the value of a MovableList set)
   std::string key;
   Value value;
+  // MovableList move / set: the element addressed (IdLp = peer + lamport), move: the source position (prop = destination)
+  PeerID elem_peer = 0;
+  Lamport elem_lamport = 0;
+  uint32_t move_from = 0;
 };
 struct Change {
   ID id;
@@ -680,6 +685,7 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
     Value lv;
     bool have_lv = false;
     uint32_t mark_len = 0;
+    uint64_t mv_from = 0, mv_peer = 0, mv_lamport = 0;
     std::string str_payload;
     switch (vt) {
       case 0: case 1: case 2: case 8: case 9: break;
@@ -706,8 +712,8 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
         if (!is_null) (void)values_b.uleb();
         break;
       }
-      case 14: (void)values_b.uleb(); (void)values_b.uleb(); (void)values_b.uleb(); break;
-      case 15: (void)values_b.uleb(); (void)values_b.uleb(); (void)read_loro_value(values_b, arena, op_id, 0, true); break;
+      case 14: mv_from = values_b.uleb(); mv_peer = values_b.uleb(); mv_lamport = values_b.uleb(); break;   // ListMove (value.rs:342-459)
+      case 15: mv_peer = values_b.uleb(); mv_lamport = values_b.uleb(); lv = read_loro_value(values_b, arena, op_id, 0, true); have_lv = true; break;
       case 16: {
         (void)values_b.uleb(); (void)values_b.uleb(); (void)values_b.uleb();
         uint8_t is_null = values_b.u8();
@@ -752,9 +758,22 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
         } else if (vt == 9) take_del();
         else fail(ST_DATA_CORRUPTION, "bad list op value");
         break;
-      case CK_MOVABLE:
-        if (vt == 9) { take_del(); op.kind = OP_OTHER; }  // consumes a delete-start row (docs/encoding.md:855-859)
-        else op.kind = OP_OTHER;
+      case CK_MOVABLE:   // outdated_encode_reordered.rs:388-459
+        if (vt == 11 && have_lv) {
+          if (lv.kind != V_LIST) fail(ST_DATA_CORRUPTION, "movable list insert value not a list");
+          op.kind = OP_LIST_INSERT;
+          op.values = std::move(lv.list);
+        } else if (vt == 9) take_del();
+        else if (vt == 14 || (vt == 15 && have_lv)) {
+          if (mv_peer >= ctx.peers.size()) fail(ST_DATA_CORRUPTION, "movable list element peer idx");
+          if (mv_lamport > 0xFFFFFFFFull || mv_from > 0x7FFFFFFFull || prop < 0) fail(ST_DATA_CORRUPTION, "movable list element id");
+          // canonical invariant (docs/encoding.md §9.6): move / set rows are one atom long
+          if (col_len[row] != 1) fail(ST_DATA_CORRUPTION, "movable list move/set len");
+          op.elem_peer = ctx.peers[(size_t)mv_peer];
+          op.elem_lamport = (Lamport)mv_lamport;
+          if (vt == 14) { op.kind = OP_LIST_MOVE; op.move_from = (uint32_t)mv_from; }
+          else { op.kind = OP_LIST_SET; op.value = std::move(lv); }
+        } else fail(ST_DATA_CORRUPTION, "bad movable list op value");
         break;
       default: op.kind = OP_OTHER; break;
     }

@@ -15,6 +15,9 @@
 //   Map LWW                                          diff_calc.rs:515-538, delta/map_delta.rs:20-46, state/map_state.rs:240-292,438-449
 //   deep value / JSON                                state.rs:1294-1329, loro-common/src/value.rs:719-738
 //   VersionVector encode                             version.rs:962-964
+//   MovableList                                      diff_calc.rs:1669-1993 (move = delete + insert on the list tracker),
+//                                                    history_cache.rs:754-1003 (last_pos / last_value: LWW by (lamport, peer)),
+//                                                    state/movable_list_state.rs:953-964 (value = items an element points at)
 // The final state of a document is the same for every import order (CRDT convergence), so the oracle
 // materialises it the way the reference itself rebuilds a container whenever an import is concurrent
 // (diff_calc.rs:1615-1643): replay the container's ops from the empty version in a causal order and
@@ -90,11 +93,23 @@ inline void json_value(const Doc& d, const Value& v, std::string& out, int depth
 // ---------------------------------------------------------------- document
 struct StyleRec { PeerID peer; Counter cnt; uint32_t end; };
 
+struct IdLpKey {   // IdLp (loro-common/src/lib.rs:524-528): ordered by lamport, then peer
+  Lamport lamport; PeerID peer;
+  bool operator<(const IdLpKey& o) const { return lamport != o.lamport ? lamport < o.lamport : peer < o.peer; }
+  bool operator==(const IdLpKey& o) const { return lamport == o.lamport && peer == o.peer; }
+};
 struct SeqState {
   Tracker tr;
   std::vector<uint32_t> cps;      // text: unicode scalars; 0xFFFFFFFF = style anchor
   std::vector<Value> values;      // list
   std::vector<StyleRec> styles;
+  // MovableList: per list item (index = content index, parallel to `values`): its own IdLp and the element it positions
+  struct ItemRec { IdLpKey item, elem; };
+  std::vector<ItemRec> items;
+  std::map<IdLpKey, uint32_t> elem_init;   // element → content index of its insert (initial value)
+  std::map<IdLpKey, IdLpKey> pos_win;      // element → greatest move op inside the rendered version (last_pos)
+  struct ValWin { IdLpKey id; Value v; };
+  std::map<IdLpKey, ValWin> val_win;       // element → greatest set op inside the rendered version (last_value)
 };
 struct MapEntry { Lamport lamp; PeerID peer; bool has; Value v; };
 
@@ -151,7 +166,7 @@ struct Doc {
     uint32_t i = (uint32_t)containers.size();
     containers.push_back(c);
     container_idx[c] = i;
-    if (c.kind > CK_TEXT) unsupported = true;
+    if (c.kind > CK_TEXT && c.kind != CK_MOVABLE) unsupported = true;
     return i;
   }
 
@@ -416,7 +431,7 @@ struct Doc {
             m[op.key] = std::move(e);
             continue;
           }
-          if (cid.kind != CK_TEXT && cid.kind != CK_LIST) continue;
+          if (cid.kind != CK_TEXT && cid.kind != CK_LIST && cid.kind != CK_MOVABLE) continue;
           auto& sp = seqs[op.container];
           if (!sp) sp.reset(new SeqState());
           SeqState& st = *sp;
@@ -437,7 +452,39 @@ struct Doc {
             case OP_LIST_INSERT: {
               uint32_t start = (uint32_t)st.values.size();
               st.values.insert(st.values.end(), op.values.begin(), op.values.end());
+              if (cid.kind == CK_MOVABLE)   // every inserted value is a new element positioned by its own list item (diff_calc.rs:1708-1725)
+                for (size_t i = 0; i < op.values.size(); i++) {
+                  IdLpKey k{ch.lamport + (Lamport)(op.counter - ch.id.counter) + (Lamport)i, ch.id.peer};
+                  st.items.push_back(SeqState::ItemRec{k, k});
+                  st.elem_init[k] = start + (uint32_t)i;
+                }
               st.tr.insert(op_id, op.prop, (int32_t)op.values.size(), start);
+              break;
+            }
+            case OP_LIST_MOVE: {
+              if (cid.kind != CK_MOVABLE) break;
+              IdLpKey me{ch.lamport + (Lamport)(op.counter - ch.id.counter), ch.id.peer}, el{op.elem_lamport, op.elem_peer};
+              // the element must exist at the op's version ("moved element should have a visible source position",
+              // diff_calc.rs:1927-1931): a blob naming an element no insert produced is damaged
+              if (!st.elem_init.count(el)) fail(ST_DATA_CORRUPTION, "move of an unknown element");
+              uint32_t start = (uint32_t)st.values.size();
+              st.values.push_back(Value());
+              st.items.push_back(SeqState::ItemRec{me, el});
+              st.tr.move_item(op_id, op.move_from, op.prop, start);
+              if (in_target(ch.id.peer, op.counter)) {   // last_pos (history_cache.rs:949-1003)
+                auto it = st.pos_win.find(el);
+                if (it == st.pos_win.end() || it->second < me) st.pos_win[el] = me;
+              }
+              break;
+            }
+            case OP_LIST_SET: {
+              if (cid.kind != CK_MOVABLE) break;
+              IdLpKey me{ch.lamport + (Lamport)(op.counter - ch.id.counter), ch.id.peer}, el{op.elem_lamport, op.elem_peer};
+              if (!st.elem_init.count(el)) fail(ST_DATA_CORRUPTION, "set of an unknown element");
+              if (in_target(ch.id.peer, op.counter)) {   // last_value (history_cache.rs:865-947)
+                auto it = st.val_win.find(el);
+                if (it == st.val_win.end() || it->second.id < me) st.val_win[el] = SeqState::ValWin{me, op.value};
+              }
               break;
             }
             case OP_SEQ_DELETE: {
@@ -483,6 +530,10 @@ struct Doc {
     for (auto& kv : seqs) {
       kv.second->tr.checkout(vv);
       if (kv.second->tr.active_len() > 0) seq_exists.insert(kv.first);
+      // MovableList: the diff also lists every element the version knows (MovableListInnerDelta::is_empty,
+      // delta/movable_list.rs:32-34; diff_calc.rs:1880-1924 keeps an element whose insert lies inside the version), so the
+      // state exists once one element was inserted — even if it was deleted again
+      if (containers[kv.first].kind == CK_MOVABLE && !kv.second->elem_init.empty()) seq_exists.insert(kv.first);
     }
     for (auto& kv : seqs) {
       kv.second->tr.checkout(target);   // tracker.rs:354-461: ops outside the version become future / un-deleted
@@ -523,6 +574,28 @@ struct Doc {
               json_value(*this, it->second->values[sp->content + (uint32_t)k], out, depth + 1);
             }
       out.push_back(']');
+    } else if (cid.kind == CK_MOVABLE) {
+      // movable_list_state.rs:953-964: the list items some element points at, in list order, each showing the element's value
+      out.push_back('[');
+      bool first = true;
+      auto it = seqs.find(idx);
+      if (it != seqs.end()) {
+        const SeqState& st = *it->second;
+        for (Span* sp = st.tr.head; sp; sp = sp->next)
+          if (sp->active())
+            for (int32_t k = 0; k < sp->len; k++) {
+              size_t ci = (size_t)sp->content + (uint32_t)k;
+              if (ci >= st.items.size()) fail(ST_DATA_CORRUPTION, "visible span without content");
+              const SeqState::ItemRec& rec = st.items[ci];
+              auto pw = st.pos_win.find(rec.elem);
+              if (!((pw == st.pos_win.end() ? rec.elem : pw->second) == rec.item)) continue;   // not the element's current position
+              auto vw = st.val_win.find(rec.elem);
+              if (!first) out.push_back(',');
+              first = false;
+              json_value(*this, vw != st.val_win.end() ? vw->second.v : st.values[st.elem_init.at(rec.elem)], out, depth + 1);
+            }
+      }
+      out.push_back(']');
     } else if (cid.kind == CK_MAP) {
       out.push_back('{');
       bool first = true;
@@ -546,7 +619,7 @@ struct Doc {
     std::map<std::string, uint32_t> roots;
     for (uint32_t i = 0; i < containers.size(); i++) {
       if (!containers[i].root || !touched.count(i)) continue;
-      if ((containers[i].kind == CK_TEXT || containers[i].kind == CK_LIST) && !seq_exists.count(i)) continue;
+      if ((containers[i].kind == CK_TEXT || containers[i].kind == CK_LIST || containers[i].kind == CK_MOVABLE) && !seq_exists.count(i)) continue;
       if (roots.count(containers[i].name)) fail(ST_UNSUPPORTED, "two root containers share a name");
       roots[containers[i].name] = i;
     }
@@ -635,7 +708,7 @@ inline void json_value(const Doc& d, const Value& v, std::string& out, int depth
         // child container that never received an op: empty value of its kind (state.rs:1550-1616)
         if (v.cid.kind == CK_TEXT) out += "\"\"";
         else if (v.cid.kind == CK_MAP) out += "{}";
-        else if (v.cid.kind == CK_LIST) out += "[]";
+        else if (v.cid.kind == CK_LIST || v.cid.kind == CK_MOVABLE) out += "[]";
         else { out += "null"; d.unsupported = true; }   // Tree / MovableList / Counter child: outside the scope
       } else d.container_json(it->second, out, depth + 1);
       break;

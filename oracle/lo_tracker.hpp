@@ -73,6 +73,7 @@ struct Tracker {
     Span* span;       // insert: the span whose ids start at the key
     ID target;        // delete: leftmost target id of this piece
     bool reversed;    // delete: op offset j deletes target + (len-1-j)
+    bool is_move = false;   // MovableList move (Cursor::new_move, id_to_cursor.rs): an insert entry whose op ALSO deleted `target`
   };
   std::unordered_map<PeerID, std::map<Counter, Entry>> index;  // id_to_cursor
 
@@ -334,6 +335,28 @@ struct Tracker {
     bump(applied_vv, op_id.peer, op_id.counter + len);
   }
 
+  // ------------------------------------------------------------ move (tracker.rs:289-347: MovableList)
+  // The element's current list item — the active item at `from` — is deleted and a new item with the op's id is inserted
+  // at `to` (evaluated after the deletion); retreating / forwarding the op undoes / redoes both halves.
+  void move_item(ID op_id, int64_t from, int64_t to, uint32_t content) {
+    if (from < 0 || from >= total_active) fail(ST_DATA_CORRUPTION, "move source beyond the end");
+    Cursor c = find_prefer_right(from);
+    Span* s = c.s;
+    int32_t off = c.off;
+    while (s && (!s->active() || off >= s->len)) { s = s->next; off = 0; }
+    if (!s) fail(ST_DATA_CORRUPTION, "move source beyond the end");
+    if (off > 0) s = split(s, off);
+    if (s->len > 1) split(s, 1);
+    add_active(s, -1);
+    s->del += 1;
+    ID target = s->id;
+    if (to < 0 || to > total_active) fail(ST_DATA_CORRUPTION, "move destination beyond the end");
+    insert(op_id, to, 1, content);
+    Entry& e = index[op_id.peer][op_id.counter];
+    e.is_move = true;
+    e.target = target;
+  }
+
   // ------------------------------------------------------------ checkout (tracker.rs:354-546)
   // apply a status change to the inserted ids [c0,c1) of `peer` (crdt_rope.rs:345-381)
   void update_ids(PeerID peer, Counter c0, Counter c1, int set_future /* -1 none, 0, 1 */, int del_diff) {
@@ -380,7 +403,10 @@ struct Tracker {
       if (a >= b) continue;
       items.push_back(Item{it->second.is_del, (Counter)(a - k), (Counter)(b - k), it->second.target, it->second.reversed,
                            it->second.len});
-      if (!it->second.is_del) { items.back().target = ID{peer, k}; }
+      if (!it->second.is_del) {
+        items.back().target = ID{peer, k};
+        if (it->second.is_move) items.push_back(Item{true, 0, 1, it->second.target, false, 1});   // the move's deleted source item
+      }
     }
     for (auto& x : items) {
       if (!x.is_del) {
