@@ -43,8 +43,10 @@ enum {
 
 /* Limits of the device path.  A document beyond one of them is reported LM_UNSUPPORTED — never a guessed value — and
  * does not disturb the other documents of the batch (tests: `documented_limits_are_reported_not_guessed`, emu + GPU):
- *   - container kinds: Map, List, Text (root or child).  A document that also holds Tree / MovableList / Counter
- *     containers is rendered with those as null and reported LM_UNSUPPORTED *together with* its JSON and VV;
+ *   - container kinds: Map, List, Text, MovableList (root or child; MovableList: insert / delete / move / set, per-element
+ *     last-writer-wins of position and value — diff_calc.rs:1669-1993, history_cache.rs:754-1003).  A document that also
+ *     holds Tree / Counter containers is rendered with those as null and reported LM_UNSUPPORTED *together with* its JSON
+ *     and VV;
  *   - blobs: EncodeMode::FastUpdates (mode 4) and FastSnapshot (mode 3).  A snapshot is ingested on the host in front of
  *     the device path: its history from the ChangeStore section (replayed like updates, fast_snapshot.rs:326-344), the set
  *     of root containers from the keys of its state section (an empty document initialises its state store from that
@@ -52,7 +54,7 @@ enum {
  *     VALUES are not read.  The first snapshot among a document's blobs plays that role (import_batch imports snapshots
  *     first).  Shallow snapshots (history trimmed below a shallow root) are LM_UNSUPPORTED;
  *   - per document: <= 255 peers, <= 256 containers of which <= 64 roots, container nesting <= 16, counters < 2^24 per
- *     peer (element ids are packed peer:8 | counter:24), < 2^24 Map op rows, <= 18,000 tracker leaves per sequence
+ *     peer (element ids are packed peer:8 | counter:24), < 2^24 Map / MovableList move+set op rows, <= 18,000 tracker leaves per sequence
  *     replay (~190k op runs; the 1M-op documents of BASELINE configs[4] use ~1,200), JSON < 4 GiB, a blob < 4 GiB;
  *   - two root containers with the same name but different kinds; a StyleEnd op that does not directly follow its
  *     StyleStart (every writer emits them as a pair).  */

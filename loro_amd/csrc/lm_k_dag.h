@@ -158,7 +158,7 @@ LM_KERNEL void k_remap(Dev d, uint32_t n_ops, uint32_t n_chg) {
       uint32_t local = r.cidx_kind & 0xffff, kind = (r.cidx_kind >> 16) & 0xff;
       uint32_t ci = d.cid_map[bo[BC_CID] + local];
       r.cidx_kind = ci | (kind << 16);
-      if (kind == OK_DEL) r.a0 = d.peer_map[bo[BC_PEER] + r.a0];
+      if (kind == OK_DEL || kind == OK_LIST_MOVE || kind == OK_LIST_SET) r.a0 = d.peer_map[bo[BC_PEER] + r.a0];
       d.op[t] = r;
       m_chg = r.chg; m_bit = ci & 63;
     }
@@ -361,9 +361,13 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   for (uint32_t i = (uint32_t)lane; i < m.n_op; i += 64) {
     const OpRow& r = d.op[m.op0 + i];
     uint32_t k = (r.cidx_kind >> 16) & 0xff;
-    n_map += (k == OK_MAP_SET || k == OK_MAP_DEL) ? 1u : 0u;
-    n_el += (k == OK_TEXT_INS || k == OK_LIST_INS || k == OK_STYLE_START || k == OK_STYLE_END) ? r.len : 0u;
+    // (MovableList move / set rows compete per element in the same LWW table; a move also places a new list item)
+    n_map += (k == OK_MAP_SET || k == OK_MAP_DEL || k == OK_LIST_MOVE || k == OK_LIST_SET) ? 1u : 0u;
+    n_el += (k == OK_TEXT_INS || k == OK_LIST_INS || k == OK_STYLE_START || k == OK_STYLE_END) ? r.len : (k == OK_LIST_MOVE ? 1u : 0u);
   }
+  bool has_ml = false;
+  for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) has_ml |= (d.cont[m.cid0 + c].kind_root & 0xff) == CK_MOVABLE;
+  has_ml = lmw::any(has_ml);
   n_map = lmw::reduce_add(n_map);
   n_el = lmw::reduce_add(n_el);
   if (lane == 0) {
@@ -373,6 +377,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     d.doc[doc].pending_hi = 0;
     d.doc[doc].n_mapop = n_map;
     d.doc[doc].n_elems = n_el;
+    if (has_ml) d.doc[doc].flags |= DF_MOVABLE;
   }
 }
 

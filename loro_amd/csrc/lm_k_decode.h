@@ -470,6 +470,7 @@ LM_KERNEL void k_block_decode(Dev d) {
       uint64_t val_at = (uint64_t)(v.p - d.data);
       uint32_t kind = OK_OTHER;
       uint32_t mark_len = 0;
+      uint64_t mv_from = 0, mv_peer = 0, mv_lam = 0;
       bool is_list_value = false;
       // value payload (docs/encoding.md §10)
       switch (vt) {
@@ -488,7 +489,7 @@ LM_KERNEL void k_block_decode(Dev d) {
             r.a0 = (uint32_t)rd_uleb(t);
           }
           // (values of containers outside the device scope are never rendered: any shape is accepted)
-          skip_loro_value(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && ckind == CK_LIST ? 1 : (ckind > CK_TEXT ? 16 : -1)));
+          skip_loro_value(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && (ckind == CK_LIST || ckind == CK_MOVABLE) ? 1 : (ckind > CK_TEXT && ckind != CK_MOVABLE ? 16 : -1)));
           break;
         }
         case 12: {
@@ -501,8 +502,14 @@ LM_KERNEL void k_block_decode(Dev d) {
           break;
         }
         case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
-        case 14: (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v); break;
-        case 15: { (void)rd_uleb(v); (void)rd_uleb(v); bool u = false; skip_loro_value(v, u); break; }
+        case 14: mv_from = rd_uleb(v); mv_peer = rd_uleb(v); mv_lam = rd_uleb(v); break;   // ListMove: source position, element peer idx, element lamport
+        case 15: {   // ListSet: element peer idx, element lamport, then the nested value (op_val points at it)
+          mv_peer = rd_uleb(v); mv_lam = rd_uleb(v);
+          val_at = (uint64_t)(v.p - d.data);
+          if (ckind == CK_MOVABLE) skip_loro_value(v, unsupported, 0);
+          else { bool u = false; skip_loro_value(v, u); }
+          break;
+        }
         case 16: {
           (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v);
           uint32_t isn = rd_u8(v);
@@ -528,8 +535,14 @@ LM_KERNEL void k_block_decode(Dev d) {
         if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else st = st ? st : ST_DATA_CORRUPTION; }
         else if (vt == 9) { kind = OK_DEL; take_del = true; }
         else st = st ? st : ST_DATA_CORRUPTION;
-      } else if (ckind == CK_MOVABLE) {
-        if (vt == 9) take_del = true;
+      } else if (ckind == CK_MOVABLE) {   // outdated_encode_reordered.rs:388-459
+        if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else st = st ? st : ST_DATA_CORRUPTION; }
+        else if (vt == 9) { kind = OK_DEL; take_del = true; }
+        else if (vt == 14 || vt == 15) {
+          kind = vt == 14 ? OK_LIST_MOVE : OK_LIST_SET;
+          if (mv_peer >= n_peers || mv_lam > 0xFFFFFFFFull || mv_from > 0x7FFFFFFFull || prop < 0 || len != 1) { st = st ? st : ST_DATA_CORRUPTION; mv_peer = 0; }
+          r.a0 = (uint32_t)mv_peer; r.a1 = (uint32_t)mv_lam; r.a2 = (int32_t)(uint32_t)mv_from;
+        } else st = st ? st : ST_DATA_CORRUPTION;
       }
       if (take_del) {
         if (!has_del) st = st ? st : ST_DATA_CORRUPTION;

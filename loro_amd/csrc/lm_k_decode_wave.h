@@ -316,7 +316,7 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
             bool is_list_value = v.p < v.end && *v.p == 7;
             if (is_list_value) { Rd t = v; (void)rd_u8(t); aux = (uint32_t)rd_uleb(t); flags = 1; }
             // (values of containers outside the device scope are never rendered: any shape is accepted)
-            skip_loro_value_fs(v, unsupported, wkind == CK_MAP ? 0 : (is_list_value && wkind == CK_LIST ? 1 : (wkind > CK_TEXT ? 16 : -1)), fs);
+            skip_loro_value_fs(v, unsupported, wkind == CK_MAP ? 0 : (is_list_value && (wkind == CK_LIST || wkind == CK_MOVABLE) ? 1 : (wkind > CK_TEXT && wkind != CK_MOVABLE ? 16 : -1)), fs);
             break;
           }
           case 12: {
@@ -329,8 +329,22 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
             break;
           }
           case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
-          case 14: (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v); break;
-          case 15: { (void)rd_uleb(v); (void)rd_uleb(v); bool u = false; skip_loro_value_fs(v, u, -1, fs); break; }
+          // ListMove / ListSet (MovableList): the element id travels in the row's delete-start words, which such a row never uses
+          case 14: {
+            uint64_t f = rd_uleb(v), pi = rd_uleb(v), lm_ = rd_uleb(v);
+            if (pi >= n_peers || lm_ > 0xFFFFFFFFull || f > 0x7FFFFFFFull) flags |= 2;
+            sx[k * 8 + 4] = (uint32_t)pi; sx[k * 8 + 5] = (uint32_t)lm_; sx[k * 8 + 6] = (uint32_t)f;
+            break;
+          }
+          case 15: {
+            uint64_t pi = rd_uleb(v), lm_ = rd_uleb(v);
+            if (pi >= n_peers || lm_ > 0xFFFFFFFFull) flags |= 2;
+            sx[k * 8 + 4] = (uint32_t)pi; sx[k * 8 + 5] = (uint32_t)lm_; sx[k * 8 + 6] = 0;
+            val_at = (uint64_t)(v.p - d.data);   // op_val of a set row points at the nested value
+            if (wkind == CK_MOVABLE) skip_loro_value_fs(v, unsupported, 0, fs);
+            else { bool u = false; skip_loro_value_fs(v, u, -1, fs); }
+            break;
+          }
           case 16: {
             (void)rd_uleb(v); (void)rd_uleb(v); (void)rd_uleb(v);
             uint32_t isn = rd_u8(v);
@@ -384,6 +398,14 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
         if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else dec_err(errk, row, 3, ST_DATA_CORRUPTION); }
         else if (vt == 9) kind = OK_DEL;
         else dec_err(errk, row, 3, ST_DATA_CORRUPTION);
+      } else if (ckind == CK_MOVABLE) {   // outdated_encode_reordered.rs:388-459
+        if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else dec_err(errk, row, 3, ST_DATA_CORRUPTION); }
+        else if (vt == 9) kind = OK_DEL;
+        else if (vt == 14 || vt == 15) {
+          kind = vt == 14 ? OK_LIST_MOVE : OK_LIST_SET;
+          orow.a0 = sx[r * 8 + 4]; orow.a1 = sx[r * 8 + 5]; orow.a2 = (int32_t)sx[r * 8 + 6];
+          if ((o[3] & 2) || (int32_t)prop < 0 || len != 1) { dec_err(errk, row, 3, ST_DATA_CORRUPTION); orow.a0 = 0; }
+        } else dec_err(errk, row, 3, ST_DATA_CORRUPTION);
       }
       if (take_del) {
         if (!has_del) dec_err(errk, row, 4, ST_DATA_CORRUPTION);

@@ -42,11 +42,12 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
   if (status_fatal(m.status)) return;
   const ChangeRow& ch = d.chg[r.chg];
   if (kind == OK_OTHER) {
-    // an applied op of a container outside the device scope (Tree / MovableList / Counter): the container is known to
+    // an applied op of a container outside the device scope (Tree / Counter): the container is known to
     // the state store (it renders as null) and the document is reported LM_UNSUPPORTED together with its JSON
     if (r.ctr + r.len <= ch.ctr + d.chg_skip[r.chg]) return;
     uint32_t ci = r.cidx_kind & 0xffff;
-    if ((d.cont[m.cid0 + ci].kind_root & 0xff) > CK_TEXT) {
+    uint32_t ock = d.cont[m.cid0 + ci].kind_root & 0xff;
+    if (ock > CK_TEXT && ock != CK_MOVABLE) {
       d.cont[m.cid0 + ci].touched = 1;
       lmw::atomic_or(&d.doc[doc].flags, DF_SOFT_UNSUPPORTED);
     }
@@ -181,6 +182,103 @@ LM_KERNEL void k_state_roots(Dev d) {
       }
     }
   }
+}
+
+// ---- MovableList (diff_calc.rs:1669-1993, history_cache.rs:754-1003, state/movable_list_state.rs:953-964)
+// A list ITEM is placed by an insert (one per inserted value) or by a move; an ELEMENT is what an insert created, named by
+// the IdLp (peer, lamport) of its insert, and it points at ONE item: that of its greatest move by (lamport, peer) inside the
+// rendered version, else its insert's (last_pos).  Its value is that of its greatest set, else the inserted one (last_value).
+// The value of the list = the visible items some element points at, in list order.  Both maxima live in the document's LWW
+// table next to the Map keys (key = bit 63 | set-bit 62 | packed id of the element's insert item).
+LM_DEV unsigned long long ml_key(uint32_t pid_e, bool is_set) { return (1ull << 63) | ((unsigned long long)(is_set ? 1u : 0u) << 62) | pid_e; }
+LM_DEV uint32_t ml_hash(unsigned long long k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 29; return (uint32_t)k; }
+LM_DEV uint32_t ml_ht_claim(unsigned long long* keys, uint32_t cap, unsigned long long mine) {
+  uint32_t slot = ml_hash(mine) & (cap - 1);
+  for (uint32_t probe = 0; probe < cap; probe++, slot = (slot + 1) & (cap - 1)) {
+    unsigned long long cur = keys[slot];
+    if (cur == HT_EMPTY) { cur = lmw::atomic_cas64(&keys[slot], HT_EMPTY, mine); if (cur == HT_EMPTY) return slot; }
+    if (cur == mine) return slot;
+  }
+  return NONE;
+}
+LM_DEV uint32_t ml_ht_find(const unsigned long long* keys, uint32_t cap, unsigned long long mine) {
+  if (cap == 0) return NONE;
+  uint32_t slot = ml_hash(mine) & (cap - 1);
+  for (uint32_t probe = 0; probe < cap; probe++, slot = (slot + 1) & (cap - 1)) {
+    unsigned long long cur = keys[slot];
+    if (cur == HT_EMPTY) return NONE;
+    if (cur == mine) return slot;
+  }
+  return NONE;
+}
+// element (peer idx, lamport) → packed id of its insert item, NONE unless an applied insert row of container `cidx` made it
+LM_DEV uint32_t ml_resolve(const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t peer, uint32_t lam) {
+  if (peer >= m.n_peers) return NONE;
+  uint32_t lo = d.peer_chg0[m.praw0 + peer], hi = d.peer_chg1[m.praw0 + peer], first = lo;
+  while (lo < hi) {   // first change whose lamport is beyond `lam` (a peer's lamports grow with its counters)
+    uint32_t mid = (lo + hi) >> 1;
+    if (d.chg_lamport[d.chg_sorted[m.chg0 + mid]] <= lam) lo = mid + 1; else hi = mid;
+  }
+  if (lo == first) return NONE;
+  uint32_t crow = d.chg_sorted[m.chg0 + lo - 1];
+  const ChangeRow ch = d.chg[crow];
+  uint32_t off = lam - d.chg_lamport[crow];
+  if (off >= ch.len) return NONE;
+  uint32_t c = ch.ctr + off;
+  uint32_t rl = ch.op0, rh = ch.op0 + ch.n_op;
+  while (rl < rh) { uint32_t mid = (rl + rh) >> 1; if (d.op[mid].ctr + d.op[mid].len <= c) rl = mid + 1; else rh = mid; }
+  if (rl >= ch.op0 + ch.n_op) return NONE;
+  const OpRow r = d.op[rl];
+  if (r.ctr > c || (r.cidx_kind & 0xffff) != cidx || ((r.cidx_kind >> 16) & 0xff) != OK_LIST_INS) return NONE;
+  return pid_make(peer, c);
+}
+
+// K9c: documents holding a MovableList only (DF_MOVABLE), one wave per document, after the integrate stage (loc[] is free
+// then): loc[item] := the element the item positions, the per-element maxima of the move / set rows inside the rendered
+// version, and the state-store rule — a MovableList exists once an element was inserted, even if nothing is visible any
+// more (its diff lists every element the version knows: delta/movable_list.rs:32-34, diff_calc.rs:1880-1924).
+LM_KERNEL void k_mlist_post(Dev d) {
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  const DocMeta m = d.doc[doc];
+  if (status_fatal(m.status) || !(m.flags & DF_MOVABLE)) return;
+  uint32_t* loc = d.loc + (((uint64_t)m.elem0_hi << 32) | m.elem0_lo);
+  uint32_t cap = d.ht_cap[doc];
+  unsigned long long* keys = d.ht_key + d.ht0[doc];
+  unsigned long long* best = d.ht_best + d.ht0[doc];
+  int32_t err = 0;
+  for (uint32_t ci = 0; ci < m.n_valid_chg; ci++) {
+    uint32_t crow = d.chg_sorted[m.chg0 + ci];
+    const ChangeRow ch = d.chg[crow];
+    uint32_t lo = ch.ctr + d.chg_skip[crow], pe = d.peer_end[m.praw0 + ch.peer];
+    uint32_t eb = d.elem_base[m.praw0 + ch.peer];
+    for (uint32_t r0 = 0; r0 < ch.n_op; r0 += 64) {
+      uint32_t ri = r0 + (uint32_t)lane;
+      if (ri >= ch.n_op) continue;
+      const OpRow r = d.op[ch.op0 + ri];
+      uint32_t cidx = r.cidx_kind & 0xffff, kind = (r.cidx_kind >> 16) & 0xff;
+      if (cidx >= m.n_cont || (d.cont[m.cid0 + cidx].kind_root & 0xff) != CK_MOVABLE) continue;
+      if (r.ctr + r.len <= lo) continue;   // already-known prefix of a sliced change
+      if (kind == OK_LIST_INS) {
+        d.cont[m.cid0 + cidx].touched = 1;
+        uint32_t a = lo > r.ctr ? lo - r.ctr : 0u, b = r.ctr + r.len <= pe ? r.len : (pe > r.ctr ? pe - r.ctr : 0u);
+        for (uint32_t i = a; i < b; i++) loc[eb + r.ctr + i] = pid_make(ch.peer, r.ctr + i);   // an inserted item positions its own element
+      } else if (kind == OK_LIST_MOVE || kind == OK_LIST_SET) {
+        // the element must exist ("moved element should have a visible source position", diff_calc.rs:1927-1931)
+        uint32_t pid_e = ml_resolve(d, m, cidx, r.a0, r.a1);
+        if (pid_e == NONE) { err = ST_DATA_CORRUPTION; continue; }
+        if (r.ctr >= pe) continue;   // past the version being rendered: does not compete (last_pos / last_value take the version)
+        if (kind == OK_LIST_MOVE) loc[eb + r.ctr] = pid_e;
+        uint32_t rel = ch.op0 + ri - m.op0;
+        if (cap == 0 || rel >= (1u << 24)) { err = ST_UNSUPPORTED; continue; }
+        uint32_t slot = ml_ht_claim(keys, cap, ml_key(pid_e, kind == OK_LIST_SET));
+        if (slot == NONE) { err = ST_INTERNAL; continue; }
+        uint32_t lam = d.chg_lamport[crow] + (r.ctr - ch.ctr);
+        lmw::atomic_max64(&best[slot], (((unsigned long long)lam << 32) | ((unsigned long long)ch.peer << 24) | rel) + 1);
+      }
+    }
+  }
+  if (err) LM_SETERR(d.doc[doc].status, err);
 }
 
 // ------------------------------------------------------------------------------------------------ sink
@@ -485,9 +583,9 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
   };
   auto empty_child = [&](uint32_t ckind) {
     if (ckind == CK_TEXT) sink_lit(s, "\"\"", 2);
-    else if (ckind == CK_LIST) sink_lit(s, "[]", 2);
+    else if (ckind == CK_LIST || ckind == CK_MOVABLE) sink_lit(s, "[]", 2);
     else if (ckind == CK_MAP) sink_lit(s, "{}", 2);
-    else { sink_lit(s, "null", 4); soft = true; }   // Tree / MovableList / Counter child: outside the device scope
+    else { sink_lit(s, "null", 4); soft = true; }   // Tree / Counter child: outside the device scope
   };
   const uint32_t ht_capd = d.ht_cap[doc];
   const unsigned long long* keys = d.ht_key + d.ht0[doc];
@@ -587,7 +685,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
         }
         sink_byte(s, '"');
         sp--;
-      } else if (!TEXT_ONLY && kind == CK_LIST) {
+      } else if (!TEXT_ONLY && (kind == CK_LIST || kind == CK_MOVABLE)) {
         if (fc & 2) { sink_byte(s, '['); fc &= ~2u; }
         uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
         const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
@@ -611,14 +709,40 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
             uint32_t eid0 = lmw::bcast(id, l0), elen = lmw::bcast(ln, l0);
             uint64_t g = elem0 + s_eb[pid_peer(eid0)] + pid_ctr(eid0);
             for (uint32_t k = ((uint32_t)l0 == slot0 ? k0 : 0u); k < elen && !err; k++) {
-              uint32_t off = d.cp[g + k];
+              uint64_t vabs, vlim = doc_end;
+              uint32_t vblk = NONE, eid = eid0 + k;   // eid: the id a child container created by this value carries
+              if (kind == CK_MOVABLE) {
+                // the item shows iff its element points at it; the value is the element's (last set, else the inserted one)
+                uint32_t pid_e = d.loc[g + k];
+                bool show = pid_e == eid;
+                uint32_t sl = ml_ht_find(keys, ht_capd, ml_key(pid_e, false));
+                if (sl != NONE && best[sl] != 0) {
+                  unsigned long long w = best[sl] - 1;
+                  show = pid_make((uint32_t)(w >> 24) & 0xffu, d.op[m.op0 + (uint32_t)(w & 0xffffffu)].ctr) == eid;
+                }
+                if (!show) continue;
+                sl = ml_ht_find(keys, ht_capd, ml_key(pid_e, true));
+                if (sl != NONE && best[sl] != 0) {
+                  uint32_t row = m.op0 + (uint32_t)((best[sl] - 1) & 0xffffffu);
+                  const OpRow wr = d.op[row];
+                  vblk = d.op_blk[row];
+                  const BlockDesc& gb = d.blk[vblk];
+                  vabs = d.op_val[row];
+                  vlim = gb.base + gb.sec_rel[SEC_VALUES] + gb.sec_len[SEC_VALUES];
+                  eid = pid_make(d.chg[wr.chg].peer, wr.ctr);
+                } else {
+                  if (pid_peer(pid_e) >= m.n_peers) { err = ST_INTERNAL; break; }
+                  vabs = doc_data0 + d.cp[elem0 + s_eb[pid_peer(pid_e)] + pid_ctr(pid_e)];
+                  eid = pid_e;
+                }
+              } else vabs = doc_data0 + d.cp[g + k];
               if (!(fc & 1)) sink_byte(s, ',');
               fc &= ~1u;
-              Rd r = rd_make(d.data + doc_data0 + off, doc_end - (doc_data0 + off));
-              if (r.p < r.end && *r.p == 9) {   // child container created by this list element
+              if (vabs > vlim) { err = ST_INTERNAL; break; }
+              Rd r = rd_make(d.data + vabs, vlim - vabs);
+              if (r.p < r.end && *r.p == 9) {   // child container created by this list element (or by the set that wrote it)
                 (void)rd_u8(r);
                 uint32_t ckind = rd_u8(r);
-                uint32_t eid = eid0 + k;
                 uint32_t child = find_child(pid_peer(eid), pid_ctr(eid), ckind);
                 if (child == NONE) { empty_child(ckind); continue; }
                 if (sp >= (int)EMIT_MAX_DEPTH) { err = ST_UNSUPPORTED; break; }
@@ -628,7 +752,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
                 pushed = true;
                 break;
               }
-              sink_value(s, r, err, d, NONE, m.blk0, m.n_blk);   // the item's block is found only if its key table is needed
+              sink_value(s, r, err, d, vblk, m.blk0, m.n_blk);   // NONE: the item's block is found only if its key table is needed
             }
           }
         }

@@ -533,6 +533,25 @@ LM_DEV void tr_update_range(Tr& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   }
 }
 
+// id of the active element at position `pos` (0-based), NONE beyond the end (MovableList moves, tracker.rs:289-347)
+LM_DEV uint32_t tr_active_id_at(Tr& t, uint32_t pos) {
+  if (pos >= t.tot_active) return NONE;
+  int lane = lmw::lane();
+  uint32_t k = pos + 1;
+  uint32_t p = dir_find_kth(t, k);
+  if (p == NONE) return NONE;
+  lmw::wave_sync();
+  uint32_t e0 = lmw::first(t.dir[p]);
+  LeafRegs R;
+  if (de_leaf(e0) == t.cache_leaf) R = t.cr;
+  else R = tr_leaf_load(t, de_leaf(e0), de_n(e0));
+  uint64_t am = lmw::ballot((uint32_t)lane < R.n && st_active(R.st));
+  uint32_t below = (uint32_t)lmw::popc64(am & ((2ull << lane) - 1));
+  uint64_t hit = lmw::ballot(((am >> lane) & 1) && below == k);
+  if (!hit) return NONE;
+  return lmw::bcast(R.id, lmw::ffs64(hit));
+}
+
 // retreat (dir < 0) / forward (dir > 0) every op of `peer` with id in [c0,c1) that belongs to container `cidx`
 LM_DEV void tr_move_ops(Tr& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t peer, uint32_t c0, uint32_t c1, int dir) {
   uint32_t ci = find_change(d, m, peer, c0);
@@ -547,20 +566,32 @@ LM_DEV void tr_move_ops(Tr& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
     uint32_t lo = ch.op0, hr = ch.op0 + ch.n_op;
     while (lo < hr) { uint32_t mid = (lo + hr) >> 1; if (d.op[mid].ctr + d.op[mid].len <= c0) lo = mid + 1; else hr = mid; }
     for (uint32_t row = lo; row < ch.op0 + ch.n_op && !t.err; row++) {
-      const OpRow r = d.op[row];
+      OpRow r = d.op[row];
       if (r.ctr >= c1) break;
       if ((r.cidx_kind & 0xffff) != cidx) continue;
       uint32_t kind = (r.cidx_kind >> 16) & 0xff;
       uint32_t a = (c0 > r.ctr ? c0 : r.ctr) - r.ctr, b = (c1 < r.ctr + r.len ? c1 : r.ctr + r.len) - r.ctr;
       if (a >= b) continue;
-      if (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END) {
-        tr_update_range(t, peer, r.ctr + a, r.ctr + b, dir < 0 ? UPD_SET_FUT : UPD_CLR_FUT);
-      } else if (kind == OK_DEL) {
-        uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
-        uint32_t t0, t1;
-        if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
-        else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }  // op offset j deletes target + (L-1-j)
-        tr_update_range(t, r.a0, t0, t1, dir < 0 ? UPD_DEL_DEC : UPD_DEL_INC);
+      // MovableList move: its own item, then (a second trip through the same call sites) the item it deleted, whose id the
+      // first application left in the move item's payload slot
+      uint32_t mv_tgt = NONE;
+      if (kind == OK_LIST_MOVE) {
+        lmw::wave_sync();
+        mv_tgt = lmw::first((d.cp + (((uint64_t)m.elem0_hi << 32) | m.elem0_lo))[tr_g(t, pid_make(peer, r.ctr))]);
+        kind = OK_LIST_INS;
+      }
+      for (;;) {
+        if (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END) {
+          tr_update_range(t, peer, r.ctr + a, r.ctr + b, dir < 0 ? UPD_SET_FUT : UPD_CLR_FUT);
+        } else if (kind == OK_DEL) {
+          uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+          uint32_t t0, t1;
+          if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
+          else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }  // op offset j deletes target + (L-1-j)
+          tr_update_range(t, r.a0, t0, t1, dir < 0 ? UPD_DEL_DEC : UPD_DEL_INC);
+        }
+        if (mv_tgt == NONE || pid_peer(mv_tgt) >= m.n_peers) break;
+        r.a0 = pid_peer(mv_tgt); r.a1 = pid_ctr(mv_tgt); r.a2 = 1; kind = OK_DEL; mv_tgt = NONE;   // (a, b) = (0, 1)
       }
     }
   }
@@ -628,7 +659,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
   if (retry_pass) {
     for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {   // sequence containers only: a Map's flag belongs to k_map_lww
       uint32_t ck = d.cont[m.cid0 + c].kind_root & 0xff;
-      if (ck == CK_TEXT || ck == CK_LIST) d.cont[m.cid0 + c].touched = 0;
+      if (ck == CK_TEXT || ck == CK_LIST || ck == CK_MOVABLE) d.cont[m.cid0 + c].touched = 0;
     }
     lmw::block_sync();  // every lane has read the status before it is cleared
     if (lane == 0) d.doc[doc].status = ST_OK;
@@ -661,7 +692,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
   for (uint32_t cidx = 0; cidx < m.n_cont && !t.err; cidx++) {
     uint32_t kr = d.cont[m.cid0 + cidx].kind_root;
     uint32_t ckind = kr & 0xff;
-    if (ckind != CK_TEXT && ckind != CK_LIST) continue;
+    if (ckind != CK_TEXT && ckind != CK_LIST && ckind != CK_MOVABLE) continue;
     // fresh tracker: one empty leaf
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     uint32_t L0 = t.n_leaf++;
@@ -718,6 +749,17 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
             PROF_ADD(t, PF_CHECKOUT);
           }
           PROF_ADD(t, PF_ROW);
+          // MovableList move (tracker.rs:289-347): the row is replayed as the delete of the active item at `from` (its id
+          // is remembered in the move item's payload slot) and then as the insert of the op's own item at `to`
+          uint32_t mv_to = NONE;
+          if (kind == OK_LIST_MOVE) {
+            uint32_t tgt = tr_active_id_at(t, (uint32_t)r.a2);
+            if (tgt == NONE || (uint32_t)r.prop >= t.tot_active) { LM_SETERR(t.err, ST_DATA_CORRUPTION); break; }
+            if (lane == 0) (d.cp + elem0)[tr_g(t, pid_make(node_peer, r.ctr))] = tgt;
+            mv_to = (uint32_t)r.prop;
+            r.a0 = pid_peer(tgt); r.a1 = pid_ctr(tgt); r.a2 = 1; kind = OK_DEL;
+          }
+          for (;;) {
           if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
             tr_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
             TR_CHECK("insert", row);
@@ -743,6 +785,9 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
             if (end_pos == NONE) { LM_SETERR(t.err, ST_UNSUPPORTED); break; }
             uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
             tr_insert(t, pos, pid_make(node_peer, r.ctr), 1);
+          }
+          if (mv_to == NONE || t.err) break;
+          r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
           }
         }
         // the node's own ops advance the tracker version

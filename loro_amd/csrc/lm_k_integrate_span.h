@@ -699,6 +699,25 @@ LM_DEV OpRow rw_get(RowWin& w, const uint32_t* op_w, uint32_t row) {
   return r;
 }
 
+// id of the active element at position `pos` (0-based), NONE beyond the end — MovableList moves name their source item by
+// position only (tracker.rs:289-347, crdt_rope.rs:286-312); not on any hot path
+LM_DEV uint32_t ts_active_id_at(Ts& t, uint32_t pos) {
+  if (pos >= t.tot_active) return NONE;
+  uint32_t k = pos + 1;
+  uint32_t p = sd_find_kth(t, k);
+  if (p == NONE) return NONE;
+  lmw::wave_sync();
+  uint32_t a = lmw::first(t.da[p]);
+  SpanRegs R = sp_load(t, sa_leaf(a), sa_n(a));
+  uint32_t al = sp_alen(R);
+  uint32_t inc = lmw::scan_incl_add(al);
+  uint64_t hit = lmw::ballot((al != 0) & (inc >= k));
+  if (!hit) return NONE;
+  int slot = lmw::ffs64(hit);
+  uint32_t off = k - (lmw::bcast(inc, slot) - lmw::bcast(al, slot));   // 1..len
+  return lmw::bcast(R.id, slot) + off - 1;
+}
+
 // retreat (dir < 0) / forward (dir > 0) every op of `peer` with id in [c0,c1) that belongs to container `cidx`
 LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t peer, uint32_t c0, uint32_t c1, int dir) {
   uint32_t ci = find_change(d, m, peer, c0);
@@ -714,20 +733,33 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
     RowWin w;
     rw_open(w, (const uint32_t*)d.op, lo, ch.op0 + ch.n_op);
     for (uint32_t row = lo; row < ch.op0 + ch.n_op && !t.err; row++) {
-      const OpRow r = rw_get(w, (const uint32_t*)d.op, row);
+      OpRow r = rw_get(w, (const uint32_t*)d.op, row);
       if (r.ctr >= c1) break;
       if ((r.cidx_kind & 0xffff) != cidx) continue;
       uint32_t kind = (r.cidx_kind >> 16) & 0xff;
       uint32_t a = (c0 > r.ctr ? c0 : r.ctr) - r.ctr, b = (c1 < r.ctr + r.len ? c1 : r.ctr + r.len) - r.ctr;
       if (a >= b) continue;
-      if (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END) {
-        ts_update_range(t, peer, r.ctr + a, r.ctr + b, dir < 0 ? UPD_SET_FUT : UPD_CLR_FUT);
-      } else if (kind == OK_DEL) {
-        uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
-        uint32_t t0, t1;
-        if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
-        else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
-        ts_update_range(t, r.a0, t0, t1, dir < 0 ? UPD_DEL_DEC : UPD_DEL_INC);
+      // a MovableList move is two halves (id_to_cursor.rs Cursor::Move): its own item, then the item it deleted, whose id the
+      // first application left in the move item's payload slot.  Both go through the call sites below (one more trip of this
+      // loop) — a second inlined copy of ts_update_range would grow the kernel by half
+      uint32_t mv_tgt = NONE;
+      if (kind == OK_LIST_MOVE) {
+        lmw::wave_sync();
+        mv_tgt = lmw::first((d.cp + (((uint64_t)m.elem0_hi << 32) | m.elem0_lo))[ts_g(t, pid_make(peer, r.ctr))]);
+        kind = OK_LIST_INS;
+      }
+      for (;;) {
+        if (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END) {
+          ts_update_range(t, peer, r.ctr + a, r.ctr + b, dir < 0 ? UPD_SET_FUT : UPD_CLR_FUT);
+        } else if (kind == OK_DEL) {
+          uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+          uint32_t t0, t1;
+          if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
+          else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
+          ts_update_range(t, r.a0, t0, t1, dir < 0 ? UPD_DEL_DEC : UPD_DEL_INC);
+        }
+        if (mv_tgt == NONE || pid_peer(mv_tgt) >= m.n_peers) break;
+        r.a0 = pid_peer(mv_tgt); r.a1 = pid_ctr(mv_tgt); r.a2 = 1; kind = OK_DEL; mv_tgt = NONE;   // (a, b) = (0, 1)
       }
     }
   }
@@ -795,7 +827,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span(Dev d, Dev
   if (retry_pass) {
     for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {   // sequence containers only: a Map's flag belongs to k_map_lww
       uint32_t ck = d.cont[m.cid0 + c].kind_root & 0xff;
-      if (ck == CK_TEXT || ck == CK_LIST) d.cont[m.cid0 + c].touched = 0;
+      if (ck == CK_TEXT || ck == CK_LIST || ck == CK_MOVABLE) d.cont[m.cid0 + c].touched = 0;
     }
     lmw::block_sync();
     if (lane == 0) d.doc[doc].status = ST_OK;
@@ -820,7 +852,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span(Dev d, Dev
   if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
   for (uint32_t cidx = 0; cidx < m.n_cont && !t.err; cidx++) {
     uint32_t ckind = d.cont[m.cid0 + cidx].kind_root & 0xff;
-    if (ckind != CK_TEXT && ckind != CK_LIST) continue;
+    if (ckind != CK_TEXT && ckind != CK_LIST && ckind != CK_MOVABLE) continue;
     if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     uint32_t L0 = t.n_leaf++;
     lmw::block_sync();
@@ -846,7 +878,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span(Dev d, Dev
         uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
         for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
-          const OpRow r = rw_get(w, op_w, row);
+          OpRow r = rw_get(w, op_w, row);
           if ((r.cidx_kind & 0xffff) != cidx) continue;
           if (r.ctr + r.len <= skip_to) continue;
           uint32_t kind = (r.cidx_kind >> 16) & 0xff;
@@ -868,6 +900,19 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span(Dev d, Dev
             TS_CHECK("checkout", row);
           }
           PROF_ADD(t, PF_ROW);
+          // MovableList move (diff_calc.rs:1917-1941 → tracker.rs:289-347): the active item at `from` is deleted — its id is kept
+          // in the move item's own payload slot (cp[], otherwise unused for a move) for later retreats / forwards — and a new
+          // item with the op's id is inserted at `to`, evaluated after the deletion.  The row is rewritten as that delete and
+          // then as that insert, each taking the ordinary path below (no second inlined copy of the two big routines)
+          uint32_t mv_to = NONE;
+          if (kind == OK_LIST_MOVE) {
+            uint32_t tgt = ts_active_id_at(t, (uint32_t)r.a2);
+            if (tgt == NONE || (uint32_t)r.prop >= t.tot_active) { LM_SETERR(t.err, ST_DATA_CORRUPTION); break; }   // (after the deletion `to` may equal the new length)
+            if (lane == 0) (d.cp + elem0)[ts_g(t, pid_make(node_peer, r.ctr))] = tgt;
+            mv_to = (uint32_t)r.prop;
+            r.prop = r.a2; r.a0 = pid_peer(tgt); r.a1 = pid_ctr(tgt); r.a2 = 1; kind = OK_DEL;
+          }
+          for (;;) {
           if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
             ts_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
             TS_CHECK("insert", row);
@@ -896,6 +941,9 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span(Dev d, Dev
             uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
             ts_insert(t, pos, pid_make(node_peer, r.ctr), 1);
           }
+          if (mv_to == NONE || t.err) break;
+          r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
+          }
         }
         if (checked_out && lane == 0) s_cur[node_peer] = ch.ctr + ch.len < pe ? ch.ctr + ch.len : pe;
       }
@@ -910,6 +958,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span(Dev d, Dev
       d.cont_nroot[m.cid0 + cidx] = t.n_dir;
       // the state store holds a root sequence once something is visible in it (diff_calc.rs:299: a container state is
       // created by a non-empty diff; from the empty version the diff is empty exactly when nothing is visible)
+      // (a MovableList exists once an element was ever inserted — k_mlist_post adds that case after this stage)
       if (touched && t.n_alive > 0) d.cont[m.cid0 + cidx].touched = 1;
     }
     dir_used += t.n_dir;

@@ -486,6 +486,11 @@ struct Engine {
     last_retries = n_retry;
     if (h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only
     if (h_froot_off.size() > n_docs && h_froot_off[n_docs] > 0) LM_LAUNCH(k_state_roots, n_docs, 64, d);        // documents initialised from a snapshot only
+    {   // documents holding a MovableList only: element → item maxima and the items' elements (loc[] is free from here on)
+      bool any_ml = false;
+      for (uint32_t i = 0; i < n_docs && !any_ml; i++) any_ml = h_doc[i].status == ST_OK && (h_doc[i].flags & DF_MOVABLE);
+      if (any_ml) LM_LAUNCH(k_mlist_post, n_docs, 64, d);
+    }
 #ifdef LM_EMU_TRACE
     if (getenv("LM_EMU_DUMP")) {  // kernel-logic harness only: leaves of document 0 in document order
       lmbe::d2h(h_doc.data(), b_doc.p, (size_t)n_docs * sizeof(DocMeta));

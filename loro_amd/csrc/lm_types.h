@@ -25,7 +25,8 @@ enum : uint32_t { CK_MAP = 0, CK_LIST = 1, CK_TEXT = 2, CK_TREE = 3, CK_MOVABLE 
 
 // decoded op kinds (outdated_encode_reordered.rs:215-476 mapping)
 enum : uint32_t {
-  OK_OTHER = 0, OK_TEXT_INS = 1, OK_DEL = 2, OK_STYLE_START = 3, OK_STYLE_END = 4, OK_LIST_INS = 5, OK_MAP_SET = 6, OK_MAP_DEL = 7
+  OK_OTHER = 0, OK_TEXT_INS = 1, OK_DEL = 2, OK_STYLE_START = 3, OK_STYLE_END = 4, OK_LIST_INS = 5, OK_MAP_SET = 6, OK_MAP_DEL = 7,
+  OK_LIST_MOVE = 8, OK_LIST_SET = 9   // MovableList (docs/encoding.md §10.5): a0 = element peer idx, a1 = element lamport, move: prop = to, a2 = from
 };
 
 // limits of the packed element id (peer_idx:8 | counter:24)
@@ -52,8 +53,8 @@ struct OpRow {               // 32 B, read with scalar loads by the integrate ke
   int32_t prop;              // position / key idx
   uint32_t len;              // atom length
   uint32_t ctr;              // absolute counter of the first atom
-  uint32_t a0, a1;           // delete: target peer idx, target counter | style start: mark len | list insert: #items
-  int32_t a2;                // delete: signed len
+  uint32_t a0, a1;           // delete: target peer idx, target counter | style start: mark len | list insert: #items | move/set: element peer idx, lamport
+  int32_t a2;                // delete: signed len | move: source position
   uint32_t chg;              // global change row
 };
 
@@ -102,9 +103,10 @@ struct DocMeta {             // per document, filled progressively
 
 // DocMeta.flags / BlockDesc.flags
 enum : uint32_t {
-  DF_SOFT_UNSUPPORTED = 1u,  // the document holds containers outside the device scope (Tree / MovableList / Counter): they render as
+  DF_SOFT_UNSUPPORTED = 1u,  // the document holds containers outside the device scope (Tree / Counter): they render as
                              // null, everything else is rendered, and the document is reported LM_UNSUPPORTED *with* its JSON
   DF_REEMIT = 2u,            // the rendered JSON did not fit the optimistic output slab: re-rendered at its exact size
+  DF_MOVABLE = 4u,           // the document holds a MovableList container: k_mlist_post runs for it after the integrate stage
 };
 
 }  // namespace lm

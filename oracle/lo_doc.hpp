@@ -709,7 +709,7 @@ inline void json_value(const Doc& d, const Value& v, std::string& out, int depth
         if (v.cid.kind == CK_TEXT) out += "\"\"";
         else if (v.cid.kind == CK_MAP) out += "{}";
         else if (v.cid.kind == CK_LIST || v.cid.kind == CK_MOVABLE) out += "[]";
-        else { out += "null"; d.unsupported = true; }   // Tree / MovableList / Counter child: outside the scope
+        else { out += "null"; d.unsupported = true; }   // Tree / Counter child: outside the scope
       } else d.container_json(it->second, out, depth + 1);
       break;
     }

@@ -147,3 +147,85 @@ def nested_session(seed, n_peers=3, n_steps=120, sync_prob=0.1, max_depth=4):
     for r in reps:
         r.commit()
     return reps
+
+
+def movable_session(seed, n_peers=3, n_steps=80, sync_prob=0.15, nested=False, snapshots=None, bulk=0):
+    """Random concurrent session over a root MovableList "ml" (+ a Map "map", and with `nested` child containers created
+    by insert_container / set_container and a child MovableList under the Map).  Peers see the list through the writer's
+    local element view (wire.Replica.mlist_*), refreshed from the oracle's item order after a sync.  `bulk` > 0 starts
+    with that many elements inserted by the first peer and synced to everyone (multi-leaf lists)."""
+    rng = random.Random(seed)
+    base = rng.randrange(1, 1 << 40)
+    reps = [wire.Replica(base + 3 * i) for i in range(n_peers)]
+    K = wire
+    ML = K.KIND_MOVABLE
+    lists = [(K.root_cid("ml", ML), None)]          # (cid, creating op id)
+    kids = []                                        # child Text / Map / List containers: (cid, creating op id)
+
+    def known(r, made):
+        return made is None or r.vv.get(made[0], 0) > made[1] or (made[0] == r.peer and made[1] < r.next_counter)
+
+    def refresh(r):
+        blob = r.export()
+        for cid, made in lists + kids:
+            if known(r, made) and cid.kind in (K.KIND_TEXT, K.KIND_LIST, ML):
+                r.set_visible(cid, cid.kind, _oracle.visible_ids([blob], cid, cid.kind))
+
+    if bulk:
+        for i in range(0, bulk, 7):
+            reps[0].mlist_insert("ml", reps[0].mlist_len("ml"), ["b%d" % k for k in range(i, min(bulk, i + 7))])
+        reps[0].commit()
+        for r in reps[1:]:
+            r.merge_from(reps[0])
+            refresh(r)
+    if nested:
+        ch = reps[0].map_set_container("map", "child_ml", ML)
+        lists.append((ch, (reps[0].peer, ch.counter)))
+    for _ in range(n_steps):
+        r = rng.choice(reps)
+        roll = rng.random()
+        if kids and roll < 0.12:
+            cid, made = rng.choice(kids)
+            if known(r, made):
+                if cid.kind == K.KIND_TEXT:
+                    ids = r.seq.setdefault(cid, [])
+                    r.text_insert(cid, rng.randint(0, len(ids)), "".join(rng.choice(ALPHA) for _ in range(rng.randint(1, 4))))
+                elif cid.kind == K.KIND_MAP:
+                    r.map_set(cid, "k%d" % rng.randint(0, 3), rng.randint(0, 99))
+                else:
+                    ids = r.seq.setdefault(cid, [])
+                    r.list_insert(cid, rng.randint(0, len(ids)), [rng.randint(0, 9)])
+        else:
+            cid, made = rng.choice(lists)
+            if not known(r, made):
+                continue
+            n = r.mlist_len(cid)
+            roll = rng.random()
+            if n == 0 or roll < 0.3:
+                r.mlist_insert(cid, rng.randint(0, n), [rng.choice([None, True, rng.randint(-99, 99), "s%d" % rng.randint(0, 9), [1, {"k": 2.5}], 0.25])
+                                                        for _ in range(rng.randint(1, 3))])
+            elif roll < 0.55 and n >= 2:
+                r.mlist_move(cid, rng.randrange(n), rng.randrange(n))
+            elif roll < 0.72:
+                r.mlist_set(cid, rng.randrange(n), rng.choice([False, rng.randint(0, 9), "t%d" % rng.randint(0, 9), {"m": [1, 2]}]))
+            elif roll < 0.86:
+                p = rng.randrange(n)
+                r.mlist_delete(cid, p, min(n - p, rng.randint(1, 2)))
+            elif nested and roll < 0.93:
+                kind = rng.choice([K.KIND_TEXT, K.KIND_MAP, K.KIND_LIST])
+                ch = r.mlist_insert_container(cid, rng.randint(0, n), kind) if rng.random() < 0.5 else r.mlist_set_container(cid, rng.randrange(n), kind)
+                kids.append((ch, (r.peer, ch.counter)))
+            else:
+                r.map_set("map", "k%d" % rng.randint(0, 3), rng.randint(0, 9))
+        if rng.random() < 0.4:
+            r.commit()
+            if snapshots is not None and r.frontiers and rng.random() < 0.5:
+                snapshots.append((list(r.frontiers), r.export()))
+        if rng.random() < sync_prob and n_peers > 1:
+            a, b = rng.sample(reps, 2)
+            a.commit(); b.commit()
+            if a.merge_from(b):
+                refresh(a)
+    for r in reps:
+        r.commit()
+    return reps

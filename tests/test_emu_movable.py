@@ -1,0 +1,132 @@
+"""MovableList on the device path, checked in the kernel-logic harness (the HIP kernels compiled for the host): decode of
+ListMove / ListSet rows (both block decoders), the move as delete + insert in both integrate kernels with its retreat /
+forward, the per-element LWW of position and value (k_mlist_post) and the rendering — against the oracle, which
+test_oracle_movable.py pins to the reference's known answers."""
+import json, os, random
+import pytest
+
+import _oracle, _emu, _fuzz
+from loro_amd import wire
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FX = json.load(open(os.path.join(HERE, "golden", "reference_fixtures.json")))
+BLOB = {k: bytes.fromhex(v) for k, v in FX["blobs"].items()}
+ML = wire.KIND_MOVABLE
+
+
+def _check(docs, frontiers=None, run=None):
+    got = (run or _emu.merge_batch)(docs, frontiers)
+    want = _oracle.merge_batch(docs, frontiers=frontiers)
+    for i, (g, w) in enumerate(zip(got, want)):
+        if w[0] == 0:
+            assert g == w, f"doc {i}: device={g[:3]!r} oracle={w[:3]!r}"
+        else:
+            assert g[0] == w[0] and (w[0] != 4 or g[1] == w[1]), f"doc {i}: device={g[:2]!r} oracle={w[:2]!r}"
+    return got
+
+
+def session_docs(seeds, **kw):
+    docs = []
+    for seed in seeds:
+        reps = _fuzz.movable_session(seed, **kw)
+        rng = random.Random(seed)
+        docs.append(_fuzz.blobs_of(reps, rng))
+        docs.append([r.export() for r in reps])          # overlapping histories: drop / slice known changes
+    return docs
+
+
+def checkout_docs(seeds, **kw):
+    docs, fronts = [], []
+    for seed in seeds:
+        snaps = []
+        reps = _fuzz.movable_session(seed, snapshots=snaps, **kw)
+        blobs = _fuzz.blobs_of(reps)
+        rng = random.Random(seed)
+        for version, _ in rng.sample(snaps, min(4, len(snaps))):
+            docs.append(blobs)
+            fronts.append(wire.encode_frontiers(version))
+    return docs, fronts
+
+
+def known_answer_docs():
+    """(docs, check): the reference's fixtures and the mov.rs / movable_list_state.rs scripts."""
+    d1 = wire.Replica(1)
+    for i, v in enumerate((1, 2, 3)):
+        d1.mlist_insert("list", i, [v])
+    d1.commit()
+    d2 = wire.Replica(2)
+    d2.merge_from(d1)
+    d2.set_visible("list", ML, list(d1.seq[wire.root_cid("list", ML)]))
+    d1.mlist_move("list", 0, 2); d2.mlist_move("list", 0, 1)
+    d1.commit(); d2.commit()
+    d = wire.Replica(8)
+    d.mlist_insert("list", 0, [1]); d.mlist_insert("list", 1, [0]); d.mlist_move("list", 0, 1); d.mlist_move("list", 1, 0)
+    d.mlist_move("list", 0, 1); d.mlist_insert("list", 2, [3]); d.mlist_set("list", 2, 2)
+    d.commit()
+    e = wire.Replica(9)
+    e.mlist_insert("gone", 0, ["a", "b"]); e.mlist_delete("gone", 0, 2); e.list_insert("l", 0, [1]); e.list_delete("l", 0, 1)
+    e.commit()
+    docs = [[BLOB["updates.blob"]], [BLOB["updates.ts.blob"]], [BLOB["runtime-updates.ts.blob"]],
+            [d1.export(), d2.export()], [d2.export(), d1.export()], [d.export()], [e.export()]]
+
+    def check(got):
+        want = FX["json"]["snapshot.deep.json"]
+        for g in got[:2]:
+            v = json.loads(g[1])
+            assert g[0] == 4 and v["mlist"] == want["mlist"] == [] and v["map"]["child_mlist"] == want["map"]["child_mlist"]
+        assert json.loads(got[2][1])["movable"] == FX["json"]["runtime.expected.json"]["movable"] == ["z", "x"]
+        assert got[3][:2] == got[4][:2] == (0, b'{"list":[2,1,3]}')                    # crates/loro/tests/mov.rs:13-62
+        assert got[5][:2] == (0, b'{"list":[0,1,2]}')                                  # movable_list_state.rs:1960-2031
+        assert got[6][:2] == (0, b'{"gone":[]}')     # a MovableList exists once an element was made; an emptied List does not
+    return docs, check
+
+
+def test_known_answers():
+    docs, check = known_answer_docs()
+    check(_check(docs))
+
+
+@pytest.mark.parametrize("variant", ["span", "element", "lane-decoder", "retry"])
+def test_random_sessions(monkeypatch, variant):
+    if variant == "element":
+        monkeypatch.setenv("LM_SPAN", "0")
+    if variant == "lane-decoder":
+        monkeypatch.setenv("LM_DECODE", "0")
+    if variant == "retry":
+        monkeypatch.setenv("LM_DIR_OPT_MAX", "4")    # the optimistic directory overflows: documents are re-run
+    docs = session_docs(range(100, 110)) + session_docs(range(200, 206), nested=True, n_steps=140, n_peers=4)
+    _check(docs)
+
+
+def test_multi_leaf_lists_and_many_moves():
+    docs = session_docs(range(300, 303), bulk=400, n_steps=260, sync_prob=0.1)
+    got = _check(docs)
+    assert all(len(json.loads(g[1])["ml"]) > 200 for g in got)
+
+
+@pytest.mark.parametrize("span", ["1", "0"])
+def test_checkouts(monkeypatch, span):
+    monkeypatch.setenv("LM_SPAN", span)
+    docs, fronts = checkout_docs(range(400, 408), nested=True, n_steps=100)
+    assert len(docs) >= 16
+    _check(docs, fronts)
+
+
+def damaged_docs():
+    """Valid envelopes around impossible MovableList rows: every one is LM_DATA_CORRUPTION on both sides."""
+    out = []
+    def rep():
+        r = wire.Replica(21)
+        r.mlist_insert("ml", 0, ["a", "b", "c"])
+        return r
+    r = rep(); r._push(wire.Op(wire.root_cid("ml", ML), r._alloc(1), "list_move", pos=1, move_from=7, elem=(21, 0))); r.commit(); out.append([r.export()])      # source beyond the end
+    r = rep(); r._push(wire.Op(wire.root_cid("ml", ML), r._alloc(1), "list_move", pos=9, move_from=0, elem=(21, 0))); r.commit(); out.append([r.export()])      # destination beyond the end
+    r = rep(); r._push(wire.Op(wire.root_cid("ml", ML), r._alloc(1), "list_move", pos=1, move_from=0, elem=(21, 77))); r.commit(); out.append([r.export()])     # unknown element
+    r = rep(); r._push(wire.Op(wire.root_cid("ml", ML), r._alloc(1), "list_set", elem=(5, 0), value=1)); r.commit(); out.append([r.export()])                     # unknown element (foreign peer)
+    r = rep(); r.text_insert("t", 0, "xy"); r._push(wire.Op(wire.root_cid("ml", ML), r._alloc(1), "list_set", elem=(21, 3), value=1)); r.commit(); out.append([r.export()])   # a text element is no list element
+    return out
+
+
+def test_damaged_rows():
+    got = _check(damaged_docs())
+    assert [g[0] for g in got] == [3] * 5

@@ -457,12 +457,14 @@ def _fixture_docs_and_check():
             # "list" / "text" end empty in this history: an updates import creates no state for them;
             # snapshot.deep.json is the value of a snapshot import, which carries the exporting document's states
             assert v.get("list", []) == deep["list"] == [] and v.get("text", "") == deep["text"] == ""
+            assert v["mlist"] == deep["mlist"] == []      # a MovableList exists once an element was inserted
             for k, x in deep["map"].items():
-                if k not in ("child_mlist", "child_tree"):
+                if k != "child_tree":
                     assert v["map"][k] == x, k
         rt = fx["json"]["runtime.expected.json"]
         v = json.loads(got[2][1])
         assert v["list"] == rt["list"] and v["text"] == rt["text"] and all(v["map"][k] == rt["map"][k] for k in ("answer", "child", "nested"))
+        assert v["movable"] == rt["movable"] == ["z", "x"]
         cc = fx["json"]["concurrent.expected.json"]
         for g in got[3:]:
             v = json.loads(g[1])
@@ -471,7 +473,7 @@ def _fixture_docs_and_check():
 
 
 def test_reference_fixtures_with_out_of_scope_containers_render_the_rest():
-    """Rust-written `updates.blob` (and the TS-written fixtures) hold MovableList / Tree / Counter containers: the device
+    """Rust-written `updates.blob` (and the TS-written fixtures) hold Tree / Counter containers: the device
     path renders every in-scope key, shows the out-of-scope containers as null and reports LM_UNSUPPORTED *with* the JSON —
     compared key by key with the oracle and with the reference's expected deep JSON (loro_js_interop.rs:42-126)."""
     docs, check = _fixture_docs_and_check()

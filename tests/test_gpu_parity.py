@@ -44,7 +44,7 @@ def test_reference_fixture_blobs(engine):
     docs = [[b["fugue-left.ts.blob"], b["fugue-right.ts.blob"]], [b["fugue-right.ts.blob"], b["fugue-left.ts.blob"]]]
     got = _same(engine, docs)
     assert got[0][1] == b'{"text":"Hello World!"}' and got[1][1] == got[0][1]
-    # fixtures with containers outside the device scope (Tree / MovableList / Counter): flagged LM_UNSUPPORTED, the in-scope
+    # fixtures with containers outside the device scope (Tree / Counter): flagged LM_UNSUPPORTED, the in-scope
     # keys rendered and compared with the oracle and the reference's expected deep JSON — this is the Rust-written
     # `updates.blob` going through the HIP decoder (DeltaRle run form, real DeltaOfDelta ranges)
     import test_emu_parity

@@ -108,38 +108,7 @@ def test_move_set_delete_races():
     assert v[0] == ("yb" if (lam_b, 12) > (lam_c, 13) else "Y")
 
 
-def movable_session(seed, n_peers=3, n_steps=80, sync_prob=0.15):
-    """Random concurrent session over a root MovableList "ml" (+ a Map so documents are mixed)."""
-    rng = random.Random(seed)
-    base = rng.randrange(1, 1 << 40)
-    reps = [wire.Replica(base + 3 * i) for i in range(n_peers)]
-    cid = wire.root_cid("ml", ML)
-    for _ in range(n_steps):
-        r = rng.choice(reps)
-        n = r.mlist_len("ml")
-        roll = rng.random()
-        if n == 0 or roll < 0.3:
-            r.mlist_insert("ml", rng.randint(0, n), [rng.choice([None, True, rng.randint(-99, 99), "s%d" % rng.randint(0, 9), [1, {"k": 2.5}]])
-                                                      for _ in range(rng.randint(1, 3))])
-        elif roll < 0.55 and n >= 2:
-            r.mlist_move("ml", rng.randrange(n), rng.randrange(n))
-        elif roll < 0.75:
-            r.mlist_set("ml", rng.randrange(n), rng.choice([False, rng.randint(0, 9), "t%d" % rng.randint(0, 9)]))
-        elif roll < 0.9:
-            p = rng.randrange(n)
-            r.mlist_delete("ml", p, min(n - p, rng.randint(1, 2)))
-        else:
-            r.map_set("map", "k%d" % rng.randint(0, 3), rng.randint(0, 9))
-        if rng.random() < 0.4:
-            r.commit()
-        if rng.random() < sync_prob and n_peers > 1:
-            a, b = rng.sample(reps, 2)
-            a.commit(); b.commit()
-            if a.merge_from(b):
-                a.set_visible(cid, ML, _oracle.visible_ids([a.export()], cid, ML))
-    for r in reps:
-        r.commit()
-    return reps
+movable_session = _fuzz.movable_session
 
 
 @pytest.mark.parametrize("seed", range(12))
