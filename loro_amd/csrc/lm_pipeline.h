@@ -465,9 +465,17 @@ struct Engine {
     uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
     lmbe::dmemset(retry_cnt, 0, 4);
     const size_t dir_words = span ? 2 : 1;   // LDS words per directory entry
+    // documents that hold a MovableList are replayed by the kernel that knows move rows (k_integrate_span_ml), the others by
+    // the common one; each kernel's waves leave the other's documents at once
+    bool any_ml = false, all_ml = true;
+    for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) { bool f = (h_doc[i].flags & DF_MOVABLE) != 0; any_ml |= f; all_ml &= f; }
     if (span) {
-      LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
-                    (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+      if (!(any_ml && all_ml))
+        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                      (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+      if (any_ml)
+        LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                      (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
     } else {
       LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                     (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
@@ -478,6 +486,9 @@ struct Engine {
       if (span) {
         LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
+        if (any_ml)
+          LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                        (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
       } else {
         LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
@@ -486,11 +497,8 @@ struct Engine {
     last_retries = n_retry;
     if (h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only
     if (h_froot_off.size() > n_docs && h_froot_off[n_docs] > 0) LM_LAUNCH(k_state_roots, n_docs, 64, d);        // documents initialised from a snapshot only
-    {   // documents holding a MovableList only: element → item maxima and the items' elements (loc[] is free from here on)
-      bool any_ml = false;
-      for (uint32_t i = 0; i < n_docs && !any_ml; i++) any_ml = h_doc[i].status == ST_OK && (h_doc[i].flags & DF_MOVABLE);
-      if (any_ml) LM_LAUNCH(k_mlist_post, n_docs, 64, d);
-    }
+    // documents holding a MovableList only: element → item maxima and the items' elements (loc[] is free from here on)
+    if (any_ml) LM_LAUNCH(k_mlist_post, n_docs, 64, d);
 #ifdef LM_EMU_TRACE
     if (getenv("LM_EMU_DUMP")) {  // kernel-logic harness only: leaves of document 0 in document order
       lmbe::d2h(h_doc.data(), b_doc.p, (size_t)n_docs * sizeof(DocMeta));
