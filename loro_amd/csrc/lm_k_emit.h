@@ -251,14 +251,14 @@ LM_KERNEL void k_mlist_post(Dev d) {
     uint32_t crow = d.chg_sorted[m.chg0 + ci];
     const ChangeRow ch = d.chg[crow];
     uint32_t lo = ch.ctr + d.chg_skip[crow], pe = d.peer_end[m.praw0 + ch.peer];
-    uint32_t eb = d.elem_base[m.praw0 + ch.peer];
+    uint32_t eb = d.elem_base[m.praw0 + ch.peer], ext = d.peer_ext[m.praw0 + ch.peer];
     for (uint32_t r0 = 0; r0 < ch.n_op; r0 += 64) {
       uint32_t ri = r0 + (uint32_t)lane;
       if (ri >= ch.n_op) continue;
       const OpRow r = d.op[ch.op0 + ri];
       uint32_t cidx = r.cidx_kind & 0xffff, kind = (r.cidx_kind >> 16) & 0xff;
       if (cidx >= m.n_cont || (d.cont[m.cid0 + cidx].kind_root & 0xff) != CK_MOVABLE) continue;
-      if (r.ctr + r.len <= lo) continue;   // already-known prefix of a sliced change
+      if (r.ctr + r.len <= lo || r.ctr + r.len > ext) continue;   // already-known prefix of a sliced change; beyond the peer's element slots
       if (kind == OK_LIST_INS) {
         d.cont[m.cid0 + cidx].touched = 1;
         uint32_t a = lo > r.ctr ? lo - r.ctr : 0u, b = r.ctr + r.len <= pe ? r.len : (pe > r.ctr ? pe - r.ctr : 0u);
@@ -731,7 +731,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
                   vlim = gb.base + gb.sec_rel[SEC_VALUES] + gb.sec_len[SEC_VALUES];
                   eid = pid_make(d.chg[wr.chg].peer, wr.ctr);
                 } else {
-                  if (pid_peer(pid_e) >= m.n_peers) { err = ST_INTERNAL; break; }
+                  if (pid_peer(pid_e) >= m.n_peers || (uint64_t)s_eb[pid_peer(pid_e)] + pid_ctr(pid_e) >= m.atoms) { err = ST_INTERNAL; break; }
                   vabs = doc_data0 + d.cp[elem0 + s_eb[pid_peer(pid_e)] + pid_ctr(pid_e)];
                   eid = pid_e;
                 }
