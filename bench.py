@@ -23,7 +23,8 @@ HIP-event duration in the timed region and alone; `traffic` from the committed r
 `traffic_source`), `cpu_baseline` (the oracle — a CPU restatement of the reference path, kind "port" — as one
 single-threaded process per core the container's cgroup grants, with the 1-core and half-cores points), and at N=1:
 `end_to_end` (every step stages the blobs from host memory and fetches JSON + VV back: PCIe-inclusive) and
-`other_configs` (BASELINE configs[0], [2], [3], [4] and a heterogeneous configs[1] batch, each checked against the
+`other_configs` (BASELINE configs[0], [2], [3], [4], a heterogeneous configs[1] batch and — not a BASELINE config, guarded —
+a MovableList batch for SURVEY §8f N4, each checked against the
 oracle before it is timed).  `--no-cpu-baseline --no-end-to-end --no-other-configs` leaves the timed steps only.
 """
 import argparse
@@ -242,6 +243,10 @@ def _gen(args):
         return workload.cfg3_doc(d, combined=False), None
     if kind == "cfg5":
         return workload.cfg5_doc(d, n_ops=1000000, turn=1000, n_checkouts=16)
+    if kind == "movable":      # concurrent session over MovableLists (root + child, nested children), 3 peers
+        import random, _fuzz
+        reps = _fuzz.movable_session(7000 + d, n_peers=3, n_steps=500, sync_prob=0.08, nested=True, bulk=300)
+        return _fuzz.blobs_of(reps, random.Random(d)), None
     if kind == "tpl":          # a configs[1]-shaped template of another size / commit granularity
         n_base, n_branch, every, fuse = d
         return workload.Cfg2Template(n_base, n_branch, seed=n_base % 97, commit_every=every, fuse=fuse), None
@@ -263,9 +268,14 @@ def other_configs(device, cores):
         shapes = [(2000, 1000, 10, True), (10000, 5000, 10, True), (25000, 12500, 10, True), (50000, 25000, 10, True),
                   (100000, 50000, 10, True), (5000, 2500, 1, False), (20000, 10000, 1, False)]
         gh = pool.map_async(_gen, [("tpl", sh) for sh in shapes])
+        gm = pool.map_async(_gen, [("movable", d) for d in range(16)])
         cfg1 = [workload.cfg1_doc(d) for d in range(100)]
         cfg4_base = _cases.cfg4_docs(96)
         g3, g5, gh = g3.get(), g5.get(), gh.get()
+        try:
+            gm = gm.get()
+        except Exception as ex:   # (not a BASELINE config: its generator must not take the bench line down)
+            gm = ex
     note("other configs: documents generated")
 
     def run(name, docs, fronts, distinct, desc, reps=3):
@@ -308,6 +318,17 @@ def other_configs(device, cores):
     run("configs[4]", [docs5[i % n5] for i in range(1024)], [fr5[i % n5] for i in range(1024)], n5,
         "1M-op rich-text documents (2 peers alternating every 1k trace actions, ~1% marks), 16 checkouts each: 1,024 renderings = "
         "64 documents x 16 versions (of the config's 1,000 documents); every rendering replays its version from the empty one", reps=2)
+    # not a BASELINE config: the MovableList row of SURVEY §8f (N4), timed like the others so the row has a number on hardware;
+    # guarded — a failure here is reported in its own entry and leaves the BASELINE entries and the headline value alone
+    try:
+        if isinstance(gm, Exception):
+            raise gm
+        dm = [g[0] for g in gm]
+        run("movable-lists (SURVEY 8f N4)", [dm[i % 16] for i in range(4096)], None, 16,
+            "MovableList documents: a root and a child list of ~300-500 elements, 3 peers x ~500 concurrent insert / move / set / delete ops "
+            "with pairwise syncs, nested child containers; 4,096 docs = 16 distinct histories")
+    except Exception as ex:
+        out["movable-lists (SURVEY 8f N4)"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     return out
 
 
