@@ -760,34 +760,34 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
             r.a0 = pid_peer(tgt); r.a1 = pid_ctr(tgt); r.a2 = 1; kind = OK_DEL;
           }
           for (;;) {
-          if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
-            tr_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
-            TR_CHECK("insert", row);
-          } else if (kind == OK_DEL) {
-            uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
-            uint32_t t0, t1;
-            if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
-            else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }  // op offset j deletes target + (L-1-j)
-            tr_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
-            PROF_ADD(t, PF_DELETE);
-            PROF_CNT(t, PF_NDEL, 1);
-            TR_CHECK("delete", row);
-          } else if (kind == OK_STYLE_START) {
-            tr_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
-          } else if (kind == OK_STYLE_END) {
-            // diff_calc.rs:1105-1119: the matching StyleStart is the op right before (same peer, counter-1)
-            uint32_t end_pos = NONE;
-            if (row > ch.op0) {
-              const OpRow pr = op_ro[row - 1];
-              if (((pr.cidx_kind >> 16) & 0xff) == OK_STYLE_START && pr.ctr + 1 == r.ctr && (pr.cidx_kind & 0xffff) == cidx)
-                end_pos = (uint32_t)pr.prop + pr.a0;
+            if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
+              tr_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
+              TR_CHECK("insert", row);
+            } else if (kind == OK_DEL) {
+              uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+              uint32_t t0, t1;
+              if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
+              else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }  // op offset j deletes target + (L-1-j)
+              tr_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
+              PROF_ADD(t, PF_DELETE);
+              PROF_CNT(t, PF_NDEL, 1);
+              TR_CHECK("delete", row);
+            } else if (kind == OK_STYLE_START) {
+              tr_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
+            } else if (kind == OK_STYLE_END) {
+              // diff_calc.rs:1105-1119: the matching StyleStart is the op right before (same peer, counter-1)
+              uint32_t end_pos = NONE;
+              if (row > ch.op0) {
+                const OpRow pr = op_ro[row - 1];
+                if (((pr.cidx_kind >> 16) & 0xff) == OK_STYLE_START && pr.ctr + 1 == r.ctr && (pr.cidx_kind & 0xffff) == cidx)
+                  end_pos = (uint32_t)pr.prop + pr.a0;
+              }
+              if (end_pos == NONE) { LM_SETERR(t.err, ST_UNSUPPORTED); break; }
+              uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
+              tr_insert(t, pos, pid_make(node_peer, r.ctr), 1);
             }
-            if (end_pos == NONE) { LM_SETERR(t.err, ST_UNSUPPORTED); break; }
-            uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
-            tr_insert(t, pos, pid_make(node_peer, r.ctr), 1);
-          }
-          if (mv_to == NONE || t.err) break;
-          r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
+            if (mv_to == NONE || t.err) break;
+            r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
           }
         }
         // the node's own ops advance the tracker version

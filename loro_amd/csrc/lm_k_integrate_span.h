@@ -923,36 +923,36 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
             r.prop = r.a2; r.a0 = pid_peer(tgt); r.a1 = pid_ctr(tgt); r.a2 = 1; kind = OK_DEL;
           }
           for (;;) {
-          if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
-            ts_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
-            TS_CHECK("insert", row);
-          } else if (kind == OK_DEL) {
-            uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
-            uint32_t t0, t1;
-            if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
-            else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
-            // unsliced row: its position addresses the leftmost target (forward: prop; backward: prop + 1 - len)
-            uint32_t hint = 0;
-            if (a == 0 && b == r.len && Ln == r.len && r.prop >= 0) { if (r.a2 > 0) hint = (uint32_t)r.prop + 1; else if ((uint32_t)r.prop + 1 >= Ln) hint = (uint32_t)r.prop + 2 - Ln; }
-            ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC, hint);
-            PROF_ADD(t, PF_DELETE);
-            PROF_CNT(t, PF_NDEL, 1);
-            TS_CHECK("delete", row);
-          } else if (kind == OK_STYLE_START) {
-            ts_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
-          } else if (kind == OK_STYLE_END) {
-            uint32_t end_pos = NONE;
-            if (row > ch.op0) {
-              const OpRow pr = op_ro[row - 1];
-              if (((pr.cidx_kind >> 16) & 0xff) == OK_STYLE_START && pr.ctr + 1 == r.ctr && (pr.cidx_kind & 0xffff) == cidx)
-                end_pos = (uint32_t)pr.prop + pr.a0;
+            if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
+              ts_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
+              TS_CHECK("insert", row);
+            } else if (kind == OK_DEL) {
+              uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+              uint32_t t0, t1;
+              if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
+              else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
+              // unsliced row: its position addresses the leftmost target (forward: prop; backward: prop + 1 - len)
+              uint32_t hint = 0;
+              if (a == 0 && b == r.len && Ln == r.len && r.prop >= 0) { if (r.a2 > 0) hint = (uint32_t)r.prop + 1; else if ((uint32_t)r.prop + 1 >= Ln) hint = (uint32_t)r.prop + 2 - Ln; }
+              ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC, hint);
+              PROF_ADD(t, PF_DELETE);
+              PROF_CNT(t, PF_NDEL, 1);
+              TS_CHECK("delete", row);
+            } else if (kind == OK_STYLE_START) {
+              ts_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
+            } else if (kind == OK_STYLE_END) {
+              uint32_t end_pos = NONE;
+              if (row > ch.op0) {
+                const OpRow pr = op_ro[row - 1];
+                if (((pr.cidx_kind >> 16) & 0xff) == OK_STYLE_START && pr.ctr + 1 == r.ctr && (pr.cidx_kind & 0xffff) == cidx)
+                  end_pos = (uint32_t)pr.prop + pr.a0;
+              }
+              if (end_pos == NONE) { LM_SETERR(t.err, ST_UNSUPPORTED); break; }
+              uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
+              ts_insert(t, pos, pid_make(node_peer, r.ctr), 1);
             }
-            if (end_pos == NONE) { LM_SETERR(t.err, ST_UNSUPPORTED); break; }
-            uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
-            ts_insert(t, pos, pid_make(node_peer, r.ctr), 1);
-          }
-          if (!ML || mv_to == NONE || t.err) break;
-          r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
+            if (!ML || mv_to == NONE || t.err) break;
+            r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
           }
         }
         if (checked_out && lane == 0) s_cur[node_peer] = ch.ctr + ch.len < pe ? ch.ctr + ch.len : pe;
