@@ -86,6 +86,35 @@ def test_known_answers():
     check(_check(docs))
 
 
+def existence_docs():
+    """(docs, frontiers, expected JSON): which MovableList roots the state store holds."""
+    r = wire.Replica(31)
+    r.map_set("m", "k", 1); r.commit()
+    v1 = list(r.frontiers)
+    r.mlist_insert("ml", 0, ["a", "b"]); r.commit()
+    v2 = list(r.frontiers)
+    r.mlist_move("ml", 0, 1); r.mlist_set("ml", 0, "B"); r.commit()
+    v3 = list(r.frontiers)
+    r.mlist_delete("ml", 0, 2); r.commit()
+    blob = [r.export()]
+    f = wire.encode_frontiers
+    docs = [blob] * 5
+    fronts = [None, f(v1), f(v2), f(v3), f([])]
+    want = [b'{"m":{"k":1},"ml":[]}',              # latest: everything deleted, the list is known
+            b'{"m":{"k":1},"ml":[]}',              # checked out before the first insert: the import already created the state
+            b'{"m":{"k":1},"ml":["a","b"]}', b'{"m":{"k":1},"ml":["B","a"]}',
+            b'{"m":{},"ml":[]}']                   # the empty version
+    return docs, fronts, want
+
+
+@pytest.mark.parametrize("span", ["1", "0"])
+def test_state_existence_and_checkout_of_moves(monkeypatch, span):
+    monkeypatch.setenv("LM_SPAN", span)
+    docs, fronts, want = existence_docs()
+    got = _check(docs, fronts)
+    assert [g[1] for g in got] == want
+
+
 @pytest.mark.parametrize("variant", ["span", "element", "lane-decoder", "retry"])
 def test_random_sessions(monkeypatch, variant):
     if variant == "element":

@@ -23,6 +23,8 @@ def test_known_answers_and_damaged_rows(engine):
     check(cases._check(docs, run=engine.merge_batch))
     got = cases._check(cases.damaged_docs(), run=engine.merge_batch)
     assert [g[0] for g in got] == [3] * 5
+    docs, fronts, want = cases.existence_docs()
+    assert [g[1] for g in cases._check(docs, fronts, run=engine.merge_batch)] == want
 
 
 def test_random_sessions_nested_children_and_overlapping_histories(engine):
