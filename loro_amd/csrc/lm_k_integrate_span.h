@@ -833,7 +833,12 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   if (((m.flags & DF_MOVABLE) != 0) != ML) return;   // the other kernel's document
   if (retry_pass && m.status != ST_RETRY) return;
   if (status_fatal(m.status) && !retry_pass) return;
-  for (uint32_t i = (uint32_t)lane; i < m.atoms; i += 64) d.loc[elem0 + i] = NONE;
+  {   // loc[] of the document := NONE, four entries per store (the slice is 16-byte aligned and padded to a multiple of four)
+    struct alignas(16) U4 { uint32_t x, y, z, w; };
+    U4* l4 = (U4*)(d.loc + elem0);
+    const U4 none4 = {NONE, NONE, NONE, NONE};
+    for (uint32_t i = (uint32_t)lane; i < (m.atoms + 3) / 4; i += 64) l4[i] = none4;
+  }
   if (retry_pass) {
     for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {   // sequence containers only: a Map's flag belongs to k_map_lww
       uint32_t ck = d.cont[m.cid0 + c].kind_root & 0xff;

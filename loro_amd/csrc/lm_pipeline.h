@@ -392,7 +392,7 @@ struct Engine {
       if (leaves + lc > 0xfffffff0ull) throw std::runtime_error("batch too large for 32-bit pool indices");
       m.leaf0 = (uint32_t)leaves; m.leaf_cap = lc;
       m.vvh0_lo = (uint32_t)vvh; m.vvh0_hi = (uint32_t)(vvh >> 32);
-      if (ok) { elem += m.atoms; leaves += lc; vvh += (uint64_t)m.n_nodes * m.n_peers; }
+      if (ok) { elem += ((uint64_t)m.atoms + 3) & ~3ull; leaves += lc; vvh += (uint64_t)m.n_nodes * m.n_peers; }   // element slices start 16-byte aligned (k_integrate_span clears loc[] four entries per store)
       if (lc > dir_cap) dir_cap = lc;
       // optimistic LDS directory: leaves are ≈3/4 full in practice (≈48 elements); sized for 40 per leaf
       uint32_t lo = ok ? m.n_elems / 40 + 2 * m.n_cont + 16 : 0;
