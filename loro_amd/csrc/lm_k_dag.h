@@ -221,6 +221,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   lmw::block_sync();
   // ---- 2. coverage walk: drop known changes, slice straddling ones, park blocks behind a counter gap
   uint32_t n_sorted = 0;
+  bool any_skip = false;   // a kept change whose prefix is already known (sliced): DF_PLAIN stays clear
   uint32_t pending = 0;
   uint32_t cur_peer = NONE, covered = 0;
   bool gap = false;
@@ -248,6 +249,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
         else if (ch.ctr + ch.len <= covered) { d.chg_flag[row] = 0; }  // already known: dropped
         else { keep = true; skip = ch.ctr < covered ? covered - ch.ctr : 0; d.chg_flag[row] = 1; }
         d.chg_skip[row] = skip;
+        any_skip |= keep && skip != 0;
       }
       uint64_t km = lmw::ballot(keep);
       if (keep) d.chg_sorted[m.chg0 + n_sorted + (uint32_t)lmw::popc64(km & ((1ull << lane) - 1))] = row;
@@ -357,19 +359,22 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     g.node_done[m.chg0 + n] = 0;
   }
   // number of Map op rows (sizes the doc's LWW hash table)
-  uint32_t n_map = 0, n_el = 0;
+  uint32_t n_map = 0, n_el = 0, n_style = 0;
   for (uint32_t i = (uint32_t)lane; i < m.n_op; i += 64) {
     const OpRow& r = d.op[m.op0 + i];
     uint32_t k = (r.cidx_kind >> 16) & 0xff;
     // (MovableList move / set rows compete per element in the same LWW table; a move also places a new list item)
     n_map += (k == OK_MAP_SET || k == OK_MAP_DEL || k == OK_LIST_MOVE || k == OK_LIST_SET) ? 1u : 0u;
     n_el += (k == OK_TEXT_INS || k == OK_LIST_INS || k == OK_STYLE_START || k == OK_STYLE_END) ? r.len : (k == OK_LIST_MOVE ? 1u : 0u);
+    n_style += (k == OK_STYLE_START || k == OK_STYLE_END) ? 1u : 0u;
   }
   bool has_ml = false;
   for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) has_ml |= (d.cont[m.cid0 + c].kind_root & 0xff) == CK_MOVABLE;
   has_ml = lmw::any(has_ml);
+  bool any_skip_doc = lmw::any(any_skip);
   n_map = lmw::reduce_add(n_map);
   n_el = lmw::reduce_add(n_el);
+  n_style = lmw::reduce_add(n_style);
   if (lane == 0) {
     d.doc[doc].n_valid_chg = n_valid;
     d.doc[doc].n_nodes = n_nodes;
@@ -378,6 +383,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     d.doc[doc].n_mapop = n_map;
     d.doc[doc].n_elems = n_el;
     if (has_ml) d.doc[doc].flags |= DF_MOVABLE;
+    else if (!any_skip_doc && n_style == 0) d.doc[doc].flags |= DF_PLAIN;
   }
 }
 

@@ -815,7 +815,10 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
 #ifndef LM_INTEGRATE_WAVES
 #define LM_INTEGRATE_WAVES 5
 #endif
-template <bool ML>
+// PLAIN = true (k_integrate_span_plain, launched only under LM_PLAIN=1 — an experiment prepared for a GPU A/B, NEXT.md §5): the
+// documents flagged DF_PLAIN — no checkout, no sliced change, no style anchor — whose row loop needs neither the slicing of a row
+// against the known prefix / the rendered version nor the style branches.
+template <bool ML, bool PLAIN>
 LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
@@ -830,7 +833,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   uint32_t* s_end = s_cur + pmax;
   DocMeta m = d.doc[doc];
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
-  if (((m.flags & DF_MOVABLE) != 0) != ML) return;   // the other kernel's document
+  if ((m.flags & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
   if (retry_pass && m.status != ST_RETRY) return;
   if (status_fatal(m.status) && !retry_pass) return;
   {   // loc[] of the document := NONE, four entries per store (the slice is 16-byte aligned and padded to a multiple of four)
@@ -888,19 +891,19 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       for (uint32_t ci = first; ci <= last && !t.err; ci++) {
         uint32_t crow = sorted_ro[m.chg0 + ci];
         const ChangeRow ch = chg_ro[crow];
-        uint32_t skip_to = ch.ctr + skip_ro[crow];
-        uint32_t pe = s_end[node_peer];
+        uint32_t skip_to = PLAIN ? ch.ctr : ch.ctr + skip_ro[crow];
+        uint32_t pe = PLAIN ? ch.ctr + ch.len : s_end[node_peer];   // (PLAIN: every applied change lies inside the rendered version)
         uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
         for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
           OpRow r = rw_get(w, op_w, row);
           if ((r.cidx_kind & 0xffff) != cidx) continue;
-          if (r.ctr + r.len <= skip_to) continue;
+          if (!PLAIN && r.ctr + r.len <= skip_to) continue;
           uint32_t kind = (r.cidx_kind >> 16) & 0xff;
-          uint32_t a = skip_to > r.ctr ? skip_to - r.ctr : 0;
+          uint32_t a = PLAIN ? 0u : (skip_to > r.ctr ? skip_to - r.ctr : 0);
           touched = true;
-          if (r.ctr + a >= pe) continue;
-          uint32_t b = r.ctr + r.len <= pe ? r.len : pe - r.ctr;
+          if (!PLAIN && r.ctr + a >= pe) continue;
+          uint32_t b = PLAIN ? r.len : (r.ctr + r.len <= pe ? r.len : pe - r.ctr);
           if (!checked_out) {
             checked_out = true;
             for (uint32_t p = 0; p < P && !t.err; p++) {
@@ -943,9 +946,9 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
               PROF_ADD(t, PF_DELETE);
               PROF_CNT(t, PF_NDEL, 1);
               TS_CHECK("delete", row);
-            } else if (kind == OK_STYLE_START) {
+            } else if (!PLAIN && kind == OK_STYLE_START) {
               ts_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
-            } else if (kind == OK_STYLE_END) {
+            } else if (!PLAIN && kind == OK_STYLE_END) {
               uint32_t end_pos = NONE;
               if (row > ch.op0) {
                 const OpRow pr = op_ro[row - 1];
@@ -993,13 +996,19 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span(Dev d, Dev
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {
-  integrate_span_body<false>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
+  integrate_span_body<false, false>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
+}
+LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_plain(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count) {
+  integrate_span_body<false, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
 }
 LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_ml(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {
-  integrate_span_body<true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
+  integrate_span_body<true, false>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
 }
 
 }  // namespace lm

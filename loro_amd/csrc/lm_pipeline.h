@@ -376,9 +376,14 @@ struct Engine {
     const uint32_t DIR_CAP_MAX = span ? 18000u : 36000u;
     std::vector<uint64_t> h_ht0(n_docs);
     std::vector<uint32_t> h_ht_cap(n_docs);
+    // DF_PLAIN (k_dag_a) survives only under LM_PLAIN=1, with the span kernel, for documents rendered at the latest version
+    const bool plain_on = span && getenv("LM_PLAIN") && atoi(getenv("LM_PLAIN")) == 1;
+    bool any_plain = false;
     for (uint32_t i = 0; i < n_docs; i++) {
       DocMeta& m = h_doc[i];
       bool ok = m.status == ST_OK;
+      if (!plain_on || !ok || (h_front_off.size() > i + 1 && h_front_off[i + 1] > h_front_off[i])) m.flags &= ~DF_PLAIN;
+      any_plain |= (m.flags & DF_PLAIN) != 0;
       m.elem0_lo = (uint32_t)elem; m.elem0_hi = (uint32_t)(elem >> 32);
       // every split leaves both halves with >= 32 elements; each container starts with one (possibly small) leaf
       uint32_t lc = ok ? m.n_elems / 32 + 2 * m.n_cont + 2 : 0;
@@ -467,10 +472,13 @@ struct Engine {
     const size_t dir_words = span ? 2 : 1;   // LDS words per directory entry
     // documents that hold a MovableList are replayed by the kernel that knows move rows (k_integrate_span_ml), the others by
     // the common one; each kernel's waves leave the other's documents at once
-    bool any_ml = false, all_ml = true;
-    for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) { bool f = (h_doc[i].flags & DF_MOVABLE) != 0; any_ml |= f; all_ml &= f; }
+    bool any_ml = false, any_common = false;
+    for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) { any_ml |= (h_doc[i].flags & DF_MOVABLE) != 0; any_common |= (h_doc[i].flags & (DF_MOVABLE | DF_PLAIN)) == 0; }
     if (span) {
-      if (!(any_ml && all_ml))
+      if (any_plain)
+        LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                      (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+      if (any_common || !(any_ml || any_plain))
         LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       if (any_ml)
@@ -488,6 +496,9 @@ struct Engine {
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         if (any_ml)
           LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                        (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
+        if (any_plain)
+          LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
       } else {
         LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
