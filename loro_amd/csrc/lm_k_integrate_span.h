@@ -720,10 +720,40 @@ LM_DEV uint32_t ts_active_id_at(Ts& t, uint32_t pos) {
 
 // retreat (dir < 0) / forward (dir > 0) every op of `peer` with id in [c0,c1) that belongs to container `cidx`
 // (ML: the instantiation for documents that hold a MovableList — see k_integrate_span_ml below)
-template <bool ML>
+// SWEEP (experiment, k_integrate_span_plain_sweep under LM_PLAIN=2): a long range toggles the future flag of its INSERT rows'
+// items in one pass over the leaves — every item of `peer` with ids inside [c0,c1) belongs to an insert row of this container —
+// instead of one by-id update per row; the runs straddling c0 / c1 are cut first by two single-element updates.
+template <bool ML, bool SWEEP>
 LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t peer, uint32_t c0, uint32_t c1, int dir) {
   uint32_t ci = find_change(d, m, peer, c0);
   if (ci == NONE) return;
+  bool swept = false;
+  if (SWEEP && c1 - c0 > 8 * t.n_dir + 64) {
+    int lane = lmw::lane();
+    int mode = dir < 0 ? UPD_SET_FUT : UPD_CLR_FUT;
+    ts_update_range(t, peer, c0, c0 + 1, mode);
+    if (!t.err) ts_update_range(t, peer, c1 - 1, c1, mode);
+    if (t.err) return;
+    sp_flush(t);                                                     // the pass works on the leaf records in HBM
+    t.cache_leaf = NONE; t.cr.n = 255; t.cache_pre = NONE; t.dirty = false; t.loc_pend = 0;
+    lmw::wave_sync();
+    uint32_t lo = pid_make(peer, c0), span = c1 - c0;
+    for (uint32_t q = 0; q < t.n_dir; q++) {
+      uint32_t a = lmw::first(t.da[q]);
+      uint32_t L = sa_leaf(a), n = sa_n(a);
+      uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+      bool in = (uint32_t)lane < n;
+      uint32_t id = in ? rec[lane] : NONE, ln = in ? rec[64 + lane] : 0u, st = in ? rec[256 + lane] : ST_FUT;
+      bool hit = in & (id - lo < span);                              // whole items: the ends of the range were cut above
+      if (!lmw::any(hit)) continue;
+      uint32_t st1 = hit ? (dir < 0 ? (st | ST_FUT) : (st & ~ST_FUT)) : st;
+      if (hit) rec[256 + lane] = st1;
+      uint32_t act = lmw::reduce_add((in && st_active(st1)) ? ln : 0u);
+      bool nf = lmw::ballot(in && !(st1 & ST_FUT)) != 0;
+      sd_set(t, q, sa_make(L, n, nf), act);
+    }
+    swept = true;
+  }
   uint32_t hi = d.peer_chg1[m.praw0 + peer];
   for (; ci < hi && !t.err; ci++) {
     uint32_t crow = d.chg_sorted[m.chg0 + ci];
@@ -744,6 +774,7 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
       // a MovableList move is two halves (id_to_cursor.rs Cursor::Move): its own item, then the item it deleted, whose id the
       // first application left in the move item's payload slot.  Both go through the call sites below (one more trip of this
       // loop) — a second inlined copy of ts_update_range would grow the kernel by half
+      if (SWEEP && swept && (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END)) continue;
       uint32_t mv_tgt = NONE;
       if (ML && kind == OK_LIST_MOVE) {
         lmw::wave_sync();
@@ -818,7 +849,7 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
 // PLAIN = true (k_integrate_span_plain, launched only under LM_PLAIN=1 — an experiment prepared for a GPU A/B, NEXT.md §5): the
 // documents flagged DF_PLAIN — no checkout, no sliced change, no style anchor — whose row loop needs neither the slicing of a row
 // against the known prefix / the rendered version nor the style branches.
-template <bool ML, bool PLAIN>
+template <bool ML, bool PLAIN, bool SWEEP = false>
 LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
@@ -834,6 +865,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   DocMeta m = d.doc[doc];
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
   if ((m.flags & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
+  (void)SWEEP;
   if (retry_pass && m.status != ST_RETRY) return;
   if (status_fatal(m.status) && !retry_pass) return;
   {   // loc[] of the document := NONE, four entries per store (the slice is 16-byte aligned and padded to a multiple of four)
@@ -908,8 +940,8 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
             checked_out = true;
             for (uint32_t p = 0; p < P && !t.err; p++) {
               uint32_t cur = s_cur[p], tgt = vv[p];
-              if (cur > tgt) ts_move_ops<ML>(t, d, m, cidx, p, tgt, cur, -1);
-              else if (cur < tgt) ts_move_ops<ML>(t, d, m, cidx, p, cur, tgt, +1);
+              if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
+              else if (cur < tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, cur, tgt, +1);
             }
             lmw::block_sync();
             for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = vv[p];
@@ -1003,6 +1035,12 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_plain(Dev 
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {
   integrate_span_body<false, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
+}
+LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_plain_sweep(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count) {
+  integrate_span_body<false, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
 }
 LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_ml(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,

@@ -377,7 +377,8 @@ struct Engine {
     std::vector<uint64_t> h_ht0(n_docs);
     std::vector<uint32_t> h_ht_cap(n_docs);
     // DF_PLAIN (k_dag_a) survives only under LM_PLAIN=1, with the span kernel, for documents rendered at the latest version
-    const bool plain_on = span && getenv("LM_PLAIN") && atoi(getenv("LM_PLAIN")) == 1;
+    const int plain_mode = (span && getenv("LM_PLAIN")) ? atoi(getenv("LM_PLAIN")) : 0;   // 1: k_integrate_span_plain, 2: ..._plain_sweep (experiments)
+    const bool plain_on = plain_mode == 1 || plain_mode == 2;
     bool any_plain = false;
     for (uint32_t i = 0; i < n_docs; i++) {
       DocMeta& m = h_doc[i];
@@ -475,7 +476,10 @@ struct Engine {
     bool any_ml = false, any_common = false;
     for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) { any_ml |= (h_doc[i].flags & DF_MOVABLE) != 0; any_common |= (h_doc[i].flags & (DF_MOVABLE | DF_PLAIN)) == 0; }
     if (span) {
-      if (any_plain)
+      if (any_plain && plain_mode == 2)
+        LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                      (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+      else if (any_plain)
         LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       if (any_common || !(any_ml || any_plain))
@@ -497,7 +501,10 @@ struct Engine {
         if (any_ml)
           LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
-        if (any_plain)
+        if (any_plain && plain_mode == 2)
+          LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                        (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
+        else if (any_plain)
           LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
       } else {

@@ -33,7 +33,7 @@ from loro_amd import workload
 docs = [workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True).stamp(0)]
 with Context(Binding(os.path.join({work!r}, 'libloroemu_cov.so'), 'lmemu_')) as c:
     assert c.merge_batch(docs)[0][0] == 0
-"""], cwd=work, stderr=subprocess.DEVNULL, env=dict(os.environ, **({"LM_PLAIN": "1"} if kernel.endswith("_plain") else {})))
+"""], cwd=work, stderr=subprocess.DEVNULL, env=dict(os.environ, **({"LM_PLAIN": "1"} if kernel.endswith("_plain") else ({"LM_PLAIN": "2"} if kernel.endswith("_plain_sweep") else {}))))
 gcda = [f for f in os.listdir(work) if f.endswith(".gcda")]
 subprocess.check_call(["gcov", "-o", work, os.path.join(work, gcda[0])], cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 counts = defaultdict(dict)   # header -> line -> wave-level executions
