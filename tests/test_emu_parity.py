@@ -49,6 +49,14 @@ def test_fuzz_sessions():
     _check(_cases.fuzz_docs(48))
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_prepared_integrate_experiments_stay_correct(monkeypatch, mode):
+    """LM_PLAIN=1 / 2 route the documents without sliced changes / style anchors / checkouts to k_integrate_span_plain /
+    k_integrate_span_plain_sweep (default off, NEXT.md §5): same results."""
+    monkeypatch.setenv("LM_PLAIN", mode)
+    _check(_cases.fuzz_docs(16, base=4200) + _cases.fuzz_docs(4, base=4300, steps=120, peers=4, max_ins=30, sync_prob=0.08) + _cases.trace_docs(3000, n_docs=1))
+
+
 def test_concurrent_sibling_scans():
     # many peers typing long runs at the same spots: stresses the run-head sibling scan
     _check(_cases.fuzz_docs(12, base=1000, steps=120, peers=4, max_ins=30, sync_prob=0.08))
