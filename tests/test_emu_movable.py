@@ -141,6 +141,32 @@ def test_checkouts(monkeypatch, span):
     _check(docs, fronts)
 
 
+def sliced_docs():
+    """One peer's history exported twice with different change boundaries: the second change is sliced on import, and the
+    slice cuts away a move and a set row (or, delivered the other way round, waits as pending)."""
+    r = wire.Replica(7)
+    r.mlist_insert("ml", 0, ["a", "b", "c"])            # counters 0-2
+    r.mlist_move("ml", 0, 2)                            # 3
+    r.mlist_set("ml", 0, "B")                           # 4
+    r.mlist_insert("ml", 1, ["d"])                      # 5
+    r.mlist_delete("ml", 0, 1)                          # 6
+    r.mlist_move("ml", 2, 0)                            # 7
+    r.mlist_set("ml", 1, "D")                           # 8
+    r.commit()
+    whole = r.changes[7][0]
+    ops = whole.ops
+    assert [o.counter for o in ops] == [0, 3, 4, 5, 6, 7, 8]
+    c1 = wire.Change(7, 0, 0, [], [o for o in ops if o.counter < 5])
+    c2 = wire.Change(7, 3, 3, [(7, 2)], [o for o in ops if o.counter >= 3])
+    b1, b2 = wire.encode_updates([[c1]]), wire.encode_updates([[c2]])
+    return [[r.export()], [b1, b2], [b2, b1], [b1, b2, r.export()]]
+
+
+def test_sliced_changes_with_move_and_set_rows():
+    got = _check(sliced_docs())
+    assert got[0][0] == 0 and all(g == got[0] for g in got[1:]) and json.loads(got[0][1]) == {"ml": ["a", "D", "c"]}
+
+
 def damaged_docs():
     """Valid envelopes around impossible MovableList rows: every one is LM_DATA_CORRUPTION on both sides."""
     out = []

@@ -25,6 +25,8 @@ def test_known_answers_and_damaged_rows(engine):
     assert [g[0] for g in got] == [3] * 5
     docs, fronts, want = cases.existence_docs()
     assert [g[1] for g in cases._check(docs, fronts, run=engine.merge_batch)] == want
+    got = cases._check(cases.sliced_docs(), run=engine.merge_batch)
+    assert all(g[:2] == (0, b'{"ml":["a","D","c"]}') for g in got)
 
 
 def test_random_sessions_nested_children_and_overlapping_histories(engine):
