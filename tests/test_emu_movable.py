@@ -167,6 +167,42 @@ def test_sliced_changes_with_move_and_set_rows():
     assert got[0][0] == 0 and all(g == got[0] for g in got[1:]) and json.loads(got[0][1]) == {"ml": ["a", "D", "c"]}
 
 
+def nesting_docs():
+    """(docs, expected): MovableLists as children of a Map, a List and another MovableList; a child that never received an op;
+    a pending change made of move rows."""
+    r = wire.Replica(5)
+    never = r.map_set_container("m", "never", ML)
+    inl = r.list_insert_container("l", 0, ML)
+    r.mlist_insert(inl, 0, [1, 2, 3]); r.mlist_move(inl, 2, 0)
+    inner = r.mlist_insert_container(inl, 1, ML)             # a MovableList inside a MovableList
+    r.mlist_insert(inner, 0, ["x", "y"]); r.mlist_move(inner, 0, 1); r.mlist_set(inner, 0, "Y")
+    setc = r.mlist_set_container(inl, 3, wire.KIND_TEXT)     # element 2 (value 2) becomes a Text container
+    r.text_insert(setc, 0, "hi")
+    r.commit()
+    _, _, b2 = sliced_parts()
+    docs = [[r.export()], [b2]]
+    want = [(0, b'{"l":[[3,["Y","x"],1,"hi"]],"m":{"never":[]}}'), (0, b"{}")]
+    return docs, want
+
+
+def sliced_parts():
+    r = wire.Replica(7)
+    r.mlist_insert("ml", 0, ["a", "b", "c"]); r.mlist_move("ml", 0, 2); r.mlist_set("ml", 0, "B")
+    r.mlist_insert("ml", 1, ["d"]); r.mlist_delete("ml", 0, 1); r.mlist_move("ml", 2, 0); r.mlist_set("ml", 1, "D")
+    r.commit()
+    ops = r.changes[7][0].ops
+    c1 = wire.Change(7, 0, 0, [], [o for o in ops if o.counter < 5])
+    c2 = wire.Change(7, 3, 3, [(7, 2)], [o for o in ops if o.counter >= 3])
+    return r, wire.encode_updates([[c1]]), wire.encode_updates([[c2]])
+
+
+def test_nesting_and_pending():
+    docs, want = nesting_docs()
+    got = _check(docs)
+    assert [g[:2] for g in got] == want
+    assert got[1][3] == 6        # the six atoms of the change whose dependency is missing
+
+
 def damaged_docs():
     """Valid envelopes around impossible MovableList rows: every one is LM_DATA_CORRUPTION on both sides."""
     out = []

@@ -27,6 +27,9 @@ def test_known_answers_and_damaged_rows(engine):
     assert [g[1] for g in cases._check(docs, fronts, run=engine.merge_batch)] == want
     got = cases._check(cases.sliced_docs(), run=engine.merge_batch)
     assert all(g[:2] == (0, b'{"ml":["a","D","c"]}') for g in got)
+    docs, want = cases.nesting_docs()
+    got = cases._check(docs, run=engine.merge_batch)
+    assert [g[:2] for g in got] == want and got[1][3] == 6
 
 
 def test_random_sessions_nested_children_and_overlapping_histories(engine):
