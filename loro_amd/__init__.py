@@ -29,14 +29,18 @@ def _stale():
     return any(os.path.getmtime(os.path.join(_CSRC, f)) > t for f in os.listdir(_CSRC) if f.endswith((".h", ".cpp")))
 
 
-def build_library(force=False):
-    """hipcc --offload-arch=gfx950 → loro_amd/csrc/libloromerge.so (cross-compiles without a GPU)."""
-    if not force and not _stale():
+def build_library(force=False, defines=(), out=None):
+    """hipcc --offload-arch=gfx950 → loro_amd/csrc/libloromerge.so (cross-compiles without a GPU).
+    `defines` / `out`: an experiment build beside the product library, e.g. build_library(defines=["LM_LOC16"],
+    out="tests/tools/ab/lib_loc16.so") for `tests/tools/gpu_ab.py ... --so` (NEXT.md §5)."""
+    if out is None and not defines and not force and not _stale():
         return LIB_PATH
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB_PATH, os.path.join(_CSRC, "lm_hip.cpp")]
+    target = os.path.abspath(out) if out else LIB_PATH
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"] + ["-D" + d for d in defines] + [
+           "-o", target, os.path.join(_CSRC, "lm_hip.cpp")]
     subprocess.check_call(cmd, cwd=_CSRC)
-    return LIB_PATH
+    return target
 
 
 _BINDING = None

@@ -89,6 +89,37 @@ LM_DEV uint64_t sp_hit(const SpanRegs& R, uint32_t x) { return lmw::ballot(x - R
 #define LM_LOC_SHORT 16
 #endif
 static constexpr uint32_t LOC_SHORT = LM_LOC_SHORT;
+#ifdef LM_LOC16
+// Experiment (compile with -DLM_LOC16; NEXT.md §5): loc[] is kept only for the HEAD of every item and for the elements whose
+// counter is a multiple of 16 — everything else stays NONE.  Items are only ever cut or appended to, never joined, so a head
+// stays a head; the nearest kept entry at or below an element of an item, inside its 16-aligned counter window, is therefore an
+// element of the same item (ts_loc_find).  A flush writes 1 + len/16 entries per pending item instead of len.
+LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
+  uint32_t len = pend ? R.len : 0u;
+  uint32_t c0 = pid_ctr(R.id);
+  uint32_t g = pend ? t.ebase[pid_peer(R.id)] + c0 : 0u;
+  if (pend) t.loc[g] = L;
+  uint32_t k = 16u - (c0 & 15u);                       // offset of the first multiple of 16 beyond the head
+  for (uint32_t i = 0; i < 4; i++, k += 16) if (k < len) t.loc[g + k] = L;
+  uint64_t m = lmw::ballot(k < len);                   // items with more than four such elements
+  while (m) {
+    int j = lmw::ffs64(m);
+    m &= m - 1;
+    uint32_t gj = lmw::bcast(g, j), lj = lmw::bcast(len, j), kj = lmw::bcast(k, j);
+    for (uint32_t kk = kj + 16u * (uint32_t)lmw::lane(); kk < lj; kk += 1024) t.loc[gj + kk] = L;
+  }
+}
+// leaf of element `pid` (wave-uniform), NONE when no kept entry lies at or below it in its window
+LM_DEV uint32_t ts_loc_find(const Ts& t, uint32_t pid) {
+  uint32_t ctr = pid_ctr(pid), lo = ctr & ~15u, eb = t.ebase[pid_peer(pid)];
+  uint32_t lane = (uint32_t)lmw::lane();
+  uint32_t v = (lane < 16 && lo + lane <= ctr) ? t.loc[eb + lo + lane] : NONE;
+  uint64_t m = lmw::ballot(v != NONE);
+  if (!m) return NONE;
+  int top = 63 - __builtin_clzll((unsigned long long)m);
+  return lmw::bcast(v, top);
+}
+#else
 LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
   uint32_t len = pend ? R.len : 0u;
   uint32_t g = pend ? t.ebase[pid_peer(R.id)] + pid_ctr(R.id) : 0u;
@@ -102,6 +133,7 @@ LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
     for (uint32_t k = LOC_SHORT + (uint32_t)lmw::lane(); k < lj; k += 64) t.loc[gj + k] = L;
   }
 }
+#endif
 // The cached leaf is write-back: an edit that stays inside it issues NO global store (on gfx9-class hardware stores share
 // the load counter, so a store per edit makes the next op-row fetch wait a full write round trip).  HBM and loc[] catch up
 // when another leaf takes the cache and at the end of the replay; a sibling scan that must read loc[] writes the pending loc[]
@@ -206,9 +238,17 @@ LM_DEV SpanRegs sp_shift_in(const SpanRegs& R, uint32_t& lp, uint32_t idx, const
   N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
   uint32_t nlp = sh ? plp : lp;
   N.id = isA ? A.id : N.id; N.len = isA ? A.len : N.len; N.ol = isA ? A.ol : N.ol; N.orr = isA ? A.orr : N.orr; N.st = isA ? A.st : N.st;
+#ifdef LM_LOC16
+  nlp = isA ? 1u : nlp;   // every new item has a new head
+#else
   nlp = isA ? ((setA ? 1u : 0u) | inh) : nlp;
+#endif
   N.id = isB ? B.id : N.id; N.len = isB ? B.len : N.len; N.ol = isB ? B.ol : N.ol; N.orr = isB ? B.orr : N.orr; N.st = isB ? B.st : N.st;
+#ifdef LM_LOC16
+  nlp = isB ? 1u : nlp;
+#else
   nlp = isB ? ((setB ? 1u : 0u) | inh) : nlp;
+#endif
   lp = nlp;
   return N;
 }
@@ -445,7 +485,11 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
           else {
             sp_flush_loc(t);
             lmw::wave_sync();
+#ifdef LM_LOC16
+            uint32_t xl = ts_loc_find(t, o_ol);
+#else
             uint32_t xl = t.loc[ts_g(t, o_ol)];
+#endif
             if (xl < t.n_leaf) { uint32_t xp = sd_find_leaf(t, xl); visited = xp != NONE && xp > p && xp < cp; }
           }
           if (!visited) { stop = true; break; }
@@ -467,7 +511,11 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
               else {
                 sp_flush_loc(t);
                 lmw::wave_sync();
+#ifdef LM_LOC16
+                uint32_t xl = ts_loc_find(t, o_or);
+#else
                 uint32_t xl = t.loc[ts_g(t, o_or)];
+#endif
                 if (xl >= t.n_leaf) { LM_SETERR(t.err, ST_INTERNAL); break; }
                 uint32_t xp = sd_find_leaf(t, xl);
                 if (xp == NONE) { LM_SETERR(t.err, ST_INTERNAL); break; }
@@ -617,7 +665,11 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       }
     }
     if (!hm) {
+#ifdef LM_LOC16
+      uint32_t lf = ts_loc_find(t, x);
+#else
       uint32_t lf = lmw::first(t.loc[eb + c]);
+#endif
       PROF_CNT(t, 15, 1);   // status updates that went through loc[] (the target was not in the cached leaf)
       if (lf >= t.n_leaf || lf == t.cache_leaf) { c++; continue; }   // not an element of this container (malformed target): ignored
       // all five arrays are requested for all 64 slots right away; the directory lookup (LDS) runs while they are in
@@ -815,8 +867,14 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
         if (ln == 0) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u item %u has length 0\n", what, row, q, L, i); ok = false; }
         if (st_active(st)) act += ln;
         nf |= !(st & ST_FUT);
-        for (uint32_t k = 0; k < ln; k++)
-          if (t.loc[ts_g(t, id0 + k)] != L) { fprintf(stderr, "CHECK %s row=%u: loc of %u:%u is %u, item lives in leaf %u\n", what, row, id0 >> 24, (id0 & 0xffffff) + k, t.loc[ts_g(t, id0 + k)], L); ok = false; break; }
+        for (uint32_t k = 0; k < ln; k++) {
+#ifdef LM_LOC16
+          uint32_t expect = (k == 0 || ((id0 + k) & 15u) == 0) ? L : NONE;   // kept entries only: heads and multiples of 16
+#else
+          uint32_t expect = L;
+#endif
+          if (t.loc[ts_g(t, id0 + k)] != expect) { fprintf(stderr, "CHECK %s row=%u: loc of %u:%u is %u, item lives in leaf %u\n", what, row, id0 >> 24, (id0 & 0xffffff) + k, t.loc[ts_g(t, id0 + k)], L); ok = false; break; }
+        }
       }
       if (act != t.db[q] || nf != sa_nf(a)) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u active %u (cached %u) nf %d (cached %d)\n", what, row, q, L, act, t.db[q], (int)nf, (int)sa_nf(a)); ok = false; }
       tot += act;

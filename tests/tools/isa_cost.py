@@ -9,10 +9,15 @@ llvm-symbolizer --inlines).  Lane-divergent loops are weighted by their mean tri
 so the absolute figure is a lower bound; it is meant for comparing builds (NEXT.md §5 holds the check against the round-2
 GPU A/B measurements).
 
-  python tests/tools/isa_cost.py [repo_dir] [kernel] [--top N]      # default: this repo, k_integrate_span"""
+  python tests/tools/isa_cost.py [repo_dir] [kernel] [--top N] [--define LM_LOC16]      # default: this repo, k_integrate_span"""
 import os, re, subprocess, sys, tempfile
 from collections import defaultdict
 
+defines = []
+if "--define" in sys.argv:
+    i = sys.argv.index("--define")
+    defines = ["-D" + sys.argv[i + 1]]
+    del sys.argv[i:i + 2]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 20
 args = [a for a in args if not a.isdigit() or a != str(top)] if "--top" in sys.argv else args
@@ -23,7 +28,7 @@ csrc = os.path.join(repo, "loro_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin/"
 
 # ---- 1. c(line): gcov build of the kernel-logic harness, one configs[1] document
-subprocess.check_call(["g++", "-O0", "-g", "--coverage", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DLM_EMU_TRACE",
+subprocess.check_call(["g++", "-O0", "-g", "--coverage", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DLM_EMU_TRACE"] + defines + [
                        "-o", os.path.join(work, "libloroemu_cov.so"), os.path.join(repo, "tests", "emu", "lm_emu.cpp")], cwd=work)
 subprocess.check_call([sys.executable, "-c", f"""
 import sys, os
@@ -47,7 +52,7 @@ c = lambda fl: counts.get(fl[0], {}).get(fl[1], 0.0)
 
 # ---- 2. the kernel's instructions and their inline chains
 obj, co = os.path.join(work, "k.o"), os.path.join(work, "k.co")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--offload-device-only", "-c", "-gline-tables-only",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--offload-device-only", "-c", "-gline-tables-only"] + defines + [
                        "-o", obj, os.path.join(csrc, "lm_hip.cpp")], cwd=csrc, stderr=subprocess.DEVNULL)
 subprocess.check_call([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + obj, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
 dis = subprocess.check_output([LLVM + "llvm-objdump", "-d", "--disassemble-symbols=" + kernel, co], text=True)
