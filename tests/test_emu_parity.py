@@ -57,6 +57,19 @@ def test_prepared_integrate_experiments_stay_correct(monkeypatch, mode):
     _check(_cases.fuzz_docs(16, base=4200) + _cases.fuzz_docs(4, base=4300, steps=120, peers=4, max_ins=30, sync_prob=0.08) + _cases.trace_docs(3000, n_docs=1))
 
 
+def test_loc16_build_variant_stays_correct(monkeypatch):
+    """-DLM_LOC16 (loc[] kept for item heads and multiples of 16 only; NEXT.md §5), with the structural checker compiled in,
+    alone and under the two LM_PLAIN experiments."""
+    from loro_amd._cabi import Context
+    b = _emu.variant(["LM_LOC16", "LM_EMU_CHECK"])
+    docs = _cases.fuzz_docs(12, base=4400) + _cases.fuzz_docs(3, base=4500, steps=120, peers=4, max_ins=30, sync_prob=0.08) + _cases.trace_docs(3000, n_docs=1)
+    want = _oracle.merge_batch(docs)
+    for mode in ("0", "2"):
+        monkeypatch.setenv("LM_PLAIN", mode)
+        with Context(b) as c:
+            assert c.merge_batch(docs) == want
+
+
 def test_concurrent_sibling_scans():
     # many peers typing long runs at the same spots: stresses the run-head sibling scan
     _check(_cases.fuzz_docs(12, base=1000, steps=120, peers=4, max_ins=30, sync_prob=0.08))
