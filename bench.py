@@ -438,8 +438,11 @@ def main():
         pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_integrate.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                traffic_src = f"profiles/{tag}_pmc_integrate.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                traffic_src = (f"profiles/{tag}_pmc_integrate.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run; "
+                               f"counted on {pj.get('dominant_kernel')} — the integrate kernel of that build: an upper bound for the "
+                               "head + every-16th loc[] layout that runs now, which writes fewer loc[] entries)")
                 break
             except Exception:
                 traffic = None

@@ -89,8 +89,15 @@ LM_DEV uint64_t sp_hit(const SpanRegs& R, uint32_t x) { return lmw::ballot(x - R
 #define LM_LOC_SHORT 16
 #endif
 static constexpr uint32_t LOC_SHORT = LM_LOC_SHORT;
+// loc[] layout.  Default (LM_LOC16): loc[] is kept only for the HEAD of every item and for the elements whose counter is a
+// multiple of 16; -DLM_LOC_FULL builds the per-element layout of rounds 1-2 instead (kept as the A/B and parity counterpart).
+// Measured on configs[1], 5,000 documents per launch (profiles/r02_ab_prepared.log): 14.95 -> 14.50 ms, 12.98 ms with the
+// PLAIN + SWEEP instantiation on top.
+#if !defined(LM_LOC_FULL) && !defined(LM_LOC16)
+#define LM_LOC16 1
+#endif
 #ifdef LM_LOC16
-// Experiment (compile with -DLM_LOC16; NEXT.md §5): loc[] is kept only for the HEAD of every item and for the elements whose
+// loc[] is kept only for the HEAD of every item and for the elements whose
 // counter is a multiple of 16 — everything else stays NONE.  Items are only ever cut or appended to, never joined, so a head
 // stays a head; the nearest kept entry at or below an element of an item, inside its 16-aligned counter window, is therefore an
 // element of the same item (ts_loc_find).  A flush writes 1 + len/16 entries per pending item instead of len.
@@ -772,7 +779,7 @@ LM_DEV uint32_t ts_active_id_at(Ts& t, uint32_t pos) {
 
 // retreat (dir < 0) / forward (dir > 0) every op of `peer` with id in [c0,c1) that belongs to container `cidx`
 // (ML: the instantiation for documents that hold a MovableList — see k_integrate_span_ml below)
-// SWEEP (experiment, k_integrate_span_plain_sweep under LM_PLAIN=2): a long range toggles the future flag of its INSERT rows'
+// SWEEP (k_integrate_span_plain_sweep, the default kernel of DF_PLAIN documents; LM_PLAIN=1 / 0 switch it off): a long range toggles the future flag of its INSERT rows'
 // items in one pass over the leaves — every item of `peer` with ids inside [c0,c1) belongs to an insert row of this container —
 // instead of one by-id update per row; the runs straddling c0 / c1 are cut first by two single-element updates.
 template <bool ML, bool SWEEP>
@@ -780,7 +787,11 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
   uint32_t ci = find_change(d, m, peer, c0);
   if (ci == NONE) return;
   bool swept = false;
+#ifdef LM_SWEEP_EAGER   // tests: every range of three or more ids goes through the sweep (the fuzz corpora's ranges are short)
+  if (SWEEP && c1 - c0 > 2) {
+#else
   if (SWEEP && c1 - c0 > 8 * t.n_dir + 64) {
+#endif
     int lane = lmw::lane();
     int mode = dir < 0 ? UPD_SET_FUT : UPD_CLR_FUT;
     ts_update_range(t, peer, c0, c0 + 1, mode);
@@ -904,7 +915,7 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
 #ifndef LM_INTEGRATE_WAVES
 #define LM_INTEGRATE_WAVES 5
 #endif
-// PLAIN = true (k_integrate_span_plain, launched only under LM_PLAIN=1 — an experiment prepared for a GPU A/B, NEXT.md §5): the
+// PLAIN = true (k_integrate_span_plain_sweep by default, k_integrate_span_plain under LM_PLAIN=1; LM_PLAIN=0 = common kernel): the
 // documents flagged DF_PLAIN — no checkout, no sliced change, no style anchor — whose row loop needs neither the slicing of a row
 // against the known prefix / the rendered version nor the style branches.
 template <bool ML, bool PLAIN, bool SWEEP = false>

@@ -376,8 +376,10 @@ struct Engine {
     const uint32_t DIR_CAP_MAX = span ? 18000u : 36000u;
     std::vector<uint64_t> h_ht0(n_docs);
     std::vector<uint32_t> h_ht_cap(n_docs);
-    // DF_PLAIN (k_dag_a) survives only under LM_PLAIN=1, with the span kernel, for documents rendered at the latest version
-    const int plain_mode = (span && getenv("LM_PLAIN")) ? atoi(getenv("LM_PLAIN")) : 0;   // 1: k_integrate_span_plain, 2: ..._plain_sweep (experiments)
+    // DF_PLAIN (k_dag_a) survives only with the span kernel, for documents rendered at the latest version.  Such documents are
+    // replayed by k_integrate_span_plain_sweep (default, = LM_PLAIN=2; measured -9 % against the common kernel on configs[1],
+    // profiles/r02_ab_prepared.log); LM_PLAIN=1 selects k_integrate_span_plain, LM_PLAIN=0 the common kernel for every document
+    const int plain_mode = !span ? 0 : getenv("LM_PLAIN") ? atoi(getenv("LM_PLAIN")) : 2;
     const bool plain_on = plain_mode == 1 || plain_mode == 2;
     bool any_plain = false;
     for (uint32_t i = 0; i < n_docs; i++) {

@@ -108,7 +108,7 @@ enum : uint32_t {
   DF_REEMIT = 2u,            // the rendered JSON did not fit the optimistic output slab: re-rendered at its exact size
   DF_MOVABLE = 4u,           // the document holds a MovableList container: k_mlist_post runs for it after the integrate stage
   DF_PLAIN = 8u,             // no sliced change, no style anchor, no MovableList (k_dag_a); the host clears it for checked-out documents
-                             // and unless LM_PLAIN=1: such a document may be replayed by k_integrate_span_plain (experiment, NEXT.md §5)
+                             // and under LM_PLAIN=0: such a document is replayed by k_integrate_span_plain_sweep (lm_pipeline.h)
 };
 
 }  // namespace lm

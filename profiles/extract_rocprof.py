@@ -28,7 +28,8 @@ def main():
         q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
         for name, n, avg in c.execute(q, (cn,)):
             out["kernels"].setdefault(name, {})[cn + "_KiB_per_launch"] = round(avg, 1)
-    dom = "k_integrate_span" if "k_integrate_span" in out["kernels"] else "k_integrate"   # the integrate kernel that ran
+    # the integrate kernel that ran (plain documents take the sweep instantiation by default, lm_pipeline.h)
+    dom = next((k for k in ("k_integrate_span_plain_sweep", "k_integrate_span_plain", "k_integrate_span", "k_integrate") if k in out["kernels"]), "k_integrate")
     out["dominant_kernel"] = dom
     k = out["kernels"].get(dom, {})
     if "FETCH_SIZE_KiB_per_launch" in k and "WRITE_SIZE_KiB_per_launch" in k:

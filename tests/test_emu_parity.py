@@ -49,25 +49,40 @@ def test_fuzz_sessions():
     _check(_cases.fuzz_docs(48))
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_prepared_integrate_experiments_stay_correct(monkeypatch, mode):
-    """LM_PLAIN=1 / 2 route the documents without sliced changes / style anchors / checkouts to k_integrate_span_plain /
-    k_integrate_span_plain_sweep (default off, NEXT.md §5): same results."""
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_other_integrate_instantiations_stay_correct(monkeypatch, mode):
+    """Documents without sliced changes / style anchors / checkouts (DF_PLAIN) are replayed by k_integrate_span_plain_sweep by
+    default (measured fastest, profiles/r02_ab_prepared.log); LM_PLAIN=0 sends them to the common kernel, LM_PLAIN=1 to
+    k_integrate_span_plain: same results."""
     monkeypatch.setenv("LM_PLAIN", mode)
     _check(_cases.fuzz_docs(16, base=4200) + _cases.fuzz_docs(4, base=4300, steps=120, peers=4, max_ins=30, sync_prob=0.08) + _cases.trace_docs(3000, n_docs=1))
 
 
-def test_loc16_build_variant_stays_correct(monkeypatch):
-    """-DLM_LOC16 (loc[] kept for item heads and multiples of 16 only; NEXT.md §5), with the structural checker compiled in,
-    alone and under the two LM_PLAIN experiments."""
+@pytest.mark.parametrize("defines", [["LM_EMU_CHECK"], ["LM_LOC_FULL", "LM_EMU_CHECK"]], ids=["loc16+checker", "loc-full+checker"])
+def test_loc_layouts_with_structural_checker(monkeypatch, defines):
+    """loc[] kept for item heads and multiples of 16 only (default) and the per-element layout (-DLM_LOC_FULL), each with the
+    structural checker compiled in (it verifies the kept / NONE pattern, the directory sums and the cached leaf after every
+    op), under every integrate instantiation of the span kernel."""
     from loro_amd._cabi import Context
-    b = _emu.variant(["LM_LOC16", "LM_EMU_CHECK"])
+    b = _emu.variant(defines)
     docs = _cases.fuzz_docs(12, base=4400) + _cases.fuzz_docs(3, base=4500, steps=120, peers=4, max_ins=30, sync_prob=0.08) + _cases.trace_docs(3000, n_docs=1)
     want = _oracle.merge_batch(docs)
-    for mode in ("0", "2"):
+    for mode in ("0", "1", "2"):
         monkeypatch.setenv("LM_PLAIN", mode)
         with Context(b) as c:
             assert c.merge_batch(docs) == want
+
+
+def test_leaf_sweep_on_every_range(monkeypatch):
+    """k_integrate_span_plain_sweep toggles a long retreat / forward range in one pass over the leaves (range longer than
+    8 x leaves + 64 ids); the fuzz corpora's ranges are short, so this build (-DLM_SWEEP_EAGER) sweeps every range of three or
+    more ids, with the structural checker compiled in."""
+    from loro_amd._cabi import Context
+    b = _emu.variant(["LM_SWEEP_EAGER", "LM_EMU_CHECK"])
+    docs = (_cases.fuzz_docs(16, base=4600) + _cases.fuzz_docs(4, base=4700, steps=120, peers=4, max_ins=30, sync_prob=0.08)
+            + _cases.fuzz_docs(2, base=7000, steps=300, peers=3, max_ins=40, sync_prob=0.03) + _cases.trace_docs(3000, n_docs=1))
+    with Context(b) as c:
+        assert c.merge_batch(docs) == _oracle.merge_batch(docs)
 
 
 def test_concurrent_sibling_scans():

@@ -280,12 +280,18 @@ def test_two_contexts_in_flight(engine):
     assert rb[:40] == want_b and rb[40:80] == want_b
 
 
-@pytest.mark.parametrize("span", ["1", "0"])
-def test_both_integrate_kernels(engine, monkeypatch, span):
+@pytest.mark.parametrize("span,plain", [("1", None), ("1", "0"), ("1", "1"), ("0", None)],
+                         ids=["span (default: plain documents by leaf sweep)", "span, common kernel for every document",
+                              "span, plain kernel without the sweep", "element-granular"])
+def test_both_integrate_kernels(engine, monkeypatch, span, plain):
     """The span-granular (default) and the element-granular (LM_SPAN=0) integrate kernels on the GPU — configs[1]-shaped
-    documents, mixed containers with DAG merges, nested containers, checkouts."""
+    documents, mixed containers with DAG merges, nested containers, checkouts.  The span kernel's instantiations: documents
+    without sliced changes / style anchors / checkouts go to k_integrate_span_plain_sweep by default, to the common kernel
+    under LM_PLAIN=0 and to k_integrate_span_plain under LM_PLAIN=1 (lm_pipeline.h)."""
     import test_emu_parity
     monkeypatch.setenv("LM_SPAN", span)
+    if plain is not None:
+        monkeypatch.setenv("LM_PLAIN", plain)
     tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
     docs = [tpl.stamp(d) for d in range(300)]
     got = engine.merge_batch(docs)
