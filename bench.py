@@ -279,6 +279,15 @@ def other_configs(device, cores):
     note("other configs: documents generated")
 
     def run(name, docs, fronts, distinct, desc, reps=3):
+        # a leg that fails (its parity assert included) is REPORTED in its own entry — "error" instead of a rate — and leaves the
+        # other entries and the headline value (which has its own parity assert) alone
+        try:
+            _run(name, docs, fronts, distinct, desc, reps)
+        except Exception as ex:
+            out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300], "workload": desc}
+            note(f"other configs: {name} FAILED: {type(ex).__name__}: {ex}"[:200])
+
+    def _run(name, docs, fronts, distinct, desc, reps):
         want = _oracle.merge_batch(docs[:distinct], threads=min(32, cores), frontiers=None if fronts is None else fronts[:distinct])
         with loro_amd.MergeEngine(device) as e:
             e.stage(docs, fronts)

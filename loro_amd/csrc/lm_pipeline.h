@@ -541,7 +541,16 @@ struct Engine {
       }
     }
 #endif
-    lmbe::toc(span ? "k_integrate_span" : "k_integrate", times, profiling);
+    {
+      // the stage is named after the kernel that ran when there was only one (so the name matches rocprofv3's)
+      const bool l_plain = span && any_plain, l_common = span && (any_common || !(any_ml || any_plain));
+      const int n_launched = (int)l_plain + (int)l_common + (int)(span && any_ml);
+      const char* stage = !span ? "k_integrate"
+                          : n_launched > 1 ? "k_integrate_span (several instantiations)"
+                          : l_plain ? (plain_mode == 2 ? "k_integrate_span_plain_sweep" : "k_integrate_span_plain")
+                          : any_ml ? "k_integrate_span_ml" : "k_integrate_span";
+      lmbe::toc(stage, times, profiling);
+    }
     // 6. emit in one pass into optimistic slabs (2 output bytes per input byte: the JSON of a text document is shorter than
     // its blobs), then compact.  The emitter never writes beyond a slab: a document whose JSON is longer (map-typed values
     // re-render their keys, child maps repeat them) comes back flagged DF_REEMIT with its exact size and is rendered again
