@@ -304,6 +304,22 @@ def test_both_integrate_kernels(engine, monkeypatch, span, plain):
         assert (g == w) if w[0] == 0 else (g[0] == w[0])
 
 
+def test_leaf_sweep_over_two_peer_documents_of_many_sizes(engine, monkeypatch):
+    """k_integrate_span_plain_sweep (the default kernel of documents without sliced changes / style anchors / checkouts) retreats
+    and forwards the concurrent branch by sweeping the leaves once the range is longer than 8 x leaves + 64 ids: two-peer
+    concurrent text documents of seven shapes — 4k ... 200k ops with fused changes, 10k and 40k ops with one change per keystroke
+    (bench.py's heterogeneous mix) — against the oracle, and the same batch through the common kernel (LM_PLAIN=0)."""
+    shapes = [(2000, 1000, 10, True), (10000, 5000, 10, True), (25000, 12500, 10, True), (50000, 25000, 10, True),
+              (100000, 50000, 10, True), (5000, 2500, 1, False), (20000, 10000, 1, False)]
+    tpls = [workload.Cfg2Template(nb, nr, seed=nb % 97, commit_every=ce, fuse=fuse) for nb, nr, ce, fuse in shapes]
+    docs = [tpls[(d * 7919) % len(tpls)].stamp(d) for d in range(280)]
+    want = _oracle.merge_batch(docs[:28], threads=8)
+    got = engine.merge_batch(docs)
+    assert got[:28] == want and all(g[0] == 0 for g in got)
+    monkeypatch.setenv("LM_PLAIN", "0")
+    assert engine.merge_batch(docs) == got
+
+
 def _gen_cfg5(args):
     d, n = args
     return workload.cfg5_doc(d, n_ops=n, turn=1000, n_checkouts=16)
