@@ -398,6 +398,21 @@ def test_retry_launch_keeps_map_containers(monkeypatch):
     assert got == want
 
 
+@pytest.mark.parametrize("plain", ["2", "1", "0"])
+def test_retry_launch_of_every_span_instantiation(monkeypatch, plain):
+    """The worst-case-directory launch re-runs each overflowed document with the instantiation that owns it (plain sweep /
+    plain / common) — a batch of plain and other documents with the optimistic directory forced down to four entries."""
+    from loro_amd._cabi import Context
+    monkeypatch.setenv("LM_DIR_OPT_MAX", "4")
+    monkeypatch.setenv("LM_PLAIN", plain)
+    docs = _cases.cfg4_docs(3, first=1016, n_steps=400) + _cases.fuzz_docs(6, base=100, steps=120) + _cases.trace_docs(3000, n_docs=1)
+    want = _oracle.merge_batch(docs)
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        assert c.sizing()[3] >= 1
+    assert got == want
+
+
 @pytest.mark.parametrize("span", ["1", "0"])
 def test_both_integrate_kernels(monkeypatch, span):
     """Both integrate kernels — span-granular (default, lm_k_integrate_span.h) and element-granular (LM_SPAN=0,

@@ -304,6 +304,20 @@ def test_both_integrate_kernels(engine, monkeypatch, span, plain):
         assert (g == w) if w[0] == 0 else (g[0] == w[0])
 
 
+@pytest.mark.parametrize("plain", ["2", "0"])
+def test_retry_launch_of_the_span_instantiations(engine, monkeypatch, plain):
+    """Optimistic LDS directory forced down to four entries: every document with more leaves overflows and is re-run by the
+    worst-case-directory launch of the instantiation that owns it (plain sweep by default, the common kernel for documents
+    with sliced changes and under LM_PLAIN=0)."""
+    import test_emu_parity
+    monkeypatch.setenv("LM_DIR_OPT_MAX", "4")
+    monkeypatch.setenv("LM_PLAIN", plain)
+    docs = _cases.cfg4_docs(8, first=1016, n_steps=400) + _cases.fuzz_docs(12, base=100, steps=120) + _cases.trace_docs(3000, n_docs=2)
+    got = engine.merge_batch(docs * 4)
+    assert engine.sizing()[3] >= 1
+    assert got[: len(docs)] == _oracle.merge_batch(docs, threads=8) and got[len(docs): 2 * len(docs)] == got[: len(docs)]
+
+
 def test_leaf_sweep_over_two_peer_documents_of_many_sizes(engine, monkeypatch):
     """k_integrate_span_plain_sweep (the default kernel of documents without sliced changes / style anchors / checkouts) retreats
     and forwards the concurrent branch by sweeping the leaves once the range is longer than 8 x leaves + 64 ids: two-peer
