@@ -23,6 +23,23 @@ def main():
     for name, calls, tot, avg, pct in rows:
         out["kernels"][name] = {"calls": calls, "avg_ms": round(avg / 1e3, 4), "total_ms": round(tot / 1e3, 3), "pct": round(pct, 2)}
         lines.append(f"| {name} | {calls} | {tot / 1e3:.3f} | {avg / 1e3:.4f} | {pct:.2f} |")
+    # bench.py ends with two passes in which the context's streams run one after the other (lm_set_profiling(1)): the last
+    # 2 x n_streams dispatches of a pipeline kernel are launches with nothing beside them — the figure bench.py's roofline uses
+    # (kernel_ms / kernel_ms_alone); the average over ALL dispatches mixes set-up, overlapped timed steps and those passes
+    alone_lines = ["", "## the serialized passes at the end of the command (last 4 dispatches per kernel: 2 passes x 2 streams, nothing beside them)", "",
+                   "| kernel | dispatches | avg ms | min ms | max ms |", "|---|---:|---:|---:|---:|"]
+    try:
+        per = {}
+        for name, st, en in c.execute("select name, start, end from kernels order by start"):
+            per.setdefault(name, []).append((en - st) / 1e6)
+        for name, v in per.items():
+            if not name.startswith("k_") or len(v) < 8:
+                continue
+            last = v[-4:]
+            out["kernels"].setdefault(name, {})["alone_avg_ms"] = round(sum(last) / len(last), 4)
+            alone_lines.append(f"| {name} | {len(last)} | {sum(last) / len(last):.4f} | {min(last):.4f} | {max(last):.4f} |")
+    except Exception as ex:   # older rocpd schema: the summary table alone
+        alone_lines.append(f"(per-dispatch table unavailable: {ex})")
     for db, cn in ((fetch_db, "FETCH_SIZE"), (write_db, "WRITE_SIZE")):
         c = sqlite3.connect(db)
         q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
@@ -40,7 +57,7 @@ def main():
         out["note"] = "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 for the integrate kernel (gfx950 FETCH_SIZE correction); raw = uncorrected"
     json.dump(out, open(f"profiles/{tag}_pmc_integrate.json", "w"), indent=1, sort_keys=True)
     open(f"profiles/{tag}_kernel_stats.md", "w").write(
-        f"# rocprofv3 --kernel-trace --stats — bench.py --steps 3 --warmup 1 (configs[1], 10k docs, 1 MI355X)\n\n" + "\n".join(lines) + "\n")
+        f"# rocprofv3 --kernel-trace --stats — bench.py --steps 3 --warmup 1 (configs[1], 10k docs, 1 MI355X)\n\n" + "\n".join(lines + alone_lines) + "\n")
     print(json.dumps(out, indent=1)[:1500])
 
 
