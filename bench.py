@@ -341,6 +341,90 @@ def other_configs(device, cores):
     return out
 
 
+def resident_configs(device, cores, n_docs=10000, full=True):
+    """Resident documents (lm_import), each checked against the oracle:
+    configs[1]-incremental — base + A's branch resident in HBM (trackers included), B's concurrent 25k-op branch imported: the
+    M REMOTE ops of the metric are all that is integrated; timed = lm_run after lm_import (the import's host-to-device copy of
+    B's blobs is reported beside it);
+    configs[4]-resident — 1M-op documents rendered at 16 versions: one replay, then 16 moves of the resident tracker."""
+    import multiprocessing as mp
+    import loro_amd, _oracle
+    from loro_amd import workload
+    from loro_amd._cabi import Context
+    out = {}
+    try:
+        tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
+        docs = [tpl.stamp(d) for d in range(n_docs)]
+        base = Context._pack([b[:2] for b in docs]); inc = Context._pack([b[2:] for b in docs]); none = Context._pack([[] for _ in docs])
+        want = _oracle.merge_batch(docs[:64], threads=min(32, cores))
+        t_run, t_imp, t_base = [], [], []
+        with loro_amd.MergeEngine(device) as e:
+            for rep in range(3):
+                e.stage_packed(base); e.import_packed(none)
+                t = time.perf_counter(); e.run(); t_base.append(time.perf_counter() - t)
+                assert e.resident_fresh() == n_docs
+                t = time.perf_counter(); e.import_packed(inc); t_imp.append(time.perf_counter() - t)
+                t = time.perf_counter(); e.run(); t_run.append(time.perf_counter() - t)
+                assert e.resident_fresh() == 0, "the import did not continue from the resident trackers"
+            got = e.fetch()
+            assert got[:64] == want and all(g[0] == 0 for g in got), "configs[1]-incremental: device results differ from the CPU oracle"
+            e.set_profiling(1); e.import_packed(none); e.run()   # (same version again: the per-stage times of a run that reuses its tables)
+            kt_reuse = {}
+            for name, ms in e.kernel_times():
+                kt_reuse[name] = round(kt_reuse.get(name, 0.0) + ms, 3)
+            e.set_profiling(0)
+            st = e.stats()
+        best = min(t_run)
+        out["configs[1]-incremental"] = {
+            "docs": n_docs, "docs_per_s": round(n_docs / best, 1), "ms_per_batch": round(best * 1e3, 2),
+            "lm_import_ms": round(min(t_imp) * 1e3, 2), "from_empty_run_of_base_plus_A_ms": round(min(t_base) * 1e3, 2),
+            "algorithmic_bytes": int(st.in_bytes + st.out_bytes),
+            "parity": f"first 64 results equal to the oracle's batch of all three blobs, all {n_docs} succeeded, every document continued from its resident tracker",
+            "kernel_ms_of_a_run_that_reuses_its_tables": kt_reuse,
+            "workload": "configs[1] documents: base + A's branch (75k ops, 2 blobs) resident with their trackers; B's concurrent branch (25k ops, 1 blob) imported by lm_import; "
+                        "timed: the lm_run that follows (decode of all blobs, DAG, integrate of B's rows only after retreating A's branch, render)"}
+        note("resident: configs[1]-incremental done")
+    except Exception as ex:
+        out["configs[1]-incremental"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        note(f"resident: configs[1]-incremental FAILED: {type(ex).__name__}: {ex}"[:300])
+    if not full:
+        return out
+    try:
+        with mp.get_context("fork").Pool(min(8, cores)) as pool:
+            g5 = pool.map(_gen, [("cfg5", d) for d in range(4)])
+        n5 = 64
+        docs5 = [g5[i % 4][0] for i in range(n5)]
+        flat_docs, flat_fr = [], []
+        for d in range(4):
+            flat_docs += [g5[d][0]] * 16; flat_fr += g5[d][1]
+        want = _oracle.merge_batch(flat_docs, threads=min(32, cores), frontiers=flat_fr)
+        none = Context._pack([[] for _ in docs5])
+        with loro_amd.MergeEngine(device) as e:
+            best = 1e9
+            for rep in range(2):
+                t0 = time.perf_counter()
+                e.stage(docs5); e.import_packed(none); e.run()
+                t_replay = time.perf_counter() - t0
+                for k in range(16):
+                    e.import_more([[] for _ in docs5], [g5[i % 4][1][k] for i in range(n5)])
+                    e.run()
+                    if rep == 0:
+                        got = e.fetch()
+                        assert all(got[i] == want[(i % 4) * 16 + k] for i in range(n5)), "configs[4]-resident: device results differ from the CPU oracle"
+                if rep:
+                    best = min(best, time.perf_counter() - t0)
+        out["configs[4]-resident"] = {
+            "renderings": n5 * 16, "renderings_per_s": round(n5 * 16 / best, 1), "ms_total": round(best * 1e3, 2), "ms_replay_incl_staging": round(t_replay * 1e3, 2),
+            "parity": "all 1,024 renderings equal to the oracle's",
+            "workload": "64 1M-op rich-text documents (4 distinct), each staged and replayed ONCE, then rendered at 16 versions by moving the resident trackers "
+                        "(lm_import with frontiers only + lm_run, 16 times); the time includes staging, the replay and every lm_fetch-less run"}
+        note("resident: configs[4]-resident done")
+    except Exception as ex:
+        out["configs[4]-resident"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        note(f"resident: configs[4]-resident FAILED: {type(ex).__name__}: {ex}"[:300])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -529,6 +613,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_other_configs:
         line["other_configs"] = other_configs(local_rank, host_cores()[0])
         note("other configs done")
+        line["other_configs"].update(resident_configs(local_rank, host_cores()[0], n_docs=args.docs))
+        note("resident configs done")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -102,6 +102,33 @@ int lm_fetch(lm_ctx* ctx, lm_doc_out* outs);
 int lm_run_async(lm_ctx* ctx);
 int lm_wait(lm_ctx* ctx);
 
+/* Resident documents: import MORE blobs into the documents the context already holds, and / or render them
+ * at other versions — what a Rust host does with
+ *     doc.import(bytes)           crates/loro/src/lib.rs:710 → loro-internal/src/loro.rs:568-649,720-851 (a document with history)
+ *     doc.checkout(&frontiers)    loro.rs:1625-1760;  doc.checkout_to_latest()  loro.rs:1396-1417
+ * on documents it keeps alive, instead of building each one again from all its blobs.  `docs` has one entry per document of
+ * the batch staged last (same count, same order): its n_blobs (possibly 0) blobs are appended to that document's history, its
+ * checkout_frontiers (NULL = the latest version) is the version the next lm_run renders.  The next lm_run then
+ *   - decodes the blobs and rebuilds the causal graph (the tables are per batch),
+ *   - continues every sequence container's tracker from where the previous run left it (the reference keeps its trackers the
+ *     same way: DiffCalculatorRetainMode::Persist, diff_calc.rs:62-68, start_tracking reuse :1371-1376): only the changes the
+ *     tracker has not applied are integrated — each after the tracker moved to the change's dependencies (Tracker::checkout /
+ *     forward, container/richtext/tracker.rs:350-546) — and the tracker finally moves to the version being rendered,
+ *   - renders JSON + VersionVector as always.  A run that only changes the versions (no new blob anywhere) skips the decode.
+ * Semantics = the sequence of calls above, NOT one import_batch of all blobs: a root Text / List whose content was visible
+ * after some earlier lm_run stays part of the value when it is empty later ("text":"" — the state store never drops a
+ * container state, state.rs:621-849), where one batch of the same blobs omits it.  Each lm_run is: checkout_to_latest,
+ * import of the step's blobs (all of a document's blobs of one lm_import, or none: a document whose import fails — status
+ * LM_DECODE_ERROR, LM_CHECKSUM_MISMATCH, LM_DATA_CORRUPTION ... — keeps exactly what it held before, loro.rs:780-838),
+ * then the optional checkout; a refused checkout (LM_FRONTIERS_NOT_FOUND) does not undo the import in front of it.
+ * lm_stage starts a new batch and drops everything resident.  Limits: the span-granular integrate kernel (the default);
+ * a document's blobs must lie within 4 GiB of the context's blob arena; a document that holds a MovableList is replayed from
+ * the empty version whenever its element layout shifts (its results are the same, its import is not incremental). */
+int lm_import(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs);
+/* Diagnostics: how many documents of the last lm_run could not continue from a resident tracker and were replayed from the
+ * empty version (first run, capacity grown, a failed run before, MovableList layout shift). */
+int lm_resident_fresh(lm_ctx* ctx);
+
 /* Per-document metadata of the last lm_run (arrays of n_docs entries, any may be NULL) without copying the
  * rendered bytes back: what a sharded deployment all-gathers as the merged-state summary. */
 int lm_result_meta(lm_ctx* ctx, int32_t* status, uint64_t* json_len, uint64_t* vv_len, uint64_t* pending_ops);

@@ -19,7 +19,7 @@ class RunStats(ctypes.Structure):
 
 
 SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
-           "encode_block", "encode_updates", "free_bytes"]
+           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh"]
 
 
 class Binding:
@@ -33,6 +33,9 @@ class Binding:
         self.merge_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocIn), ctypes.c_size_t, ctypes.POINTER(DocOut)]
         self.stage = g("stage"); self.stage.restype = ctypes.c_int
         self.stage.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocIn), ctypes.c_size_t]
+        self.import_ = g("import"); self.import_.restype = ctypes.c_int
+        self.import_.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocIn), ctypes.c_size_t]
+        self.resident_fresh = g("resident_fresh"); self.resident_fresh.restype = ctypes.c_int; self.resident_fresh.argtypes = [ctypes.c_void_p]
         self.run = g("run"); self.run.restype = ctypes.c_int; self.run.argtypes = [ctypes.c_void_p]
         self.run_async = g("run_async"); self.run_async.restype = ctypes.c_int; self.run_async.argtypes = [ctypes.c_void_p]
         self.wait = g("wait"); self.wait.restype = ctypes.c_int; self.wait.argtypes = [ctypes.c_void_p]
@@ -118,6 +121,30 @@ class Context:
         if self.b.stage(self.h, arr, self.n) != 0:
             raise RuntimeError(self.b.last_error(self.h).decode())
         del keep  # the engine copied the blobs into its staging buffer
+
+    def import_more(self, docs, frontiers=None):
+        """lm_import: more blobs (docs[i] may be empty) and the checkout (None = latest) of the next run for every document of
+        the resident batch — LoroDoc::import on a document that already holds history, then LoroDoc::checkout."""
+        assert len(docs) == self.n
+        arr, keep = self._pack(docs, frontiers)
+        if self.b.import_(self.h, arr, self.n) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        del keep
+
+    def import_packed(self, packed):
+        arr, keep = packed
+        if self.b.import_(self.h, arr, self.n) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+
+    def step(self, docs, frontiers=None):
+        """import_more + run + fetch"""
+        self.import_more(docs, frontiers)
+        self.run()
+        return self.fetch()
+
+    def resident_fresh(self):
+        """documents of the last run that were replayed from the empty version (no usable resident tracker)"""
+        return self.b.resident_fresh(self.h)
 
     def stage_packed(self, packed):
         """lm_stage on an lm_doc_in array prepared once with Context._pack (bench.py: the host-side call alone)"""

@@ -60,6 +60,23 @@ struct lm_ctx_impl {
     for (auto& t : th) t.join();
     for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
   }
+  // lm_import: more blobs / other checkouts for the documents of the resident batch — each part takes its own documents
+  void import_more(const lm::Engine::DocIn* docs, size_t n) {
+    if (n != n_docs) throw std::runtime_error("lm_import: the document count differs from the resident batch");
+    ran = false;
+    uint32_t np2 = n_parts();
+    std::vector<std::string> errs(np2);
+    auto body = [&](uint32_t p) { try { parts[p]->import_more(docs + first[p], first[p + 1] - first[p]); } catch (const std::exception& e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "error"; } };
+    std::vector<std::thread> th;
+#ifdef LM_PARALLEL_PARTS
+    for (uint32_t p = 1; p < np2; p++) th.emplace_back(body, p);
+    body(0);
+#else
+    for (uint32_t p = 0; p < np2; p++) body(p);
+#endif
+    for (auto& t : th) t.join();
+    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+  }
   void run() {
     uint32_t np = n_parts();
     for (uint32_t p = 0; p < np; p++) parts[p]->profiling = profiling != 0;
@@ -111,6 +128,24 @@ int LM_API(stage)(void* c, const lm_doc_in_c* docs, size_t n) {
     x->stage(v.data(), n);
     return 0;
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
+// Resident documents: more blobs and / or other checkout versions for the documents of the batch staged last (same count, same
+// order; n_blobs may be 0).  The next lm_run imports them into the documents the context already holds.
+int LM_API(import)(void* c, const lm_doc_in_c* docs, size_t n) {
+  auto* x = (lm_ctx_impl*)c;
+  try {
+    std::vector<lm::Engine::DocIn> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = lm::Engine::DocIn{docs[i].blobs, docs[i].blob_lens, docs[i].n_blobs, docs[i].checkout_frontiers, docs[i].checkout_len};
+    x->import_more(v.data(), n);
+    return 0;
+  } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
+// documents of the last run that were replayed from the empty version (no usable resident tracker); diagnostics
+int LM_API(resident_fresh)(void* c) {
+  auto* x = (lm_ctx_impl*)c;
+  int n = 0;
+  for (uint32_t p = 0; p < x->n_parts(); p++) n += (int)x->parts[p]->last_fresh;
+  return n;
 }
 int LM_API(run)(void* c) {
   auto* x = (lm_ctx_impl*)c;

@@ -62,6 +62,7 @@ inline void dmemset(void* p, int v, size_t n) { LM_HIP_CHECK(hipMemsetAsync(p, v
 inline void h2d(void* d, const void* h, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, cur->s)); LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
 inline void h2d_async(void* d, const void* h, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, cur->s)); }   // h pinned; completed by the next sync()
 inline void d2h(void* h, const void* d, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, cur->s)); LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
+inline void d2d(void* dst, const void* src, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, cur->s)); }   // stream-ordered
 inline void sync() { LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
 inline void* halloc(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
 inline void hfree(void* p) { (void)hipHostFree(p); }

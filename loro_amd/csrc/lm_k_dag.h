@@ -388,7 +388,11 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
 }
 
 // K7b: one wave per doc — Kahn passes over nodes: replay order, lamports, vv at node heads.
-LM_KERNEL void k_dag_b(Dev d, DevDag g) {
+// res_mode (resident documents, lm_k_integrate_span.h DevRes): 0 = a batch: the DAG pass, then the optional checkout;
+// 1 = the DAG pass only, and peer_end_all := the applied end of EVERY document (the resident trackers replay every applied
+// op, whatever version is rendered); 2 = the checkout only, from peer_end_all — the part a run repeats when the same tables
+// are rendered at another version.
+LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   DocMeta m = d.doc[doc];
@@ -396,6 +400,12 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
   uint32_t P = m.n_peers, N = m.n_nodes;
   uint64_t vvh0 = ((uint64_t)m.vvh0_hi << 32) | m.vvh0_lo;
   uint32_t n_done = 0;
+  if (res_mode == 2) {
+    for (uint32_t p = (uint32_t)lane; p < P; p += 64) d.peer_end[m.praw0 + p] = d.peer_end_all[m.praw0 + p];
+    lmw::mem_fence();
+    lmw::block_sync();
+    N = 0;   // (skips the DAG pass below)
+  }
   for (uint32_t pass = 0; pass <= N && n_done < N; pass++) {
     uint32_t batch0 = n_done;
     // collect nodes whose dependencies are all done
@@ -449,6 +459,10 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
   // ---- optional checkout (loro.rs:1625-1760): frontiers → version vector (AppDag::frontiers_to_vv,
   // loro_dag.rs:1190-1207) = merge over the ids of (vv at the head of the id's node) ∪ {peer: counter+1}.
   // The version replaces peer_end: integrate / LWW / emit only see ops below it.
+  if (res_mode == 1) {
+    for (uint32_t p = (uint32_t)lane; p < P; p += 64) d.peer_end_all[m.praw0 + p] = d.peer_end[m.praw0 + p];
+    return;
+  }
   uint64_t f0 = d.front_off[doc], f1 = d.front_off[doc + 1];
   if (f1 == f0) return;
   int32_t ferr = ST_OK;
@@ -471,8 +485,9 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g) {
     if (!ferr && rd_left(r) != 0) ferr = ST_DECODE_ERROR;
   }
   lmw::block_sync();  // every lane has read peer_end before it is rewritten
+  if (ferr && res_mode == 2) { if (lane == 0) { d.doc[doc].front_err = ferr; d.doc[doc].flags |= DF_FRONT_ERR; } return; }   // (peer_end stays at the latest version)
   if (ferr) { if (lane == 0) LM_SETERR(d.doc[doc].status, ferr); return; }
-  for (uint32_t p = (uint32_t)lane; p < P; p += 64) d.peer_end_all[m.praw0 + p] = d.peer_end[m.praw0 + p];
+  if (res_mode == 0) for (uint32_t p = (uint32_t)lane; p < P; p += 64) d.peer_end_all[m.praw0 + p] = d.peer_end[m.praw0 + p];
   lmw::block_sync();
   for (uint32_t p0 = 0; p0 < P; p0 += 64) {
     uint32_t p = p0 + (uint32_t)lane, acc = 0;

@@ -553,6 +553,10 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
   lmw::block_sync();
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
   uint64_t doc_data0 = d.blob_off[d.doc_blob[doc]];
+  // which items show: a replay from the empty version of exactly the rendered version's ops leaves "never deleted" as the
+  // answer; a resident tracker (lm_k_integrate_span.h, DevRes) holds every applied op and stands AT the rendered version:
+  // an item shows iff it is active there (not future, delete count 0)
+  const uint32_t vis_mask = d.res_vis ? (ST_FUT | ST_DELMASK) : ST_EVER;
   LM_SHARED(uint32_t, s_eb, MAX_PEERS);   // element base per peer (the text gather reads it once per lane and leaf)
   for (uint32_t p = (uint32_t)lane; p < m.n_peers && p < MAX_PEERS; p += 64) s_eb[p] = d.elem_base[m.praw0 + p];
   lmw::block_sync();
@@ -624,7 +628,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
           const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * SP_REC;
           bool in = (uint32_t)lane < n;
           uint32_t id0 = in ? rec[lane] : NONE, ln = in ? rec[64 + lane] : 0u, st = in ? rec[256 + lane] : ST_EVER;
-          uint32_t vl = (in && !(st & ST_EVER)) ? ln : 0u;
+          uint32_t vl = (in && !(st & vis_mask)) ? ln : 0u;
           uint32_t inc = lmw::scan_incl_add(vl);
           uint32_t total = lmw::bcast(inc, 63);
           lmw::block_sync();
@@ -701,7 +705,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
             id = rec[lane];
             if (d.span) { ln = rec[64 + lane]; st = rec[256 + lane]; } else st = rec[192 + lane];
           }
-          bool vis = id != NONE && !(st & ST_EVER) && (uint32_t)lane >= slot0;
+          bool vis = id != NONE && !(st & vis_mask) && (uint32_t)lane >= slot0;
           uint64_t vm = lmw::ballot(vis);
           while (vm && !err && !pushed) {
             int l0 = lmw::ffs64(vm);

@@ -905,6 +905,36 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
 #define TS_CHECK(what, row) do {} while (0)
 #endif
 
+// ---- resident documents (DiffCalculatorRetainMode::Persist, diff_calc.rs:62-68,1371-1376; Tracker::checkout /
+// forward, tracker.rs:350-546).  A context in resident mode keeps every document's trackers in HBM between runs: the leaf pool,
+// each sequence container's leaf directory (both words), the tracker's version per (container, peer) and what it has applied
+// per peer.  The next run — more blobs imported, or another checkout — starts from that state: it applies only the changes
+// beyond the applied version (each after moving the tracker to the change's dependencies, as in the replay from the empty
+// version) and finally moves the tracker to the version being rendered; visibility is then "active" (not future, delete count
+// 0), not "never deleted".  Element ids are packed with the document's peer INDEX, which follows PeerID order: when a new
+// peer sorts in front of an old one the stored leaves are renumbered first; loc[] is rebuilt from the leaves in every run.
+struct ResDoc {            // one per document, written by the host for every run (lm_pipeline.h)
+  uint64_t tk_off;         // first word of the document's record in DevRes::tk
+  uint32_t pcap, ccap;     // peers / containers the record has room for
+  uint32_t reset;          // 1: the stored tracker is not to be used (first run, capacity grown, a failed run before): replay from the empty version
+  uint32_t pad;
+};
+struct DevRes {
+  const ResDoc* doc;
+  uint32_t* tk;                  // per-document tracker records (tk_* layout below)
+  const uint32_t* dir_a_prev;    // leaf directories as the previous run left them: word A / word B, [leaf0 + i]
+  const uint32_t* dir_b_prev;
+  uint32_t* dir_b;               // this run's word B (word A goes to Dev::dir_out, which the emit stage reads)
+};
+// record: [0] tracker valid  [1] peers  [2] containers  [3] leaves used  [4,5] first element slot of the document  [6,7] reserved
+//         peers × (PeerID lo, hi) | peers × applied end | peers × element base | containers × (TK_CW + pcap words)
+static constexpr uint32_t TK_HDR = 8, TK_CW = 8;   // container record: root0, n_dir, n_alive, exists (sticky, k_res_exists), 4 reserved, then cur[pcap]
+LM_DEV uint32_t tk_words(uint32_t pcap, uint32_t ccap) { return TK_HDR + 4 * pcap + ccap * (TK_CW + pcap); }
+LM_DEV uint32_t* tk_peers(uint32_t* tk) { return tk + TK_HDR; }
+LM_DEV uint32_t* tk_applied(uint32_t* tk, uint32_t pcap) { return tk + TK_HDR + 2 * pcap; }
+LM_DEV uint32_t* tk_ebase(uint32_t* tk, uint32_t pcap) { return tk + TK_HDR + 3 * pcap; }
+LM_DEV uint32_t* tk_cont(uint32_t* tk, uint32_t pcap, uint32_t c) { return tk + TK_HDR + 4 * pcap + c * (TK_CW + pcap); }
+
 // K9 (span-granular): one wave per document.  Dynamic LDS: [dir_cap] word A, [dir_cap] word B, then 3 × pmax.
 // Two kernels share this body.  ML = false (k_integrate_span) is the replay of Text / List containers and takes the documents
 // WITHOUT a MovableList; ML = true (k_integrate_span_ml) also knows the move rows and takes the documents WITH one (DF_MOVABLE);
@@ -918,11 +948,11 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
 // PLAIN = true (k_integrate_span_plain_sweep by default, k_integrate_span_plain under LM_PLAIN=1; LM_PLAIN=0 = common kernel): the
 // documents flagged DF_PLAIN — no checkout, no sliced change, no style anchor — whose row loop needs neither the slicing of a row
 // against the known prefix / the rendered version nor the style branches.
-template <bool ML, bool PLAIN, bool SWEEP = false>
+template <bool ML, bool PLAIN, bool SWEEP = false, bool RES = false>
 LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
-                                uint32_t* retry_count) {
+                                uint32_t* retry_count, DevRes rs = DevRes{}) {
   uint32_t doc = d.doc_order[(uint32_t)lmw::bid()];
   int lane = lmw::lane();
   LM_DYN_SHARED(uint32_t, s_mem);
@@ -931,7 +961,16 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   uint32_t* s_ebase = s_db + dir_cap;
   uint32_t* s_cur = s_ebase + pmax;
   uint32_t* s_end = s_cur + pmax;
+  uint32_t* s_tgt = s_end + pmax;    // RES only: the version being rendered (s_end is the latest applied version there)
+  uint32_t* s_app = s_tgt + pmax;    // RES only: what the stored tracker has applied, per peer
+  uint32_t* s_pmap = s_app + pmax;   // RES only: peer index of the stored tracker → peer index of this run
   DocMeta m = d.doc[doc];
+  if (RES) {
+    // the document's record is needed again when the tracker record is written at the very end: as wave-uniform scalars it
+    // costs SGPRs (spilled to VGPR lanes at worst), as loaded vector values it cost 70+ bytes of scratch per lane
+    uint32_t* mw = (uint32_t*)&m;
+    for (uint32_t i = 0; i < sizeof(DocMeta) / 4; i++) mw[i] = lmw::first(mw[i]);
+  }
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
   if ((m.flags & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
   (void)SWEEP;
@@ -956,6 +995,51 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   if (status_fatal(m.status)) return;
   uint32_t P = m.n_peers;
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_ebase[p] = d.elem_base[m.praw0 + p]; s_end[p] = d.peer_end[m.praw0 + p]; }
+  // RES: the stored tracker of this document, if it can be used
+  uint32_t* tk = nullptr;
+  uint32_t tk_pcap = 0, P0 = 0, C0 = 0;
+  bool fresh = true, renumber = false;
+  if (RES) {
+    // (the record is read with vector loads: its words are made wave-uniform scalars explicitly, or the record pointer and the
+    // capacities live in VGPRs for the whole kernel)
+    ResDoc rd;
+    {
+      const uint32_t* rw = (const uint32_t*)(rs.doc + doc);
+      rd.tk_off = ((uint64_t)lmw::first(rw[1]) << 32) | lmw::first(rw[0]);
+      rd.pcap = lmw::first(rw[2]); rd.ccap = lmw::first(rw[3]); rd.reset = lmw::first(rw[4]); rd.pad = 0;
+    }
+    tk = rs.tk + rd.tk_off;
+    tk_pcap = rd.pcap;
+    if (P > pmax || P > rd.pcap || m.n_cont > rd.ccap) { if (lane == 0) { LM_SETERR(d.doc[doc].status, ST_INTERNAL); tk[0] = 0; } return; }   // (the host sizes the record)
+    // every applied op is replayed; the version being rendered only decides where the tracker is left (peer_end_all = the
+    // applied end at the latest version, written by k_dag_b for every resident document)
+    for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_tgt[p] = d.peer_end[m.praw0 + p]; s_end[p] = d.peer_end_all[m.praw0 + p]; s_app[p] = 0; }
+    lmw::block_sync();
+    P0 = lmw::first(tk[1]); C0 = lmw::first(tk[2]);
+    fresh = rd.reset != 0 || retry_pass != 0 || lmw::first(tk[0]) != 1u || P0 > P || C0 > m.n_cont || P0 > rd.pcap;
+    if (!fresh) {
+      bool lost = false;
+      for (uint32_t q = (uint32_t)lane; q < P0; q += 64) {
+        uint64_t id = ((uint64_t)tk_peers(tk)[2 * q + 1] << 32) | tk_peers(tk)[2 * q];
+        uint32_t lo = 0, hi = P;
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.peer_uniq[m.praw0 + mid] < id) lo = mid + 1; else hi = mid; }
+        bool ok = lo < P && d.peer_uniq[m.praw0 + lo] == id;
+        s_pmap[q] = ok ? lo : 0u;
+        lost |= !ok;
+        renumber |= ok && lo != q;
+        // a MovableList move keeps the id of the item it deleted in its element slot (cp[]): the stored tracker is only usable
+        // while the element layout is the one it was written under
+        if (ML && ok && tk_ebase(tk, tk_pcap)[q] != d.elem_base[m.praw0 + lo]) lost = true;
+      }
+      if (ML && (lmw::first(tk[4]) != m.elem0_lo || lmw::first(tk[5]) != m.elem0_hi)) lost = true;   // (the document's element slice moved)
+      fresh = lmw::any(lost);
+      renumber = lmw::any(renumber);
+      lmw::block_sync();
+      if (!fresh) for (uint32_t q = (uint32_t)lane; q < P0; q += 64) s_app[s_pmap[q]] = tk_applied(tk, tk_pcap)[q];
+    }
+    if (lane == 0) tk[0] = 0;   // the record is being rewritten: valid again only when this run completes
+    if (fresh && !retry_pass && lane == 0) lmw::atomic_add(retry_count + 1, 1u);   // diagnostics: documents replayed from the empty version
+  }
   lmw::block_sync();
   uint64_t vvh0 = ((uint64_t)m.vvh0_hi << 32) | m.vvh0_lo;
   Ts t;
@@ -969,15 +1053,59 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
 #endif
   uint32_t dir_used = 0;
   if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
+  if (RES && !fresh) {
+    // the stored leaves: renumbered when the peer order changed, and loc[] (cleared above) written again for every item
+    t.n_leaf = lmw::first(tk[3]);
+    if (t.n_leaf > t.leaf_cap) { fresh = true; t.n_leaf = 0; }
+    for (uint32_t c = 0; c < C0 && !fresh; c++) {
+      const uint32_t* rec = tk_cont(tk, tk_pcap, c);
+      uint32_t r0 = lmw::first(rec[0]), nr = lmw::first(rec[1]);
+      for (uint32_t q = 0; q < nr; q++) {
+        uint32_t a = lmw::first(rs.dir_a_prev[m.leaf0 + r0 + q]);
+        uint32_t L = sa_leaf(a), n = sa_n(a);
+        uint32_t* lr = t.it + (uint64_t)L * SP_REC;
+        bool in = (uint32_t)lane < n;
+        SpanRegs R;
+        R.n = n;
+        R.id = in ? lr[lane] : NONE; R.len = in ? lr[64 + lane] : 0u;
+        if (renumber) {
+          uint32_t ol = in ? lr[128 + lane] : NONE, orr = in ? lr[192 + lane] : NONE;
+          if (in) {
+            R.id = pid_make(s_pmap[pid_peer(R.id)], pid_ctr(R.id));
+            if (ol != NONE) ol = pid_make(s_pmap[pid_peer(ol)], pid_ctr(ol));
+            if (orr != NONE) orr = pid_make(s_pmap[pid_peer(orr)], pid_ctr(orr));
+            lr[lane] = R.id; lr[128 + lane] = ol; lr[192 + lane] = orr;
+          }
+        }
+        sp_set_loc_lanes(t, R, in, L);
+      }
+    }
+    lmw::mem_fence();
+    lmw::block_sync();
+  }
   for (uint32_t cidx = 0; cidx < m.n_cont && !t.err; cidx++) {
     uint32_t ckind = d.cont[m.cid0 + cidx].kind_root & 0xff;
     if (ckind != CK_TEXT && ckind != CK_LIST && !(ML && ckind == CK_MOVABLE)) continue;
-    if (t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
-    uint32_t L0 = t.n_leaf++;
+    const bool resume = RES && !fresh && cidx < C0;
+    if (!resume && t.n_leaf >= t.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     lmw::block_sync();
-    if (lane == 0) { s_da[0] = sa_make(L0, 0, false); s_db[0] = 0; }
-    t.n_dir = 1; t.tot_active = 0; t.n_alive = 0; t.cache_leaf = NONE; t.cr.n = 255; t.cache_pre = NONE; t.dirty = false; t.loc_pend = 0;
+    t.cache_leaf = NONE; t.cr.n = 255; t.cache_pre = NONE; t.dirty = false; t.loc_pend = 0;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = 0;
+    if (resume) {
+      // the container's tracker as the previous run left it: directory, element counts, version
+      const uint32_t* rec = tk_cont(tk, tk_pcap, cidx);
+      uint32_t r0 = lmw::first(rec[0]), nr = lmw::first(rec[1]);
+      if (nr == 0 || nr > dir_cap) { t.err = nr ? ST_RETRY : ST_INTERNAL; break; }   // (optimistic LDS directory: the retry launch replays from the empty version)
+      uint32_t act = 0;
+      for (uint32_t i = (uint32_t)lane; i < nr; i += 64) { uint32_t b = rs.dir_b_prev[m.leaf0 + r0 + i]; s_da[i] = rs.dir_a_prev[m.leaf0 + r0 + i]; s_db[i] = b; act += b; }
+      t.n_dir = nr; t.tot_active = lmw::reduce_add(act); t.n_alive = lmw::first(rec[2]);
+      lmw::block_sync();
+      for (uint32_t q = (uint32_t)lane; q < P0; q += 64) s_cur[s_pmap[q]] = rec[TK_CW + q];
+    } else {
+      uint32_t L0 = t.n_leaf++;
+      if (lane == 0) { s_da[0] = sa_make(L0, 0, false); s_db[0] = 0; }
+      t.n_dir = 1; t.tot_active = 0; t.n_alive = 0;
+    }
     lmw::block_sync();
     bool touched = false;
     for (uint32_t oi = 0; oi < m.n_nodes && !t.err; oi++) {
@@ -985,6 +1113,10 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
       const uint32_t* vv = vvh_ro + vvh0 + (uint64_t)n * P;
       uint32_t node_peer = chg_ro[sorted_ro[m.chg0 + first]].peer;
+      if (RES) {   // a node the stored tracker has applied to its end
+        const ChangeRow lc = chg_ro[sorted_ro[m.chg0 + last]];
+        if (lc.ctr + lc.len <= s_app[node_peer]) continue;
+      }
       bool checked_out = false;
       const uint32_t* op_w = (const uint32_t*)op_ro;
       RowWin w;
@@ -993,8 +1125,10 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
         uint32_t crow = sorted_ro[m.chg0 + ci];
         const ChangeRow ch = chg_ro[crow];
         uint32_t skip_to = PLAIN ? ch.ctr : ch.ctr + skip_ro[crow];
+        if (RES) { uint32_t ap = s_app[node_peer]; if (ap > skip_to) skip_to = ap; }   // what the stored tracker has applied is skipped like a known prefix
         uint32_t pe = PLAIN ? ch.ctr + ch.len : s_end[node_peer];   // (PLAIN: every applied change lies inside the rendered version)
         uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
+        if (RES && ch.ctr + ch.len <= skip_to) n_rows = 0;
         for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
           OpRow r = rw_get(w, op_w, row);
@@ -1009,11 +1143,14 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
             checked_out = true;
             for (uint32_t p = 0; p < P && !t.err; p++) {
               uint32_t cur = s_cur[p], tgt = vv[p];
+              // RES: the stored tracker may stand below this peer's own earlier ops (a previous run left it at an older
+              // version): everything of the peer in front of this op belongs to the op's version
+              if (RES && p == node_peer) tgt = r.ctr + a;
               if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
               else if (cur < tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, cur, tgt, +1);
             }
             lmw::block_sync();
-            for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = vv[p];
+            for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = (RES && p == node_peer) ? r.ctr + a : vv[p];
             lmw::block_sync();
             PROF_ADD(t, PF_CHECKOUT);
             TS_CHECK("checkout", row);
@@ -1068,17 +1205,39 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       }
       lmw::block_sync();
     }
+    if (RES && !t.err) {
+      // the tracker moves to the version being rendered (Tracker::checkout, tracker.rs:354-461)
+      for (uint32_t p = 0; p < P && !t.err; p++) {
+        uint32_t cur = s_cur[p], tgt = s_tgt[p];
+        if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
+        else if (cur < tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, cur, tgt, +1);
+      }
+      lmw::block_sync();
+      for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = s_tgt[p];
+      lmw::block_sync();
+      TS_CHECK("closing checkout", 0);
+      if (t.err) break;
+      touched = true;
+    }
     sp_flush(t);
     lmw::block_sync();
     if (dir_used + t.n_dir > m.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
     for (uint32_t i = (uint32_t)lane; i < t.n_dir; i += 64) d.dir_out[m.leaf0 + dir_used + i] = s_da[i];
+    if (RES) {
+      for (uint32_t i = (uint32_t)lane; i < t.n_dir; i += 64) rs.dir_b[m.leaf0 + dir_used + i] = s_db[i];
+      uint32_t* rec = tk_cont(tk, tk_pcap, cidx);
+      for (uint32_t p = (uint32_t)lane; p < P; p += 64) rec[TK_CW + p] = s_cur[p];
+      if (lane == 0) { rec[0] = dir_used; rec[1] = t.n_dir; rec[2] = t.n_alive; }
+    }
     if (lane == 0) {
       d.cont_root0[m.cid0 + cidx] = dir_used;
       d.cont_nroot[m.cid0 + cidx] = t.n_dir;
       // the state store holds a root sequence once something is visible in it (diff_calc.rs:299: a container state is
       // created by a non-empty diff; from the empty version the diff is empty exactly when nothing is visible)
       // (a MovableList exists once an element was ever inserted — k_mlist_post adds that case after this stage)
-      if (touched && t.n_alive > 0) d.cont[m.cid0 + cidx].touched = 1;
+      // (RES: visible at the latest version — n_alive counts every applied op — or at the version the tracker was just moved to;
+      // earlier runs' verdicts are OR-ed in by k_res_exists)
+      if (touched && (t.n_alive > 0 || (RES && t.tot_active > 0))) d.cont[m.cid0 + cidx].touched = 1;
     }
     dir_used += t.n_dir;
     lmw::block_sync();
@@ -1086,6 +1245,23 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   if (t.err && lane == 0) {
     d.doc[doc].status = t.err;
     if (t.err == ST_RETRY) lmw::atomic_add(retry_count, 1u);
+  }
+  if (RES && !t.err) {
+    // the record of this run: peers (the numbering the leaves are packed with), what has been applied, the element layout
+    for (uint32_t p = (uint32_t)lane; p < P; p += 64) {
+      uint64_t id = d.peer_uniq[m.praw0 + p];
+      tk_peers(tk)[2 * p] = (uint32_t)id; tk_peers(tk)[2 * p + 1] = (uint32_t)(id >> 32);
+      tk_applied(tk, tk_pcap)[p] = s_end[p];
+      tk_ebase(tk, tk_pcap)[p] = s_ebase[p];
+    }
+    // containers that are not sequences keep an empty tracker record (their sticky `exists` word is k_res_exists's)
+    for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {
+      uint32_t ck = d.cont[m.cid0 + c].kind_root & 0xff;
+      if (ck != CK_TEXT && ck != CK_LIST && !(ML && ck == CK_MOVABLE)) { uint32_t* rec = tk_cont(tk, tk_pcap, c); rec[0] = 0; rec[1] = 0; rec[2] = 0; }
+    }
+    lmw::mem_fence();
+    lmw::block_sync();
+    if (lane == 0) { tk[1] = P; tk[2] = m.n_cont; tk[3] = t.n_leaf; tk[4] = m.elem0_lo; tk[5] = m.elem0_hi; tk[0] = 1; }
   }
   if (lane == 0) d.doc[doc].pad0 = dir_used;
 #ifdef LM_PROF
@@ -1116,6 +1292,39 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_ml(Dev d, 
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {
   integrate_span_body<true, false>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
+}
+// Resident documents (DevRes above): the common body with PLAIN = false (sliced rows: the applied prefix), SWEEP, RES.
+// (128 VGPRs: the prologue / epilogue state of a resident document does not fit the 96 of five waves per SIMD without scratch)
+LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count, DevRes rs) {
+  integrate_span_body<false, false, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count, rs);
+}
+LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res_ml(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count, DevRes rs) {
+  integrate_span_body<true, false, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count, rs);
+}
+
+// After every stage that decides which containers the state store holds (integrate, k_map_lww, k_mlist_post, k_state_roots):
+// a container state, once created, stays (state.rs:621-849 never drops one) — `touched` of a resident document is the OR over
+// all its runs.  One wave per document.
+LM_KERNEL void k_res_exists(Dev d, DevRes rs) {
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  const DocMeta m = d.doc[doc];
+  if (status_fatal(m.status)) return;
+  const ResDoc rd = rs.doc[doc];
+  if (m.n_cont > rd.ccap) return;
+  uint32_t* tk = rs.tk + rd.tk_off;
+  for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {
+    uint32_t* rec = tk_cont(tk, rd.pcap, c);
+    uint32_t e = (rec[3] == 1u ? 1u : 0u) | (d.cont[m.cid0 + c].touched ? 1u : 0u);
+    rec[3] = e;
+    d.cont[m.cid0 + c].touched = e;
+  }
 }
 
 }  // namespace lm

@@ -32,6 +32,17 @@ struct DBuf {  // grow-only device buffer
     if (!p) throw std::runtime_error("device allocation failed");
     cap = want;
   }
+  // grow and keep the first `keep` bytes (resident documents: arenas that outlive a run); stream-ordered copy
+  void ensure_keep(size_t n, size_t keep) {
+    if (n <= cap) return;
+    size_t want = n + n / 2 + 256;
+    void* q = lmbe::dalloc(want);
+    if (!q) throw std::runtime_error("device allocation failed");
+    if (p && keep) { lmbe::d2d(q, p, keep < cap ? keep : cap); lmbe::sync(); }
+    if (p) lmbe::dfree(p);
+    p = q;
+    cap = want;
+  }
   void release() { if (p) lmbe::dfree(p); p = nullptr; cap = 0; }
   template <class T> T* as() { return (T*)p; }
 };
@@ -49,6 +60,7 @@ struct Engine {
   uint32_t n_docs = 0, n_blobs = 0;
   uint64_t data_bytes = 0, in_bytes = 0;
   std::vector<uint64_t> h_blob_off, h_front_off, h_froot_off;
+  std::vector<uint8_t> h_front_bytes;             // the staged checkout frontiers, back to back (h_front_off)
   std::vector<uint32_t> h_blob_len, h_doc_blob, h_blob_doc;
   DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc, b_front, b_front_off, b_froot, b_froot_off, b_blob_hash, b_big;
   // work buffers
@@ -79,6 +91,37 @@ struct Engine {
   uint32_t last_retries = 0, last_reemits = 0;
   lmbe::StreamCtx* sc = nullptr;   // this engine's HIP stream + timing events
 
+  // ---- resident documents (lm_import; SURVEY §8f N2 — diff_calc.rs:62-68 DiffCalculatorRetainMode::Persist, loro.rs:568-649
+  // import on a document that already holds history).  The blobs stay in `b_data`, used as an append-only arena; every
+  // document keeps the list of its blobs, and the trackers of its sequence containers stay in HBM between runs (leaf pool,
+  // both directory words — double-buffered, a run reads the previous run's and writes its own — and one record per document
+  // in `b_tk`, lm_k_integrate_span.h).  A run after lm_import decodes the document's blobs again (old and new: the tables are
+  // laid out per batch) but integrates only the changes the trackers have not applied; a run that only changes the rendered
+  // versions reuses the tables as well.
+  struct BlobRef { uint64_t off; uint32_t len; };
+  bool resident = false;
+  std::vector<std::vector<BlobRef>> r_blobs;      // per document: its blobs in import order (arena offsets)
+  std::vector<uint32_t> r_step;                   // per document: blobs appended since the last run (dropped again if that run fails for it)
+  std::vector<std::vector<uint8_t>> r_front;      // per document: checkout frontiers of the next run (empty = latest)
+  uint64_t arena_top = 0;
+  bool tables_valid = false;                      // the decoded tables belong to the current blob lists
+  std::vector<uint32_t> tk_leaf0, tk_leaf_cap, tk_pcap, tk_ccap;
+  std::vector<uint64_t> tk_off;
+  std::vector<uint8_t> tk_reset;
+  uint64_t tk_top = 0;                            // words used in b_tk
+  uint32_t leaf_top = 0;                          // leaves handed out in the resident pool
+  int dir_parity = 0;                             // which directory buffers the next run writes
+  DBuf b_tk, b_res, b_dir_out2, b_dir_b, b_dir_b2, b_doc_saved;
+  uint32_t last_fresh = 0;
+  // what a run that reuses the tables needs from the run that built them
+  struct Saved {
+    Dev d; DevDag g;
+    uint32_t NB = 0, NC = 0, NO = 0, NCID = 0, NP = 0, dir_cap = 0, dir_opt = 0, pmax = 0;
+    uint64_t ht = 0;
+    bool any_ml = false, any_common = false;
+    std::vector<DocMeta> h_doc;
+  } sv;
+
   explicit Engine(int device) { sc = lmbe::stream_create(device); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -93,7 +136,7 @@ struct Engine {
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
-                   &b_vv_out, &b_vv_off};
+                   &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved};
     for (DBuf* b : all) b->release();
   }
 
@@ -207,7 +250,8 @@ struct Engine {
     b_blob_doc.ensure(nb * 4 + 4); if (nb) lmbe::h2d(b_blob_doc.p, h_blob_doc.data(), nb * 4);
     // optional checkout frontiers, back to back
     h_front_off.assign(nd + 1, 0);
-    std::vector<uint8_t> fr;
+    std::vector<uint8_t>& fr = h_front_bytes;
+    fr.clear();
     for (size_t i = 0; i < nd; i++) {
       h_front_off[i] = fr.size();
       if (docs[i].front) {
@@ -218,6 +262,127 @@ struct Engine {
     h_front_off[nd] = fr.size();
     b_front.ensure(fr.size() + 16); if (!fr.empty()) lmbe::h2d(b_front.p, fr.data(), fr.size());
     b_front_off.ensure((nd + 1) * 8); lmbe::h2d(b_front_off.p, h_front_off.data(), (nd + 1) * 8);
+    lmbe::sync();
+    ran = fetched = false;
+    resident = false; tables_valid = false;   // a new batch: whatever was resident is gone
+  }
+
+  // ---- lm_import: more blobs (and / or other checkouts) for the documents of the resident batch
+  static const uint8_t* snapshot_or_same(const uint8_t* p, size_t& l, std::vector<std::vector<uint8_t>>& conv) {
+    static const uint8_t stub_decode[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xff, 0xff};
+    static const uint8_t stub_checksum[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4};
+    if (l >= 22 && memcmp(p, "loro", 4) == 0 && p[20] == 0 && p[21] == 3) {
+      // a snapshot imported into a document that already holds history contributes its ChangeStore only (fast_snapshot.rs:326-344)
+      std::vector<uint8_t> o;
+      int st = lmsnap::snapshot_to_updates(p, l, o, nullptr);
+      if (st == lmsnap::SN_OK) { conv.push_back(std::move(o)); p = conv.back().data(); l = conv.back().size(); }
+      else if (st == lmsnap::SN_CHECKSUM) { p = stub_checksum; l = 22; }
+      else if (st == lmsnap::SN_DECODE) { p = stub_decode; l = 22; }
+    }
+    return p;
+  }
+  void adopt_resident() {   // the staged batch becomes the first generation of the resident documents
+    r_blobs.assign(n_docs, {});
+    for (uint32_t i = 0; i < n_docs; i++)
+      for (uint32_t b = h_doc_blob[i]; b < h_doc_blob[i + 1]; b++) r_blobs[i].push_back(BlobRef{h_blob_off[b], h_blob_len[b]});
+    arena_top = h_blob_off[n_blobs];
+    r_step.assign(n_docs, 0);
+    r_front.assign(n_docs, {});
+    for (uint32_t i = 0; i < n_docs; i++) r_front[i].assign(h_front_bytes.begin() + h_front_off[i], h_front_bytes.begin() + h_front_off[i + 1]);
+    tk_leaf0.assign(n_docs, 0); tk_leaf_cap.assign(n_docs, 0); tk_pcap.assign(n_docs, 0); tk_ccap.assign(n_docs, 0);
+    tk_off.assign(n_docs, 0); tk_reset.assign(n_docs, 1);
+    tk_top = 0; leaf_top = 0; dir_parity = 0;
+    resident = true; tables_valid = false;
+  }
+  void rebuild_blob_tables() {
+    size_t nd = n_docs, nb = 0;
+    h_doc_blob.assign(nd + 1, 0);
+    for (size_t i = 0; i < nd; i++) { h_doc_blob[i] = (uint32_t)nb; nb += r_blobs[i].size(); }
+    h_doc_blob[nd] = (uint32_t)nb;
+    n_blobs = (uint32_t)nb;
+    h_blob_off.assign(nb + 1, 0); h_blob_len.assign(nb, 0); h_blob_doc.assign(nb, 0);
+    in_bytes = 0;
+    size_t b = 0;
+    for (size_t i = 0; i < nd; i++) {
+      // list values are addressed by 32-bit offsets from the document's first blob (cp[], lm_k_dag.h k_elem_fill)
+      if (!r_blobs[i].empty() && r_blobs[i].back().off + r_blobs[i].back().len - r_blobs[i].front().off >= 0xfffffff0ull)
+        throw std::runtime_error("lm_import: a resident document's blobs span more than 4 GiB of the arena (stage the batch again)");
+      for (const BlobRef& r : r_blobs[i]) { h_blob_off[b] = r.off; h_blob_len[b] = r.len; h_blob_doc[b] = (uint32_t)i; in_bytes += r.len; b++; }
+    }
+    h_blob_off[nb] = arena_top;
+    data_bytes = arena_top + 64;
+    b_blob_off.ensure((nb + 1) * 8); lmbe::h2d(b_blob_off.p, h_blob_off.data(), (nb + 1) * 8);
+    b_blob_len.ensure(nb * 4 + 4); if (nb) lmbe::h2d(b_blob_len.p, h_blob_len.data(), nb * 4);
+    b_doc_blob.ensure((nd + 1) * 4); lmbe::h2d(b_doc_blob.p, h_doc_blob.data(), (nd + 1) * 4);
+    b_blob_doc.ensure(nb * 4 + 4); if (nb) lmbe::h2d(b_blob_doc.p, h_blob_doc.data(), nb * 4);
+    h_front_off.assign(nd + 1, 0);
+    h_front_bytes.clear();
+    for (size_t i = 0; i < nd; i++) { h_front_off[i] = h_front_bytes.size(); h_front_bytes.insert(h_front_bytes.end(), r_front[i].begin(), r_front[i].end()); }
+    h_front_off[nd] = h_front_bytes.size();
+    b_front.ensure(h_front_bytes.size() + 16); if (!h_front_bytes.empty()) lmbe::h2d(b_front.p, h_front_bytes.data(), h_front_bytes.size());
+    b_front_off.ensure((nd + 1) * 8); lmbe::h2d(b_front_off.p, h_front_off.data(), (nd + 1) * 8);
+  }
+  // a (larger) tracker record for document i; the sticky "the state store holds this container" words move over, the tracker
+  // itself is not carried (the document is replayed from the empty version by the next run)
+  void tk_grow(uint32_t i, uint32_t P, uint32_t C) {
+    uint32_t pcap = P + P / 2 + 2, ccap = C + C / 2 + 4;
+    uint64_t words = (uint64_t)TK_HDR + 4ull * pcap + (uint64_t)ccap * (TK_CW + pcap);
+    std::vector<uint32_t> rec(words, 0u);
+    if (tk_pcap[i]) {
+      uint32_t op = tk_pcap[i], oc = tk_ccap[i];
+      uint64_t ow = (uint64_t)TK_HDR + 4ull * op + (uint64_t)oc * (TK_CW + op);
+      std::vector<uint32_t> old(ow);
+      lmbe::d2h(old.data(), b_tk.as<uint32_t>() + tk_off[i], ow * 4);
+      for (uint32_t c = 0; c < oc && c < ccap; c++)
+        rec[TK_HDR + 4ull * pcap + (uint64_t)c * (TK_CW + pcap) + 3] = old[TK_HDR + 4ull * op + (uint64_t)c * (TK_CW + op) + 3] == 1u ? 1u : 0u;
+    }
+    b_tk.ensure_keep((tk_top + words + 16) * 4, tk_top * 4);
+    lmbe::h2d(b_tk.as<uint32_t>() + tk_top, rec.data(), words * 4);
+    tk_off[i] = tk_top; tk_top += words; tk_pcap[i] = pcap; tk_ccap[i] = ccap; tk_reset[i] = 1;
+  }
+  void import_more(const DocIn* docs, size_t nd) {
+    lmbe::bind(sc);
+    if (nd != n_docs) throw std::runtime_error("lm_import: the document count differs from the resident batch");
+    if (!resident) adopt_resident();
+    std::vector<std::vector<uint8_t>> conv;
+    struct Src { const uint8_t* p; size_t l; uint64_t off; };
+    std::vector<Src> src;
+    uint64_t top = arena_top;
+    for (size_t i = 0; i < nd; i++) {
+      for (size_t k = 0; k < docs[i].n; k++) {
+        size_t l = docs[i].lens[k];
+        const uint8_t* p = snapshot_or_same(docs[i].blobs[k], l, conv);
+        if (l > 0xfffffff0ull) throw std::runtime_error("blob larger than 4 GiB");
+        src.push_back(Src{p, l, top});
+        r_blobs[i].push_back(BlobRef{top, (uint32_t)l});
+        r_step[i]++;
+        top += (l + 15) & ~(uint64_t)15;
+      }
+      if (docs[i].front && docs[i].front_len == 0) throw std::runtime_error("checkout_frontiers with zero length (the empty version is the byte 00)");
+      std::vector<uint8_t> f;
+      if (docs[i].front) f.assign(docs[i].front, docs[i].front + docs[i].front_len);
+      r_front[i].swap(f);
+    }
+    uint64_t add = top - arena_top;
+    if (add) {
+      if (add + 64 > h_stage_cap) {
+        if (h_stage) lmbe::hfree(h_stage);
+        h_stage_cap = add + add / 4 + 4096;
+        h_stage = (uint8_t*)lmbe::halloc(h_stage_cap);
+        if (!h_stage) { h_stage_cap = 0; throw std::runtime_error("host staging allocation failed"); }
+      }
+      for (const Src& x : src) {
+        uint64_t o = x.off - arena_top, pad = ((x.l + 15) & ~(uint64_t)15) - x.l;
+        memcpy(h_stage + o, x.p, x.l);
+        if (pad) memset(h_stage + o + x.l, 0, pad);
+      }
+      memset(h_stage + add, 0, 64);
+      b_data.ensure_keep(top + 64, arena_top);
+      lmbe::h2d_async((uint8_t*)b_data.p + arena_top, h_stage, add + 64);
+      arena_top = top;
+      tables_valid = false;
+    }
+    rebuild_blob_tables();
     lmbe::sync();
     ran = fetched = false;
   }
@@ -263,6 +428,33 @@ struct Engine {
     d.n_docs = n_docs;
     results.assign(n_docs, DocResult{0, 0, 0, 0, 0, 0});
     if (n_docs == 0) { ran = true; return; }
+    // resident documents whose blob lists did not change since the tables were built: only the rendered versions differ —
+    // the decode / DAG stages are skipped, the saved tables are rendered again (k_dag_b's checkout part onwards)
+    const bool reuse = resident && tables_valid;
+    uint32_t NB = 0, NC = 0, NO = 0, NCID = 0, NP = 0;
+    DevDag g;
+    memset(&g, 0, sizeof g);
+    const bool span = !(getenv("LM_SPAN") && atoi(getenv("LM_SPAN")) == 0);
+    if (resident && !span) throw std::runtime_error("resident documents need the span-granular integrate kernel (LM_SPAN=0 is set)");
+    uint64_t ht = 0;
+    uint32_t dir_cap = 64, dir_opt = 64, pmax = 2;
+    const uint32_t DIR_CAP_MAX = span ? 18000u : 36000u;
+    // DF_PLAIN (k_dag_a) survives only with the span kernel, for documents rendered at the latest version.  Such documents are
+    // replayed by k_integrate_span_plain_sweep (default, = LM_PLAIN=2; measured -9 % against the common kernel on configs[1],
+    // profiles/r02_ab_prepared.log); LM_PLAIN=1 selects k_integrate_span_plain, LM_PLAIN=0 the common kernel for every document
+    const int plain_mode = (!span || resident) ? 0 : getenv("LM_PLAIN") ? atoi(getenv("LM_PLAIN")) : 2;
+    const bool plain_on = plain_mode == 1 || plain_mode == 2;
+    bool any_plain = false;
+    if (reuse) {
+      d = sv.d; g = sv.g;
+      d.front = b_front.as<uint8_t>(); d.front_off = b_front_off.as<uint64_t>();
+      d.blob_off = b_blob_off.as<uint64_t>(); d.blob_len = b_blob_len.as<uint32_t>(); d.doc_blob = b_doc_blob.as<uint32_t>(); d.blob_doc = b_blob_doc.as<uint32_t>();
+      NB = sv.NB; NC = sv.NC; NO = sv.NO; NCID = sv.NCID; NP = sv.NP; ht = sv.ht; dir_cap = sv.dir_cap; dir_opt = sv.dir_opt; pmax = sv.pmax;
+      h_doc = sv.h_doc;
+      lmbe::d2d(b_doc.p, b_doc_saved.p, (size_t)n_docs * sizeof(DocMeta));   // the documents' records as they were in front of the checkout
+      if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
+      lmbe::dmemset(b_ht_cnt.p, 0, (size_t)n_docs * 4 + 4);
+    } else {
     // 1. envelope / checksum / block count
     b_blob_status.ensure((size_t)n_blobs * 4 + 4);
     b_blob_nblk.ensure((size_t)(n_blobs + 1) * 4);
@@ -286,7 +478,6 @@ struct Engine {
     if (n_blobs) LM_LAUNCH(k_frame_count, cdiv(n_blobs, 64), 64, d);
     lmbe::toc("k_frame_count", times, profiling);
     scan(d.blob_nblk, d.blob_blk0, n_blobs, 1);
-    uint32_t NB = 0;
     lmbe::d2h(&NB, d.blob_blk0 + n_blobs, 4);
     d.n_blocks = NB;
     // 2. block descriptors + row counts
@@ -303,7 +494,8 @@ struct Engine {
     scan(d.bcnt, d.boff, NB, BCN);
     uint32_t tot[BCN];
     lmbe::d2h(tot, d.boff + (uint64_t)NB * BCN, sizeof tot);
-    uint32_t NC = tot[BC_CHG], ND = tot[BC_DEP], NO = tot[BC_OP], NK = tot[BC_KEY], NCID = tot[BC_CID], NP = tot[BC_PEER];
+    uint32_t ND = tot[BC_DEP], NK = tot[BC_KEY];
+    NC = tot[BC_CHG]; NO = tot[BC_OP]; NCID = tot[BC_CID]; NP = tot[BC_PEER];
     // 3. row tables
     b_chg.ensure((size_t)(NC + 1) * sizeof(ChangeRow));
     b_dep_peer.ensure((size_t)(ND + 1) * 4); b_dep_ctr.ensure((size_t)(ND + 1) * 4);
@@ -334,7 +526,6 @@ struct Engine {
     d.chg_skip = b_chg_skip.as<uint32_t>(); d.chg_flag = b_chg_flag.as<uint32_t>(); d.chg_mask = b_chg_mask.as<uint32_t>();
     d.node_first = b_node_first.as<uint32_t>(); d.node_last = b_node_last.as<uint32_t>(); d.node_order = b_node_order.as<uint32_t>();
     d.cont_root0 = b_cont_root0.as<uint32_t>(); d.cont_nroot = b_cont_nroot.as<uint32_t>();
-    DevDag g;
     g.blk_sorted = b_blk_sorted.as<uint32_t>(); g.chg_node = b_chg_node.as<uint32_t>();
     g.node_done = b_node_done.as<uint32_t>(); g.node_lam = b_node_lam.as<uint32_t>();
     lmbe::dmemset(b_chg_flag.p, 0, (size_t)(NC + 1) * 4);
@@ -367,21 +558,13 @@ struct Engine {
     lmbe::d2h(h_doc.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
     // integrate kernel: span-granular leaves (lm_k_integrate_span.h) by default; LM_SPAN=0 selects the element-granular
     // kernel (lm_k_integrate.h), kept as the second implementation the parity suites also run
-    const bool span = !(getenv("LM_SPAN") && atoi(getenv("LM_SPAN")) == 0);
+    // (directory entries that fit the 160 KiB LDS of a CU next to 3·MAX_PEERS words: one word per entry in the
+    // element-granular kernel, two in the span-granular one: DIR_CAP_MAX)
     d.span = span ? 1u : 0u;
-    uint64_t elem = 0, leaves = 0, vvh = 0, ht = 0;
-    uint32_t dir_cap = 64, dir_opt = 64, pmax = 2;
-    // directory entries that fit the 160 KiB LDS of a CU next to 3·MAX_PEERS words: one word per entry in the
-    // element-granular kernel, two in the span-granular one
-    const uint32_t DIR_CAP_MAX = span ? 18000u : 36000u;
+    d.res_vis = resident ? 1u : 0u;
+    uint64_t elem = 0, leaves = 0, vvh = 0;
     std::vector<uint64_t> h_ht0(n_docs);
     std::vector<uint32_t> h_ht_cap(n_docs);
-    // DF_PLAIN (k_dag_a) survives only with the span kernel, for documents rendered at the latest version.  Such documents are
-    // replayed by k_integrate_span_plain_sweep (default, = LM_PLAIN=2; measured -9 % against the common kernel on configs[1],
-    // profiles/r02_ab_prepared.log); LM_PLAIN=1 selects k_integrate_span_plain, LM_PLAIN=0 the common kernel for every document
-    const int plain_mode = !span ? 0 : getenv("LM_PLAIN") ? atoi(getenv("LM_PLAIN")) : 2;
-    const bool plain_on = plain_mode == 1 || plain_mode == 2;
-    bool any_plain = false;
     for (uint32_t i = 0; i < n_docs; i++) {
       DocMeta& m = h_doc[i];
       bool ok = m.status == ST_OK;
@@ -399,6 +582,17 @@ struct Engine {
       }
       if (leaves + lc > 0xfffffff0ull) throw std::runtime_error("batch too large for 32-bit pool indices");
       m.leaf0 = (uint32_t)leaves; m.leaf_cap = lc;
+      if (resident) {
+        // the document's region of the resident leaf pool and its tracker record: kept while they are large enough, handed out
+        // anew (with room to grow) otherwise — the stored tracker is then not used, the document is replayed from the empty version
+        if (ok && lc > tk_leaf_cap[i]) {
+          uint32_t cap = lc + lc / 2 + 8;
+          if ((uint64_t)leaf_top + cap > 0xfffffff0ull) throw std::runtime_error("resident leaf pool beyond 32-bit indices");
+          tk_leaf0[i] = leaf_top; tk_leaf_cap[i] = cap; leaf_top += cap; tk_reset[i] = 1;
+        }
+        m.leaf0 = tk_leaf0[i]; m.leaf_cap = ok ? tk_leaf_cap[i] : 0;
+        if (ok && (m.n_peers > tk_pcap[i] || m.n_cont > tk_ccap[i])) tk_grow(i, m.n_peers, m.n_cont);
+      }
       m.vvh0_lo = (uint32_t)vvh; m.vvh0_hi = (uint32_t)(vvh >> 32);
       if (ok) { elem += ((uint64_t)m.atoms + 3) & ~3ull; leaves += lc; vvh += (uint64_t)m.n_nodes * m.n_peers; }   // element slices start 16-byte aligned (k_integrate_span clears loc[] four entries per store)
       if (lc > dir_cap) dir_cap = lc;
@@ -426,9 +620,17 @@ struct Engine {
       d.doc_order = b_order.as<uint32_t>();
     }
     lmbe::h2d(d.doc, h_doc.data(), (size_t)n_docs * sizeof(DocMeta));
-    b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
-    b_it.ensure((leaves + 1) * (span ? (size_t)SP_REC : 256) * 4);
-    b_dir_out.ensure((leaves + 1) * 4);
+    if (resident) {
+      // arenas that outlive the run: element payloads (a MovableList move keeps the id of the item it deleted in its own slot),
+      // the leaf pool and the two generations of the leaf directories
+      b_cp.ensure_keep((elem + 1) * 4, b_cp.cap); b_loc.ensure((elem + 1) * 4);
+      b_it.ensure_keep(((size_t)leaf_top + 1) * SP_REC * 4, b_it.cap);
+      for (DBuf* b : {&b_dir_out, &b_dir_out2, &b_dir_b, &b_dir_b2}) b->ensure_keep(((size_t)leaf_top + 1) * 4, b->cap);
+    } else {
+      b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
+      b_it.ensure((leaves + 1) * (span ? (size_t)SP_REC : 256) * 4);
+      b_dir_out.ensure((leaves + 1) * 4);
+    }
     b_lf_chunk.ensure(leaves + 64);
     b_vvh.ensure((vvh + 1) * 4);
     b_prof.ensure((size_t)n_docs * 16 * 8);
@@ -450,14 +652,27 @@ struct Engine {
     // loc[] is initialised by k_integrate (each document's wave clears its own slice); cp[] needs no fill: every
     // element that can be placed was written by k_elem_fill
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
+      if (resident) {
+        sv.d = d; sv.g = g; sv.NB = NB; sv.NC = NC; sv.NO = NO; sv.NCID = NCID; sv.NP = NP; sv.ht = ht;
+        sv.dir_cap = dir_cap; sv.dir_opt = dir_opt; sv.pmax = pmax; sv.h_doc = h_doc;
+      }
+    }   // (!reuse)
     lmbe::dmemset(b_cont_root0.p, 0, (size_t)(NCID + 1) * 4);
     lmbe::dmemset(b_cont_nroot.p, 0, (size_t)(NCID + 1) * 4);
     // 5. causal order, element payloads, LWW, integrate
     lmbe::tic(profiling);
-    LM_LAUNCH(k_dag_b, n_docs, 64, d, g);
+    if (!resident) LM_LAUNCH(k_dag_b, n_docs, 64, d, g, 0u);
+    else {
+      if (!reuse) {
+        LM_LAUNCH(k_dag_b, n_docs, 64, d, g, 1u);    // the DAG pass; the documents' records are kept as they are in front of the checkout
+        b_doc_saved.ensure((size_t)n_docs * sizeof(DocMeta));
+        lmbe::d2d(b_doc_saved.p, b_doc.p, (size_t)n_docs * sizeof(DocMeta));
+      }
+      LM_LAUNCH(k_dag_b, n_docs, 64, d, g, 2u);      // the checkout of this run
+    }
     lmbe::toc("k_dag_b", times, profiling);
     lmbe::tic(profiling);
-    if (NB) LM_LAUNCH(k_elem_fill, NB, 64, d);
+    if (NB && !reuse) LM_LAUNCH(k_elem_fill, NB, 64, d);
     lmbe::toc("k_elem_fill", times, profiling);
     lmbe::tic(profiling);
     if (NO) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
@@ -471,13 +686,32 @@ struct Engine {
     if (getenv("LM_DIR_OPT_MAX")) { uint32_t mx = (uint32_t)atoi(getenv("LM_DIR_OPT_MAX")); if (mx >= 4 && mx < dir_opt) dir_opt = mx & ~3u; }   // tests: force the retry launch
     b_tot.ensure(64 * 4);
     uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
-    lmbe::dmemset(retry_cnt, 0, 4);
+    lmbe::dmemset(retry_cnt, 0, 8);   // [0] documents to re-run with the worst-case directory, [1] resident documents replayed from the empty version
     const size_t dir_words = span ? 2 : 1;   // LDS words per directory entry
     // documents that hold a MovableList are replayed by the kernel that knows move rows (k_integrate_span_ml), the others by
     // the common one; each kernel's waves leave the other's documents at once
     bool any_ml = false, any_common = false;
     for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) { any_ml |= (h_doc[i].flags & DF_MOVABLE) != 0; any_common |= (h_doc[i].flags & (DF_MOVABLE | DF_PLAIN)) == 0; }
-    if (span) {
+    DevRes rs;
+    memset(&rs, 0, sizeof rs);
+    if (resident) {
+      // every document's tracker record and its two directory generations: this run reads what the previous run wrote
+      std::vector<ResDoc> hres(n_docs);
+      for (uint32_t i = 0; i < n_docs; i++) hres[i] = ResDoc{tk_off[i], tk_pcap[i], tk_ccap[i], tk_reset[i], 0u};
+      b_res.ensure((size_t)n_docs * sizeof(ResDoc));
+      lmbe::h2d(b_res.p, hres.data(), (size_t)n_docs * sizeof(ResDoc));
+      rs.doc = b_res.as<ResDoc>(); rs.tk = b_tk.as<uint32_t>();
+      DBuf& wa = dir_parity ? b_dir_out2 : b_dir_out; DBuf& ra = dir_parity ? b_dir_out : b_dir_out2;
+      DBuf& wb = dir_parity ? b_dir_b2 : b_dir_b;     DBuf& rb = dir_parity ? b_dir_b : b_dir_b2;
+      d.dir_out = wa.as<uint32_t>(); rs.dir_a_prev = ra.as<uint32_t>(); rs.dir_b = wb.as<uint32_t>(); rs.dir_b_prev = rb.as<uint32_t>();
+      const size_t lds = (size_t)(2 * dir_opt + 6 * pmax) * 4 + lds_pad;
+      if (any_common || !any_ml)
+        LM_LAUNCH_DYN(k_integrate_span_res, n_docs, 64, lds, d, g, dir_opt, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
+                      (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
+      if (any_ml)
+        LM_LAUNCH_DYN(k_integrate_span_res_ml, n_docs, 64, lds, d, g, dir_opt, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
+                      (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
+    } else if (span) {
       if (any_plain && plain_mode == 2)
         LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
@@ -495,9 +729,22 @@ struct Engine {
                     (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
     }
     uint32_t n_retry = 0;
-    lmbe::d2h(&n_retry, retry_cnt, 4);
+    {
+      uint32_t two[2] = {0, 0};
+      lmbe::d2h(two, retry_cnt, 8);
+      n_retry = two[0];
+      if (resident) last_fresh = two[1];
+    }
     if (n_retry) {  // rare: re-run the overflowed documents with the worst-case directory
-      if (span) {
+      if (resident) {
+        const size_t lds = (size_t)(2 * dir_cap + 6 * pmax) * 4;
+        if (any_common || !any_ml)
+          LM_LAUNCH_DYN(k_integrate_span_res, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
+                        (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
+        if (any_ml)
+          LM_LAUNCH_DYN(k_integrate_span_res_ml, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
+                        (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
+      } else if (span) {
         LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         if (any_ml)
@@ -515,10 +762,11 @@ struct Engine {
       }
     }
     last_retries = n_retry;
-    if (h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only
+    if (!resident && h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only (a resident tracker knows both versions)
     if (h_froot_off.size() > n_docs && h_froot_off[n_docs] > 0) LM_LAUNCH(k_state_roots, n_docs, 64, d);        // documents initialised from a snapshot only
     // documents holding a MovableList only: element → item maxima and the items' elements (loc[] is free from here on)
     if (any_ml) LM_LAUNCH(k_mlist_post, n_docs, 64, d);
+    if (resident) LM_LAUNCH(k_res_exists, n_docs, 64, d, rs);   // the state store keeps what it once held: OR over the document's runs
 #ifdef LM_EMU_TRACE
     if (getenv("LM_EMU_DUMP")) {  // kernel-logic harness only: leaves of document 0 in document order
       lmbe::d2h(h_doc.data(), b_doc.p, (size_t)n_docs * sizeof(DocMeta));
@@ -545,7 +793,8 @@ struct Engine {
       // the stage is named after the kernel that ran when there was only one (so the name matches rocprofv3's)
       const bool l_plain = span && any_plain, l_common = span && (any_common || !(any_ml || any_plain));
       const int n_launched = (int)l_plain + (int)l_common + (int)(span && any_ml);
-      const char* stage = !span ? "k_integrate"
+      const char* stage = resident ? (any_ml && any_common ? "k_integrate_span_res (both instantiations)" : any_ml ? "k_integrate_span_res_ml" : "k_integrate_span_res")
+                          : !span ? "k_integrate"
                           : n_launched > 1 ? "k_integrate_span (several instantiations)"
                           : l_plain ? (plain_mode == 2 ? "k_integrate_span_plain_sweep" : "k_integrate_span_plain")
                           : any_ml ? "k_integrate_span_ml" : "k_integrate_span";
@@ -646,12 +895,28 @@ struct Engine {
       bool ok = r.status == ST_OK;
       // out-of-scope containers met: everything in scope is rendered (they appear as null) and the document is flagged
       if (ok && (h_doc[i].flags & DF_SOFT_UNSUPPORTED)) r.status = ST_UNSUPPORTED;
+      if (ok && (h_doc[i].flags & DF_FRONT_ERR)) { r.status = h_doc[i].front_err; ok = false; }   // resident: the import went through, the checkout was refused
       r.json_off = h_out_off[i]; r.json_len = ok ? h_doc[i].out_len : 0;
       r.vv_off = h_vv_off[i]; r.vv_len = ok ? h_doc[i].vv_len : 0;
       r.pending = ok ? (((uint64_t)h_doc[i].pending_hi << 32) | h_doc[i].pending_lo) : 0;
       r.json_xxh64 = ok ? h_hash[i] : 0;
     }
     lmbe::flush_times(times);
+    if (resident) {
+      // a document whose run failed keeps what it held before: the blobs of this step are dropped again (reference import is
+      // atomic per document, loro.rs:780-838) and its tracker — possibly half moved — is not used by the next run
+      bool dropped = false;
+      for (uint32_t i = 0; i < n_docs; i++) {
+        if (h_doc[i].status != ST_OK) {
+          if (r_step[i]) { r_blobs[i].resize(r_blobs[i].size() - r_step[i]); dropped = true; }
+          tk_reset[i] = 1;
+        } else tk_reset[i] = 0;
+        r_step[i] = 0;
+      }
+      dir_parity ^= 1;
+      tables_valid = !dropped;
+      if (dropped) { rebuild_blob_tables(); lmbe::sync(); }
+    }
     ran = true;
     fetched = false;
   }

@@ -99,6 +99,7 @@ struct DocMeta {             // per document, filled progressively
   uint32_t vv_len;           // VV bytes
   uint32_t pad0;             // directory entries used by the integrate stage (sizing diagnostics)
   uint32_t flags;            // DF_* bits
+  int32_t front_err;         // resident documents: why the requested checkout was refused (DF_FRONT_ERR); the import itself went through
 };
 
 // DocMeta.flags / BlockDesc.flags
@@ -107,6 +108,9 @@ enum : uint32_t {
                              // null, everything else is rendered, and the document is reported LM_UNSUPPORTED *with* its JSON
   DF_REEMIT = 2u,            // the rendered JSON did not fit the optimistic output slab: re-rendered at its exact size
   DF_MOVABLE = 4u,           // the document holds a MovableList container: k_mlist_post runs for it after the integrate stage
+  DF_FRONT_ERR = 16u,        // resident documents (lm_import): the checkout frontiers were refused (DocMeta.front_err) — LoroDoc::checkout fails
+                             // after LoroDoc::import succeeded: the blobs stay imported, the document is rendered at the latest version for
+                             // the state store's sake and reported with that error
   DF_PLAIN = 8u,             // no sliced change, no style anchor, no MovableList (k_dag_a); the host clears it for checked-out documents
                              // and under LM_PLAIN=0: such a document is replayed by k_integrate_span_plain_sweep (lm_pipeline.h)
 };

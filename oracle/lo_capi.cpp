@@ -81,6 +81,55 @@ const char* lo_batch_vv(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*
 const char* lo_batch_err(void* h, uint32_t i) { return ((Batch*)h)->res[i].err.c_str(); }
 void lo_batch_free(void* h) { delete (Batch*)h; }
 
+// ---- resident documents rendered step by step (the counterpart of lm_import + lm_run, include/loro_merge.h): every step
+// imports more blobs into the same document — LoroDoc::import on an attached document, loro.rs:568-649 — and renders it at
+// the latest version or at a checkout (loro.rs:1625-1760).  A step whose import or rendering fails leaves the document as
+// it was (reference import is atomic, loro.rs:780-838).  The checker rebuilds the document from the accepted blobs at every
+// step (O(steps²), sizes the tests use); what carries over is the blob list and the set of sequence containers the state
+// store already holds (Doc::seq_exists).
+struct Session { std::vector<std::string> blobs; std::set<uint32_t> sticky; DocResult last; };
+void* lo_session_new() { return new Session(); }
+void lo_session_free(void* h) { delete (Session*)h; }
+// new blobs: data + blob_off[n_new+1]; front: optional checkout (NULL = latest).  Returns the step's status.
+int32_t lo_session_step(void* h, const uint8_t* data, const uint64_t* blob_off, uint32_t n_new, const uint8_t* front, uint64_t front_len) {
+  Session* s = (Session*)h;
+  DocResult r;
+  std::set<uint32_t> sticky;
+  bool imported = false;
+  try {
+    Doc d;
+    for (auto& b : s->blobs) d.import((const uint8_t*)b.data(), b.size());
+    for (uint32_t b = 0; b < n_new; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    d.seq_exists = s->sticky;
+    // LoroDoc::import: the state follows to the latest version
+    r.json = d.to_json();
+    r.vv = d.vv_bytes();
+    r.pending = d.pending_atoms();
+    r.status = d.unsupported ? ST_UNSUPPORTED : ST_OK;
+    imported = true;
+    for (uint32_t b = 0; b < n_new; b++) s->blobs.emplace_back((const char*)data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    s->sticky = d.seq_exists;
+    if (front) {
+      // LoroDoc::checkout: a second call — when it fails the import above stays
+      d.set_checkout(front, (size_t)front_len);
+      r.json = d.to_json();
+      r.vv = d.vv_bytes();
+      s->sticky = d.seq_exists;
+    }
+  } catch (const DecodeErr& e) {
+    r.status = e.st; r.err = e.what; r.json.clear(); r.vv.clear(); r.pending = 0;
+  } catch (const std::exception& e) {
+    r.status = ST_INTERNAL; r.err = e.what(); r.json.clear(); r.vv.clear(); r.pending = 0;
+  }
+  (void)imported; (void)sticky;
+  s->last = std::move(r);
+  return s->last.status;
+}
+uint64_t lo_session_pending(void* h) { return ((Session*)h)->last.pending; }
+const char* lo_session_json(void* h, uint64_t* len) { auto& r = ((Session*)h)->last; *len = r.json.size(); return r.json.data(); }
+const char* lo_session_vv(void* h, uint64_t* len) { auto& r = ((Session*)h)->last; *len = r.vv.size(); return r.vv.data(); }
+const char* lo_session_err(void* h) { return ((Session*)h)->last.err.c_str(); }
+
 uint32_t lo_xxh32(const uint8_t* p, uint64_t n, uint32_t seed) { return xxh32(p, (size_t)n, seed); }
 
 // visible element ids of the root sequence container `name` (kind 1 List / 2 Text) after importing the blobs.

@@ -525,8 +525,10 @@ struct Doc {
         Tracker::bump(cur, ch.id.peer, ch.ctr_end());
       }
     }
-    // the state store's containers: step 1 = diff(∅ → latest), step 2 (checkout) = diff(latest → version)
-    seq_exists.clear();
+    // the state store's containers: step 1 = diff(∅ → latest), step 2 (checkout) = diff(latest → version).
+    // A container state, once created, stays (state.rs:621-849 never drops one): when a document is rendered in several
+    // steps (import, render, import more, checkout, ... — lo_session_step), `seq_exists` carries over from step to step;
+    // a batch is one step, for which it starts empty.
     for (auto& kv : seqs) {
       kv.second->tr.checkout(vv);
       if (kv.second->tr.active_len() > 0) seq_exists.insert(kv.first);

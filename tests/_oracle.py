@@ -81,6 +81,43 @@ def merge_batch(docs, threads=1, packed=None, frontiers=None):
     return out
 
 
+class Session:
+    """One resident document rendered step by step: step(new_blobs, frontiers=None) imports more blobs into the same
+    document and renders it — the checker of lm_import + lm_run.  Returns (status, json, vv, pending) like merge()."""
+
+    def __init__(self):
+        L = lib()
+        L.lo_session_new.restype = ctypes.c_void_p
+        L.lo_session_free.argtypes = [ctypes.c_void_p]
+        L.lo_session_step.restype = ctypes.c_int32
+        L.lo_session_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64]
+        L.lo_session_pending.restype = ctypes.c_uint64
+        L.lo_session_pending.argtypes = [ctypes.c_void_p]
+        for f in (L.lo_session_json, L.lo_session_vv):
+            f.restype = ctypes.c_void_p
+            f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        self.L, self.h = L, L.lo_session_new()
+
+    def step(self, new_blobs, frontiers=None):
+        L = self.L
+        data, off, _ = pack([list(new_blobs)])
+        st = L.lo_session_step(self.h, data.ctypes.data, off.ctypes.data, len(new_blobs), frontiers, len(frontiers) if frontiers else 0)
+        ln = ctypes.c_uint64()
+        p = L.lo_session_json(self.h, ctypes.byref(ln))
+        js = ctypes.string_at(p, ln.value) if ln.value else b""
+        p = L.lo_session_vv(self.h, ctypes.byref(ln))
+        vv = ctypes.string_at(p, ln.value) if ln.value else b""
+        return (st, js, vv, L.lo_session_pending(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.lo_session_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 def merge(blobs, frontiers=None):
     return merge_batch([list(blobs)], frontiers=None if frontiers is None else [frontiers])[0]
 

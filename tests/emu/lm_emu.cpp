@@ -24,6 +24,7 @@ inline void dmemset(void* p, int v, size_t n) { memset(p, v, n); }
 inline void h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); }
 inline void h2d_async(void* d, const void* h, size_t n) { memcpy(d, h, n); }
 inline void d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); }
+inline void d2d(void* dst, const void* src, size_t n) { memmove(dst, src, n); }
 inline void sync() {}
 inline void* halloc(size_t n) { return malloc(n ? n : 1); }
 inline void hfree(void* p) { free(p); }
