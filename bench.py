@@ -359,13 +359,29 @@ def resident_configs(device, cores, n_docs=10000, full=True):
         want = _oracle.merge_batch(docs[:64], threads=min(32, cores))
         t_run, t_imp, t_base = [], [], []
         with loro_amd.MergeEngine(device) as e:
-            for rep in range(3):
+            kt_base, kt_inc = {}, {}
+            for rep in range(4):
+                prof = rep == 3   # the last repetition with the streams serialized: every stage's own duration
+                e.set_profiling(1 if prof else 0)
                 e.stage_packed(base); e.import_packed(none)
-                t = time.perf_counter(); e.run(); t_base.append(time.perf_counter() - t)
+                t = time.perf_counter(); e.run(); dt = time.perf_counter() - t
+                if prof:
+                    for name, ms in e.kernel_times():
+                        kt_base[name] = round(kt_base.get(name, 0.0) + ms, 3)
+                else:
+                    t_base.append(dt)
                 assert e.resident_fresh() == n_docs
-                t = time.perf_counter(); e.import_packed(inc); t_imp.append(time.perf_counter() - t)
-                t = time.perf_counter(); e.run(); t_run.append(time.perf_counter() - t)
+                t = time.perf_counter(); e.import_packed(inc); dt = time.perf_counter() - t
+                if not prof:
+                    t_imp.append(dt)
+                t = time.perf_counter(); e.run(); dt = time.perf_counter() - t
+                if prof:
+                    for name, ms in e.kernel_times():
+                        kt_inc[name] = round(kt_inc.get(name, 0.0) + ms, 3)
+                else:
+                    t_run.append(dt)
                 assert e.resident_fresh() == 0, "the import did not continue from the resident trackers"
+            e.set_profiling(0)
             got = e.fetch()
             assert got[:64] == want and all(g[0] == 0 for g in got), "configs[1]-incremental: device results differ from the CPU oracle"
             e.set_profiling(1); e.import_packed(none); e.run()   # (same version again: the per-stage times of a run that reuses its tables)
@@ -380,7 +396,8 @@ def resident_configs(device, cores, n_docs=10000, full=True):
             "lm_import_ms": round(min(t_imp) * 1e3, 2), "from_empty_run_of_base_plus_A_ms": round(min(t_base) * 1e3, 2),
             "algorithmic_bytes": int(st.in_bytes + st.out_bytes),
             "parity": f"first 64 results equal to the oracle's batch of all three blobs, all {n_docs} succeeded, every document continued from its resident tracker",
-            "kernel_ms_of_a_run_that_reuses_its_tables": kt_reuse,
+            "stage_ms_of_the_import_run_streams_serialized": kt_inc, "stage_ms_of_the_from_empty_run_streams_serialized": kt_base,
+            "stage_ms_of_a_run_that_reuses_its_tables": kt_reuse,
             "workload": "configs[1] documents: base + A's branch (75k ops, 2 blobs) resident with their trackers; B's concurrent branch (25k ops, 1 blob) imported by lm_import; "
                         "timed: the lm_run that follows (decode of all blobs, DAG, integrate of B's rows only after retreating A's branch, render)"}
         note("resident: configs[1]-incremental done")

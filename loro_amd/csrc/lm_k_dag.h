@@ -565,6 +565,8 @@ LM_KERNEL void k_elem_fill(Dev d) {
   uint32_t doc = bd.doc;
   const DocMeta& m = d.doc[doc];
   if (status_fatal(m.status)) return;
+  // resident document whose element layout did not move: the payload slots of the blocks earlier runs filled are still right
+  if (d.res_old_blobs && (m.flags & DF_FILL_KEPT) && bd.blob - d.doc_blob[doc] < d.res_old_blobs[doc]) return;
   const uint32_t* off = d.boff + (uint64_t)bi * BCN;
   uint32_t op0 = off[BC_OP], n_op = d.bcnt[(uint64_t)bi * BCN + BC_OP];
   uint32_t chg0 = off[BC_CHG];

@@ -556,7 +556,9 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
   // which items show: a replay from the empty version of exactly the rendered version's ops leaves "never deleted" as the
   // answer; a resident tracker (lm_k_integrate_span.h, DevRes) holds every applied op and stands AT the rendered version:
   // an item shows iff it is active there (not future, delete count 0)
-  const uint32_t vis_mask = d.res_vis ? (ST_FUT | ST_DELMASK) : ST_EVER;
+  // (only when it was moved to a checked-out version: rendered at the latest version, every applied op is in the tracker and
+  // "never deleted" is the answer as well — the integrate stage then leaves the tracker where its last change put it)
+  const uint32_t vis_mask = (d.res_vis && d.front_off[doc + 1] > d.front_off[doc] && !(m.flags & DF_FRONT_ERR)) ? (ST_FUT | ST_DELMASK) : ST_EVER;
   LM_SHARED(uint32_t, s_eb, MAX_PEERS);   // element base per peer (the text gather reads it once per lane and leaf)
   for (uint32_t p = (uint32_t)lane; p < m.n_peers && p < MAX_PEERS; p += 64) s_eb[p] = d.elem_base[m.praw0 + p];
   lmw::block_sync();

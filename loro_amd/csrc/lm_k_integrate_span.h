@@ -926,7 +926,7 @@ struct DevRes {
   const uint32_t* dir_b_prev;
   uint32_t* dir_b;               // this run's word B (word A goes to Dev::dir_out, which the emit stage reads)
 };
-// record: [0] tracker valid  [1] peers  [2] containers  [3] leaves used  [4,5] first element slot of the document  [6,7] reserved
+// record: [0] tracker valid  [1] peers  [2] containers  [3] leaves used  [4,5] first element slot of the document  [6] element slots cleared so far  [7] != 0: that run left changes pending
 //         peers × (PeerID lo, hi) | peers × applied end | peers × element base | containers × (TK_CW + pcap words)
 static constexpr uint32_t TK_HDR = 8, TK_CW = 8;   // container record: root0, n_dir, n_alive, exists (sticky, k_res_exists), 4 reserved, then cur[pcap]
 LM_DEV uint32_t tk_words(uint32_t pcap, uint32_t ccap) { return TK_HDR + 4 * pcap + ccap * (TK_CW + pcap); }
@@ -972,15 +972,23 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     for (uint32_t i = 0; i < sizeof(DocMeta) / 4; i++) mw[i] = lmw::first(mw[i]);
   }
   uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
-  if ((m.flags & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
+  {
+    uint32_t fl = m.flags;
+    if (RES && (fl & DF_PLAIN) && d.front_off[doc + 1] > d.front_off[doc]) fl &= ~DF_PLAIN;   // resident, rendered at a checked-out version: the general instantiation's
+    if ((fl & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
+  }
   (void)SWEEP;
   if (retry_pass && m.status != ST_RETRY) return;
   if (status_fatal(m.status) && !retry_pass) return;
+  // RES: the element layout is the stored tracker's (k_res_layout) — loc[] is kept, only the slots new to this run are cleared
+  const bool keep_loc = RES && !ML && !retry_pass && (m.flags & DF_LAYOUT_SAME) != 0;
   {   // loc[] of the document := NONE, four entries per store (the slice is 16-byte aligned and padded to a multiple of four)
     struct alignas(16) U4 { uint32_t x, y, z, w; };
     U4* l4 = (U4*)(d.loc + elem0);
     const U4 none4 = {NONE, NONE, NONE, NONE};
-    for (uint32_t i = (uint32_t)lane; i < (m.atoms + 3) / 4; i += 64) l4[i] = none4;
+    uint32_t from4 = 0;
+    if (keep_loc) from4 = lmw::first((rs.tk + rs.doc[doc].tk_off)[6]) / 4;   // (slices are padded to multiples of four: the boundary group is cleared again only if it was never used — it holds no kept entry, see k_res_layout)
+    for (uint32_t i = from4 + (uint32_t)lane; i < (m.atoms + 3) / 4; i += 64) l4[i] = none4;
   }
   if (retry_pass) {
     for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {   // sequence containers only: a Map's flag belongs to k_map_lww
@@ -999,6 +1007,8 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   uint32_t* tk = nullptr;
   uint32_t tk_pcap = 0, P0 = 0, C0 = 0;
   bool fresh = true, renumber = false;
+  // RES: rendered at a checked-out version (the frontiers were accepted): the tracker ends there and "active" is what shows
+  const bool to_version = RES && !PLAIN && d.front_off[doc + 1] > d.front_off[doc] && !(m.flags & DF_FRONT_ERR);
   if (RES) {
     // (the record is read with vector loads: its words are made wave-uniform scalars explicitly, or the record pointer and the
     // capacities live in VGPRs for the whole kernel)
@@ -1054,10 +1064,11 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   uint32_t dir_used = 0;
   if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
   if (RES && !fresh) {
-    // the stored leaves: renumbered when the peer order changed, and loc[] (cleared above) written again for every item
+    // the stored leaves: renumbered when the peer order changed, and loc[] (cleared above) written again for every item —
+    // unless the layout did not move (keep_loc: then nothing was cleared and nothing is renumbered)
     t.n_leaf = lmw::first(tk[3]);
     if (t.n_leaf > t.leaf_cap) { fresh = true; t.n_leaf = 0; }
-    for (uint32_t c = 0; c < C0 && !fresh; c++) {
+    for (uint32_t c = 0; c < C0 && !fresh && !keep_loc; c++) {
       const uint32_t* rec = tk_cont(tk, tk_pcap, c);
       uint32_t r0 = lmw::first(rec[0]), nr = lmw::first(rec[1]);
       for (uint32_t q = 0; q < nr; q++) {
@@ -1095,7 +1106,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       // the container's tracker as the previous run left it: directory, element counts, version
       const uint32_t* rec = tk_cont(tk, tk_pcap, cidx);
       uint32_t r0 = lmw::first(rec[0]), nr = lmw::first(rec[1]);
-      if (nr == 0 || nr > dir_cap) { t.err = nr ? ST_RETRY : ST_INTERNAL; break; }   // (optimistic LDS directory: the retry launch replays from the empty version)
+      if (nr == 0 || nr > dir_cap) { if (nr) t.err = ST_RETRY; else LM_SETERR(t.err, ST_INTERNAL); break; }   // (optimistic LDS directory: the retry launch replays from the empty version)
       uint32_t act = 0;
       for (uint32_t i = (uint32_t)lane; i < nr; i += 64) { uint32_t b = rs.dir_b_prev[m.leaf0 + r0 + i]; s_da[i] = rs.dir_a_prev[m.leaf0 + r0 + i]; s_db[i] = b; act += b; }
       t.n_dir = nr; t.tot_active = lmw::reduce_add(act); t.n_alive = lmw::first(rec[2]);
@@ -1128,7 +1139,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
         if (RES) { uint32_t ap = s_app[node_peer]; if (ap > skip_to) skip_to = ap; }   // what the stored tracker has applied is skipped like a known prefix
         uint32_t pe = PLAIN ? ch.ctr + ch.len : s_end[node_peer];   // (PLAIN: every applied change lies inside the rendered version)
         uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
-        if (RES && ch.ctr + ch.len <= skip_to) n_rows = 0;
+        if (RES && ch.ctr + ch.len <= (PLAIN ? s_app[node_peer] : skip_to)) n_rows = 0;   // (PLAIN: the applied end lies on a change boundary — no sliced change)
         for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
           OpRow r = rw_get(w, op_w, row);
@@ -1205,8 +1216,10 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       }
       lmw::block_sync();
     }
-    if (RES && !t.err) {
-      // the tracker moves to the version being rendered (Tracker::checkout, tracker.rs:354-461)
+    if (RES && !PLAIN && to_version && !t.err) {
+      // the tracker moves to the version being rendered (Tracker::checkout, tracker.rs:354-461).  A document rendered at the
+      // latest version needs no move: every applied op has been replayed, "never deleted" is what shows (as in a batch), and the
+      // tracker stays where the last change left it — the next run moves it wherever its first change needs it
       for (uint32_t p = 0; p < P && !t.err; p++) {
         uint32_t cur = s_cur[p], tgt = s_tgt[p];
         if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
@@ -1217,8 +1230,8 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       lmw::block_sync();
       TS_CHECK("closing checkout", 0);
       if (t.err) break;
-      touched = true;
     }
+    if (RES) touched = true;
     sp_flush(t);
     lmw::block_sync();
     if (dir_used + t.n_dir > m.leaf_cap) { LM_SETERR(t.err, ST_INTERNAL); break; }
@@ -1237,7 +1250,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       // (a MovableList exists once an element was ever inserted — k_mlist_post adds that case after this stage)
       // (RES: visible at the latest version — n_alive counts every applied op — or at the version the tracker was just moved to;
       // earlier runs' verdicts are OR-ed in by k_res_exists)
-      if (touched && (t.n_alive > 0 || (RES && t.tot_active > 0))) d.cont[m.cid0 + cidx].touched = 1;
+      if (touched && (t.n_alive > 0 || (RES && !PLAIN && to_version && t.tot_active > 0))) d.cont[m.cid0 + cidx].touched = 1;
     }
     dir_used += t.n_dir;
     lmw::block_sync();
@@ -1261,7 +1274,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     }
     lmw::mem_fence();
     lmw::block_sync();
-    if (lane == 0) { tk[1] = P; tk[2] = m.n_cont; tk[3] = t.n_leaf; tk[4] = m.elem0_lo; tk[5] = m.elem0_hi; tk[0] = 1; }
+    if (lane == 0) { tk[1] = P; tk[2] = m.n_cont; tk[3] = t.n_leaf; tk[4] = m.elem0_lo; tk[5] = m.elem0_hi; tk[6] = (m.atoms + 3) & ~3u; tk[7] = m.pending_lo | m.pending_hi; tk[0] = 1; }
   }
   if (lane == 0) d.doc[doc].pad0 = dir_used;
 #ifdef LM_PROF
@@ -1301,11 +1314,46 @@ LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res(Dev d, DevDag g, uint32
                                 uint32_t* retry_count, DevRes rs) {
   integrate_span_body<false, false, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count, rs);
 }
+// the documents flagged DF_PLAIN (no sliced change, no style anchor, no MovableList, rendered at the latest version)
+LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_res_plain(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count, DevRes rs) {
+  integrate_span_body<false, true, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count, rs);
+}
 LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res_ml(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count, DevRes rs) {
   integrate_span_body<true, false, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count, rs);
+}
+
+// Before the payload fill and the integrate stage of a run: does the stored tracker's element layout still hold?  (the
+// document's slice did not move, every peer it knows sits at the same index with the same element base — only the last peer
+// grew, or new peers came behind it; not for documents with a MovableList, whose k_mlist_post reuses loc[].)  One wave per document.
+LM_KERNEL void k_res_layout(Dev d, DevRes rs) {
+  uint32_t doc = (uint32_t)lmw::bid();
+  int lane = lmw::lane();
+  const DocMeta m = d.doc[doc];
+  if (status_fatal(m.status)) return;
+  const ResDoc rd = rs.doc[doc];
+  uint32_t* tk = rs.tk + rd.tk_off;
+  bool same = !rd.reset && tk[0] == 1u && !(m.flags & DF_MOVABLE) && tk[4] == m.elem0_lo && tk[5] == m.elem0_hi && tk[1] <= m.n_peers && tk[1] <= rd.pcap && tk[6] <= ((m.atoms + 3) & ~3u) &&
+              tk[2] <= m.n_cont && tk[3] <= m.leaf_cap;   // (everything that would make the integrate stage start from the empty version)
+  if (same) {
+    uint32_t P0 = tk[1];
+    bool bad = false;
+    for (uint32_t q = (uint32_t)lane; q < P0; q += 64) {
+      uint64_t id = ((uint64_t)tk_peers(tk)[2 * q + 1] << 32) | tk_peers(tk)[2 * q];
+      bad |= d.peer_uniq[m.praw0 + q] != id || tk_ebase(tk, rd.pcap)[q] != d.elem_base[m.praw0 + q];
+    }
+    same = !lmw::any(bad);
+  }
+  if (lane == 0) {
+    uint32_t fl = d.doc[doc].flags & ~(DF_LAYOUT_SAME | DF_FILL_KEPT);
+    if (same) fl |= DF_LAYOUT_SAME | (tk[7] == 0u ? DF_FILL_KEPT : 0u);   // [7]: atoms the stored run left pending — their rows were not filled
+    d.doc[doc].flags = fl;
+  }
 }
 
 // After every stage that decides which containers the state store holds (integrate, k_map_lww, k_mlist_post, k_state_roots):

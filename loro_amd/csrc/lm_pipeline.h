@@ -105,9 +105,17 @@ struct Engine {
   std::vector<std::vector<uint8_t>> r_front;      // per document: checkout frontiers of the next run (empty = latest)
   uint64_t arena_top = 0;
   bool tables_valid = false;                      // the decoded tables belong to the current blob lists
-  std::vector<uint32_t> tk_leaf0, tk_leaf_cap, tk_pcap, tk_ccap;
-  std::vector<uint64_t> tk_off;
+  std::vector<uint32_t> tk_leaf0, tk_leaf_cap, tk_pcap, tk_ccap, tk_elem_cap, h_old_blobs;
+  std::vector<uint64_t> tk_off, tk_elem0;
+  uint64_t elem_top = 0;                          // element slots handed out in the resident element arena (cp[] / loc[])
+  DBuf b_old_blobs;
   std::vector<uint8_t> tk_reset;
+  void upload_res() {   // the per-document records of this run (tracker record, capacities, reset flag)
+    std::vector<ResDoc> hres(n_docs);
+    for (uint32_t i = 0; i < n_docs; i++) hres[i] = ResDoc{tk_off[i], tk_pcap[i], tk_ccap[i], tk_reset[i], 0u};
+    b_res.ensure((size_t)n_docs * sizeof(ResDoc));
+    lmbe::h2d(b_res.p, hres.data(), (size_t)n_docs * sizeof(ResDoc));
+  }
   uint64_t tk_top = 0;                            // words used in b_tk
   uint32_t leaf_top = 0;                          // leaves handed out in the resident pool
   int dir_parity = 0;                             // which directory buffers the next run writes
@@ -136,7 +144,7 @@ struct Engine {
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
-                   &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved};
+                   &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_old_blobs};
     for (DBuf* b : all) b->release();
   }
 
@@ -291,6 +299,7 @@ struct Engine {
     for (uint32_t i = 0; i < n_docs; i++) r_front[i].assign(h_front_bytes.begin() + h_front_off[i], h_front_bytes.begin() + h_front_off[i + 1]);
     tk_leaf0.assign(n_docs, 0); tk_leaf_cap.assign(n_docs, 0); tk_pcap.assign(n_docs, 0); tk_ccap.assign(n_docs, 0);
     tk_off.assign(n_docs, 0); tk_reset.assign(n_docs, 1);
+    tk_elem0.assign(n_docs, 0); tk_elem_cap.assign(n_docs, 0); elem_top = 0;
     tk_top = 0; leaf_top = 0; dir_parity = 0;
     resident = true; tables_valid = false;
   }
@@ -323,22 +332,31 @@ struct Engine {
     b_front_off.ensure((nd + 1) * 8); lmbe::h2d(b_front_off.p, h_front_off.data(), (nd + 1) * 8);
   }
   // a (larger) tracker record for document i; the sticky "the state store holds this container" words move over, the tracker
-  // itself is not carried (the document is replayed from the empty version by the next run)
+  // itself is not carried (the document is replayed from the empty version by the next run).  The new records are collected
+  // in tk_new and uploaded together by tk_flush (one copy per run, not one per document)
+  std::vector<uint32_t> tk_new;
+  uint64_t tk_new_at = 0;
   void tk_grow(uint32_t i, uint32_t P, uint32_t C) {
     uint32_t pcap = P + P / 2 + 2, ccap = C + C / 2 + 4;
     uint64_t words = (uint64_t)TK_HDR + 4ull * pcap + (uint64_t)ccap * (TK_CW + pcap);
-    std::vector<uint32_t> rec(words, 0u);
+    if (tk_new.empty()) tk_new_at = tk_top;
+    size_t at = tk_new.size();
+    tk_new.resize(at + words, 0u);
     if (tk_pcap[i]) {
       uint32_t op = tk_pcap[i], oc = tk_ccap[i];
       uint64_t ow = (uint64_t)TK_HDR + 4ull * op + (uint64_t)oc * (TK_CW + op);
       std::vector<uint32_t> old(ow);
       lmbe::d2h(old.data(), b_tk.as<uint32_t>() + tk_off[i], ow * 4);
       for (uint32_t c = 0; c < oc && c < ccap; c++)
-        rec[TK_HDR + 4ull * pcap + (uint64_t)c * (TK_CW + pcap) + 3] = old[TK_HDR + 4ull * op + (uint64_t)c * (TK_CW + op) + 3] == 1u ? 1u : 0u;
+        tk_new[at + TK_HDR + 4ull * pcap + (uint64_t)c * (TK_CW + pcap) + 3] = old[TK_HDR + 4ull * op + (uint64_t)c * (TK_CW + op) + 3] == 1u ? 1u : 0u;
     }
-    b_tk.ensure_keep((tk_top + words + 16) * 4, tk_top * 4);
-    lmbe::h2d(b_tk.as<uint32_t>() + tk_top, rec.data(), words * 4);
     tk_off[i] = tk_top; tk_top += words; tk_pcap[i] = pcap; tk_ccap[i] = ccap; tk_reset[i] = 1;
+  }
+  void tk_flush() {
+    if (tk_new.empty()) return;
+    b_tk.ensure_keep((tk_top + 16) * 4, tk_new_at * 4);
+    lmbe::h2d(b_tk.as<uint32_t>() + tk_new_at, tk_new.data(), tk_new.size() * 4);
+    tk_new.clear();
   }
   void import_more(const DocIn* docs, size_t nd) {
     lmbe::bind(sc);
@@ -442,7 +460,7 @@ struct Engine {
     // DF_PLAIN (k_dag_a) survives only with the span kernel, for documents rendered at the latest version.  Such documents are
     // replayed by k_integrate_span_plain_sweep (default, = LM_PLAIN=2; measured -9 % against the common kernel on configs[1],
     // profiles/r02_ab_prepared.log); LM_PLAIN=1 selects k_integrate_span_plain, LM_PLAIN=0 the common kernel for every document
-    const int plain_mode = (!span || resident) ? 0 : getenv("LM_PLAIN") ? atoi(getenv("LM_PLAIN")) : 2;
+    const int plain_mode = !span ? 0 : getenv("LM_PLAIN") ? atoi(getenv("LM_PLAIN")) : 2;   // (resident documents: 0 = the general kernel for all, otherwise k_integrate_span_res_plain for the DF_PLAIN ones)
     const bool plain_on = plain_mode == 1 || plain_mode == 2;
     bool any_plain = false;
     if (reuse) {
@@ -568,9 +586,21 @@ struct Engine {
     for (uint32_t i = 0; i < n_docs; i++) {
       DocMeta& m = h_doc[i];
       bool ok = m.status == ST_OK;
-      if (!plain_on || !ok || (h_front_off.size() > i + 1 && h_front_off[i + 1] > h_front_off[i])) m.flags &= ~DF_PLAIN;
+      // (resident documents keep the flag: which version is rendered changes from run to run — the kernels look at the frontiers)
+      if (!plain_on || !ok || (!resident && h_front_off.size() > i + 1 && h_front_off[i + 1] > h_front_off[i])) m.flags &= ~DF_PLAIN;
       any_plain |= (m.flags & DF_PLAIN) != 0;
       m.elem0_lo = (uint32_t)elem; m.elem0_hi = (uint32_t)(elem >> 32);
+      if (resident) {
+        // the document's slice of the element arena stays where it is while it is large enough (loc[] and the payload slots of
+        // earlier runs stay valid, k_res_layout); a larger one is handed out with room to grow
+        uint64_t need = ((uint64_t)m.atoms + 3) & ~3ull;
+        if (ok && need > tk_elem_cap[i]) {
+          uint64_t cap = need + need / 2 + 64;
+          if (cap > 0xfffffff0ull) cap = need;
+          tk_elem0[i] = elem_top; tk_elem_cap[i] = (uint32_t)cap; elem_top += cap;
+        }
+        m.elem0_lo = (uint32_t)tk_elem0[i]; m.elem0_hi = (uint32_t)(tk_elem0[i] >> 32);
+      }
       // every split leaves both halves with >= 32 elements; each container starts with one (possibly small) leaf
       uint32_t lc = ok ? m.n_elems / 32 + 2 * m.n_cont + 2 : 0;
       if (ok && span) {
@@ -591,7 +621,7 @@ struct Engine {
           tk_leaf0[i] = leaf_top; tk_leaf_cap[i] = cap; leaf_top += cap; tk_reset[i] = 1;
         }
         m.leaf0 = tk_leaf0[i]; m.leaf_cap = ok ? tk_leaf_cap[i] : 0;
-        if (ok && (m.n_peers > tk_pcap[i] || m.n_cont > tk_ccap[i])) tk_grow(i, m.n_peers, m.n_cont);
+        if (ok && (tk_pcap[i] == 0 || m.n_peers > tk_pcap[i] || m.n_cont > tk_ccap[i])) tk_grow(i, m.n_peers, m.n_cont);   // (a record for every document that runs, an empty one included)
       }
       m.vvh0_lo = (uint32_t)vvh; m.vvh0_hi = (uint32_t)(vvh >> 32);
       if (ok) { elem += ((uint64_t)m.atoms + 3) & ~3ull; leaves += lc; vvh += (uint64_t)m.n_nodes * m.n_peers; }   // element slices start 16-byte aligned (k_integrate_span clears loc[] four entries per store)
@@ -608,6 +638,7 @@ struct Engine {
       h_ht0[i] = ht; h_ht_cap[i] = cap;
       ht += cap;
     }
+    if (resident) tk_flush();
     if (dir_cap > DIR_CAP_MAX) dir_cap = DIR_CAP_MAX;  // larger documents are reported LM_UNSUPPORTED by k_integrate
     // longest first: workgroups are dispatched in index order, so the integrate stage takes its documents by descending op
     // rows — a batch of mixed sizes does not end with a few long replays that started in the last round
@@ -623,7 +654,7 @@ struct Engine {
     if (resident) {
       // arenas that outlive the run: element payloads (a MovableList move keeps the id of the item it deleted in its own slot),
       // the leaf pool and the two generations of the leaf directories
-      b_cp.ensure_keep((elem + 1) * 4, b_cp.cap); b_loc.ensure((elem + 1) * 4);
+      b_cp.ensure_keep((elem_top + 1) * 4, b_cp.cap); b_loc.ensure_keep((elem_top + 1) * 4, b_loc.cap);
       b_it.ensure_keep(((size_t)leaf_top + 1) * SP_REC * 4, b_it.cap);
       for (DBuf* b : {&b_dir_out, &b_dir_out2, &b_dir_b, &b_dir_b2}) b->ensure_keep(((size_t)leaf_top + 1) * 4, b->cap);
     } else {
@@ -660,6 +691,21 @@ struct Engine {
     lmbe::dmemset(b_cont_root0.p, 0, (size_t)(NCID + 1) * 4);
     lmbe::dmemset(b_cont_nroot.p, 0, (size_t)(NCID + 1) * 4);
     // 5. causal order, element payloads, LWW, integrate
+    DevRes rs;
+    memset(&rs, 0, sizeof rs);
+    if (resident) {
+      upload_res();
+      rs.doc = b_res.as<ResDoc>(); rs.tk = b_tk.as<uint32_t>();
+      if (!reuse) {
+        h_old_blobs.resize(n_docs);
+        for (uint32_t i = 0; i < n_docs; i++) h_old_blobs[i] = (uint32_t)r_blobs[i].size() - r_step[i];
+        b_old_blobs.ensure((size_t)n_docs * 4 + 4);
+        lmbe::h2d(b_old_blobs.p, h_old_blobs.data(), (size_t)n_docs * 4);
+        d.res_old_blobs = b_old_blobs.as<uint32_t>();
+        sv.d.res_old_blobs = d.res_old_blobs;
+      }
+      LM_LAUNCH(k_res_layout, n_docs, 64, d, rs);   // (a run that reuses its tables: the layout is the previous run's, unless that run failed for the document)
+    }
     lmbe::tic(profiling);
     if (!resident) LM_LAUNCH(k_dag_b, n_docs, 64, d, g, 0u);
     else {
@@ -691,21 +737,23 @@ struct Engine {
     // documents that hold a MovableList are replayed by the kernel that knows move rows (k_integrate_span_ml), the others by
     // the common one; each kernel's waves leave the other's documents at once
     bool any_ml = false, any_common = false;
-    for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) { any_ml |= (h_doc[i].flags & DF_MOVABLE) != 0; any_common |= (h_doc[i].flags & (DF_MOVABLE | DF_PLAIN)) == 0; }
-    DevRes rs;
-    memset(&rs, 0, sizeof rs);
+    if (resident) any_plain = false;
+    for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) {
+      uint32_t fl = h_doc[i].flags;
+      if (resident && (fl & DF_PLAIN) && h_front_off[i + 1] > h_front_off[i]) fl &= ~DF_PLAIN;   // rendered at a checked-out version: the general instantiation
+      any_ml |= (fl & DF_MOVABLE) != 0; any_common |= (fl & (DF_MOVABLE | DF_PLAIN)) == 0;
+      if (resident) any_plain |= (fl & (DF_MOVABLE | DF_PLAIN)) == DF_PLAIN;
+    }
     if (resident) {
-      // every document's tracker record and its two directory generations: this run reads what the previous run wrote
-      std::vector<ResDoc> hres(n_docs);
-      for (uint32_t i = 0; i < n_docs; i++) hres[i] = ResDoc{tk_off[i], tk_pcap[i], tk_ccap[i], tk_reset[i], 0u};
-      b_res.ensure((size_t)n_docs * sizeof(ResDoc));
-      lmbe::h2d(b_res.p, hres.data(), (size_t)n_docs * sizeof(ResDoc));
-      rs.doc = b_res.as<ResDoc>(); rs.tk = b_tk.as<uint32_t>();
+      // every document's tracker record (uploaded above) and its two directory generations: this run reads what the previous run wrote
       DBuf& wa = dir_parity ? b_dir_out2 : b_dir_out; DBuf& ra = dir_parity ? b_dir_out : b_dir_out2;
       DBuf& wb = dir_parity ? b_dir_b2 : b_dir_b;     DBuf& rb = dir_parity ? b_dir_b : b_dir_b2;
       d.dir_out = wa.as<uint32_t>(); rs.dir_a_prev = ra.as<uint32_t>(); rs.dir_b = wb.as<uint32_t>(); rs.dir_b_prev = rb.as<uint32_t>();
       const size_t lds = (size_t)(2 * dir_opt + 6 * pmax) * 4 + lds_pad;
-      if (any_common || !any_ml)
+      if (any_plain)
+        LM_LAUNCH_DYN(k_integrate_span_res_plain, n_docs, 64, lds, d, g, dir_opt, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
+                      (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
+      if (any_common || !(any_ml || any_plain))
         LM_LAUNCH_DYN(k_integrate_span_res, n_docs, 64, lds, d, g, dir_opt, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                       (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
       if (any_ml)
@@ -738,7 +786,10 @@ struct Engine {
     if (n_retry) {  // rare: re-run the overflowed documents with the worst-case directory
       if (resident) {
         const size_t lds = (size_t)(2 * dir_cap + 6 * pmax) * 4;
-        if (any_common || !any_ml)
+        if (any_plain)
+          LM_LAUNCH_DYN(k_integrate_span_res_plain, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
+                        (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
+        if (any_common || !(any_ml || any_plain))
           LM_LAUNCH_DYN(k_integrate_span_res, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                         (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
         if (any_ml)
@@ -793,7 +844,8 @@ struct Engine {
       // the stage is named after the kernel that ran when there was only one (so the name matches rocprofv3's)
       const bool l_plain = span && any_plain, l_common = span && (any_common || !(any_ml || any_plain));
       const int n_launched = (int)l_plain + (int)l_common + (int)(span && any_ml);
-      const char* stage = resident ? (any_ml && any_common ? "k_integrate_span_res (both instantiations)" : any_ml ? "k_integrate_span_res_ml" : "k_integrate_span_res")
+      const char* stage = resident ? ((int)any_ml + (int)any_common + (int)any_plain > 1 ? "k_integrate_span_res (several instantiations)"
+                                      : any_ml ? "k_integrate_span_res_ml" : any_plain ? "k_integrate_span_res_plain" : "k_integrate_span_res")
                           : !span ? "k_integrate"
                           : n_launched > 1 ? "k_integrate_span (several instantiations)"
                           : l_plain ? (plain_mode == 2 ? "k_integrate_span_plain_sweep" : "k_integrate_span_plain")

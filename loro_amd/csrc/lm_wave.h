@@ -237,7 +237,7 @@ inline uint64_t clock() { return 0; }
 #endif
 
 #if defined(LM_EMU) && defined(LM_EMU_TRACE)
-#define LM_SETERR(lhs, code) do { if (lmw::lane() == 0) fprintf(stderr, "lm emu: " #lhs " = " #code " at %s:%d\n", __FILE__, __LINE__); (lhs) = (code); } while (0)
+#define LM_SETERR(lhs, code) do { if (lmw::lane() == 0 || getenv("LM_EMU_ERR_ALL")) fprintf(stderr, "lm emu: " #lhs " = " #code " at %s:%d\n", __FILE__, __LINE__); (lhs) = (code); } while (0)
 #else
 #define LM_SETERR(lhs, code) do { (lhs) = (code); } while (0)
 #endif
