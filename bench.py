@@ -409,7 +409,7 @@ def resident_configs(device, cores, n_docs=10000, full=True):
     try:
         with mp.get_context("fork").Pool(min(8, cores)) as pool:
             g5 = pool.map(_gen, [("cfg5", d) for d in range(4)])
-        n5 = 64
+        n5 = 1000 if full else 64   # the config's stated size: 1,000 documents x 16 versions
         docs5 = [g5[i % 4][0] for i in range(n5)]
         flat_docs, flat_fr = [], []
         for d in range(4):
@@ -432,9 +432,10 @@ def resident_configs(device, cores, n_docs=10000, full=True):
                     best = min(best, time.perf_counter() - t0)
         out["configs[4]-resident"] = {
             "renderings": n5 * 16, "renderings_per_s": round(n5 * 16 / best, 1), "ms_total": round(best * 1e3, 2), "ms_replay_incl_staging": round(t_replay * 1e3, 2),
-            "parity": "all 1,024 renderings equal to the oracle's",
-            "workload": "64 1M-op rich-text documents (4 distinct), each staged and replayed ONCE, then rendered at 16 versions by moving the resident trackers "
-                        "(lm_import with frontiers only + lm_run, 16 times); the time includes staging, the replay and every lm_fetch-less run"}
+            "parity": f"all {n5 * 16} renderings equal to the oracle's",
+            "workload": f"{n5} 1M-op rich-text documents (4 distinct) — the config's stated size — each staged and replayed ONCE, then rendered at 16 versions by moving "
+                        "the resident trackers (lm_import with frontiers only + lm_run, 16 times); the time includes staging (host to device), the replay and all 16 runs. "
+                        "One wave per document: 1,000 documents keep 1,000 waves busy, where the batch entry above replays every rendering from the empty version"}
         note("resident: configs[4]-resident done")
     except Exception as ex:
         out["configs[4]-resident"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}

@@ -1315,7 +1315,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res(Dev d, DevDag g, uint32
   integrate_span_body<false, false, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count, rs);
 }
 // the documents flagged DF_PLAIN (no sliced change, no style anchor, no MovableList, rendered at the latest version)
-LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_res_plain(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+#ifndef LM_RES_PLAIN_WAVES
+#define LM_RES_PLAIN_WAVES LM_INTEGRATE_WAVES
+#endif
+LM_KERNEL LM_WAVES_PER_SIMD(LM_RES_PLAIN_WAVES) void k_integrate_span_res_plain(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count, DevRes rs) {
