@@ -178,7 +178,7 @@ LM_KERNEL void k_state_roots(Dev d) {
       const ContRow o = d.cont[m.cid0 + c];
       if ((o.kind_root & 0x100) && (o.kind_root & 0xff) == kind && o.name_len == nl && bytes_eq(d.data + o.name_off, name, (uint32_t)nl)) {
         d.cont[m.cid0 + c].touched = 1;
-        if (kind > CK_TEXT) lmw::atomic_or(&d.doc[doc].flags, DF_SOFT_UNSUPPORTED);   // renders as null: the document is flagged
+        if (kind > CK_TEXT && kind != CK_MOVABLE) lmw::atomic_or(&d.doc[doc].flags, DF_SOFT_UNSUPPORTED);   // Tree / Counter root: renders as null, the document is flagged
       }
     }
   }
@@ -530,19 +530,57 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
     if (isr && at < MAX_ROOTS) s_root[at] = c0 + (uint32_t)lane;
     n_roots += (uint32_t)lmw::popc64(rm);
   }
+  // roots that only the state section of the initialising snapshot knows (k_state_roots marks those the history addresses too):
+  // no op ever touched them, the state store holds them all the same (fast_snapshot.rs:168-258) — they render as the empty value
+  // of their kind.  Entry = GHOST | byte offset of its [kind, uleb len, name] record in froot.
+  static constexpr uint32_t GHOST = 0x80000000u;
+  {
+    uint64_t f0 = d.froot_off[doc], f1 = d.froot_off[doc + 1];
+    Rd fr = rd_make(d.froot + f0, f1 - f0);
+    while (fr.p < fr.end && !fr.bad && n_roots <= MAX_ROOTS) {
+      uint32_t at = (uint32_t)(fr.p - (d.froot + f0));
+      uint32_t gk = rd_u8(fr);
+      uint64_t nl = rd_uleb(fr);
+      if (fr.bad || nl > rd_left(fr)) break;
+      const uint8_t* nm = fr.p;
+      fr.p += nl;
+      bool known = false;
+      for (uint32_t c0 = (uint32_t)lane; c0 < C; c0 += 64) {
+        const ContRow o = d.cont[m.cid0 + c0];
+        known |= (o.kind_root & 0x100) && (o.kind_root & 0xff) == gk && o.name_len == nl && bytes_eq(d.data + o.name_off, nm, (uint32_t)nl);
+      }
+      if (lmw::any(known)) continue;
+      if (n_roots < MAX_ROOTS && lane == 0) s_root[n_roots] = GHOST | at;
+      n_roots++;
+    }
+  }
   if (n_roots > MAX_ROOTS) { err = ST_UNSUPPORTED; n_roots = 0; }
   lmw::block_sync();
+  // name (and, for a state-only root, kind) of an entry of s_root / s_order
+  auto root_name = [&](uint32_t e, const uint8_t*& np, uint32_t& nl, uint32_t& gkind) {
+    if (e & GHOST) {
+      Rd fr = rd_make(d.froot + d.froot_off[doc] + (e & ~GHOST), d.froot_off[doc + 1] - d.froot_off[doc] - (e & ~GHOST));
+      gkind = rd_u8(fr);
+      nl = (uint32_t)rd_uleb(fr);
+      np = fr.p;
+    } else {
+      const ContRow o = d.cont[m.cid0 + e];
+      np = d.data + o.name_off; nl = o.name_len; gkind = o.kind_root & 0xff;
+    }
+  };
   {
     bool mine = (uint32_t)lane < n_roots;
-    ContRow my;
-    my.name_off = 0; my.name_len = 0; my.kind_root = 0; my.touched = 0;
-    if (mine) my = d.cont[m.cid0 + s_root[lane]];
+    const uint8_t* my_p = d.data;
+    uint32_t my_l = 0, my_k = 0;
+    if (mine) root_name(s_root[lane], my_p, my_l, my_k);
     uint32_t rank = 0;
     bool dup = false;
     for (uint32_t j = 0; j < n_roots; j++) {
-      const ContRow o = d.cont[m.cid0 + s_root[j]];
+      const uint8_t* op = d.data;
+      uint32_t ol = 0, ok = 0;
+      root_name(s_root[j], op, ol, ok);
       if (mine && j != (uint32_t)lane) {
-        int c = bytes_cmp(d.data + o.name_off, o.name_len, d.data + my.name_off, my.name_len);
+        int c = bytes_cmp(op, ol, my_p, my_l);
         if (c < 0) rank++;
         if (c == 0) dup = true;
       }
@@ -605,10 +643,13 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
   sink_byte(s, '{');
   for (uint32_t oi = 0; oi < n_roots && !err; oi++) {
     {
-      const ContRow c = d.cont[m.cid0 + s_order[oi]];
+      const uint8_t* np = d.data;
+      uint32_t nl = 0, gk = 0;
+      root_name(s_order[oi], np, nl, gk);
       if (oi) sink_byte(s, ',');
-      sink_string(s, d.data + c.name_off, c.name_len);
+      sink_string(s, np, nl);
       sink_byte(s, ':');
+      if (s_order[oi] & GHOST) { empty_child(gk); continue; }
     }
     int sp = 1;
     frame_set(0, s_order[oi], 0, 0, 0x3);   // c bit 1 = frame not entered yet

@@ -170,7 +170,9 @@ struct Engine {
     std::vector<const uint8_t*> bsrc(nb);
     std::vector<size_t> blen(nb);
     std::vector<std::vector<uint8_t>> conv;
-    std::vector<uint8_t> froot;                 // per document: root containers of its first snapshot's state section
+    std::vector<uint8_t> froot;                 // per document: root containers of the state section of the snapshot that initialises it
+    size_t best_changes = 0;
+    bool have_snapshot = false;
     h_froot_off.assign(nd + 1, 0);
     static const uint8_t stub_decode[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xff, 0xff};
     static const uint8_t stub_checksum[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4};
@@ -179,11 +181,17 @@ struct Engine {
         const uint8_t* p = docs[i].blobs[k];
         size_t l = docs[i].lens[k];
         if (k == 0) h_froot_off[i] = froot.size();
+        if (k == 0) { best_changes = 0; have_snapshot = false; }
         if (l >= 22 && memcmp(p, "loro", 4) == 0 && p[20] == 0 && p[21] == 3) {
+          // import_batch imports snapshots first, the one with the most changes first (loro.rs:1445-1449): THAT snapshot's state
+          // section initialises the empty document's state store; the others arrive as updates
           std::vector<uint8_t> o, roots;
-          bool first_snapshot = froot.size() == h_froot_off[i];
-          int st = lmsnap::snapshot_to_updates(p, l, o, first_snapshot ? &roots : nullptr);
-          if (st == lmsnap::SN_OK) { conv.push_back(std::move(o)); p = conv.back().data(); l = conv.back().size(); froot.insert(froot.end(), roots.begin(), roots.end()); }
+          size_t n_changes = 0;
+          int st = lmsnap::snapshot_to_updates(p, l, o, &roots, &n_changes);
+          if (st == lmsnap::SN_OK) {
+            conv.push_back(std::move(o)); p = conv.back().data(); l = conv.back().size();
+            if (!have_snapshot || n_changes > best_changes) { froot.resize(h_froot_off[i]); froot.insert(froot.end(), roots.begin(), roots.end()); best_changes = n_changes; have_snapshot = true; }
+          }
           else if (st == lmsnap::SN_CHECKSUM) { p = stub_checksum; l = 22; }
           else if (st == lmsnap::SN_DECODE) { p = stub_decode; l = 22; }
         }
@@ -244,10 +252,16 @@ struct Engine {
       for (size_t t = 0; t < nt; t++) th.emplace_back(gather);
       if (!nt) gather();
       memset(host + off, 0, 64);
-      for (size_t c = 0; c < nc; c++) {
-        while (!done[c].load(std::memory_order_acquire)) std::this_thread::yield();
-        uint64_t o0 = h_blob_off[cut[c]], o1 = c + 1 == nc ? data_bytes : h_blob_off[cut[c + 1]];
-        lmbe::h2d_async((uint8_t*)b_data.p + o0, host + o0, o1 - o0);
+      try {
+        for (size_t c = 0; c < nc; c++) {
+          while (!done[c].load(std::memory_order_acquire)) std::this_thread::yield();
+          uint64_t o0 = h_blob_off[cut[c]], o1 = c + 1 == nc ? data_bytes : h_blob_off[cut[c + 1]];
+          lmbe::h2d_async((uint8_t*)b_data.p + o0, host + o0, o1 - o0);
+        }
+      } catch (...) {   // a failed copy must not unwind past joinable threads (std::terminate): stop the workers, join, report
+        next.store(nc);
+        for (auto& t : th) t.join();
+        throw;
       }
       for (auto& t : th) t.join();
       if (!nb) lmbe::h2d_async(b_data.p, host, data_bytes);

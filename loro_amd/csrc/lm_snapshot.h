@@ -81,6 +81,9 @@ inline bool sstable_for_each(const uint8_t* p, size_t n, F&& f) {
   if (n < 13 || memcmp(p, "LORO", 4) != 0 || p[4] != 0) return false;
   size_t M = rd32(p + n - 4);
   if (M < 5 || M + 8 > n - 4) return false;   // metadata = count + entries + checksum, in front of the footer
+  // the metadata (count + entries) is followed by its xxh32, every stored block by its own (crates/kv-store/src/sstable.rs:164-307,
+  // block.rs:18-228; seed = "LORO" little endian, the envelope's)
+  if (lmenc::xxh32(p + M + 4, n - 4 - 4 - (M + 4), 0x4F524F4Cu) != rd32(p + n - 8)) return false;   // (the entries, without the count in front: sstable.rs:89,110)
   size_t i = M;
   uint32_t nb = rd32(p + i);
   i += 4;
@@ -108,6 +111,7 @@ inline bool sstable_for_each(const uint8_t* p, size_t n, F&& f) {
     if (end - metas[b].off < 4) return false;
     const uint8_t* sp = p + metas[b].off;
     size_t sl = end - metas[b].off - 4;   // stored payload; the last four bytes are its xxh32
+    if (lmenc::xxh32(sp, sl, 0x4F524F4Cu) != rd32(sp + sl)) return false;
     const uint8_t* bp = sp;
     size_t bl = sl;
     if (metas[b].comp == 1) { body.clear(); if (!lz4_frame(sp, sl, body)) return false; bp = body.data(); bl = body.size(); }
@@ -139,7 +143,7 @@ inline bool sstable_for_each(const uint8_t* p, size_t n, F&& f) {
 // the state SSTable (docs/encoding-container-states.md §1.1: root key = kind | 0x80, uleb len, name).  An empty document
 // importing the snapshot initialises its state store from that section (fast_snapshot.rs:168-258), so these roots are
 // part of the value even when nothing is visible in them.
-inline int snapshot_to_updates(const uint8_t* blob, size_t len, std::vector<uint8_t>& out, std::vector<uint8_t>* roots = nullptr) {
+inline int snapshot_to_updates(const uint8_t* blob, size_t len, std::vector<uint8_t>& out, std::vector<uint8_t>* roots = nullptr, size_t* n_changes = nullptr) {
   if (len < 22 || memcmp(blob, "loro", 4) != 0) return SN_DECODE;
   if (blob[20] != 0 || blob[21] != 3) return SN_DECODE;
   if (lmenc::xxh32(blob + 20, len - 20, 0x4F524F4Cu) != rd32(blob + 16)) return SN_CHECKSUM;
@@ -177,6 +181,15 @@ inline int snapshot_to_updates(const uint8_t* blob, size_t len, std::vector<uint
       roots->insert(roots->end(), k + i, k + kl);
     });
     if (!ok2) return SN_DECODE;
+  }
+  if (n_changes) {   // Σ n_changes over the change blocks (the fifth postcard varint of a block, block_encode.rs:94-119)
+    *n_changes = 0;
+    for (auto& b : blocks) {
+      size_t i = 0;
+      uint64_t v = 0;
+      for (int f = 0; f < 5; f++) { v = 0; int sh = 0; while (i < b.size()) { uint8_t c = b[i++]; v |= (uint64_t)(c & 0x7f) << sh; sh += 7; if (!(c & 0x80) || sh > 63) break; } }
+      *n_changes += (size_t)v;
+    }
   }
   std::vector<const uint8_t*> ptrs;
   std::vector<size_t> lens;

@@ -487,6 +487,131 @@ def split_blocks(changes: List[Change], max_block: int = 4096) -> List[List[Chan
     return blocks
 
 
+# ---------------------------------------------------------------- FastSnapshot (mode 3) writer — test inputs for the snapshot ingest
+# (docs/encoding.md §3-5, §11; crates/kv-store/src/{sstable,block,compress}.rs; docs/encoding-lz4.md)
+def lz4_block(data: bytes) -> bytes:
+    """one raw LZ4 block, greedy single-probe matcher (any valid LZ4 stream will do: the readers are what is tested)"""
+    n, out, i, anchor, table = len(data), bytearray(), 0, 0, {}
+
+    def emit(lit: bytes, mlen: int, off: int):
+        ll = len(lit)
+        tok_l = 15 if ll >= 15 else ll
+        tok_m = 0 if mlen == 0 else (15 if mlen - 4 >= 15 else mlen - 4)
+        out.append((tok_l << 4) | tok_m)
+        if ll >= 15:
+            r = ll - 15
+            while r >= 255:
+                out.append(255); r -= 255
+            out.append(r)
+        out.extend(lit)
+        if mlen:
+            out.extend(struct.pack("<H", off))
+            if mlen - 4 >= 15:
+                r = mlen - 4 - 15
+                while r >= 255:
+                    out.append(255); r -= 255
+                out.append(r)
+
+    while i + 4 <= n - 5:   # the last five bytes are always literals (end-of-block rule)
+        key = data[i:i + 4]
+        j = table.get(key)
+        table[key] = i
+        if j is not None and i - j <= 0xFFFF:
+            m = 4
+            while i + m < n - 5 and data[j + m] == data[i + m]:
+                m += 1
+            emit(data[anchor:i], m, i - j)
+            i += m
+            anchor = i
+        else:
+            i += 1
+    emit(data[anchor:], 0, 0)
+    return bytes(out)
+
+
+def lz4_frame(data: bytes) -> bytes:
+    """LZ4 frame, version 01, independent blocks, no checksums, 4 MiB block size (docs/encoding-lz4.md §3)"""
+    flg, bd = 0x60, 0x70
+    hc = (xxh32(bytes([flg, bd]), 0) >> 8) & 0xFF
+    out = bytearray(struct.pack("<I", 0x184D2204) + bytes([flg, bd, hc]))
+    for o in range(0, len(data), 4 << 20):
+        chunk = data[o:o + (4 << 20)]
+        c = lz4_block(chunk)
+        if len(c) < len(chunk):
+            out += struct.pack("<I", len(c)) + c
+        else:
+            out += struct.pack("<I", len(chunk) | 0x80000000) + chunk
+    out += struct.pack("<I", 0)
+    return bytes(out)
+
+
+def sstable(kvs, block_size: int = 4096, compress: bool = True) -> bytes:
+    """loro-kv-store SSTable of the (key, value) pairs (docs/encoding.md §4): normal blocks with prefix-compressed keys, a
+    large-value block for a value beyond the block size that opens a block, per-block and metadata xxh32, LZ4 where it is smaller"""
+    kvs = sorted(kvs)
+    if not kvs:
+        return b""
+    out = bytearray(b"LORO\x00")
+    metas = []
+
+    def store(body: bytes):
+        comp = 0
+        if compress:
+            f = lz4_frame(body)
+            if len(f) <= len(body):
+                body, comp = f, 1
+        out.extend(body + struct.pack("<I", xxh32(bytes(body))))
+        return comp
+
+    i = 0
+    while i < len(kvs):
+        k0, v0 = kvs[i]
+        off = len(out)
+        if len(v0) > block_size or len(v0) > 0xFFFF:
+            comp = store(v0)
+            metas.append((off, k0, 0x80 | comp, None))
+            i += 1
+            continue
+        data, offs, last = bytearray(v0), [0], k0
+        i += 1
+        while i < len(kvs):
+            k, v = kvs[i]
+            if len(v) > block_size or len(data) + len(v) + len(k) > block_size:
+                break
+            pre = 0
+            while pre < min(len(k0), len(k), 255) and k0[pre] == k[pre]:
+                pre += 1
+            offs.append(len(data))
+            data += bytes([pre]) + struct.pack("<H", len(k) - pre) + k[pre:] + v
+            last = k
+            i += 1
+        body = bytes(data) + b"".join(struct.pack("<H", o) for o in offs) + struct.pack("<H", len(offs))
+        comp = store(body)
+        metas.append((off, k0, comp, last))
+    m_off = len(out)
+    ent = bytearray()
+    for off, fk, flags, lk in metas:
+        ent += struct.pack("<I", off) + struct.pack("<H", len(fk)) + fk + bytes([flags])
+        if lk is not None:
+            ent += struct.pack("<H", len(lk)) + lk
+    out += struct.pack("<I", len(metas)) + ent + struct.pack("<I", xxh32(bytes(ent)))
+    out += struct.pack("<I", m_off)
+    return bytes(out)
+
+
+def encode_snapshot(blocks: List[List["Change"]], roots, vv: Dict[int, int], frontiers, block_size: int = 4096, compress: bool = True,
+                    shallow_root_state: bytes = b"") -> bytes:
+    """A FastSnapshot: ChangeStore SSTable (12-byte ID keys -> change blocks, `vv`, `fr`), state SSTable holding the root
+    containers `roots` = [(kind, name)] (values are placeholders: neither reader looks at them), empty shallow-root section."""
+    oplog = [(b"vv", encode_vv(vv)), (b"fr", encode_frontiers(frontiers))]
+    for blk in blocks:
+        oplog.append((struct.pack(">Qi", blk[0].peer, blk[0].counter), encode_block(blk)))
+    state = [(bytes([0x80 | kind]) + uleb(len(name.encode())) + name.encode(), b"\x00") for kind, name in roots]
+    o, st = sstable(oplog, block_size, compress), sstable(state, block_size, compress)
+    body = struct.pack("<I", len(o)) + o + struct.pack("<I", len(st)) + st + struct.pack("<I", len(shallow_root_state)) + shallow_root_state
+    return envelope(body, mode=3)
+
+
 def encode_vv(vv: Dict[int, int]) -> bytes:
     """postcard map with entries sorted by peer (the canonical order of the C ABI outputs)."""
     out = bytearray(uleb(len(vv)))
@@ -877,6 +1002,23 @@ class Replica:
                 assert sel[0].counter >= from_vv.get(p, 0), "export starts on a change boundary"
                 blocks += split_blocks(sel, max_block)
         return encode_updates(blocks)
+
+    def export_snapshot(self, roots=None, max_block: int = 4096, block_size: int = 4096, compress: bool = True) -> bytes:
+        """ExportMode::Snapshot of everything this replica knows; `roots` = [(kind, name)] of the state section (default: every
+        root container an op of the history addresses)."""
+        assert not self.pending_ops
+        blocks = []
+        for p in sorted(self.changes):
+            blocks += split_blocks(self.changes[p], max_block)
+        if roots is None:
+            seen = []
+            for p in sorted(self.changes):
+                for c in self.changes[p]:
+                    for o in c.ops:
+                        if o.cid.root and (o.cid.kind, o.cid.name) not in seen:
+                            seen.append((o.cid.kind, o.cid.name))
+            roots = seen
+        return encode_snapshot(blocks, roots, dict(self.vv), list(self.frontiers), block_size, compress)
 
     def set_visible(self, name, kind: int, ids: List[Tuple[int, int]]):
         self.seq[self._cid(name, kind)] = list(ids)

@@ -21,7 +21,30 @@ struct Batch {
 static void run_one(const uint8_t* data, const uint64_t* blob_off, uint32_t b0, uint32_t b1, const uint8_t* front, size_t front_len, DocResult& r) {
   try {
     Doc d;
-    for (uint32_t b = b0; b < b1; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    // LoroDoc::import_batch (loro.rs:1432-1523): the blobs are imported by mode, snapshots first, and inside a mode by their
+    // number of changes, most first (stable) — the snapshot that meets the empty document initialises its state store
+    std::vector<uint32_t> order;
+    for (uint32_t b = b0; b < b1; b++) order.push_back(b);
+    if (b1 - b0 > 1) {
+      std::vector<uint64_t> key(b1 - b0, 0);
+      bool any3 = false;
+      for (uint32_t b = b0; b < b1; b++) any3 |= blob_mode(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b])) == 3;
+      if (any3) {   // (without a snapshot the order cannot be observed: the result of a batch of updates is order independent)
+        for (uint32_t b = b0; b < b1; b++) {
+          const uint8_t* p = data + blob_off[b];
+          size_t l = (size_t)(blob_off[b + 1] - blob_off[b]);
+          uint16_t mode = blob_mode(p, l);
+          uint64_t n = 0;
+          try {
+            if (mode == 3) { SnapshotParts sp; decode_snapshot_blob(p, l, sp); n = sp.n_changes; }
+            else { std::vector<Change> tmp; decode_updates_blob(p, l, tmp); n = tmp.size(); }
+          } catch (...) { n = 0; }
+          key[b - b0] = ((uint64_t)mode << 40) | (0xffffffffffull - n);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x - b0] < key[y - b0]; });
+      }
+    }
+    for (uint32_t b : order) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
     if (front) d.set_checkout(front, front_len);
     r.json = d.to_json();
     r.vv = d.vv_bytes();
@@ -121,7 +144,7 @@ int32_t lo_session_step(void* h, const uint8_t* data, const uint64_t* blob_off, 
   } catch (const std::exception& e) {
     r.status = ST_INTERNAL; r.err = e.what(); r.json.clear(); r.vv.clear(); r.pending = 0;
   }
-  (void)imported; (void)sticky;
+  (void)imported; (void)sticky;   // (kept for readability of the two phases above)
   s->last = std::move(r);
   return s->last.status;
 }

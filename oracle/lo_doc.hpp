@@ -32,6 +32,7 @@
 #include "lo_codec.hpp"
 #include "lo_tracker.hpp"
 #include "lo_dag.hpp"
+#include "lo_snapshot.hpp"
 
 namespace lo {
 
@@ -133,6 +134,9 @@ struct Doc {
   // delta_item.rs:353-363) is empty exactly when nothing is visible at the target; a Map diff lists every key with an
   // op (deleted ones too, diff_calc.rs:553-605), so a Map exists once it was written.
   std::set<uint32_t> seq_exists;
+  // Root containers an EMPTY document took over from the state section of a snapshot (fast_snapshot.rs:168-258): part of the
+  // value even when nothing is visible in them
+  std::set<uint32_t> state_roots;
   // Frontiers of the OpLog (version/frontiers.rs:233 update_frontiers_on_new_change) and the import steps taken
   std::vector<ID> oplog_frontiers;
   struct ImportStep { Frontiers from_f, to_f; VV from_vv, to_vv; };
@@ -278,7 +282,16 @@ struct Doc {
   }
   void import(const uint8_t* blob, size_t len) {
     std::vector<Change> decoded;
-    decode_updates_blob(blob, len, decoded);
+    if (blob_mode(blob, len) == 3) {
+      // FastSnapshot: its ChangeStore arrives as changes (decode_oplog, fast_snapshot.rs:326-344); a document that holds
+      // nothing yet also takes the state section's containers (loro.rs:582-638, fast_snapshot.rs:168-258)
+      SnapshotParts sp;
+      decode_snapshot_blob(blob, len, sp);
+      if (changes.empty() && pending.empty())
+        for (auto& r : sp.roots) { ContainerID c; c.root = true; c.kind = r.first; c.name = r.second; state_roots.insert(reg(c)); }
+      decoded.swap(sp.changes);
+    } else
+      decode_updates_blob(blob, len, decoded);
     materialized = false;
     ImportStep step;
     step.from_f = oplog_frontiers; step.from_vv = vv;
@@ -620,8 +633,8 @@ struct Doc {
     materialize();
     std::map<std::string, uint32_t> roots;
     for (uint32_t i = 0; i < containers.size(); i++) {
-      if (!containers[i].root || !touched.count(i)) continue;
-      if ((containers[i].kind == CK_TEXT || containers[i].kind == CK_LIST || containers[i].kind == CK_MOVABLE) && !seq_exists.count(i)) continue;
+      if (!containers[i].root || !(touched.count(i) || state_roots.count(i))) continue;
+      if ((containers[i].kind == CK_TEXT || containers[i].kind == CK_LIST || containers[i].kind == CK_MOVABLE) && !seq_exists.count(i) && !state_roots.count(i)) continue;
       if (roots.count(containers[i].name)) fail(ST_UNSUPPORTED, "two root containers share a name");
       roots[containers[i].name] = i;
     }

@@ -154,7 +154,7 @@ def snapshot_cases():
     def check(got):
         snap, upd, snap_ts, rsnap, rupd, shallow, bad_sum, cut, both, plain = got
         assert snap[0] == upd[0] == 4 and snap[1] and snap_ts[1:] == snap[1:] and snap[2] == upd[2]   # out-of-scope containers ride along as null
-        assert rsnap[2] == rupd[2]
+        assert rsnap[2] == rupd[2] and rsnap[0] == rupd[0]
         deep = fx["json"]["snapshot.deep.json"]
         v, u = json.loads(snap[1]), json.loads(upd[1])
         # an empty document takes its state store from the snapshot's state section: every root of snapshot.deep.json is there,

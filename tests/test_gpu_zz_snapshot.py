@@ -1,0 +1,46 @@
+"""GPU parity of the FastSnapshot ingest on written snapshots (tests/test_emu_snapshot.py builds them): many SSTable blocks,
+large-value blocks, LZ4 frames, state-only roots, damaged tables — the HIP path through the C ABI against the oracle."""
+import pytest
+
+import _oracle, _resident
+import test_emu_snapshot as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    import loro_amd
+    return loro_amd.MergeEngine(0)
+
+
+def test_written_snapshots_match_the_oracle():
+    names, docs = S.snapshot_docs(48, first=1000)
+    docs = docs + S.damaged_snapshots()
+    want = _oracle.merge_batch(docs, threads=16)
+    with _engine() as e:
+        got = e.merge_batch(docs)
+    for i, (g, w) in enumerate(zip(got, want)):
+        if w[0] == 0:
+            assert g == w, (names[i] if i < len(names) else i, g[:2], w[:2])
+        else:
+            assert g[0] != 0, i
+
+
+def test_snapshot_of_a_large_document_and_resident_documents():
+    import loro_amd
+    S_emu = S._emu
+    class _B:   # run the harness-based tests of the CPU file on the device
+        @staticmethod
+        def merge_batch(docs, frontiers=None):
+            with _engine() as e:
+                return e.merge_batch(docs, frontiers)
+        @staticmethod
+        def binding():
+            return loro_amd._binding()
+    S._emu = _B
+    try:
+        S.test_a_configs1_sized_document_as_one_snapshot()
+        S.test_state_only_roots_and_a_movable_list_root_do_not_flag_the_document()
+        S.test_snapshots_and_resident_documents()
+    finally:
+        S._emu = S_emu

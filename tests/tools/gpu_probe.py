@@ -27,7 +27,7 @@ with loro_amd.MergeEngine(0) as e:
         t = time.time(); e.run(); dt = time.time() - t
         print("run(noprof) %d: %.1f ms  -> %.0f docs/s" % (it, dt * 1e3, n_docs / dt), flush=True)
     import ctypes
-    out3 = (ctypes.c_uint32 * 4)()
+    out3 = (ctypes.c_uint32 * 5)()
     e.b.lib.lm_sizing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
     e.b.lib.lm_sizing(e.h, out3)
     print("sizing: leaves used max %d, leaf_cap max %d, n_elems max %d, retried docs %d" % (out3[0], out3[1], out3[2], out3[3]))
