@@ -125,6 +125,15 @@ int lm_wait(lm_ctx* ctx);
  * a document's blobs must lie within 4 GiB of the context's blob arena; a document that holds a MovableList is replayed from
  * the empty version whenever its element layout shifts (its results are the same, its import is not incremental). */
 int lm_import(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs);
+/* What the reference computes before it diffs an import — the common ancestors of the version a document was at and the version
+ * it reaches, and the DiffMode they imply (dag.rs:318-332,487-765 `find_common_ancestor`; oplog.rs:591-615; diff_calc.rs:72-103) —
+ * computed on the device for every resident document by the last lm_run (one step = one import of all the step's blobs).
+ * modes[i]: 0 Checkout, 1 Import, 2 ImportGreaterUpdates, 3 Linear, -1 unknown (no resident run, failed document, more than 16
+ * common-ancestor ids).  lm_import_lca writes Frontiers::encode() of document `doc`'s common ancestors into buf (returns the
+ * length, -1 when unknown or cap is too small).  The engine itself does not branch on the mode — its trackers hold the whole
+ * history, so the replay base is wherever the tracker stands — it reports what a host that mirrors the reference needs. */
+int lm_import_modes(lm_ctx* ctx, int32_t* modes);
+long lm_import_lca(lm_ctx* ctx, size_t doc, uint8_t* buf, size_t cap);
 /* Diagnostics: how many documents of the last lm_run could not continue from a resident tracker and were replayed from the
  * empty version (first run, capacity grown, a failed run before, MovableList layout shift). */
 int lm_resident_fresh(lm_ctx* ctx);

@@ -19,7 +19,7 @@ class RunStats(ctypes.Structure):
 
 
 SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
-           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh"]
+           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca"]
 
 
 class Binding:
@@ -35,6 +35,9 @@ class Binding:
         self.stage.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocIn), ctypes.c_size_t]
         self.import_ = g("import"); self.import_.restype = ctypes.c_int
         self.import_.argtypes = [ctypes.c_void_p, ctypes.POINTER(DocIn), ctypes.c_size_t]
+        self.import_modes = g("import_modes"); self.import_modes.restype = ctypes.c_int; self.import_modes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.import_lca = g("import_lca"); self.import_lca.restype = ctypes.c_long
+        self.import_lca.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
         self.resident_fresh = g("resident_fresh"); self.resident_fresh.restype = ctypes.c_int; self.resident_fresh.argtypes = [ctypes.c_void_p]
         self.run = g("run"); self.run.restype = ctypes.c_int; self.run.argtypes = [ctypes.c_void_p]
         self.run_async = g("run_async"); self.run_async.restype = ctypes.c_int; self.run_async.argtypes = [ctypes.c_void_p]
@@ -141,6 +144,19 @@ class Context:
         self.import_more(docs, frontiers)
         self.run()
         return self.fetch()
+
+    def import_info(self):
+        """[(DiffMode name or None, encoded LCA Frontiers or None)] of the last run's import, per resident document"""
+        import numpy as np
+        modes = np.full(self.n, -1, dtype=np.int32)
+        self.b.import_modes(self.h, modes.ctypes.data)
+        names = {0: "Checkout", 1: "Import", 2: "ImportGreaterUpdates", 3: "Linear"}
+        out = []
+        buf = ctypes.create_string_buffer(4096)
+        for i in range(self.n):
+            n = self.b.import_lca(self.h, i, buf, 4096)
+            out.append((names.get(int(modes[i])), buf.raw[:n] if n >= 0 else None))
+        return out
 
     def resident_fresh(self):
         """documents of the last run that were replayed from the empty version (no usable resident tracker)"""

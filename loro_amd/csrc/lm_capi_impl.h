@@ -140,6 +140,46 @@ int LM_API(import)(void* c, const lm_doc_in_c* docs, size_t n) {
     return 0;
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
+// DiffMode of the last lm_run's import per resident document (0 Checkout, 1 Import, 2 ImportGreaterUpdates, 3 Linear; -1 = not
+// computed: no resident run yet, a failed document, more than 16 common-ancestor ids), computed on the device by k_import_lca
+int LM_API(import_modes)(void* c, int32_t* modes) {
+  auto* x = (lm_ctx_impl*)c;
+  x->for_docs([&](uint32_t i, lm::Engine& e, const lm::DocResult&) {
+    uint32_t k = i - 0;
+    (void)k;
+    modes[i] = -1;
+  });
+  for (uint32_t p = 0; p < x->n_parts(); p++) {
+    lm::Engine& e = *x->parts[p];
+    for (uint32_t i = 0; i < e.n_docs; i++)
+      if ((size_t)(i + 1) * lm::LCA_OUT <= e.h_lca.size()) { uint32_t m = e.h_lca[(size_t)i * lm::LCA_OUT]; modes[x->first[p] + i] = m == lm::DM_UNKNOWN ? -1 : (int32_t)m; }
+  }
+  return 0;
+}
+// the common ancestors that import was measured from (dag.rs:487-765) as Frontiers::encode() bytes (postcard Vec<ID>, sorted);
+// returns the length, or -1 when unknown / `cap` too small
+long LM_API(import_lca)(void* c, size_t doc, uint8_t* buf, size_t cap) {
+  auto* x = (lm_ctx_impl*)c;
+  for (uint32_t p = 0; p < x->n_parts(); p++) {
+    if (doc < x->first[p] || doc >= x->first[p + 1]) continue;
+    lm::Engine& e = *x->parts[p];
+    size_t i = doc - x->first[p];
+    if ((i + 1) * lm::LCA_OUT > e.h_lca.size()) return -1;
+    const uint32_t* o = e.h_lca.data() + i * lm::LCA_OUT;
+    if (o[0] == lm::DM_UNKNOWN) return -1;
+    std::vector<uint8_t> b;
+    lmenc::put_uleb(b, o[1]);
+    for (uint32_t k = 0; k < o[1]; k++) {
+      uint64_t peer = ((uint64_t)o[3 + 3 * k] << 32) | o[2 + 3 * k];
+      lmenc::put_uleb(b, peer);
+      lmenc::put_uleb(b, (uint64_t)o[4 + 3 * k] << 1);   // zigzag of a non-negative counter
+    }
+    if (b.size() > cap) return -1;
+    memcpy(buf, b.data(), b.size());
+    return (long)b.size();
+  }
+  return -1;
+}
 // documents of the last run that were replayed from the empty version (no usable resident tracker); diagnostics
 int LM_API(resident_fresh)(void* c) {
   auto* x = (lm_ctx_impl*)c;

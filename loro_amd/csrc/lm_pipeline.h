@@ -17,6 +17,7 @@
 #include <stdexcept>
 #include "lm_k_scan.h"
 #include "lm_k_emit.h"
+#include "lm_k_lca.h"
 #include "lm_snapshot.h"
 
 namespace lm {
@@ -108,7 +109,9 @@ struct Engine {
   std::vector<uint32_t> tk_leaf0, tk_leaf_cap, tk_pcap, tk_ccap, tk_elem_cap, h_old_blobs;
   std::vector<uint64_t> tk_off, tk_elem0;
   uint64_t elem_top = 0;                          // element slots handed out in the resident element arena (cp[] / loc[])
-  DBuf b_old_blobs;
+  DBuf b_old_blobs, b_prev_doc, b_prev_uniq, b_prev_end, b_lca_out, b_lca_scratch, b_lca_off;
+  bool have_prev = false;                         // the tables of a previous resident run exist (what k_import_lca measures the import against)
+  std::vector<uint32_t> h_lca;                    // per document LCA_OUT words of the last run: DiffMode + common ancestors of its import
   std::vector<uint8_t> tk_reset;
   void upload_res() {   // the per-document records of this run (tracker record, capacities, reset flag)
     std::vector<ResDoc> hres(n_docs);
@@ -144,7 +147,7 @@ struct Engine {
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
-                   &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_old_blobs};
+                   &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_old_blobs, &b_prev_doc, &b_prev_uniq, &b_prev_end, &b_lca_out, &b_lca_scratch, &b_lca_off};
     for (DBuf* b : all) b->release();
   }
 
@@ -315,7 +318,7 @@ struct Engine {
     tk_off.assign(n_docs, 0); tk_reset.assign(n_docs, 1);
     tk_elem0.assign(n_docs, 0); tk_elem_cap.assign(n_docs, 0); elem_top = 0;
     tk_top = 0; leaf_top = 0; dir_parity = 0;
-    resident = true; tables_valid = false;
+    resident = true; tables_valid = false; have_prev = false;
   }
   void rebuild_blob_tables() {
     size_t nd = n_docs, nb = 0;
@@ -463,6 +466,13 @@ struct Engine {
     // resident documents whose blob lists did not change since the tables were built: only the rendered versions differ —
     // the decode / DAG stages are skipped, the saved tables are rendered again (k_dag_b's checkout part onwards)
     const bool reuse = resident && tables_valid;
+    if (resident && have_prev) {
+      // the version every document was at before this run (k_import_lca: LCA + DiffMode of the import, dag.rs:487-765): the
+      // previous run's document records, peers and applied ends, copied before this run's kernels rebuild the tables
+      b_prev_doc.ensure((size_t)n_docs * sizeof(DocMeta)); lmbe::d2d(b_prev_doc.p, b_doc_saved.p, (size_t)n_docs * sizeof(DocMeta));
+      b_prev_uniq.ensure((size_t)(sv.NP + 1) * 8); lmbe::d2d(b_prev_uniq.p, b_peer_uniq.p, (size_t)(sv.NP + 1) * 8);
+      b_prev_end.ensure((size_t)(sv.NP + 1) * 4); lmbe::d2d(b_prev_end.p, b_peer_end_all.p, (size_t)(sv.NP + 1) * 4);
+    }
     uint32_t NB = 0, NC = 0, NO = 0, NCID = 0, NP = 0;
     DevDag g;
     memset(&g, 0, sizeof g);
@@ -731,6 +741,19 @@ struct Engine {
       LM_LAUNCH(k_dag_b, n_docs, 64, d, g, 2u);      // the checkout of this run
     }
     lmbe::toc("k_dag_b", times, profiling);
+    if (resident) {
+      std::vector<uint64_t> loff(n_docs + 1, 0);
+      for (uint32_t i = 0; i < n_docs; i++) { uint64_t N = h_doc[i].status == ST_OK ? h_doc[i].n_nodes : 0; loff[i + 1] = loff[i] + 3 * (8 * N + 64) + 3 * (4 * N + 64) + N + 16; }
+      b_lca_off.ensure((size_t)(n_docs + 1) * 8); lmbe::h2d(b_lca_off.p, loff.data(), (size_t)(n_docs + 1) * 8);
+      b_lca_scratch.ensure((loff[n_docs] + 16) * 4);
+      b_lca_out.ensure((size_t)n_docs * LCA_OUT * 4 + 16);
+      DevLca lc;
+      lc.out = b_lca_out.as<uint32_t>(); lc.scratch = b_lca_scratch.as<uint32_t>(); lc.scratch_off = b_lca_off.as<uint64_t>();
+      lc.prev_doc = have_prev ? b_prev_doc.as<DocMeta>() : nullptr; lc.prev_uniq = b_prev_uniq.as<uint64_t>(); lc.prev_end = b_prev_end.as<uint32_t>();
+      lmbe::tic(profiling);
+      LM_LAUNCH(k_import_lca, n_docs, 64, d, g, lc);
+      lmbe::toc("k_import_lca", times, profiling);
+    }
     lmbe::tic(profiling);
     if (NB && !reuse) LM_LAUNCH(k_elem_fill, NB, 64, d);
     lmbe::toc("k_elem_fill", times, profiling);
@@ -979,6 +1002,9 @@ struct Engine {
         } else tk_reset[i] = 0;
         r_step[i] = 0;
       }
+      h_lca.resize((size_t)n_docs * LCA_OUT);
+      lmbe::d2h(h_lca.data(), b_lca_out.p, (size_t)n_docs * LCA_OUT * 4);
+      have_prev = true;
       dir_parity ^= 1;
       tables_valid = !dropped;
       if (dropped) { rebuild_blob_tables(); lmbe::sync(); }

@@ -110,7 +110,7 @@ void lo_batch_free(void* h) { delete (Batch*)h; }
 // it was (reference import is atomic, loro.rs:780-838).  The checker rebuilds the document from the accepted blobs at every
 // step (O(steps²), sizes the tests use); what carries over is the blob list and the set of sequence containers the state
 // store already holds (Doc::seq_exists).
-struct Session { std::vector<std::string> blobs; std::set<uint32_t> sticky; DocResult last; };
+struct Session { std::vector<std::string> blobs; std::set<uint32_t> sticky; DocResult last; int32_t mode = -1; std::string lca; };
 void* lo_session_new() { return new Session(); }
 void lo_session_free(void* h) { delete (Session*)h; }
 // new blobs: data + blob_off[n_new+1]; front: optional checkout (NULL = latest).  Returns the step's status.
@@ -130,6 +130,33 @@ int32_t lo_session_step(void* h, const uint8_t* data, const uint64_t* blob_off, 
     r.pending = d.pending_atoms();
     r.status = d.unsupported ? ST_UNSUPPORTED : ST_OK;
     imported = true;
+    {
+      // the import of this step as ONE import: common ancestors + DiffMode of (version before, version after), oplog.rs:591-615
+      Frontiers from_f, to_f = d.oplog_frontiers;
+      VV from_vv;
+      size_t n_old = s->blobs.size();
+      if (n_old < d.steps.size()) { from_f = d.steps[n_old].from_f; from_vv = d.steps[n_old].from_vv; } else { from_f = d.oplog_frontiers; from_vv = d.vv; }
+      std::pair<Frontiers, DiffMode> r2;
+      if (from_vv == d.vv) r2 = {from_f, DM_LINEAR};
+      else {
+        std::vector<DagNodeT> nodes = d.dag_nodes();
+        DagGet get = [&nodes](ID id) -> const DagNodeT* { for (const DagNodeT& n : nodes) if (n.contains(id)) return &n; return nullptr; };
+        r2 = find_common_ancestor(get, from_f, to_f);
+        if (r2.second == DM_CHECKOUT) {
+          bool ge = true, gt = false;
+          for (auto& kv : from_vv) { auto it = d.vv.find(kv.first); Counter t = it == d.vv.end() ? 0 : it->second; if (t < kv.second) ge = false; }
+          for (auto& kv : d.vv) { auto it = from_vv.find(kv.first); Counter f = it == from_vv.end() ? 0 : it->second; if (kv.second > f) gt = true; }
+          if (ge && gt) r2.second = DM_IMPORT;
+        }
+      }
+      s->mode = (int32_t)r2.second;
+      fr_norm(r2.first);
+      std::string enc;
+      auto uleb = [&](uint64_t v) { do { uint8_t b = v & 0x7f; v >>= 7; if (v) b |= 0x80; enc.push_back((char)b); } while (v); };
+      uleb(r2.first.size());
+      for (const ID& id : r2.first) { uleb(id.peer); int64_t c = id.counter; uleb((uint64_t)((c << 1) ^ (c >> 63))); }
+      s->lca = enc;
+    }
     for (uint32_t b = 0; b < n_new; b++) s->blobs.emplace_back((const char*)data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
     s->sticky = d.seq_exists;
     if (front) {
@@ -148,6 +175,8 @@ int32_t lo_session_step(void* h, const uint8_t* data, const uint64_t* blob_off, 
   s->last = std::move(r);
   return s->last.status;
 }
+int32_t lo_session_mode(void* h) { return ((Session*)h)->mode; }
+const char* lo_session_lca(void* h, uint64_t* len) { auto& l = ((Session*)h)->lca; *len = l.size(); return l.data(); }
 uint64_t lo_session_pending(void* h) { return ((Session*)h)->last.pending; }
 const char* lo_session_json(void* h, uint64_t* len) { auto& r = ((Session*)h)->last; *len = r.json.size(); return r.json.data(); }
 const char* lo_session_vv(void* h, uint64_t* len) { auto& r = ((Session*)h)->last; *len = r.vv.size(); return r.vv.data(); }

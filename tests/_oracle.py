@@ -93,7 +93,9 @@ class Session:
         L.lo_session_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64]
         L.lo_session_pending.restype = ctypes.c_uint64
         L.lo_session_pending.argtypes = [ctypes.c_void_p]
-        for f in (L.lo_session_json, L.lo_session_vv):
+        L.lo_session_mode.restype = ctypes.c_int32
+        L.lo_session_mode.argtypes = [ctypes.c_void_p]
+        for f in (L.lo_session_json, L.lo_session_vv, L.lo_session_lca):
             f.restype = ctypes.c_void_p
             f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         self.L, self.h = L, L.lo_session_new()
@@ -108,6 +110,12 @@ class Session:
         p = L.lo_session_vv(self.h, ctypes.byref(ln))
         vv = ctypes.string_at(p, ln.value) if ln.value else b""
         return (st, js, vv, L.lo_session_pending(self.h))
+
+    def import_info(self):
+        """(DiffMode name, encoded LCA frontiers) of the last successful step's import (oplog.rs:591-615, dag.rs:487-765)"""
+        ln = ctypes.c_uint64()
+        p = self.L.lo_session_lca(self.h, ctypes.byref(ln))
+        return MODES.get(self.L.lo_session_mode(self.h)), (ctypes.string_at(p, ln.value) if ln.value else b"")
 
     def close(self):
         if self.h:

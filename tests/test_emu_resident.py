@@ -157,3 +157,51 @@ def test_directory_overflow_and_output_overflow_in_a_resident_run():
         _check(_sessions("text", range(700, 706)), expect_incremental=False)
     finally:
         del os.environ["LM_DIR_OPT_MAX"], os.environ["LM_SLAB_CAP"]
+
+
+def _import_info_matches(make_ctx, sessions):
+    """LCA + DiffMode of every step's import, computed on the device (k_import_lca), against the oracle's find_common_ancestor"""
+    oss = [_oracle.Session() for _ in sessions]
+    modes = set()
+    with make_ctx() as c:
+        for k in range(len(sessions[0])):
+            docs = [s[k][0] for s in sessions]
+            fr = [s[k][1] for s in sessions]
+            if k == 0:
+                c.stage(docs, fr); c.import_more([[] for _ in docs], fr)
+            else:
+                c.import_more(docs, fr)
+            c.run()
+            got, info = c.fetch(), c.import_info()
+            for i, o in enumerate(oss):
+                w = o.step(docs[i], fr[i])
+                assert w == got[i], (k, i)
+                if w[0] in (0, 4, 6):       # the import went through (6: only the checkout behind it was refused)
+                    assert info[i] == o.import_info(), (k, i, info[i], o.import_info())
+                    modes.add(info[i][0])
+    return modes
+
+
+def test_import_mode_and_common_ancestors_on_the_device():
+    """SURVEY §8 a9 on the device: dag.rs:487-765 (_find_common_ancestor_new) + the DiffMode it implies (oplog.rs:591-615)"""
+    modes = set()
+    for mode in ("flat", "text", "movable"):
+        modes |= _import_info_matches(lambda: Context(_emu.binding()), _sessions(mode, range(2000, 2016)))
+    assert {"Linear", "Import", "ImportGreaterUpdates"} <= modes
+    # two peers fork after A's first change; B's branch is imported into base + A's branch.  The mode is Import (a Checkout promoted
+    # because the target is greater, oplog.rs:610-615); the walk reaches the root on B's side without a match, so the reference
+    # falls back to the empty version as the replay base (dag.rs:727-747) — the oracle, pinned to dag.rs:1108-1340, says the same
+    a = wire.Replica(10); a.text_insert("text", 0, "base"); a.commit()
+    b = wire.Replica(20); b.merge_from(a); b.seq = {k: list(v) for k, v in a.seq.items()}
+    a.text_insert("text", 4, " A"); a.commit()
+    b.text_insert("text", 0, "B "); b.commit()
+    own_b = wire.Replica(20); own_b.changes = {20: b.changes[20]}
+    with Context(_emu.binding()) as c:
+        c.stage([[a.export()]]); c.import_more([[]]); c.run()
+        assert c.import_info() == [("Linear", wire.encode_frontiers([]))]            # the empty document grew along one chain
+        c.import_more([[own_b.export()]]); c.run()
+        assert c.fetch()[0][1] == b'{"text":"B base A"}'
+        o = _oracle.Session(); o.step([a.export()]); o.step([own_b.export()])
+        assert c.import_info() == [o.import_info()] == [("Import", wire.encode_frontiers([]))]
+        c.import_more([[]]); c.run()
+        assert c.import_info()[0][0] == "Linear"                                   # nothing imported: diff_calc.rs:150-152

@@ -124,3 +124,11 @@ def test_config5_checkouts_as_one_replay_and_sixteen_moves():
             assert c.resident_fresh() == 0
             for i in range(n):
                 assert got[i] == res[(i % 4) * 17 + k], (k, i)
+
+
+def test_import_mode_and_common_ancestors_on_the_device():
+    """k_import_lca (dag.rs:487-765 on the device) against the oracle's find_common_ancestor, step by step"""
+    modes = set()
+    for mode in ("flat", "text", "movable"):
+        modes |= T._import_info_matches(_engine, T._sessions(mode, range(6000, 6064)))
+    assert {"Linear", "Import", "ImportGreaterUpdates"} <= modes
