@@ -155,6 +155,15 @@ int lm_result_hashes(lm_ctx* ctx, uint64_t* json_xxh64);
 #include "loro_block_tables.h"   /* lm_block_tables */
 int lm_encode_block(const lm_block_tables* tables, uint8_t** out, size_t* out_len);
 int lm_encode_updates(const uint8_t* const* blocks, const size_t* block_lens, size_t n_blocks, uint8_t** out, size_t* out_len);
+/* LoroDoc::export(ExportMode::Updates{from}) (crates/loro/src/lib.rs:1306 → encoding.rs:399-405 export_fast_updates →
+ * oplog/change_store.rs:718-752 export_blocks_from) for document `doc` of the batch the context holds, after lm_run: the changes
+ * its oplog holds beyond `from_vv` (VersionVector::encode() bytes, version.rs:962-968; NULL / 0 = from the empty version) as one
+ * FastUpdates blob — blocks ordered by (peer, counter), blocks the version covers dropped, a block it cuts sliced at the cut
+ * (the first change then depends on its peer's previous op; a run cut inside an insert / delete is sliced like the reference
+ * slices it, list_op.rs:251-277,426-433).  Changes still pending are not part of the oplog and are not exported.  Host work on
+ * the blobs read back from the context's arena (lm_export.h); the block boundaries are those of the imported blobs, so what was
+ * staged from one writer's export comes back byte for byte from the empty version.  malloc'ed: release with lm_free_bytes. */
+int lm_export(lm_ctx* ctx, size_t doc, const uint8_t* from_vv, size_t from_vv_len, uint8_t** out, size_t* out_len);
 void lm_free_bytes(uint8_t* p);
 
 /* Wave-primitive self test on the device (DPP scan, ballot ranks); returns the number of mismatches. */

@@ -19,7 +19,7 @@ class RunStats(ctypes.Structure):
 
 
 SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
-           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca"]
+           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca", "export"]
 
 
 class Binding:
@@ -38,6 +38,8 @@ class Binding:
         self.import_modes = g("import_modes"); self.import_modes.restype = ctypes.c_int; self.import_modes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.import_lca = g("import_lca"); self.import_lca.restype = ctypes.c_long
         self.import_lca.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+        self.export = g("export"); self.export.restype = ctypes.c_int
+        self.export.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
         self.resident_fresh = g("resident_fresh"); self.resident_fresh.restype = ctypes.c_int; self.resident_fresh.argtypes = [ctypes.c_void_p]
         self.run = g("run"); self.run.restype = ctypes.c_int; self.run.argtypes = [ctypes.c_void_p]
         self.run_async = g("run_async"); self.run_async.restype = ctypes.c_int; self.run_async.argtypes = [ctypes.c_void_p]
@@ -144,6 +146,15 @@ class Context:
         self.import_more(docs, frontiers)
         self.run()
         return self.fetch()
+
+    def export(self, doc, from_vv=None):
+        """lm_export: the updates document `doc` holds beyond the version `from_vv` (VersionVector::encode bytes; None = all)"""
+        out, n = ctypes.c_void_p(), ctypes.c_size_t()
+        if self.b.export(self.h, doc, from_vv, len(from_vv) if from_vv else 0, ctypes.byref(out), ctypes.byref(n)) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        b = ctypes.string_at(out.value, n.value)
+        self.b.free_bytes(out)
+        return b
 
     def import_info(self):
         """[(DiffMode name or None, encoded LCA Frontiers or None)] of the last run's import, per resident document"""

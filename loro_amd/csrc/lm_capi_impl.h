@@ -281,6 +281,24 @@ int LM_API(encode_updates)(const uint8_t* const* blocks, const size_t* lens, siz
     return -1;
   }
 }
+// LoroDoc::export(ExportMode::Updates{from}) for document `doc` of the batch the context holds (after lm_run): the changes beyond
+// `from_vv` (VersionVector::encode bytes; NULL / 0 = everything) as a FastUpdates blob.  malloc'ed; release with lm_free_bytes.
+int LM_API(export)(void* c, size_t doc, const uint8_t* from_vv, size_t from_len, uint8_t** out, size_t* out_len) {
+  auto* x = (lm_ctx_impl*)c;
+  try {
+    if (!x->ran) throw std::runtime_error("lm_export before lm_run");
+    for (uint32_t p = 0; p < x->n_parts(); p++) {
+      if (doc < x->first[p] || doc >= x->first[p + 1]) continue;
+      lmenc::Bytes b = x->parts[p]->export_doc((uint32_t)(doc - x->first[p]), from_vv, from_len);
+      *out = (uint8_t*)malloc(b.size() ? b.size() : 1);
+      if (!*out) throw std::runtime_error("out of memory");
+      memcpy(*out, b.data(), b.size());
+      *out_len = b.size();
+      return 0;
+    }
+    throw std::runtime_error("lm_export: no such document");
+  } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
 void LM_API(free_bytes)(uint8_t* p) { free(p); }
 int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   auto* x = (lm_ctx_impl*)c;

@@ -19,6 +19,7 @@
 #include "lm_k_emit.h"
 #include "lm_k_lca.h"
 #include "lm_snapshot.h"
+#include "lm_export.h"
 
 namespace lm {
 
@@ -1011,6 +1012,33 @@ struct Engine {
     }
     ran = true;
     fetched = false;
+  }
+
+  // ---- lm_export: the updates document `i` holds beyond `from_vv` (lm_export.h).  The blobs come back from the arena, the
+  // applied version from the tables of the last run
+  lmexp::Bytes export_doc(uint32_t i, const uint8_t* from_vv, size_t from_len) {
+    lmbe::bind(sc);
+    if (!ran) throw std::runtime_error("lm_export before lm_run");
+    if (i >= n_docs) throw std::runtime_error("lm_export: no such document");
+    const DocMeta& m = h_doc[i];
+    if (m.status != ST_OK) throw std::runtime_error("lm_export: the document failed to import");
+    std::map<uint64_t, uint32_t> applied;
+    if (m.n_peers) {
+      std::vector<uint64_t> ids(m.n_peers);
+      std::vector<uint32_t> ends(m.n_peers);
+      bool checked_out = h_front_off.size() > i + 1 && h_front_off[i + 1] > h_front_off[i];
+      lmbe::d2h(ids.data(), b_peer_uniq.as<uint64_t>() + m.praw0, (size_t)m.n_peers * 8);
+      lmbe::d2h(ends.data(), ((resident || checked_out) ? b_peer_end_all.as<uint32_t>() : b_peer_end.as<uint32_t>()) + m.praw0, (size_t)m.n_peers * 4);
+      for (uint32_t p = 0; p < m.n_peers; p++) if (ends[p]) applied[ids[p]] = ends[p];
+    }
+    std::vector<lmexp::Block> blocks;
+    std::vector<uint8_t> buf;
+    for (uint32_t b = h_doc_blob[i]; b < h_doc_blob[i + 1]; b++) {
+      buf.resize(h_blob_len[b]);
+      if (h_blob_len[b]) lmbe::d2h(buf.data(), b_data.as<uint8_t>() + h_blob_off[b], h_blob_len[b]);
+      lmexp::blocks_of_blob(buf.data(), buf.size(), blocks);
+    }
+    return lmexp::export_updates(blocks, lmexp::decode_vv(from_vv, from_len), applied);
   }
 
   // ---- fetch: copy the rendered states back to the host
