@@ -301,10 +301,22 @@ def other_configs(device, cores):
             for _ in range(reps):
                 t = time.perf_counter(); e.run(); best = min(best, time.perf_counter() - t)
             st = e.stats()
+            # every stage's own duration: one more pass with the context's streams run one after the other (HIP events per stage);
+            # a stage's figure is the sum over the context's streams = the time the stage needs for the whole batch
+            e.set_profiling(1); e.run()
+            stage_ms = {}
+            for kname, ms in e.kernel_times():
+                stage_ms[kname] = round(stage_ms.get(kname, 0.0) + ms, 3)
+            e.set_profiling(0)
         alg = float(st.in_bytes + st.out_bytes)
+        dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
         note(f"other configs: {name} done")
         out[name] = {"docs": len(docs), "distinct_docs": distinct, "docs_per_s": round(len(docs) / best, 1), "ms_per_batch": round(best * 1e3, 2),
                      "algorithmic_bytes": int(alg), "algorithmic_GBps": round(alg / best / 1e9, 2), "frac_of_hbm_peak": round(alg / best / 1e9 / HBM_PEAK_GBS, 5),
+                     "stage_ms": stage_ms,
+                     "roofline": None if not dom else {"bound": "hbm", "kernel": dom, "kernel_ms": stage_ms[dom], "achieved": round(alg / (stage_ms[dom] * 1e-3) / 1e9, 2),
+                                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                                                       "what": "algorithmic bytes of the batch over the dominant stage's time for the whole batch (streams serialized); per stage: algorithmic bytes / stage_ms"},
                      "parity": (f"first {distinct} results equal to the oracle's, all {len(docs)} succeeded" if name.endswith("heterogeneous") else f"all {len(docs)} results equal to the oracle's"),
                      "workload": desc}
 

@@ -106,9 +106,15 @@ inline void check_launch(const char* name) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, lmbe::cur->s, __VA_ARGS__); \
     lmbe::check_launch(#kern);                                                                     \
   } while (0)
+// (the dynamic-LDS ceiling of a kernel is raised when a launch needs more than any launch before it from this site — not on
+// every launch: hipFuncSetAttribute is a driver round trip)
 #define LM_LAUNCH_DYN(kern, grid, block, shmem, ...)                                               \
   do {                                                                                             \
-    LM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shmem))); \
+    static std::atomic<size_t> lm_dyn_set_{0};                                                     \
+    if ((size_t)(shmem) > lm_dyn_set_.load(std::memory_order_relaxed)) {                           \
+      LM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shmem))); \
+      lm_dyn_set_.store((size_t)(shmem), std::memory_order_relaxed);                               \
+    }                                                                                              \
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (shmem), lmbe::cur->s, __VA_ARGS__); \
     lmbe::check_launch(#kern);                                                                     \
   } while (0)

@@ -134,6 +134,21 @@ struct Engine {
     std::vector<DocMeta> h_doc;
   } sv;
 
+  // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false; int plain = 2; uint32_t dec_slot = 1280, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; } kn;
+  void read_knobs() {
+    Knobs k;
+    if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
+    if (const char* e = getenv("LM_PLAIN")) k.plain = atoi(e);
+    if (const char* e = getenv("LM_DECODE")) k.decode_wave = atoi(e) != 0;
+    if (const char* e = getenv("LM_DEC_SLOT")) k.dec_slot = ((uint32_t)atoi(e) + 15u) & ~15u;   // LDS bytes per block for everything before its value payloads (per 5k configs[1] documents: 512 5.4 ms, 1024 4.5, 1280 4.2, 1536 4.9, 2048 5.7 — occupancy against the share of heads that fit; larger heads are read from HBM)
+    if (const char* e = getenv("LM_LDS_PAD")) k.lds_pad = (size_t)atoi(e);                       // occupancy experiments only
+    k.no_opt_dir = getenv("LM_NO_OPT_DIR") != nullptr;
+    if (const char* e = getenv("LM_DIR_OPT_MAX")) k.dir_opt_max = (uint32_t)atoi(e);             // tests: force the retry launch
+    if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
+    kn = k;
+  }
+
   explicit Engine(int device) { sc = lmbe::stream_create(device); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -156,6 +171,7 @@ struct Engine {
   struct DocIn { const uint8_t* const* blobs; const size_t* lens; size_t n; const uint8_t* front; size_t front_len; };
   void stage(const DocIn* docs, size_t nd) {
     lmbe::bind(sc);
+    read_knobs();
     n_docs = (uint32_t)nd;
     h_doc_blob.assign(nd + 1, 0);
     size_t nb = 0;
@@ -379,6 +395,7 @@ struct Engine {
   void import_more(const DocIn* docs, size_t nd) {
     lmbe::bind(sc);
     if (nd != n_docs) throw std::runtime_error("lm_import: the document count differs from the resident batch");
+    read_knobs();
     if (!resident) adopt_resident();
     std::vector<std::vector<uint8_t>> conv;
     struct Src { const uint8_t* p; size_t l; uint64_t off; };
@@ -477,7 +494,7 @@ struct Engine {
     uint32_t NB = 0, NC = 0, NO = 0, NCID = 0, NP = 0;
     DevDag g;
     memset(&g, 0, sizeof g);
-    const bool span = !(getenv("LM_SPAN") && atoi(getenv("LM_SPAN")) == 0);
+    const bool span = kn.span;
     if (resident && !span) throw std::runtime_error("resident documents need the span-granular integrate kernel (LM_SPAN=0 is set)");
     uint64_t ht = 0;
     uint32_t dir_cap = 64, dir_opt = 64, pmax = 2;
@@ -485,7 +502,7 @@ struct Engine {
     // DF_PLAIN (k_dag_a) survives only with the span kernel, for documents rendered at the latest version.  Such documents are
     // replayed by k_integrate_span_plain_sweep (default, = LM_PLAIN=2; measured -9 % against the common kernel on configs[1],
     // profiles/r02_ab_prepared.log); LM_PLAIN=1 selects k_integrate_span_plain, LM_PLAIN=0 the common kernel for every document
-    const int plain_mode = !span ? 0 : getenv("LM_PLAIN") ? atoi(getenv("LM_PLAIN")) : 2;   // (resident documents: 0 = the general kernel for all, otherwise k_integrate_span_res_plain for the DF_PLAIN ones)
+    const int plain_mode = !span ? 0 : kn.plain;   // (resident documents: 0 = the general kernel for all, otherwise k_integrate_span_res_plain for the DF_PLAIN ones)
     const bool plain_on = plain_mode == 1 || plain_mode == 2;
     bool any_plain = false;
     if (reuse) {
@@ -579,10 +596,9 @@ struct Engine {
     // one wave per group of DEC_G blocks, staged through LDS (lm_k_decode_wave.h); LM_DECODE=0 selects the one-lane-per-block
     // decoder (kept as the second, independently structured implementation the parity suites also run)
     if (NB) {
-      if (getenv("LM_DECODE") && atoi(getenv("LM_DECODE")) == 0) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
+      if (!kn.decode_wave) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
       else {
-        uint32_t slot_cap = 1280;   // LDS bytes per block for everything before its value payloads (per 5k configs[1] documents: 512 5.4 ms, 1024 4.5, 1280 4.2, 1536 4.9, 2048 5.7 — occupancy against the share of heads that fit; larger heads are read from HBM)
-        if (const char* e = getenv("LM_DEC_SLOT")) slot_cap = ((uint32_t)atoi(e) + 15u) & ~15u;
+        uint32_t slot_cap = kn.dec_slot;
         LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_cap);
       }
     }
@@ -765,9 +781,9 @@ struct Engine {
     dir_cap = (dir_cap + 3) & ~3u;
     dir_opt = (dir_opt + 3) & ~3u;
     if (dir_opt > DIR_CAP_MAX) dir_opt = DIR_CAP_MAX;
-    size_t lds_pad = getenv("LM_LDS_PAD") ? (size_t)atoi(getenv("LM_LDS_PAD")) : 0;  // occupancy experiments only
-    if (getenv("LM_NO_OPT_DIR")) dir_opt = dir_cap;
-    if (getenv("LM_DIR_OPT_MAX")) { uint32_t mx = (uint32_t)atoi(getenv("LM_DIR_OPT_MAX")); if (mx >= 4 && mx < dir_opt) dir_opt = mx & ~3u; }   // tests: force the retry launch
+    size_t lds_pad = kn.lds_pad;
+    if (kn.no_opt_dir) dir_opt = dir_cap;
+    if (kn.dir_opt_max) { uint32_t mx = kn.dir_opt_max; if (mx >= 4 && mx < dir_opt) dir_opt = mx & ~3u; }
     b_tot.ensure(64 * 4);
     uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
     lmbe::dmemset(retry_cnt, 0, 8);   // [0] documents to re-run with the worst-case directory, [1] resident documents replayed from the empty version
@@ -901,7 +917,7 @@ struct Engine {
         for (uint32_t b = h_doc_blob[i]; b < h_doc_blob[i + 1]; b++) in_b += h_blob_len[b];
         bool ok = h_doc[i].status == ST_OK;
         uint64_t cap = ok ? 2 * in_b + 64ull * h_doc[i].n_cont + 256 : 0;
-        if (const char* e = getenv("LM_SLAB_CAP")) cap = ok ? (uint64_t)atoll(e) : 0;   // tests: force the re-emit pass
+        if (kn.slab_cap >= 0) cap = ok ? (uint64_t)kn.slab_cap : 0;
         uint64_t vcap = ok ? 16ull * h_doc[i].n_peers + 16 : 0;
         slab_off[i + 1] = slab_off[i] + ((cap + 15) & ~15ull);
         vslab_off[i + 1] = vslab_off[i] + ((vcap + 15) & ~15ull);
