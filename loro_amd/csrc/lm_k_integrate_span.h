@@ -217,6 +217,29 @@ LM_DEV uint32_t sd_find_leaf(const Ts& t, uint32_t L) {
   }
   return NONE;
 }
+// active elements in front of directory position p
+LM_DEV uint32_t sd_prefix(const Ts& t, uint32_t p) {
+  int lane = lmw::lane();
+  lmw::wave_sync();
+  uint32_t acc = 0;
+  for (uint32_t i0 = 0; i0 < p; i0 += 64) {
+    uint32_t i = i0 + (uint32_t)lane;
+    acc += i < p ? t.db[i] : 0u;
+  }
+  return lmw::reduce_add(acc);
+}
+// A delete row of the replay carries the position of its leftmost target (DeleteSpan, list_op.rs:288-379) next to the target
+// ids.  The reference deletes BY POSITION (crdt_rope.rs:256-335) and only records which ids it met; this kernel deletes by id.
+// For every blob a writer produces the two agree; for a damaged one they may not — so every piece of such a row is checked:
+// it must be active and sit exactly at the row's position (everything deleted before it in this row is inactive by then).
+// A disagreement is LM_DATA_CORRUPTION, never a value the reference would not have computed.
+LM_DEV bool ts_del_pos_ok(Ts& t, const SpanRegs& R, uint32_t slot, uint32_t s_off, uint32_t st0, uint32_t hint_k) {
+  if (t.cache_pre == NONE) t.cache_pre = sd_prefix(t, t.cache_p);
+  uint32_t al = sp_alen(R);
+  uint32_t inc = lmw::scan_incl_add(al);
+  uint32_t before = lmw::bcast(inc, (int)slot) - lmw::bcast(al, (int)slot);
+  return st_active(st0) && t.cache_pre + before + s_off + 1 == hint_k;
+}
 LM_DEV void sd_refresh(Ts& t, uint32_t p, uint32_t L, const SpanRegs& R) {   // directory entry of leaf L from its registers
   sd_set(t, p, sa_make(L, R.n, sp_nf(R)), lmw::reduce_add(sp_alen(R)));
 }
@@ -587,7 +610,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
 
 // ---- the common status update, instruction-lean: the run holding element (peer, c) sits in the cached leaf, which has room
 // for a cut; the run (or its part inside [c, c1)) gets the new status, c advances.  false = general path.
-LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int mode) {
+LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int mode, uint32_t hint_k = 0) {
   if (t.cr.n > 62) return false;   // (no cached leaf: n = 255)
   int lane = lmw::lane();
   uint32_t x = pid_make(peer, c);
@@ -604,6 +627,7 @@ LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int m
   uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
   uint32_t tail = pid_ctr(id0) + ln - endc, mid = endc - c;
   uint32_t n = t.cr.n;
+  if (hint_k && !ts_del_pos_ok(t, t.cr, slot, s_off, st0, hint_k)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); c = c1; return true; }
   if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= mid;
   if ((s_off | tail) == 0) {
     t.cr.st = (uint32_t)lane == slot ? st1 : t.cr.st;
@@ -643,14 +667,14 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   int lane = lmw::lane();
   uint32_t c = c0;
   // items only hold applied elements, so the in-leaf path needs neither the peer's element base nor its end (two LDS round trips)
-  while (c < c1 && ts_update_fast(t, peer, c, c1, mode)) { PROF_CNT(t, PF_LEAF, 1); }
+  while (c < c1 && ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); }
   if (c >= c1) return;
   uint32_t eb = t.ebase[peer];
   if (c1 > t.end[peer]) c1 = t.end[peer];   // a damaged target range cannot make the walk longer than the peer's history
   bool tried = true;   // the in-leaf path has just declined this very element
   for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
     lmw::wave_sync();
-    if (!tried && ts_update_fast(t, peer, c, c1, mode)) { PROF_CNT(t, PF_LEAF, 1); continue; }
+    if (!tried && ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); continue; }
     tried = false;
     uint32_t x = pid_make(peer, c);
     uint32_t p;
@@ -658,7 +682,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     uint64_t hm = 0;
     if (t.cache_leaf != NONE) hm = sp_hit(t.cr, x);
     if (hm) { R = t.cr; p = t.cache_p; }
-    else if (hint_k && c == c0 && hint_k <= t.tot_active) {
+    else if (hint_k && hint_k <= t.tot_active) {
       uint32_t k = hint_k;
       lmw::wave_sync();
       if (t.cache_leaf != NONE && t.cache_pre != NONE && hint_k > t.cache_pre && hint_k - t.cache_pre <= lmw::first(t.db[t.cache_p])) { p = t.cache_p; k = hint_k - t.cache_pre; }
@@ -678,6 +702,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       uint32_t lf = lmw::first(t.loc[eb + c]);
 #endif
       PROF_CNT(t, 15, 1);   // status updates that went through loc[] (the target was not in the cached leaf)
+      if (hint_k) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }   // the element at the row's position is not the row's target (see ts_del_pos_ok)
       if (lf >= t.n_leaf || lf == t.cache_leaf) { c++; continue; }   // not an element of this container (malformed target): ignored
       // all five arrays are requested for all 64 slots right away; the directory lookup (LDS) runs while they are in
       // flight, and the item count then masks the unused slots.  The leaf becomes the cached leaf: a delete run arrives
@@ -704,6 +729,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     uint32_t s_off = x - id0;                                   // elements of the run before the range
     uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
     uint32_t tail = pid_ctr(id0) + ln - endc;                   // elements of the run beyond the range
+    if (hint_k && !ts_del_pos_ok(t, R, slot, s_off, st0, hint_k)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
     if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= endc - c;
     lmw::wave_sync();
     uint32_t L = sa_leaf(lmw::first(t.da[p]));
@@ -1188,6 +1214,10 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
               uint32_t t0, t1;
               if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
               else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
+              // a delete span as long as its op and with a position inside the sequence (what every writer emits; the reference's
+              // decoder does not compare the two lengths, block_encode.rs:651-704, and would delete |span| elements at the position
+              // while the counters advance by the op's length — not a value this engine reproduces: LM_DATA_CORRUPTION)
+              if (Ln != r.len || r.prop < 0 || (r.a2 < 0 && (uint32_t)r.prop + 1 < Ln)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); break; }
               // unsliced row: its position addresses the leftmost target (forward: prop; backward: prop + 1 - len)
               uint32_t hint = 0;
               if (a == 0 && b == r.len && Ln == r.len && r.prop >= 0) { if (r.a2 > 0) hint = (uint32_t)r.prop + 1; else if ((uint32_t)r.prop + 1 >= Ln) hint = (uint32_t)r.prop + 2 - Ln; }

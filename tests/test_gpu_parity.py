@@ -259,7 +259,10 @@ def test_damaged_blobs_never_take_the_batch_down(engine):
         if i % 8 == 0:
             assert got[k] == want[k] and want[k][0] == 0      # the healthy neighbour
             k += 1
-    assert n_both_ok > 0 and n_same >= 0.8 * n_both_ok
+    # a damaged delete row whose position and target ids disagree (the reference deletes by position, crdt_rope.rs:256-335, the
+    # kernel by id) or whose span length differs from its op length is LM_DATA_CORRUPTION since round 3 (ts_del_pos_ok,
+    # lm_k_integrate_span.h): what both sides accept, they render alike
+    assert n_both_ok > 0 and n_same == n_both_ok
 
 
 def test_two_contexts_in_flight(engine):
