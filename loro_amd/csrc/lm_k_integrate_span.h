@@ -627,7 +627,13 @@ LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int m
   uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
   uint32_t tail = pid_ctr(id0) + ln - endc, mid = endc - c;
   uint32_t n = t.cr.n;
+#if defined(LM_NO_DEL_CHECK)
+  (void)hint_k;
+#elif defined(LM_DEL_CHECK_LIGHT)
+  if (hint_k && t.cache_pre != NONE && !ts_del_pos_ok(t, t.cr, slot, s_off, st0, hint_k)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); c = c1; return true; }
+#else
   if (hint_k && !ts_del_pos_ok(t, t.cr, slot, s_off, st0, hint_k)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); c = c1; return true; }
+#endif
   if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= mid;
   if ((s_off | tail) == 0) {
     t.cr.st = (uint32_t)lane == slot ? st1 : t.cr.st;
@@ -729,7 +735,9 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     uint32_t s_off = x - id0;                                   // elements of the run before the range
     uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
     uint32_t tail = pid_ctr(id0) + ln - endc;                   // elements of the run beyond the range
+#ifndef LM_NO_DEL_CHECK
     if (hint_k && !ts_del_pos_ok(t, R, slot, s_off, st0, hint_k)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+#endif
     if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= endc - c;
     lmw::wave_sync();
     uint32_t L = sa_leaf(lmw::first(t.da[p]));
@@ -1014,7 +1022,8 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     const U4 none4 = {NONE, NONE, NONE, NONE};
     uint32_t from4 = 0;
     if (keep_loc) from4 = lmw::first((rs.tk + rs.doc[doc].tk_off)[6]) / 4;   // (slices are padded to multiples of four: the boundary group is cleared again only if it was never used — it holds no kept entry, see k_res_layout)
-    for (uint32_t i = from4 + (uint32_t)lane; i < (m.atoms + 3) / 4; i += 64) l4[i] = none4;
+    if (RES || !d.loc_cleared || retry_pass)
+      for (uint32_t i = from4 + (uint32_t)lane; i < (m.atoms + 3) / 4; i += 64) l4[i] = none4;
   }
   if (retry_pass) {
     for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {   // sequence containers only: a Map's flag belongs to k_map_lww

@@ -135,7 +135,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false; int plain = 2; uint32_t dec_slot = 1280, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1280, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -144,6 +144,7 @@ struct Engine {
     if (const char* e = getenv("LM_DEC_SLOT")) k.dec_slot = ((uint32_t)atoi(e) + 15u) & ~15u;   // LDS bytes per block for everything before its value payloads (per 5k configs[1] documents: 512 5.4 ms, 1024 4.5, 1280 4.2, 1536 4.9, 2048 5.7 — occupancy against the share of heads that fit; larger heads are read from HBM)
     if (const char* e = getenv("LM_LDS_PAD")) k.lds_pad = (size_t)atoi(e);                       // occupancy experiments only
     k.no_opt_dir = getenv("LM_NO_OPT_DIR") != nullptr;
+    if (const char* e = getenv("LM_LOC_MEMSET")) k.loc_memset = atoi(e) != 0;
     if (const char* e = getenv("LM_DIR_OPT_MAX")) k.dir_opt_max = (uint32_t)atoi(e);             // tests: force the retry launch
     if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
     kn = k;
@@ -721,8 +722,12 @@ struct Engine {
     d.ht0 = b_ht0.as<uint64_t>(); d.ht_cap = b_ht_cap.as<uint32_t>();
     d.ht_list = b_ht_list.as<uint32_t>(); d.ht_cnt = b_ht_cnt.as<uint32_t>();
     lmbe::dmemset(b_ht_cnt.p, 0, (size_t)n_docs * 4 + 4);
-    // loc[] is initialised by k_integrate (each document's wave clears its own slice); cp[] needs no fill: every
-    // element that can be placed was written by k_elem_fill
+    // loc[] := NONE.  A batch: one memset on the stream, in front of the payload fill — it runs beside the other stream's /
+    // context's issue-bound integrate kernel instead of inside this one (LM_LOC_MEMSET=0: every document's wave clears its own
+    // slice, as resident documents always do — they keep loc[] between runs).  cp[] needs no fill: every element that can be
+    // placed was written by k_elem_fill
+    d.loc_cleared = (!resident && span && kn.loc_memset) ? 1u : 0u;
+    if (d.loc_cleared && elem) lmbe::dmemset(b_loc.p, 0xff, (size_t)elem * 4);
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
       if (resident) {
         sv.d = d; sv.g = g; sv.NB = NB; sv.NC = NC; sv.NO = NO; sv.NCID = NCID; sv.NP = NP; sv.ht = ht;
