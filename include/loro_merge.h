@@ -145,6 +145,17 @@ int lm_result_meta(lm_ctx* ctx, int32_t* status, uint64_t* json_len, uint64_t* v
  * word of the merged-state summary — ranks compare merged states without moving the JSON. */
 int lm_result_hashes(lm_ctx* ctx, uint64_t* json_xxh64);
 
+/* ---- The exchange step of a sharded deployment for a host without Python: documents shard across GPUs with no
+ * data-path collective; after lm_run every rank contributes the summary of its own documents — 6 int64 words per document:
+ * document id, status, pending ops, JSON length, VV length, xxh64(JSON) computed on the device — and receives the table of all
+ * documents of all ranks, sorted by document id, through ONE RCCL all-gather over xGMI (preceded by a one-word all-gather of the
+ * shard sizes).  One process per GPU: rank 0 calls lm_comm_unique_id and hands the 128 bytes to the others out of band; every
+ * rank calls lm_comm_init(ctx, rank, world, id) once (world == 1 needs neither an id nor RCCL), then lm_summary_allgather after
+ * each lm_run.  RCCL is dlopen'ed at lm_comm_init; the library does not link it.  Returns rows written, -1 on error. */
+int lm_comm_unique_id(uint8_t out128[128]);
+int lm_comm_init(lm_ctx* ctx, int rank, int world, const uint8_t id128[128]);
+long lm_summary_allgather(lm_ctx* ctx, const int64_t* doc_ids, int64_t* table, size_t cap_rows);
+
 /* ---- Export / encode side (host only, no device needed): the inverse of the decode stage.
  * lm_block_tables = the tables of ONE change block — the changes of one peer, counter-contiguous — exactly what the decode
  * stage extracts from a block (crates/loro-internal/src/oplog/change_store/block_encode.rs:535-706); lm_encode_block writes

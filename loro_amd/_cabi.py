@@ -19,7 +19,7 @@ class RunStats(ctypes.Structure):
 
 
 SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
-           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca", "export"]
+           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca", "export", "comm_unique_id", "comm_init", "summary_allgather"]
 
 
 class Binding:
@@ -40,6 +40,10 @@ class Binding:
         self.import_lca.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
         self.export = g("export"); self.export.restype = ctypes.c_int
         self.export.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        self.comm_unique_id = g("comm_unique_id"); self.comm_unique_id.restype = ctypes.c_int; self.comm_unique_id.argtypes = [ctypes.c_char_p]
+        self.comm_init = g("comm_init"); self.comm_init.restype = ctypes.c_int; self.comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+        self.summary_allgather = g("summary_allgather"); self.summary_allgather.restype = ctypes.c_long
+        self.summary_allgather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         self.resident_fresh = g("resident_fresh"); self.resident_fresh.restype = ctypes.c_int; self.resident_fresh.argtypes = [ctypes.c_void_p]
         self.run = g("run"); self.run.restype = ctypes.c_int; self.run.argtypes = [ctypes.c_void_p]
         self.run_async = g("run_async"); self.run_async.restype = ctypes.c_int; self.run_async.argtypes = [ctypes.c_void_p]
@@ -155,6 +159,20 @@ class Context:
         b = ctypes.string_at(out.value, n.value)
         self.b.free_bytes(out)
         return b
+
+    def comm_init(self, rank=0, world=1, unique_id=None):
+        if self.b.comm_init(self.h, rank, world, unique_id or bytes(128)) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+
+    def summary_allgather(self, doc_ids, total_docs):
+        """lm_summary_allgather: the [total_docs, 6] int64 summary table of all ranks' documents (this rank's ids = doc_ids)"""
+        import numpy as np
+        ids = np.asarray(doc_ids, dtype=np.int64)
+        table = np.zeros((total_docs, 6), dtype=np.int64)
+        n = self.b.summary_allgather(self.h, ids.ctypes.data, table.ctypes.data, total_docs)
+        if n < 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        return table[:n]
 
     def import_info(self):
         """[(DiffMode name or None, encoded LCA Frontiers or None)] of the last run's import, per resident document"""

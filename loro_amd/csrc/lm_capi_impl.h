@@ -3,6 +3,7 @@
 #pragma once
 #include <memory>
 #include <thread>
+#include <map>
 #include "lm_pipeline.h"
 #include "lm_encode.h"
 
@@ -117,7 +118,7 @@ void* LM_API(create)(int device) {
   if (!lmbe::init(device)) return nullptr;
   try { return new lm_ctx_impl(device); } catch (const std::exception&) { return nullptr; }
 }
-void LM_API(destroy)(void* c) { delete (lm_ctx_impl*)c; }
+void LM_API(destroy)(void* c);
 const char* LM_API(last_error)(void* c) { return c ? ((lm_ctx_impl*)c)->err.c_str() : "no context (HIP device unavailable)"; }
 
 int LM_API(stage)(void* c, const lm_doc_in_c* docs, size_t n) {
@@ -347,6 +348,133 @@ int LM_API(kernel_time)(void* c, uint32_t i, const char** name, double* ms) {
   *name = x->times[i].name.c_str();
   *ms = x->times[i].ms;
   return 0;
+}
+// ---- the exchange step of a sharded deployment for a host without Python / torch: every rank contributes the
+// summary of its own documents — 6 words each: document id, status, pending ops, JSON length, VV length, xxh64 of the JSON
+// (computed on the device, k_hash_json) — and receives the table of all documents, by ONE RCCL all-gather over xGMI (after a
+// one-word all-gather of the shard sizes).  RCCL is loaded at lm_comm_init (dlopen): the library itself does not depend on it.
+#ifndef LM_EMU
+#include <dlfcn.h>
+namespace lmcomm {
+typedef struct { char internal[128]; } UniqueId;
+typedef int (*GetUniqueIdFn)(UniqueId*);
+typedef int (*CommInitRankFn)(void**, int, UniqueId, int);
+typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*CommDestroyFn)(void*);
+struct Api { void* h = nullptr; GetUniqueIdFn get_id = nullptr; CommInitRankFn init = nullptr; AllGatherFn all_gather = nullptr; CommDestroyFn destroy = nullptr; };
+inline Api& api() {
+  static Api a;
+  if (!a.h) {
+    a.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!a.h) a.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (a.h) {
+      a.get_id = (GetUniqueIdFn)dlsym(a.h, "ncclGetUniqueId"); a.init = (CommInitRankFn)dlsym(a.h, "ncclCommInitRank");
+      a.all_gather = (AllGatherFn)dlsym(a.h, "ncclAllGather"); a.destroy = (CommDestroyFn)dlsym(a.h, "ncclCommDestroy");
+    }
+  }
+  return a;
+}
+}  // namespace lmcomm
+#endif
+struct lm_comm_state { int rank = 0, world = 1; void* comm = nullptr; };
+static std::map<void*, lm_comm_state>& lm_comms() { static std::map<void*, lm_comm_state> m; return m; }
+
+// rank 0 creates the id and hands it to the other ranks out of band (128 bytes)
+int LM_API(comm_unique_id)(uint8_t* out128) {
+#ifndef LM_EMU
+  auto& a = lmcomm::api();
+  if (!a.get_id) return -1;
+  lmcomm::UniqueId id;
+  if (a.get_id(&id) != 0) return -1;
+  memcpy(out128, id.internal, 128);
+  return 0;
+#else
+  memset(out128, 0, 128);
+  return 0;
+#endif
+}
+// world == 1 needs no communicator (and no RCCL); otherwise every rank calls this with the same id, on its own context
+int LM_API(comm_init)(void* c, int rank, int world, const uint8_t* id128) {
+  auto* x = (lm_ctx_impl*)c;
+  if (world < 1 || rank < 0 || rank >= world) { x->err = "lm_comm_init: rank / world"; return -1; }
+  lm_comm_state st;
+  st.rank = rank; st.world = world;
+  if (world > 1) {
+#ifndef LM_EMU
+    auto& a = lmcomm::api();
+    if (!a.init || !a.all_gather) { x->err = "lm_comm_init: librccl.so could not be loaded"; return -1; }
+    (void)hipSetDevice(x->device);
+    lmcomm::UniqueId id;
+    memcpy(id.internal, id128, 128);
+    if (a.init(&st.comm, world, id, rank) != 0) { x->err = "ncclCommInitRank failed"; return -1; }
+#else
+    x->err = "the kernel-logic harness has no collective"; return -1;
+#endif
+  }
+  lm_comms()[c] = st;
+  return 0;
+}
+// doc_ids[n_docs] = the global ids of this context's documents; table receives rows of 6 int64 (layout above = loro_amd/dist.py
+// SUMMARY_WORDS) for the documents of ALL ranks, sorted by document id; returns the number of rows, -1 on error
+long LM_API(summary_allgather)(void* c, const int64_t* doc_ids, int64_t* table, size_t cap_rows) {
+  auto* x = (lm_ctx_impl*)c;
+  try {
+    if (!x->ran) throw std::runtime_error("lm_summary_allgather before lm_run");
+    auto it = lm_comms().find(c);
+    lm_comm_state st = it == lm_comms().end() ? lm_comm_state() : it->second;
+    size_t n = x->n_docs;
+    std::vector<int64_t> local(n * 6);
+    x->for_docs([&](uint32_t i, lm::Engine&, const lm::DocResult& r) {
+      int64_t* w = local.data() + (size_t)i * 6;
+      w[0] = doc_ids[i]; w[1] = r.status; w[2] = (int64_t)r.pending; w[3] = (int64_t)r.json_len; w[4] = (int64_t)r.vv_len; w[5] = (int64_t)r.json_xxh64;
+    });
+    std::vector<int64_t> all;
+    if (st.world == 1) all = local;
+#ifndef LM_EMU
+    else {
+      auto& a = lmcomm::api();
+      lm::Engine& e = *x->parts[0];
+      lmbe::bind(e.sc);
+      // shard sizes, then the tables padded to the largest shard: the same two collectives loro_amd/dist.py issues
+      lm::DBuf sz_in, sz_out, tb_in, tb_out;
+      sz_in.ensure(8); sz_out.ensure((size_t)st.world * 8);
+      int64_t nn = (int64_t)n;
+      lmbe::h2d(sz_in.p, &nn, 8);
+      if (a.all_gather(sz_in.p, sz_out.p, 1, /*ncclInt64*/ 4, st.comm, lmbe::cur->s) != 0) throw std::runtime_error("ncclAllGather (sizes) failed");
+      std::vector<int64_t> sizes(st.world);
+      lmbe::d2h(sizes.data(), sz_out.p, (size_t)st.world * 8);
+      int64_t n_max = 0;
+      for (int64_t s2 : sizes) n_max = s2 > n_max ? s2 : n_max;
+      std::vector<int64_t> padded((size_t)n_max * 6, -1);
+      memcpy(padded.data(), local.data(), local.size() * 8);
+      tb_in.ensure((size_t)n_max * 48 + 8); tb_out.ensure((size_t)st.world * n_max * 48 + 8);
+      lmbe::h2d(tb_in.p, padded.data(), padded.size() * 8);
+      if (a.all_gather(tb_in.p, tb_out.p, (size_t)n_max * 6, 4, st.comm, lmbe::cur->s) != 0) throw std::runtime_error("ncclAllGather (summaries) failed");
+      std::vector<int64_t> raw((size_t)st.world * n_max * 6);
+      lmbe::d2h(raw.data(), tb_out.p, raw.size() * 8);
+      for (int r = 0; r < st.world; r++) all.insert(all.end(), raw.begin() + (size_t)r * n_max * 6, raw.begin() + ((size_t)r * n_max + sizes[r]) * 6);
+      sz_in.release(); sz_out.release(); tb_in.release(); tb_out.release();
+    }
+#endif
+    size_t rows = all.size() / 6;
+    if (rows > cap_rows) throw std::runtime_error("lm_summary_allgather: the table does not fit");
+    std::vector<size_t> order(rows);
+    for (size_t i = 0; i < rows; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t p, size_t q) { return all[p * 6] < all[q * 6]; });
+    for (size_t i = 0; i < rows; i++) memcpy(table + i * 6, all.data() + order[i] * 6, 48);
+    return (long)rows;
+  } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
+
+void LM_API(destroy)(void* c) {
+  auto it = lm_comms().find(c);
+  if (it != lm_comms().end()) {
+#ifndef LM_EMU
+    if (it->second.comm && lmcomm::api().destroy) (void)lmcomm::api().destroy(it->second.comm);
+#endif
+    lm_comms().erase(it);
+  }
+  delete (lm_ctx_impl*)c;
 }
 // number of engine parts (HIP streams) the last staged batch was split into
 int LM_API(n_streams)(void* c) { return (int)((lm_ctx_impl*)c)->n_parts(); }

@@ -87,3 +87,23 @@ def test_bench_step_loop_two_ranks(tmp_path):
 def _emu_binding_is_built():
     import _emu
     _emu.binding()   # compile once in the parent, not concurrently in both ranks
+
+
+def test_c_abi_summary_matches_the_python_exchange():
+    """lm_summary_allgather (the exchange step in the C ABI, for hosts without torch): with one rank it returns this context's
+    table — the same six words per document loro_amd/dist.py builds and all-gathers"""
+    import numpy as np
+    import _emu, _cases, _oracle
+    from loro_amd._cabi import Context
+    from loro_amd import dist as lmdist
+    names, docs = _cases.edge_case_docs()
+    with Context(_emu.binding()) as c:
+        c.stage(docs); c.run()
+        st, jl, vl, pe = c.result_meta()
+        ids = [1000 + 3 * i for i in range(len(docs))][::-1]          # any global numbering: the table comes back sorted by id
+        want = lmdist.summarize_device(ids, st, pe, jl, vl, c.result_hashes())
+        want = want[np.argsort(want[:, 0], kind="stable")]
+        c.comm_init(0, 1)
+        got = c.summary_allgather(ids, len(docs))
+        assert got.shape == want.shape and (got == want).all()
+        assert (got == lmdist.summarize(sorted(ids), [c.fetch()[len(docs) - 1 - k] for k in range(len(docs))])).all()

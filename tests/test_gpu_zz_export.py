@@ -33,3 +33,23 @@ def test_every_bench_blob_comes_back():
     assert again == want
     for blobs, o in zip(docs, out):   # the frames of the three blobs, in order (A's blocks, then B's: peers ascend), are the export's
         assert o[22:] == b"".join(b[22:] for b in blobs)
+
+
+def test_summary_exchange_in_the_c_abi():
+    """lm_comm_init / lm_summary_allgather on the device: one rank (no RCCL needed), the six words per document of loro_amd/dist.py"""
+    import numpy as np
+    import _cases
+    from loro_amd import dist as lmdist
+    names, docs = _cases.edge_case_docs()
+    docs = docs * 12
+    with _engine() as c:
+        c.stage(docs); c.run()
+        st, jl, vl, pe = c.result_meta()
+        ids = list(range(len(docs)))
+        want = lmdist.summarize_device(ids, st, pe, jl, vl, c.result_hashes())
+        c.comm_init(0, 1)
+        got = c.summary_allgather(ids, len(docs))
+        assert (got == want).all()
+        uid = bytes(128)
+        buf = __import__("ctypes").create_string_buffer(128)
+        assert c.b.comm_unique_id(buf) == 0      # librccl loads on the GPU box
