@@ -30,6 +30,10 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   const uint32_t* end;            // LDS: version being rendered per peer (no element exists at or beyond it)
   uint32_t* da;                   // LDS directory, word A per leaf in document order
   uint32_t* db;                   // LDS directory, word B (active length)
+  uint32_t* ds;                   // LDS: per 64 directory entries the sum of their active lengths — kept once the directory is longer than
+                                  // SD_LINEAR entries (ds_on); exact for every block except the cached leaf's, whose entry the fast paths
+                                  // change in place: that block is re-summed when the leaf leaves the cache and before a search
+  bool ds_on;
   uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
   uint32_t n_alive;               // elements inserted and never deleted by a replayed op = visible at the rendered version
   uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); WRITE-BACK: `cr` is the truth, HBM is updated by sp_flush
@@ -155,16 +159,32 @@ LM_DEV void sp_flush_loc(Ts& t) {
   if (t.cache_leaf != NONE && lmw::any(t.loc_pend != 0)) { sp_set_loc_lanes(t, t.cr, t.loc_pend != 0, t.cache_leaf); t.loc_pend = 0; }
 }
 // leaf L becomes the cached leaf (its registers are set by the caller); another cached leaf is written back first
+LM_DEV void sd_sync_cached(Ts& t);
 LM_DEV void sp_take(Ts& t, uint32_t L) {
-  if (t.cache_leaf != L) { sp_flush(t); t.cache_leaf = L; t.dirty = false; t.loc_pend = 0; }
+  if (t.cache_leaf != L) { sp_flush(t); sd_sync_cached(t); t.cache_leaf = L; t.dirty = false; t.loc_pend = 0; }
 }
 
-// ---- directory (LDS, a few hundred entries: linear, 64 per step)
+// ---- directory (LDS).  Up to SD_LINEAR entries it is searched linearly, 64 entries per step (configs[1]: ≈120 leaves, two
+// steps); a longer one — deep histories: ≈1,200 leaves for a 1M-op document, 19 steps per search — gets a second level, the sums
+// of 64 entries each, so that a search is one step over the sums and one inside a block.
+#ifndef LM_SD_LINEAR
+#define LM_SD_LINEAR 128
+#endif
+static constexpr uint32_t SD_LINEAR = LM_SD_LINEAR;   // (tests build the harness with LM_SD_LINEAR=2: every document gets the second level)
+LM_DEV void sd_block_sum(Ts& t, uint32_t j) {   // ds[j] := Σ db[64j .. 64j+63]
+  uint32_t i = 64 * j + (uint32_t)lmw::lane();
+  lmw::wave_sync();
+  uint32_t s = lmw::reduce_add(i < t.n_dir ? t.db[i] : 0u);
+  if (lmw::lane() == 0) t.ds[j] = s;
+  lmw::wave_sync();
+}
+LM_DEV void sd_sums_from(Ts& t, uint32_t j0) { for (uint32_t j = j0; 64 * j < t.n_dir; j++) sd_block_sum(t, j); }
+LM_DEV void sd_sync_cached(Ts& t) { if (t.ds_on && t.cache_leaf != NONE && t.cache_p < t.n_dir) sd_block_sum(t, t.cache_p >> 6); }
 LM_DEV void sd_set(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
   lmw::wave_sync();
   uint32_t old = t.db[p];
   lmw::wave_sync();
-  if (lmw::lane() == 0) { t.da[p] = a; t.db[p] = b; }
+  if (lmw::lane() == 0) { t.da[p] = a; t.db[p] = b; if (t.ds_on) t.ds[p >> 6] += b - old; }
   t.tot_active += b - old;
   lmw::wave_sync();
 }
@@ -188,12 +208,29 @@ LM_DEV void sd_insert_after(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
   t.tot_active += b;
   if (t.cache_leaf != NONE && t.cache_p >= q) t.cache_p++;
   lmw::wave_sync();
+  if (!t.ds_on && t.n_dir > SD_LINEAR) { t.ds_on = true; sd_sums_from(t, 0); }
+  else if (t.ds_on) sd_sums_from(t, q >> 6);   // every entry behind q moved up by one
 }
 // k-th active element (1 <= k <= tot_active) → directory position; k becomes the rank inside that leaf
-LM_DEV uint32_t sd_find_kth(const Ts& t, uint32_t& k) {
+LM_DEV uint32_t sd_find_kth(Ts& t, uint32_t& k) {
   int lane = lmw::lane();
   lmw::wave_sync();
-  for (uint32_t i0 = 0; i0 < t.n_dir; i0 += 64) {
+  uint32_t first = 0;
+  if (t.ds_on) {
+    sd_sync_cached(t);
+    uint32_t nb = (t.n_dir + 63) >> 6, blk = NONE;
+    for (uint32_t j0 = 0; j0 < nb && blk == NONE; j0 += 64) {
+      uint32_t j = j0 + (uint32_t)lane;
+      uint32_t a = j < nb ? t.ds[j] : 0u;
+      uint32_t inc = lmw::scan_incl_add(a);
+      uint64_t m = lmw::ballot(inc >= k);
+      if (m) { int s2 = lmw::ffs64(m); k -= lmw::bcast(inc, s2) - lmw::bcast(a, s2); blk = j0 + (uint32_t)s2; }
+      else k -= lmw::bcast(inc, 63);
+    }
+    if (blk == NONE) return NONE;
+    first = 64 * blk;
+  }
+  for (uint32_t i0 = first; i0 < t.n_dir; i0 += 64) {
     uint32_t i = i0 + (uint32_t)lane;
     uint32_t a = i < t.n_dir ? t.db[i] : 0u;
     uint32_t inc = lmw::scan_incl_add(a);
@@ -218,11 +255,17 @@ LM_DEV uint32_t sd_find_leaf(const Ts& t, uint32_t L) {
   return NONE;
 }
 // active elements in front of directory position p
-LM_DEV uint32_t sd_prefix(const Ts& t, uint32_t p) {
+LM_DEV uint32_t sd_prefix(Ts& t, uint32_t p) {
   int lane = lmw::lane();
   lmw::wave_sync();
-  uint32_t acc = 0;
-  for (uint32_t i0 = 0; i0 < p; i0 += 64) {
+  uint32_t acc = 0, first = 0;
+  if (t.ds_on) {
+    sd_sync_cached(t);
+    uint32_t nbp = p >> 6;
+    for (uint32_t j = (uint32_t)lane; j < nbp; j += 64) acc += t.ds[j];
+    first = 64 * nbp;
+  }
+  for (uint32_t i0 = first; i0 < p; i0 += 64) {
     uint32_t i = i0 + (uint32_t)lane;
     acc += i < p ? t.db[i] : 0u;
   }
@@ -832,6 +875,7 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
     if (!t.err) ts_update_range(t, peer, c1 - 1, c1, mode);
     if (t.err) return;
     sp_flush(t);                                                     // the pass works on the leaf records in HBM
+    sd_sync_cached(t);
     t.cache_leaf = NONE; t.cr.n = 255; t.cache_pre = NONE; t.dirty = false; t.loc_pend = 0;
     lmw::wave_sync();
     uint32_t lo = pid_make(peer, c0), span = c1 - c0;
@@ -924,6 +968,13 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
       if (act != t.db[q] || nf != sa_nf(a)) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u active %u (cached %u) nf %d (cached %d)\n", what, row, q, L, act, t.db[q], (int)nf, (int)sa_nf(a)); ok = false; }
       tot += act;
     }
+    if (ok && t.ds_on)   // the block sums, except the cached leaf's block (re-summed when the leaf leaves the cache / before a search)
+      for (uint32_t j = 0; 64 * j < t.n_dir && ok; j++) {
+        if (t.cache_leaf != NONE && j == (t.cache_p >> 6)) continue;
+        uint32_t sum = 0;
+        for (uint32_t q = 64 * j; q < 64 * j + 64 && q < t.n_dir; q++) sum += t.db[q];
+        if (sum != t.ds[j]) { fprintf(stderr, "CHECK %s row=%u: block %u sums to %u, cached sum %u\n", what, row, j, sum, t.ds[j]); ok = false; }
+      }
     if (ok && tot != t.tot_active) { fprintf(stderr, "CHECK %s row=%u: total active %u, cached %u\n", what, row, tot, t.tot_active); ok = false; }
     if (ok && t.cache_leaf != NONE) {
       if (t.cache_p >= t.n_dir || sa_leaf(t.da[t.cache_p]) != t.cache_leaf) { fprintf(stderr, "CHECK %s row=%u: cached leaf %u is not at directory position %u\n", what, row, t.cache_leaf, t.cache_p); ok = false; }
@@ -992,7 +1043,8 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   LM_DYN_SHARED(uint32_t, s_mem);
   uint32_t* s_da = s_mem;
   uint32_t* s_db = s_mem + dir_cap;
-  uint32_t* s_ebase = s_db + dir_cap;
+  uint32_t* s_ds = s_db + dir_cap;                 // dir_cap / 64 + 2 block sums
+  uint32_t* s_ebase = s_ds + (dir_cap / 64 + 2);
   uint32_t* s_cur = s_ebase + pmax;
   uint32_t* s_end = s_cur + pmax;
   uint32_t* s_tgt = s_end + pmax;    // RES only: the version being rendered (s_end is the latest applied version there)
@@ -1090,7 +1142,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   Ts t;
   t.it = d.it + (uint64_t)m.leaf0 * SP_REC;
   t.loc = d.loc + elem0;
-  t.ebase = s_ebase; t.cur = s_cur; t.end = s_end; t.da = s_da; t.db = s_db;
+  t.ebase = s_ebase; t.cur = s_cur; t.end = s_end; t.da = s_da; t.db = s_db; t.ds = s_ds; t.ds_on = false;
   t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0;
 #ifdef LM_PROF
   for (int i = 0; i < PF_N; i++) t.prof[i] = 0;
@@ -1146,11 +1198,13 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       for (uint32_t i = (uint32_t)lane; i < nr; i += 64) { uint32_t b = rs.dir_b_prev[m.leaf0 + r0 + i]; s_da[i] = rs.dir_a_prev[m.leaf0 + r0 + i]; s_db[i] = b; act += b; }
       t.n_dir = nr; t.tot_active = lmw::reduce_add(act); t.n_alive = lmw::first(rec[2]);
       lmw::block_sync();
+      t.ds_on = nr > SD_LINEAR;
+      if (t.ds_on) sd_sums_from(t, 0);
       for (uint32_t q = (uint32_t)lane; q < P0; q += 64) s_cur[s_pmap[q]] = rec[TK_CW + q];
     } else {
       uint32_t L0 = t.n_leaf++;
       if (lane == 0) { s_da[0] = sa_make(L0, 0, false); s_db[0] = 0; }
-      t.n_dir = 1; t.tot_active = 0; t.n_alive = 0;
+      t.n_dir = 1; t.tot_active = 0; t.n_alive = 0; t.ds_on = false;
     }
     lmw::block_sync();
     bool touched = false;

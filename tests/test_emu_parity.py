@@ -553,3 +553,36 @@ def test_block_decoders_agree(monkeypatch, variant):
     ref = _emu.merge_batch(bad)          # the sequential decoder's verdicts
     assert [g[0] for g in got] == [x[0] for x in ref]
     assert got == ref
+
+
+def test_two_level_directory_of_deep_histories():
+    """the leaf directory's second level (sums of 64 entries, lm_k_integrate_span.h SD_LINEAR) — built with LM_SD_LINEAR=2 so that
+    every document uses it, with the structural checker after every op: documents with > 64 leaves (several blocks of sums),
+    checkouts, concurrent sessions, MovableLists"""
+    import _fuzz
+    from loro_amd import workload
+    from loro_amd._cabi import Context
+    b = _emu.variant(["LM_SD_LINEAR=2", "LM_EMU_CHECK"])
+    names, edge = _cases.edge_case_docs()
+    docs = [edge[names.index("many leaves")], edge[names.index("long pastes")]] + _cases.fuzz_docs(12, base=8100)
+    docs += [_fuzz.blobs_of(_fuzz.movable_session(8200 + i, n_steps=80, nested=True)) for i in range(4)]
+    import random
+    rng = random.Random(9)
+    big = wire.Replica(77)
+    n = 0
+    for i in range(6000):                      # single characters at random positions: every one its own run — > 100 leaves
+        big.text_insert("text", rng.randint(0, n), "abcdefghij"[i % 10]); n += 1
+        if i % 9 == 0 and n > 4:
+            big.text_delete("text", rng.randint(0, n - 2), 1); n -= 1
+        if i % 40 == 0:
+            big.commit()
+    big.commit()
+    docs.append([big.export()])
+    fr = [None] * len(docs)
+    blobs, f = workload.cfg5_doc(3, n_ops=12000, turn=500, n_checkouts=6, commit_every=1)
+    docs += [blobs] * 6; fr += f
+    want = _oracle.merge_batch(docs, threads=4, frontiers=fr)
+    with Context(b) as c:
+        got = c.merge_batch(docs, fr)
+        assert c.sizing()[0] > 64        # leaves used by the largest document: more than one block of sums
+    assert got == want and all(w[0] == 0 for w in want)
