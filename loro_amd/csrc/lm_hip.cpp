@@ -6,6 +6,8 @@
 #include <string>
 #include <vector>
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 #include "lm_wave.h"
 
 namespace lm { struct KernelTime; }
@@ -106,15 +108,23 @@ inline void check_launch(const char* name) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, lmbe::cur->s, __VA_ARGS__); \
     lmbe::check_launch(#kern);                                                                     \
   } while (0)
-// (the dynamic-LDS ceiling of a kernel is raised when a launch needs more than any launch before it from this site — not on
-// every launch: hipFuncSetAttribute is a driver round trip)
+// (the dynamic-LDS ceiling of a kernel is raised when a launch needs more than any launch of that kernel before it — not on every
+// launch: hipFuncSetAttribute is a driver round trip.  Per kernel function, whatever site launches it.)
+namespace lmbe {
+inline bool dyn_lds_needs_raise(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> set;
+  std::lock_guard<std::mutex> g(mu);
+  size_t& cur_max = set[fn];
+  if (bytes <= cur_max) return false;
+  cur_max = bytes;
+  return true;
+}
+}  // namespace lmbe
 #define LM_LAUNCH_DYN(kern, grid, block, shmem, ...)                                               \
   do {                                                                                             \
-    static std::atomic<size_t> lm_dyn_set_{0};                                                     \
-    if ((size_t)(shmem) > lm_dyn_set_.load(std::memory_order_relaxed)) {                           \
+    if (lmbe::dyn_lds_needs_raise((const void*)kern, (size_t)(shmem)))                             \
       LM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shmem))); \
-      lm_dyn_set_.store((size_t)(shmem), std::memory_order_relaxed);                               \
-    }                                                                                              \
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (shmem), lmbe::cur->s, __VA_ARGS__); \
     lmbe::check_launch(#kern);                                                                     \
   } while (0)

@@ -170,21 +170,25 @@ LM_DEV void sp_take(Ts& t, uint32_t L) {
 #ifndef LM_SD_LINEAR
 #define LM_SD_LINEAR 128
 #endif
-static constexpr uint32_t SD_LINEAR = LM_SD_LINEAR;   // (tests build the harness with LM_SD_LINEAR=2: every document gets the second level)
-LM_DEV void sd_block_sum(Ts& t, uint32_t j) {   // ds[j] := Σ db[64j .. 64j+63]
-  uint32_t i = 64 * j + (uint32_t)lmw::lane();
+static constexpr uint32_t SD_LINEAR = LM_SD_LINEAR;
+#ifndef LM_SD_BSH
+#define LM_SD_BSH 6
+#endif
+static constexpr uint32_t SD_BSH = LM_SD_BSH, SD_BS = 1u << LM_SD_BSH;   // entries per block of sums (tests: LM_SD_BSH=2 — block boundaries everywhere)   // (tests build the harness with LM_SD_LINEAR=2: every document gets the second level)
+LM_DEV void sd_block_sum(Ts& t, uint32_t j) {   // ds[j] := Σ db over block j
+  uint32_t i = (j << SD_BSH) + (uint32_t)lmw::lane();
   lmw::wave_sync();
-  uint32_t s = lmw::reduce_add(i < t.n_dir ? t.db[i] : 0u);
+  uint32_t s = lmw::reduce_add(((uint32_t)lmw::lane() < SD_BS && i < t.n_dir) ? t.db[i] : 0u);
   if (lmw::lane() == 0) t.ds[j] = s;
   lmw::wave_sync();
 }
-LM_DEV void sd_sums_from(Ts& t, uint32_t j0) { for (uint32_t j = j0; 64 * j < t.n_dir; j++) sd_block_sum(t, j); }
-LM_DEV void sd_sync_cached(Ts& t) { if (t.ds_on && t.cache_leaf != NONE && t.cache_p < t.n_dir) sd_block_sum(t, t.cache_p >> 6); }
+LM_DEV void sd_sums_from(Ts& t, uint32_t j0) { for (uint32_t j = j0; (j << SD_BSH) < t.n_dir; j++) sd_block_sum(t, j); }
+LM_DEV void sd_sync_cached(Ts& t) { if (t.ds_on && t.cache_leaf != NONE && t.cache_p < t.n_dir) sd_block_sum(t, t.cache_p >> SD_BSH); }
 LM_DEV void sd_set(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
   lmw::wave_sync();
   uint32_t old = t.db[p];
   lmw::wave_sync();
-  if (lmw::lane() == 0) { t.da[p] = a; t.db[p] = b; if (t.ds_on) t.ds[p >> 6] += b - old; }
+  if (lmw::lane() == 0) { t.da[p] = a; t.db[p] = b; if (t.ds_on) t.ds[p >> SD_BSH] += b - old; }
   t.tot_active += b - old;
   lmw::wave_sync();
 }
@@ -209,7 +213,7 @@ LM_DEV void sd_insert_after(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
   if (t.cache_leaf != NONE && t.cache_p >= q) t.cache_p++;
   lmw::wave_sync();
   if (!t.ds_on && t.n_dir > SD_LINEAR) { t.ds_on = true; sd_sums_from(t, 0); }
-  else if (t.ds_on) sd_sums_from(t, q >> 6);   // every entry behind q moved up by one
+  else if (t.ds_on) sd_sums_from(t, q >> SD_BSH);   // every entry behind q moved up by one
 }
 // k-th active element (1 <= k <= tot_active) → directory position; k becomes the rank inside that leaf
 LM_DEV uint32_t sd_find_kth(Ts& t, uint32_t& k) {
@@ -218,7 +222,7 @@ LM_DEV uint32_t sd_find_kth(Ts& t, uint32_t& k) {
   uint32_t first = 0;
   if (t.ds_on) {
     sd_sync_cached(t);
-    uint32_t nb = (t.n_dir + 63) >> 6, blk = NONE;
+    uint32_t nb = (t.n_dir + SD_BS - 1) >> SD_BSH, blk = NONE;
     for (uint32_t j0 = 0; j0 < nb && blk == NONE; j0 += 64) {
       uint32_t j = j0 + (uint32_t)lane;
       uint32_t a = j < nb ? t.ds[j] : 0u;
@@ -228,7 +232,7 @@ LM_DEV uint32_t sd_find_kth(Ts& t, uint32_t& k) {
       else k -= lmw::bcast(inc, 63);
     }
     if (blk == NONE) return NONE;
-    first = 64 * blk;
+    first = blk << SD_BSH;
   }
   for (uint32_t i0 = first; i0 < t.n_dir; i0 += 64) {
     uint32_t i = i0 + (uint32_t)lane;
@@ -261,9 +265,9 @@ LM_DEV uint32_t sd_prefix(Ts& t, uint32_t p) {
   uint32_t acc = 0, first = 0;
   if (t.ds_on) {
     sd_sync_cached(t);
-    uint32_t nbp = p >> 6;
+    uint32_t nbp = p >> SD_BSH;
     for (uint32_t j = (uint32_t)lane; j < nbp; j += 64) acc += t.ds[j];
-    first = 64 * nbp;
+    first = nbp << SD_BSH;
   }
   for (uint32_t i0 = first; i0 < p; i0 += 64) {
     uint32_t i = i0 + (uint32_t)lane;
@@ -334,6 +338,7 @@ LM_DEV void sp_insert_items(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, cons
                             bool newA, bool newB, uint32_t pre) {   // pre: active elements before leaf p (NONE = unknown)
   int lane = lmw::lane();
   lmw::wave_sync();
+  sd_sync_cached(t);   // (a split below may hand the cache to the new leaf without going through sp_take)
   uint32_t L = sa_leaf(lmw::first(t.da[p]));
   sp_take(t, L);
   uint32_t lp = t.loc_pend;
@@ -969,10 +974,10 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
       tot += act;
     }
     if (ok && t.ds_on)   // the block sums, except the cached leaf's block (re-summed when the leaf leaves the cache / before a search)
-      for (uint32_t j = 0; 64 * j < t.n_dir && ok; j++) {
-        if (t.cache_leaf != NONE && j == (t.cache_p >> 6)) continue;
+      for (uint32_t j = 0; (j << SD_BSH) < t.n_dir && ok; j++) {
+        if (t.cache_leaf != NONE && j == (t.cache_p >> SD_BSH)) continue;
         uint32_t sum = 0;
-        for (uint32_t q = 64 * j; q < 64 * j + 64 && q < t.n_dir; q++) sum += t.db[q];
+        for (uint32_t q = j << SD_BSH; q < ((j + 1) << SD_BSH) && q < t.n_dir; q++) sum += t.db[q];
         if (sum != t.ds[j]) { fprintf(stderr, "CHECK %s row=%u: block %u sums to %u, cached sum %u\n", what, row, j, sum, t.ds[j]); ok = false; }
       }
     if (ok && tot != t.tot_active) { fprintf(stderr, "CHECK %s row=%u: total active %u, cached %u\n", what, row, tot, t.tot_active); ok = false; }
@@ -1043,8 +1048,8 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   LM_DYN_SHARED(uint32_t, s_mem);
   uint32_t* s_da = s_mem;
   uint32_t* s_db = s_mem + dir_cap;
-  uint32_t* s_ds = s_db + dir_cap;                 // dir_cap / 64 + 2 block sums
-  uint32_t* s_ebase = s_ds + (dir_cap / 64 + 2);
+  uint32_t* s_ds = s_db + dir_cap;                 // block sums
+  uint32_t* s_ebase = s_ds + ((dir_cap >> SD_BSH) + 2);
   uint32_t* s_cur = s_ebase + pmax;
   uint32_t* s_end = s_cur + pmax;
   uint32_t* s_tgt = s_end + pmax;    // RES only: the version being rendered (s_end is the latest applied version there)

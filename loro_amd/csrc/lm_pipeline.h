@@ -808,7 +808,7 @@ struct Engine {
       DBuf& wa = dir_parity ? b_dir_out2 : b_dir_out; DBuf& ra = dir_parity ? b_dir_out : b_dir_out2;
       DBuf& wb = dir_parity ? b_dir_b2 : b_dir_b;     DBuf& rb = dir_parity ? b_dir_b : b_dir_b2;
       d.dir_out = wa.as<uint32_t>(); rs.dir_a_prev = ra.as<uint32_t>(); rs.dir_b = wb.as<uint32_t>(); rs.dir_b_prev = rb.as<uint32_t>();
-      const size_t lds = (size_t)(2 * dir_opt + dir_opt / 64 + 2 + 6 * pmax) * 4 + lds_pad;
+      const size_t lds = (size_t)(2 * dir_opt + (dir_opt >> SD_BSH) + 2 + 6 * pmax) * 4 + lds_pad;
       if (any_plain)
         LM_LAUNCH_DYN(k_integrate_span_res_plain, n_docs, 64, lds, d, g, dir_opt, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                       (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
@@ -820,16 +820,16 @@ struct Engine {
                       (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
     } else if (span) {
       if (any_plain && plain_mode == 2)
-        LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? dir_opt / 64 + 2 : 0) + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       else if (any_plain)
-        LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? dir_opt / 64 + 2 : 0) + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       if (any_common || !(any_ml || any_plain))
-        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? dir_opt / 64 + 2 : 0) + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       if (any_ml)
-        LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? dir_opt / 64 + 2 : 0) + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
     } else {
       LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
@@ -844,7 +844,7 @@ struct Engine {
     }
     if (n_retry) {  // rare: re-run the overflowed documents with the worst-case directory
       if (resident) {
-        const size_t lds = (size_t)(2 * dir_cap + dir_cap / 64 + 2 + 6 * pmax) * 4;
+        const size_t lds = (size_t)(2 * dir_cap + (dir_cap >> SD_BSH) + 2 + 6 * pmax) * 4;
         if (any_plain)
           LM_LAUNCH_DYN(k_integrate_span_res_plain, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                         (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
@@ -855,16 +855,16 @@ struct Engine {
           LM_LAUNCH_DYN(k_integrate_span_res_ml, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                         (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
       } else if (span) {
-        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? dir_cap / 64 + 2 : 0) + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         if (any_ml)
-          LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? dir_cap / 64 + 2 : 0) + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         if (any_plain && plain_mode == 2)
-          LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? dir_cap / 64 + 2 : 0) + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         else if (any_plain)
-          LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? dir_cap / 64 + 2 : 0) + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
       } else {
         LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,

@@ -562,7 +562,7 @@ def test_two_level_directory_of_deep_histories():
     import _fuzz
     from loro_amd import workload
     from loro_amd._cabi import Context
-    b = _emu.variant(["LM_SD_LINEAR=2", "LM_EMU_CHECK"])
+    b = _emu.variant(["LM_SD_LINEAR=2", "LM_SD_BSH=2", "LM_EMU_CHECK"])   # blocks of four entries: block boundaries everywhere
     names, edge = _cases.edge_case_docs()
     docs = [edge[names.index("many leaves")], edge[names.index("long pastes")]] + _cases.fuzz_docs(12, base=8100)
     docs += [_fuzz.blobs_of(_fuzz.movable_session(8200 + i, n_steps=80, nested=True)) for i in range(4)]
