@@ -59,6 +59,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* peer_ext;    // contiguous covered end
   uint32_t* peer_end_all;// checked-out documents: the applied end at the LATEST version (peer_end before k_dag_b lowered it)
   uint32_t* elem_base;   // first element slot of the peer inside the doc's element range
+  uint32_t* elem_cap;    // resident documents: element slots the peer's region holds (k_res_layout)
   uint32_t* peer_chg0;   // range of the peer's changes in chg_sorted
   uint32_t* peer_chg1;
   ContRow* cont;         // [cid0 + i], i < n_cont

@@ -1007,7 +1007,7 @@ struct ResDoc {            // one per document, written by the host for every ru
   uint64_t tk_off;         // first word of the document's record in DevRes::tk
   uint32_t pcap, ccap;     // peers / containers the record has room for
   uint32_t reset;          // 1: the stored tracker is not to be used (first run, capacity grown, a failed run before): replay from the empty version
-  uint32_t pad;
+  uint32_t elem_cap;       // element slots of the document's slice of the element arena (cp[] / loc[])
 };
 struct DevRes {
   const ResDoc* doc;
@@ -1017,13 +1017,15 @@ struct DevRes {
   uint32_t* dir_b;               // this run's word B (word A goes to Dev::dir_out, which the emit stage reads)
 };
 // record: [0] tracker valid  [1] peers  [2] containers  [3] leaves used  [4,5] first element slot of the document  [6] element slots cleared so far  [7] != 0: that run left changes pending
-//         peers × (PeerID lo, hi) | peers × applied end | peers × element base | containers × (TK_CW + pcap words)
-static constexpr uint32_t TK_HDR = 8, TK_CW = 8;   // container record: root0, n_dir, n_alive, exists (sticky, k_res_exists), 4 reserved, then cur[pcap]
-LM_DEV uint32_t tk_words(uint32_t pcap, uint32_t ccap) { return TK_HDR + 4 * pcap + ccap * (TK_CW + pcap); }
+//         [8] element slots handed out in the document's slice (bases + capacities below)  [9..11] reserved
+//         peers × (PeerID lo, hi) | peers × applied end | peers × element base | peers × element capacity | containers × (TK_CW + pcap words)
+static constexpr uint32_t TK_HDR = 12, TK_CW = 8;   // container record: root0, n_dir, n_alive, exists (sticky, k_res_exists), 4 reserved, then cur[pcap]
+LM_DEV uint32_t tk_words(uint32_t pcap, uint32_t ccap) { return TK_HDR + 5 * pcap + ccap * (TK_CW + pcap); }
 LM_DEV uint32_t* tk_peers(uint32_t* tk) { return tk + TK_HDR; }
 LM_DEV uint32_t* tk_applied(uint32_t* tk, uint32_t pcap) { return tk + TK_HDR + 2 * pcap; }
 LM_DEV uint32_t* tk_ebase(uint32_t* tk, uint32_t pcap) { return tk + TK_HDR + 3 * pcap; }
-LM_DEV uint32_t* tk_cont(uint32_t* tk, uint32_t pcap, uint32_t c) { return tk + TK_HDR + 4 * pcap + c * (TK_CW + pcap); }
+LM_DEV uint32_t* tk_ecap(uint32_t* tk, uint32_t pcap) { return tk + TK_HDR + 4 * pcap; }
+LM_DEV uint32_t* tk_cont(uint32_t* tk, uint32_t pcap, uint32_t c) { return tk + TK_HDR + 5 * pcap + c * (TK_CW + pcap); }
 
 // K9 (span-granular): one wave per document.  Dynamic LDS: [dir_cap] word A, [dir_cap] word B, then 3 × pmax.
 // Two kernels share this body.  ML = false (k_integrate_span) is the replay of Text / List containers and takes the documents
@@ -1108,7 +1110,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     {
       const uint32_t* rw = (const uint32_t*)(rs.doc + doc);
       rd.tk_off = ((uint64_t)lmw::first(rw[1]) << 32) | lmw::first(rw[0]);
-      rd.pcap = lmw::first(rw[2]); rd.ccap = lmw::first(rw[3]); rd.reset = lmw::first(rw[4]); rd.pad = 0;
+      rd.pcap = lmw::first(rw[2]); rd.ccap = lmw::first(rw[3]); rd.reset = lmw::first(rw[4]); rd.elem_cap = lmw::first(rw[5]);
     }
     tk = rs.tk + rd.tk_off;
     tk_pcap = rd.pcap;
@@ -1160,7 +1162,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     // unless the layout did not move (keep_loc: then nothing was cleared and nothing is renumbered)
     t.n_leaf = lmw::first(tk[3]);
     if (t.n_leaf > t.leaf_cap) { fresh = true; t.n_leaf = 0; }
-    for (uint32_t c = 0; c < C0 && !fresh && !keep_loc; c++) {
+    for (uint32_t c = 0; c < C0 && !fresh && (!keep_loc || renumber); c++) {
       const uint32_t* rec = tk_cont(tk, tk_pcap, c);
       uint32_t r0 = lmw::first(rec[0]), nr = lmw::first(rec[1]);
       for (uint32_t q = 0; q < nr; q++) {
@@ -1180,7 +1182,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
             lr[lane] = R.id; lr[128 + lane] = ol; lr[192 + lane] = orr;
           }
         }
-        sp_set_loc_lanes(t, R, in, L);
+        if (!keep_loc) sp_set_loc_lanes(t, R, in, L);
       }
     }
     lmw::mem_fence();
@@ -1364,6 +1366,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       tk_peers(tk)[2 * p] = (uint32_t)id; tk_peers(tk)[2 * p + 1] = (uint32_t)(id >> 32);
       tk_applied(tk, tk_pcap)[p] = s_end[p];
       tk_ebase(tk, tk_pcap)[p] = s_ebase[p];
+      tk_ecap(tk, tk_pcap)[p] = d.elem_cap[m.praw0 + p];
     }
     // containers that are not sequences keep an empty tracker record (their sticky `exists` word is k_res_exists's)
     for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {
@@ -1372,7 +1375,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     }
     lmw::mem_fence();
     lmw::block_sync();
-    if (lane == 0) { tk[1] = P; tk[2] = m.n_cont; tk[3] = t.n_leaf; tk[4] = m.elem0_lo; tk[5] = m.elem0_hi; tk[6] = (m.atoms + 3) & ~3u; tk[7] = m.pending_lo | m.pending_hi; tk[0] = 1; }
+    if (lane == 0) { tk[1] = P; tk[2] = m.n_cont; tk[3] = t.n_leaf; tk[4] = m.elem0_lo; tk[5] = m.elem0_hi; tk[6] = (m.atoms + 3) & ~3u; tk[7] = m.pending_lo | m.pending_hi; tk[8] = m.atoms; tk[0] = 1; }
   }
   if (lane == 0) d.doc[doc].pad0 = dir_used;
 #ifdef LM_PROF
@@ -1429,31 +1432,78 @@ LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res_ml(Dev d, DevDag g, uin
   integrate_span_body<true, false, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count, rs);
 }
 
-// Before the payload fill and the integrate stage of a run: does the stored tracker's element layout still hold?  (the
-// document's slice did not move, every peer it knows sits at the same index with the same element base — only the last peer
-// grew, or new peers came behind it; not for documents with a MovableList, whose k_mlist_post reuses loc[].)  One wave per document.
+// Before the payload fill and the integrate stage of a run: the element layout of a resident document.  A batch lays a
+// document's elements out peer after peer (k_dag_a: base = Σ extents of the peers in front); a resident document would then move
+// every later peer's elements whenever an earlier peer grows — and with them loc[], the payload slots and everything else that
+// is indexed by element.  Here every peer owns a region with room to grow (extent × 1.5 + 64), handed out at the end of the
+// document's slice when the peer is first seen; a known peer keeps its base as long as its extent fits its region, whatever
+// index it has now.  Only when a region (or the slice) is outgrown the document is laid out anew — its stored tracker is then
+// not used (DF_LAYOUT_SAME off: k_elem_fill fills everything, the integrate stage rebuilds loc[] — or replays, for what cannot
+// be rebuilt).  DocMeta.atoms becomes the extent of the layout (slots up to it are cleared / bounded).  One wave per document.
 LM_KERNEL void k_res_layout(Dev d, DevRes rs) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
+  LM_SHARED(uint32_t, s_base, MAX_PEERS);
+  LM_SHARED(uint32_t, s_cap, MAX_PEERS);
   const DocMeta m = d.doc[doc];
   if (status_fatal(m.status)) return;
   const ResDoc rd = rs.doc[doc];
   uint32_t* tk = rs.tk + rd.tk_off;
-  bool same = !rd.reset && tk[0] == 1u && !(m.flags & DF_MOVABLE) && tk[4] == m.elem0_lo && tk[5] == m.elem0_hi && tk[1] <= m.n_peers && tk[1] <= rd.pcap && tk[6] <= ((m.atoms + 3) & ~3u) &&
-              tk[2] <= m.n_cont && tk[3] <= m.leaf_cap;   // (everything that would make the integrate stage start from the empty version)
+  const uint32_t P = m.n_peers;
+  if (P > MAX_PEERS) return;
+  for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_base[p] = NONE; s_cap[p] = 0; }
+  lmw::block_sync();
+  bool same = !rd.reset && tk[0] == 1u && tk[4] == m.elem0_lo && tk[5] == m.elem0_hi && tk[1] <= P && tk[1] <= rd.pcap &&
+              tk[2] <= m.n_cont && tk[3] <= m.leaf_cap;   // (everything else that makes the integrate stage start from the empty version)
+  uint32_t top = 0;
   if (same) {
     uint32_t P0 = tk[1];
     bool bad = false;
     for (uint32_t q = (uint32_t)lane; q < P0; q += 64) {
       uint64_t id = ((uint64_t)tk_peers(tk)[2 * q + 1] << 32) | tk_peers(tk)[2 * q];
-      bad |= d.peer_uniq[m.praw0 + q] != id || tk_ebase(tk, rd.pcap)[q] != d.elem_base[m.praw0 + q];
+      uint32_t lo = 0, hi = P;
+      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.peer_uniq[m.praw0 + mid] < id) lo = mid + 1; else hi = mid; }
+      if (lo < P && d.peer_uniq[m.praw0 + lo] == id && d.peer_ext[m.praw0 + lo] <= tk_ecap(tk, rd.pcap)[q]) { s_base[lo] = tk_ebase(tk, rd.pcap)[q]; s_cap[lo] = tk_ecap(tk, rd.pcap)[q]; }
+      else bad = true;
     }
     same = !lmw::any(bad);
+    top = tk[8];
   }
+  lmw::block_sync();
+  if (!same) { top = 0; for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_base[p] = NONE; }
+  lmw::block_sync();
+  // peers without a region (all of them when the document is laid out anew), in index order
+  for (uint32_t p0 = 0; p0 < P; p0 += 64) {
+    uint32_t p = p0 + (uint32_t)lane;
+    bool need = p < P && s_base[p] == NONE;
+    uint32_t ext = p < P ? d.peer_ext[m.praw0 + p] : 0u;
+    uint32_t cap = need ? ((ext + ext / 2 + 64 + 3) & ~3u) : 0u;
+    uint32_t inc = lmw::scan_incl_add(cap);
+    if (need) { s_base[p] = top + inc - cap; s_cap[p] = cap; }
+    top += lmw::bcast(inc, 63);
+  }
+  lmw::block_sync();
+  if (top > rd.elem_cap) {
+    if (same) {   // the new peers do not fit behind the old ones: lay the document out anew (the host sized the slice for that)
+      same = false; top = 0;
+      for (uint32_t p0 = 0; p0 < P; p0 += 64) {
+        uint32_t p = p0 + (uint32_t)lane;
+        uint32_t ext = p < P ? d.peer_ext[m.praw0 + p] : 0u;
+        uint32_t cap = p < P ? ((ext + ext / 2 + 64 + 3) & ~3u) : 0u;
+        uint32_t inc = lmw::scan_incl_add(cap);
+        if (p < P) { s_base[p] = top + inc - cap; s_cap[p] = cap; }
+        top += lmw::bcast(inc, 63);
+      }
+      lmw::block_sync();
+    }
+    if (top > rd.elem_cap) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }
+  }
+  for (uint32_t p = (uint32_t)lane; p < P; p += 64) { d.elem_base[m.praw0 + p] = s_base[p]; d.elem_cap[m.praw0 + p] = s_cap[p]; }
   if (lane == 0) {
     uint32_t fl = d.doc[doc].flags & ~(DF_LAYOUT_SAME | DF_FILL_KEPT);
     if (same) fl |= DF_LAYOUT_SAME | (tk[7] == 0u ? DF_FILL_KEPT : 0u);   // [7]: atoms the stored run left pending — their rows were not filled
     d.doc[doc].flags = fl;
+    d.doc[doc].atoms = top;
   }
 }
 

@@ -110,13 +110,13 @@ struct Engine {
   std::vector<uint32_t> tk_leaf0, tk_leaf_cap, tk_pcap, tk_ccap, tk_elem_cap, h_old_blobs;
   std::vector<uint64_t> tk_off, tk_elem0;
   uint64_t elem_top = 0;                          // element slots handed out in the resident element arena (cp[] / loc[])
-  DBuf b_old_blobs, b_prev_doc, b_prev_uniq, b_prev_end, b_lca_out, b_lca_scratch, b_lca_off;
+  DBuf b_elem_cap, b_old_blobs, b_prev_doc, b_prev_uniq, b_prev_end, b_lca_out, b_lca_scratch, b_lca_off;
   bool have_prev = false;                         // the tables of a previous resident run exist (what k_import_lca measures the import against)
   std::vector<uint32_t> h_lca;                    // per document LCA_OUT words of the last run: DiffMode + common ancestors of its import
   std::vector<uint8_t> tk_reset;
   void upload_res() {   // the per-document records of this run (tracker record, capacities, reset flag)
     std::vector<ResDoc> hres(n_docs);
-    for (uint32_t i = 0; i < n_docs; i++) hres[i] = ResDoc{tk_off[i], tk_pcap[i], tk_ccap[i], tk_reset[i], 0u};
+    for (uint32_t i = 0; i < n_docs; i++) hres[i] = ResDoc{tk_off[i], tk_pcap[i], tk_ccap[i], tk_reset[i], tk_elem_cap[i]};
     b_res.ensure((size_t)n_docs * sizeof(ResDoc));
     lmbe::h2d(b_res.p, hres.data(), (size_t)n_docs * sizeof(ResDoc));
   }
@@ -164,7 +164,7 @@ struct Engine {
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
                    &b_dir_out, &b_lf_chunk,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
-                   &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_old_blobs, &b_prev_doc, &b_prev_uniq, &b_prev_end, &b_lca_out, &b_lca_scratch, &b_lca_off};
+                   &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_elem_cap, &b_old_blobs, &b_prev_doc, &b_prev_uniq, &b_prev_end, &b_lca_out, &b_lca_scratch, &b_lca_off};
     for (DBuf* b : all) b->release();
   }
 
@@ -373,17 +373,17 @@ struct Engine {
   uint64_t tk_new_at = 0;
   void tk_grow(uint32_t i, uint32_t P, uint32_t C) {
     uint32_t pcap = P + P / 2 + 2, ccap = C + C / 2 + 4;
-    uint64_t words = (uint64_t)TK_HDR + 4ull * pcap + (uint64_t)ccap * (TK_CW + pcap);
+    uint64_t words = (uint64_t)TK_HDR + 5ull * pcap + (uint64_t)ccap * (TK_CW + pcap);
     if (tk_new.empty()) tk_new_at = tk_top;
     size_t at = tk_new.size();
     tk_new.resize(at + words, 0u);
     if (tk_pcap[i]) {
       uint32_t op = tk_pcap[i], oc = tk_ccap[i];
-      uint64_t ow = (uint64_t)TK_HDR + 4ull * op + (uint64_t)oc * (TK_CW + op);
+      uint64_t ow = (uint64_t)TK_HDR + 5ull * op + (uint64_t)oc * (TK_CW + op);
       std::vector<uint32_t> old(ow);
       lmbe::d2h(old.data(), b_tk.as<uint32_t>() + tk_off[i], ow * 4);
       for (uint32_t c = 0; c < oc && c < ccap; c++)
-        tk_new[at + TK_HDR + 4ull * pcap + (uint64_t)c * (TK_CW + pcap) + 3] = old[TK_HDR + 4ull * op + (uint64_t)c * (TK_CW + op) + 3] == 1u ? 1u : 0u;
+        tk_new[at + TK_HDR + 5ull * pcap + (uint64_t)c * (TK_CW + pcap) + 3] = old[TK_HDR + 5ull * op + (uint64_t)c * (TK_CW + op) + 3] == 1u ? 1u : 0u;
     }
     tk_off[i] = tk_top; tk_top += words; tk_pcap[i] = pcap; tk_ccap[i] = ccap; tk_reset[i] = 1;
   }
@@ -635,10 +635,11 @@ struct Engine {
       if (resident) {
         // the document's slice of the element arena stays where it is while it is large enough (loc[] and the payload slots of
         // earlier runs stay valid, k_res_layout); a larger one is handed out with room to grow
-        uint64_t need = ((uint64_t)m.atoms + 3) & ~3ull;
+        // (k_res_layout gives every peer a region of extent x 1.5 + 64 slots: a fresh layout needs at most 1.5 x atoms + 68 per peer)
+        uint64_t need = (uint64_t)m.atoms + m.atoms / 2 + 68ull * (m.n_peers + 1) + 8;
         if (ok && need > tk_elem_cap[i]) {
-          uint64_t cap = need + need / 2 + 64;
-          if (cap > 0xfffffff0ull) cap = need;
+          uint64_t cap = ((need + need / 2 + 80ull * 8) + 3) & ~3ull;
+          if (cap > 0xfffffff0ull) throw std::runtime_error("resident element slice beyond 32-bit indices");
           tk_elem0[i] = elem_top; tk_elem_cap[i] = (uint32_t)cap; elem_top += cap;
         }
         m.elem0_lo = (uint32_t)tk_elem0[i]; m.elem0_hi = (uint32_t)(tk_elem0[i] >> 32);
@@ -750,6 +751,7 @@ struct Engine {
         d.res_old_blobs = b_old_blobs.as<uint32_t>();
         sv.d.res_old_blobs = d.res_old_blobs;
       }
+      if (!reuse) { b_elem_cap.ensure((size_t)(NP + 1) * 4); d.elem_cap = b_elem_cap.as<uint32_t>(); sv.d.elem_cap = d.elem_cap; }
       LM_LAUNCH(k_res_layout, n_docs, 64, d, rs);   // (a run that reuses its tables: the layout is the previous run's, unless that run failed for the document)
     }
     lmbe::tic(profiling);

@@ -66,9 +66,9 @@ def test_two_imports_are_not_one_import_batch():
 
 @pytest.mark.parametrize("mode", ["flat", "text", "nested", "movable"])
 def test_random_sessions_delivered_in_steps(mode):
-    # (MovableList documents keep the id of the item a move deleted in the element table, whose layout shifts when the
-    # document grows: they are replayed from the empty version whenever that happens — correct, not incremental)
-    _check(_sessions(mode, range(100, 116)), expect_incremental=mode != "movable")
+    # (every peer owns a region of the document's element slice with room to grow, k_res_layout: loc[], payload slots and the
+    # slots MovableList moves keep the id of the item they deleted in stay where they are — all kinds continue incrementally)
+    _check(_sessions(mode, range(100, 116)))
 
 
 def test_several_streams_keep_their_documents():
