@@ -721,11 +721,13 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   int lane = lmw::lane();
   uint32_t c = c0;
   // items only hold applied elements, so the in-leaf path needs neither the peer's element base nor its end (two LDS round trips)
-  while (c < c1 && ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); }
+  // (one attempt outside any loop: a row's range mostly lies in one run of the cached leaf, and a loop around the attempt carried
+  // the whole cached leaf through its phi nodes — 70 instructions per row, most of them register moves)
   if (c >= c1) return;
+  bool tried = true;   // the in-leaf path has just declined this very element
+  if (ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); if (c >= c1) return; tried = false; }
   uint32_t eb = t.ebase[peer];
   if (c1 > t.end[peer]) c1 = t.end[peer];   // a damaged target range cannot make the walk longer than the peer's history
-  bool tried = true;   // the in-leaf path has just declined this very element
   for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
     lmw::wave_sync();
     if (!tried && ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); continue; }
@@ -1279,7 +1281,9 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
             if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
               ts_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
               TS_CHECK("insert", row);
-            } else if (kind == OK_DEL) {
+            } else if (PLAIN || kind == OK_DEL) {
+              // (PLAIN: a two-way dispatch — a row that is neither an insert nor a delete becomes an empty range below; a third
+              // edge to the end of the row cost 17 register moves per delete row, hoisted in front of its branch)
               uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
               uint32_t t0, t1;
               if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
@@ -1287,10 +1291,15 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
               // a delete span as long as its op and with a position inside the sequence (what every writer emits; the reference's
               // decoder does not compare the two lengths, block_encode.rs:651-704, and would delete |span| elements at the position
               // while the counters advance by the op's length — not a value this engine reproduces: LM_DATA_CORRUPTION)
-              if (Ln != r.len || r.prop < 0 || (r.a2 < 0 && (uint32_t)r.prop + 1 < Ln)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); break; }
+              // (no branch out of the row for it: the finding empties the range, and the row loop ends on t.err as for any other error —
+              // an extra exit edge here cost 46 register moves per delete row, hoisted in front of the branch)
+              const bool is_del = !PLAIN || kind == OK_DEL;
+              const bool bad_del = is_del & ((Ln != r.len) | (r.prop < 0) | ((r.a2 < 0) & ((uint32_t)r.prop + 1 < Ln)));
               // unsliced row: its position addresses the leftmost target (forward: prop; backward: prop + 1 - len)
               uint32_t hint = 0;
-              if (a == 0 && b == r.len && Ln == r.len && r.prop >= 0) { if (r.a2 > 0) hint = (uint32_t)r.prop + 1; else if ((uint32_t)r.prop + 1 >= Ln) hint = (uint32_t)r.prop + 2 - Ln; }
+              if (a == 0 && b == r.len) hint = r.a2 > 0 ? (uint32_t)r.prop + 1 : (uint32_t)r.prop + 2 - Ln;
+              if (bad_del) { LM_SETERR(t.err, ST_DATA_CORRUPTION); t1 = t0; hint = 0; }
+              if (!is_del) { t1 = t0; hint = 0; }
               ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC, hint);
               PROF_ADD(t, PF_DELETE);
               PROF_CNT(t, PF_NDEL, 1);

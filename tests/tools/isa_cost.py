@@ -19,6 +19,7 @@ if "--define" in sys.argv:
     defines = ["-D" + sys.argv[i + 1]]
     del sys.argv[i:i + 2]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
+
 top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 20
 args = [a for a in args if not a.isdigit() or a != str(top)] if "--top" in sys.argv else args
 repo = os.path.abspath(args[0]) if args else os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,8 +53,25 @@ c = lambda fl: counts.get(fl[0], {}).get(fl[1], 0.0)
 
 # ---- 2. the kernel's instructions and their inline chains
 obj, co = os.path.join(work, "k.o"), os.path.join(work, "k.co")
+if "--fast" in sys.argv:
+    # compile a copy of csrc in which every OTHER instantiation of the span body (and the element-granular kernel) is emptied:
+    # the target kernel's code is the same, the compile takes a fraction of the time.  Line numbers are kept.
+    import shutil
+    fast = os.path.join(work, "loro_amd", "csrc")
+    shutil.copytree(csrc, fast, ignore=shutil.ignore_patterns("*.so"))
+    os.symlink(os.path.join(repo, "include"), os.path.join(work, "include"))
+    for fn, pat in (("lm_k_integrate_span.h", r"^(LM_KERNEL[^\n]*void (k_integrate_span\w*)\([^{]*\{\n)([^\n]*integrate_span_body<[^\n]*\n)"), ):
+        src = open(os.path.join(fast, fn)).read()
+        src = re.sub(pat, lambda m: m.group(1) + (m.group(3) if m.group(2) == kernel else "\n"), src, flags=re.M)
+        open(os.path.join(fast, fn), "w").write(src)
+    src = open(os.path.join(fast, "lm_k_integrate.h")).read()
+    src = re.sub(r"(LM_KERNEL[^\n]*void k_integrate\([^{]*\{\n)", r"\1  return;\n" if False else r"\1", src)   # (left as is: its body is a template-free kernel)
+    open(os.path.join(fast, "lm_k_integrate.h"), "w").write(src)
+    csrc_c = fast
+else:
+    csrc_c = csrc
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--offload-device-only", "-c", "-gline-tables-only"] + defines + [
-                       "-o", obj, os.path.join(csrc, "lm_hip.cpp")], cwd=csrc, stderr=subprocess.DEVNULL)
+                       "-o", obj, os.path.join(csrc_c, "lm_hip.cpp")], cwd=csrc_c, stderr=subprocess.DEVNULL)
 subprocess.check_call([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + obj, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
 dis = subprocess.check_output([LLVM + "llvm-objdump", "-d", "--disassemble-symbols=" + kernel, co], text=True)
 ins = []   # (address, opcode)
@@ -82,6 +100,9 @@ tot = sc = ve = sp = 0.0
 by_line = defaultdict(lambda: [0.0, 0])
 by_path = defaultdict(float)
 by_func = defaultdict(float)   # inclusive of inlined callees
+by_op = defaultdict(float)
+by_line_f = defaultdict(lambda: [0.0, 0])   # --ops REGEX: the by-line table restricted to matching opcodes
+ops_re = re.compile(os.environ['ISA_OPS']) if os.environ.get('ISA_OPS') else None
 for (addr, op), fr in zip(ins, stacks):
     if not fr:
         continue
@@ -93,6 +114,9 @@ for (addr, op), fr in zip(ins, stacks):
     if op.startswith("s_"): sc += w
     else: ve += w
     if op in ("v_readlane_b32", "v_writelane_b32"): sp += w
+    by_op[op] += w
+    if ops_re and ops_re.match(op):
+        by_line_f[(fr[0][1], fr[0][2])][0] += w; by_line_f[(fr[0][1], fr[0][2])][1] += 1
     by_line[(fr[0][1], fr[0][2])][0] += w; by_line[(fr[0][1], fr[0][2])][1] += 1
     for fn in {f[0] for f in fr}:
         by_func[fn] += w
@@ -106,6 +130,13 @@ print(f"  estimated executions for one configs[1] document: total {tot / 1e6:.3f
 print("  by source line:")
 for (f, ln), (w, n) in sorted(by_line.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f"    {w / 1e3:9.1f} k  {n:4d} instr  {f}:{ln}")
+if ops_re:
+    print("  by source line, opcodes matching", ops_re.pattern, ":")
+    for (f, ln), (w, n) in sorted(by_line_f.items(), key=lambda kv: -kv[1][0])[:top]:
+        print(f"    {w / 1e3:9.1f} k  {n:4d} instr  {f}:{ln}")
+print("  by opcode:")
+for op_, w in sorted(by_op.items(), key=lambda kv: -kv[1])[:top]:
+    print(f"    {w / 1e3:9.1f} k  {op_}")
 print("  by function, inclusive of what is inlined into it:")
 for fn, w in sorted(by_func.items(), key=lambda kv: -kv[1])[:top]:
     print(f"    {w / 1e3:9.1f} k  {fn}")
