@@ -364,7 +364,9 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     const OpRow& r = d.op[m.op0 + i];
     uint32_t k = (r.cidx_kind >> 16) & 0xff;
     // (MovableList move / set rows compete per element in the same LWW table; a move also places a new list item)
-    n_map += (k == OK_MAP_SET || k == OK_MAP_DEL || k == OK_LIST_MOVE || k == OK_LIST_SET) ? 1u : 0u;
+    // (rows of containers outside the device scope count too: k_map_lww is what marks their containers, and a batch without any
+    // such row skips that kernel — it reads every op row of the batch, 0.75 GB per configs[1] launch)
+    n_map += (k == OK_MAP_SET || k == OK_MAP_DEL || k == OK_LIST_MOVE || k == OK_LIST_SET || k == OK_OTHER) ? 1u : 0u;
     n_el += (k == OK_TEXT_INS || k == OK_LIST_INS || k == OK_STYLE_START || k == OK_STYLE_END) ? r.len : (k == OK_LIST_MOVE ? 1u : 0u);
     n_style += (k == OK_STYLE_START || k == OK_STYLE_END) ? 1u : 0u;
   }

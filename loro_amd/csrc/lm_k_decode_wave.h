@@ -25,7 +25,10 @@
 
 namespace lm {
 
-static constexpr uint32_t DEC_G = 8;            // blocks per wave
+#ifndef LM_DEC_G
+#define LM_DEC_G 8
+#endif
+static constexpr uint32_t DEC_G = LM_DEC_G;     // blocks per wave (8 lanes each; -DLM_DEC_G=4: half the lanes idle, half the LDS per wave — twice the waves per CU)
 static constexpr uint32_t DEC_R = 8;            // rows per chunk (one lane per row in the assembly phase)
 static constexpr uint32_t DEC_WW = 6;           // words the walker hands over per row: value offset lo/hi, aux, flags, counter, change
 static constexpr uint32_t DEC_LDS_FIXED = DEC_G * 16 * 4 + DEC_G * DEC_R * 8 * 4 + DEC_G * DEC_R * DEC_WW * 4;   // frame stacks + s_x + s_w
@@ -46,7 +49,7 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
   uint32_t* s_x = s_fs + DEC_G * 16;                  // DEC_G x DEC_R rows x 8 column words
   uint32_t* s_w = s_x + DEC_G * DEC_R * 8;            // DEC_G x DEC_R rows x DEC_WW walker words
   uint8_t* s_kinds = (uint8_t*)(s_w + DEC_G * DEC_R * DEC_WW);
-  bool have = bi < d.n_blocks;
+  bool have = b < DEC_G && bi < d.n_blocks;
   // only the scalar fields of the descriptor stay in registers; section extents are read where a section is opened
   struct { uint64_t base; uint32_t counter_start, counter_len, n_changes; } bd = {0, 0, 0, 0};
   const BlockDesc* bdp = d.blk + (have ? bi : 0);

@@ -1293,13 +1293,14 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
               // while the counters advance by the op's length — not a value this engine reproduces: LM_DATA_CORRUPTION)
               // (no branch out of the row for it: the finding empties the range, and the row loop ends on t.err as for any other error —
               // an extra exit edge here cost 46 register moves per delete row, hoisted in front of the branch)
-              const bool is_del = !PLAIN || kind == OK_DEL;
-              const bool bad_del = is_del & ((Ln != r.len) | (r.prop < 0) | ((r.a2 < 0) & ((uint32_t)r.prop + 1 < Ln)));
+              // (as integer arithmetic: a boolean expression of wave-uniform compares becomes a chain of 64-bit lane-mask selects.
+              // Ln <= 2^31 and, where the last term counts, 0 <= prop: the sign bit of prop + 1 - Ln says prop + 1 < Ln)
+              const uint32_t not_del = PLAIN ? (kind ^ OK_DEL) : 0u;
+              const uint32_t bad_bits = (Ln ^ r.len) | ((uint32_t)r.prop >> 31) | (((uint32_t)r.a2 >> 31) & (((uint32_t)r.prop + 1u - Ln) >> 31));
               // unsliced row: its position addresses the leftmost target (forward: prop; backward: prop + 1 - len)
               uint32_t hint = 0;
               if (a == 0 && b == r.len) hint = r.a2 > 0 ? (uint32_t)r.prop + 1 : (uint32_t)r.prop + 2 - Ln;
-              if (bad_del) { LM_SETERR(t.err, ST_DATA_CORRUPTION); t1 = t0; hint = 0; }
-              if (!is_del) { t1 = t0; hint = 0; }
+              if (not_del | bad_bits) { if (!not_del) LM_SETERR(t.err, ST_DATA_CORRUPTION); t1 = t0; hint = 0; }
               ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC, hint);
               PROF_ADD(t, PF_DELETE);
               PROF_CNT(t, PF_NDEL, 1);

@@ -782,7 +782,7 @@ struct Engine {
     if (NB && !reuse) LM_LAUNCH(k_elem_fill, NB, 64, d);
     lmbe::toc("k_elem_fill", times, profiling);
     lmbe::tic(profiling);
-    if (NO) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);
+    if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);   // (ht == 0: no document holds a Map / MovableList-LWW / out-of-scope row, k_dag_a)
     lmbe::toc("k_map_lww", times, profiling);
     lmbe::tic(profiling);
     dir_cap = (dir_cap + 3) & ~3u;
