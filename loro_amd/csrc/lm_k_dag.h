@@ -528,10 +528,16 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
   }
 }
 
+// unaligned 32-bit access (gfx950 global memory takes it in one instruction)
+LM_DEV uint32_t ld32u(const uint8_t* p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+LM_DEV void st32u(uint8_t* p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
+
 // cooperative UTF-8 → scalars of ONE long string with coalesced loads: 64 bytes per step while the text is ASCII (byte =
 // scalar, no lane traffic), otherwise 61 — a scalar spans at most 4 bytes, so a lead byte below lane 61 has its tail loaded;
 // scalar boundaries come from a ballot over the lead bytes and each lead lane assembles its scalar from the following lanes.
 // (32-bit offsets: a value is shorter than its blob, and a blob shorter than 4 GiB.)
+// BYTES: the span-granular layout — tb[] takes one byte per scalar, cp[] only the scalars beyond ASCII.
+template <bool BYTES>
 LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint32_t nbytes, uint64_t e0, uint32_t len) {
   uint32_t lane = (uint32_t)lmw::lane();
   bool bad = false;
@@ -541,7 +547,7 @@ LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint32_t nbytes, uint
     bool inb = i < nbytes;
     uint32_t b = inb ? s[i] : 0u;
     if (!lmw::ballot(b >= 0x80)) {
-      if (inb & (n + lane < len)) d.cp[e0 + n + lane] = b;
+      if (inb & (n + lane < len)) { if (BYTES) d.tb[e0 + n + lane] = (uint8_t)b; else d.cp[e0 + n + lane] = b; }
       uint32_t took = nbytes - c < 64 ? nbytes - c : 64u;
       n += took; c += 64;
       continue;
@@ -564,7 +570,10 @@ LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint32_t nbytes, uint
       if (extra >= 2 && (b2 & 0xC0) != 0x80) bad = true;
       if (extra >= 3 && (b3 & 0xC0) != 0x80) bad = true;
       if (lane + extra > 63) bad = true;  // cannot happen: leads above lane 60 only exist in the last chunk
-      if (n + rank < len) d.cp[e0 + n + rank] = cpv;
+      if (n + rank < len) {
+        if (BYTES) { d.tb[e0 + n + rank] = (uint8_t)(extra ? TB_WIDE : cpv); if (extra) d.cp[e0 + n + rank] = cpv; }
+        else d.cp[e0 + n + rank] = cpv;
+      }
     }
     n += (uint32_t)lmw::popc64(lm_);
     c += 61;
@@ -572,10 +581,20 @@ LM_DEV bool fill_text_coop(const Dev& d, const uint8_t* s, uint32_t nbytes, uint
   return lmw::any(bad) || n != len;
 }
 
-// K8: one wave per change block — element payload table (unicode scalars / list value offsets).
-// Rows are taken 64 at a time, ONE ROW PER LANE: typing produces short runs, so each lane decodes its own string
-// (neighbouring rows' payloads and element slots are adjacent, so the per-lane byte loads and scalar stores of a
-// wave fall into the same few cache lines).  Strings longer than 64 bytes are left to the cooperative routine above.
+// K8: one wave per change block — element payload tables.
+//  * span-granular leaves (the default): tb[] holds one BYTE per Text element — the scalar itself when it is ASCII, TB_WIDE
+//    when the scalar needs more (then cp[] holds it), TB_ANCHOR for a style anchor.  A string with as many bytes as the row
+//    has elements is copied four bytes per load / store (it is ASCII, or it is not UTF-8 of that many scalars: the reference
+//    decodes the string and counts its chars, outdated_encode_reordered.rs:215-476); the emit stage gathers one byte per
+//    element.  (Rounds 1-2 kept a 4-byte scalar per element: 4x the traffic on both sides and a byte-by-byte decode here.
+//    Rendering straight from blob byte ranges through a row index was built and measured, tests/tools/wip/
+//    text_from_blob_ranges.patch: fine for long rows, 1.8x slower on keystroke-per-change histories, where a run spans
+//    hundreds of one-character rows — profiles/r03_bench_text_from_blob_ranges.json.)
+//  * List / MovableList inserts: cp[] keeps each item's byte offset (values have no fixed size).
+//  * element-granular leaves (LM_SPAN=0, the second implementation): cp[] holds every Text scalar, as in rounds 1-2.
+// Rows are taken 64 at a time, ONE ROW PER LANE: typing produces short runs, so each lane handles its own string
+// (neighbouring rows' payloads and element slots are adjacent, so the per-lane accesses of a wave fall into the same few
+// cache lines).  Strings longer than 64 bytes are left to the cooperative routine above.
 LM_KERNEL void k_elem_fill(Dev d) {
   uint32_t bi = (uint32_t)lmw::bid();
   int lane = lmw::lane();
@@ -586,6 +605,7 @@ LM_KERNEL void k_elem_fill(Dev d) {
   if (status_fatal(m.status)) return;
   // resident document whose element layout did not move: the payload slots of the blocks earlier runs filled are still right
   if (d.res_old_blobs && (m.flags & DF_FILL_KEPT) && bd.blob - d.doc_blob[doc] < d.res_old_blobs[doc]) return;
+  const bool span = d.span != 0;
   const uint32_t* off = d.boff + (uint64_t)bi * BCN;
   uint32_t op0 = off[BC_OP], n_op = d.bcnt[(uint64_t)bi * BCN + BC_OP];
   uint32_t chg0 = off[BC_CHG];
@@ -593,7 +613,12 @@ LM_KERNEL void k_elem_fill(Dev d) {
   uint64_t ebase = (((uint64_t)m.elem0_hi << 32) | m.elem0_lo) + d.elem_base[m.praw0 + peer];
   uint32_t ext = d.peer_ext[m.praw0 + peer];
   uint64_t doc_data0 = d.blob_off[d.doc_blob[doc]];
-  const uint8_t* lim = d.data + bd.base + bd.sec_rel[SEC_VALUES] + bd.sec_len[SEC_VALUES];
+  const uint8_t* vsec = d.data + bd.base + bd.sec_rel[SEC_VALUES];
+  const uint8_t* lim = vsec + bd.sec_len[SEC_VALUES];
+  LM_SHARED(uint32_t, s_inc, 64);
+  LM_SHARED(uint32_t, s_nb, 64);
+  LM_SHARED(uint32_t, s_src, 64);
+  LM_SHARED(uint32_t, s_dst, 64);
   bool bad = false;
   for (uint32_t g0 = 0; g0 < n_op; g0 += 64) {
     uint32_t row = op0 + g0 + (uint32_t)lane;
@@ -606,20 +631,25 @@ LM_KERNEL void k_elem_fill(Dev d) {
     if (want && !d.chg_flag[r.chg]) want = false;
     if (want && r.ctr + r.len > ext) want = false;
     uint64_t e0 = ebase + r.ctr;
-    if (want && (kind == OK_STYLE_START || kind == OK_STYLE_END)) { d.cp[e0] = 0xFFFFFFFFu; want = false; }
+    if (want && (kind == OK_STYLE_START || kind == OK_STYLE_END)) { if (span) d.tb[e0] = (uint8_t)TB_ANCHOR; else d.cp[e0] = 0xFFFFFFFFu; want = false; }
     const uint8_t* p = want ? d.data + d.op_val[row] : lim;
     Rd v = rd_make(p, (uint64_t)(lim - p));
     uint64_t nbytes = 0;
-    bool is_long = false;
+    bool is_long = false, flat = false;
     if (want && kind == OK_TEXT_INS) {
       nbytes = rd_uleb(v);
       if (v.bad || nbytes > rd_left(v)) { bad = true; want = false; }
+      else if (span && nbytes == r.len) flat = true;   // as many bytes as elements: ASCII (copied below) — or not UTF-8 of that many scalars
       else if (nbytes > 64) { is_long = true; }
       else {
         const uint8_t* s = v.p;
         uint32_t n = 0;
         for (uint32_t i = 0; i < (uint32_t)nbytes;) {
-          if (i + 4 <= (uint32_t)nbytes) {
+          if (span && i + 4 <= (uint32_t)nbytes && n + 3 < r.len) {
+            uint32_t w = ld32u(s + i);
+            if (!(w & 0x80808080u)) { st32u(d.tb + e0 + n, w); n += 4; i += 4; continue; }
+          }
+          if (!span && i + 4 <= (uint32_t)nbytes) {
             // four ASCII bytes at once: the loads go out together and four scalars are stored (the pipeline is issue bound —
             // one byte per trip cost ≈25 instructions per character)
             uint32_t q0 = s[i], q1 = s[i + 1], q2 = s[i + 2], q3 = s[i + 3];
@@ -642,7 +672,10 @@ LM_KERNEL void k_elem_fill(Dev d) {
             if ((t & 0xC0) != 0x80) bad = true;
             cpv = (cpv << 6) | (t & 0x3F);
           }
-          if (n < r.len) d.cp[e0 + n] = cpv;
+          if (n < r.len) {
+            if (span) { d.tb[e0 + n] = (uint8_t)(extra ? TB_WIDE : cpv); if (extra) d.cp[e0 + n] = cpv; }
+            else d.cp[e0 + n] = cpv;
+          }
           n++;
           i += extra + 1;
         }
@@ -659,6 +692,35 @@ LM_KERNEL void k_elem_fill(Dev d) {
         if (v.bad) bad = true;
       }
     }
+    if (span) {
+      // the ASCII strings of these 64 rows as ONE flat copy, four bytes per lane and step: lane → (row, dword of the row) by a
+      // search over the running dword counts kept in LDS.  Typing comes in runs: 70 % of a configs[1] document's text sits in
+      // rows longer than 64 bytes, and a row-at-a-time copy is a chain of dependent round trips per row; here every load of a
+      // step is independent of the others
+      uint32_t nd = flat ? ((uint32_t)nbytes + 3) / 4 : 0u;
+      uint32_t inc = lmw::scan_incl_add(nd);
+      uint32_t total = lmw::bcast(inc, 63);
+      if (total) {
+        lmw::block_sync();
+        s_inc[lane] = inc; s_nb[lane] = (uint32_t)nbytes; s_src[lane] = (uint32_t)(v.p - vsec); s_dst[lane] = r.ctr;
+        lmw::block_sync();
+        uint32_t hi = 0;
+        for (uint32_t f0 = 0; f0 < total; f0 += 64) {
+          uint32_t f = f0 + (uint32_t)lane;
+          if (f < total) {
+            uint32_t lo = 0, hh = 63;                    // first row whose running count exceeds f
+            while (lo < hh) { uint32_t mid = (lo + hh) >> 1; if (s_inc[mid] > f) hh = mid; else lo = mid + 1; }
+            uint32_t nbr = s_nb[lo];
+            uint32_t k4 = 4u * (f - (s_inc[lo] - (nbr + 3) / 4));
+            const uint8_t* src = vsec + s_src[lo] + k4;
+            uint8_t* dst = d.tb + ebase + s_dst[lo] + k4;
+            if (k4 + 4 <= nbr) { uint32_t w = ld32u(src); hi |= w; st32u(dst, w); }
+            else for (uint32_t i = 0; k4 + i < nbr; i++) { uint32_t b = src[i]; hi |= b; dst[i] = (uint8_t)b; }
+          }
+        }
+        if (hi & 0x80808080u) bad = true;
+      }
+    }
     // long strings: the whole wave works on one at a time
     uint64_t lm_ = lmw::ballot(is_long);
     while (lm_) {
@@ -669,7 +731,9 @@ LM_KERNEL void k_elem_fill(Dev d) {
       uint32_t nb = lmw::bcast((uint32_t)nbytes, l);
       uint32_t e_lo = lmw::bcast((uint32_t)e0, l), e_hi = lmw::bcast((uint32_t)(e0 >> 32), l);
       uint32_t ln = lmw::bcast(r.len, l);
-      if (fill_text_coop(d, d.data + (((uint64_t)sp_hi << 32) | sp_lo), nb, ((uint64_t)e_hi << 32) | e_lo, ln)) bad = true;
+      const uint8_t* str = d.data + (((uint64_t)sp_hi << 32) | sp_lo);
+      uint64_t e0l = ((uint64_t)e_hi << 32) | e_lo;
+      if (span ? fill_text_coop<true>(d, str, nb, e0l, ln) : fill_text_coop<false>(d, str, nb, e0l, ln)) bad = true;
     }
   }
   if (lmw::any(bad) && lane == 0) LM_SETERR(d.doc[doc].status, ST_DATA_CORRUPTION);

@@ -76,6 +76,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   // elements
   uint32_t* cp;          // text: unicode scalar (0xFFFFFFFF = style anchor) | list: value offset rel. to the doc's first byte
   uint32_t* loc;         // element → leaf
+  uint8_t* tb;           // span-granular leaves: one byte per Text element — the scalar when it is ASCII, TB_WIDE: cp[] holds it, TB_ANCHOR: a style anchor
   // tracker pools
   uint32_t* it;          // leaf records, 256 dwords each: id[64] | origin_left[64] | origin_right[64] | status[64]
   uint8_t* lf_chunk;     // [leaf0 + leaf] chunk (owning lane) of the leaf's directory entry
@@ -100,6 +101,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
 static constexpr int BCN = 8;  // counters per block: chg, dep, op, key, cid, peer, mapop, atoms
 enum { BC_CHG = 0, BC_DEP, BC_OP, BC_KEY, BC_CID, BC_PEER, BC_MAPOP, BC_ATOMS };
 static constexpr uint32_t VIS_CAP = 1024;
+static constexpr uint32_t TB_WIDE = 0xFF, TB_ANCHOR = 0xFE;   // Dev::tb markers (neither is a byte of an ASCII scalar)
 
 // -------------------------------------------------------------------------------------------------
 static constexpr uint64_t BIG_BLOB = 32768;   // blobs from this size on are hashed by a whole wave

@@ -87,7 +87,9 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
       uint32_t rel = t - m.op0;
       if (rel >= (1u << 24)) { LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
       unsigned long long v = ((unsigned long long)lam << 32) | ((unsigned long long)ch.peer << 24) | rel;
-      lmw::atomic_max64(&best[slot], v + 1);  // +1 so that 0 stays "no write"
+      // (+1 so that 0 stays "no write".  The slot only ever grows: a row that a plain load already shows beaten needs no atomic — with
+      // 16 peers x 10,000 writes on 1,024 keys all but a few dozen rows per key lose, and 328 M atomics on 2 M addresses were the kernel)
+      if (best[slot] < v + 1) lmw::atomic_max64(&best[slot], v + 1);
       d.cont[m.cid0 + cidx].touched = 1;
       return;
     }
@@ -659,44 +661,72 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
       uint32_t kind = d.cont[m.cid0 + cidx].kind_root & 0xff;
       if (kind == CK_TEXT && d.span) {
         // span-granular leaves: per leaf, the visible runs are flattened 64 elements per step — lane → (run, offset)
-        // by a search over the running lengths kept in LDS; a run's scalars are consecutive in cp[]
+        // by a search over the running lengths kept in LDS; a run's elements are consecutive in tb[] — one BYTE per element:
+        // the scalar itself when it is ASCII, TB_WIDE when cp[] holds it (a multi-byte scalar), TB_ANCHOR for a style anchor
         sink_byte(s, '"');
         uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
         const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
         LM_SHARED(uint32_t, s_inc, 64);
         LM_SHARED(uint32_t, s_g0, 64);
+        // (one wave renders a document, so every HBM round trip is on its critical path: the leaf records are requested one
+        // leaf ahead, the directory entries two, and the byte gathers of four steps go out together — a step-at-a-time loop
+        // took ≈1,200 dependent round trips per configs[1] document)
+        static constexpr int EU = 4;
+        uint32_t de1 = nr > 0 ? dirp[0] : 0u, de2 = nr > 1 ? dirp[1] : 0u;
+        uint32_t p_id = NONE, p_ln = 0, p_st = ST_EVER;
+        if (nr > 0 && (uint32_t)lane < de_n(de1)) {
+          const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + de_leaf(de1)) * SP_REC;
+          p_id = rec[lane]; p_ln = rec[64 + lane]; p_st = rec[256 + lane];
+        }
         for (uint32_t ri = 0; ri < nr && !err; ri++) {
-          uint32_t de = dirp[ri];
-          uint32_t L = de_leaf(de), n = de_n(de);
-          const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * SP_REC;
-          bool in = (uint32_t)lane < n;
-          uint32_t id0 = in ? rec[lane] : NONE, ln = in ? rec[64 + lane] : 0u, st = in ? rec[256 + lane] : ST_EVER;
-          uint32_t vl = (in && !(st & vis_mask)) ? ln : 0u;
+          uint32_t id0 = p_id, ln = p_ln, st = p_st;
+          de1 = de2;
+          de2 = ri + 2 < nr ? dirp[ri + 2] : 0u;
+          p_id = NONE; p_ln = 0; p_st = ST_EVER;
+          if (ri + 1 < nr && (uint32_t)lane < de_n(de1)) {
+            const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + de_leaf(de1)) * SP_REC;
+            p_id = rec[lane]; p_ln = rec[64 + lane]; p_st = rec[256 + lane];
+          }
+          uint32_t vl = (id0 != NONE && !(st & vis_mask)) ? ln : 0u;
           uint32_t inc = lmw::scan_incl_add(vl);
           uint32_t total = lmw::bcast(inc, 63);
           lmw::block_sync();
           s_inc[lane] = inc;
-          s_g0[lane] = vl ? s_eb[pid_peer(id0)] + pid_ctr(id0) - (inc - vl) : 0u;   // element index minus position: cp index = g0 + position
+          s_g0[lane] = vl ? s_eb[pid_peer(id0)] + pid_ctr(id0) - (inc - vl) : 0u;   // element index minus position: tb index = g0 + position
           lmw::block_sync();
-          for (uint32_t e0 = 0; e0 < total; e0 += 64) {
-            uint32_t e = e0 + (uint32_t)lane;
-            uint64_t bytes = 0;
-            uint32_t nb = 0, cpv = 0x20;
-            if (e < total) {
-              uint32_t lo = 0, hi = 63;                    // first run whose running length exceeds e
-              while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_inc[mid] > e) hi = mid; else lo = mid + 1; }
-              uint32_t gi = s_g0[lo] + e;                  // 32-bit wrap-around arithmetic: g0 may be "negative"
-              cpv = d.cp[elem0 + gi];
+          for (uint32_t e0 = 0; e0 < total; e0 += 64 * EU) {
+            uint32_t cv[EU], gv[EU];
+#pragma unroll
+            for (int u = 0; u < EU; u++) {
+              uint32_t e = e0 + 64u * (uint32_t)u + (uint32_t)lane;
+              cv[u] = 0x20; gv[u] = 0;
+              if (e < total) {
+                uint32_t lo = 0, hi = 63;                  // first run whose running length exceeds e
+                while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_inc[mid] > e) hi = mid; else lo = mid + 1; }
+                gv[u] = s_g0[lo] + e;                      // 32-bit wrap-around arithmetic: g0 may be "negative"
+                cv[u] = d.tb[elem0 + gv[u]];
+              }
             }
-            // a step of plain ASCII (nothing to escape): scalar = byte, lane = output position — no scan, no byte loop
-            if (!lmw::ballot(cpv < 0x20 || cpv >= 0x80 || cpv == '"' || cpv == '\\')) {
-              uint32_t cnt = total - e0 < 64 ? total - e0 : 64;
-              if (s.out && s.pos + cnt <= s.cap && e < total) s.out[s.pos + (uint32_t)lane] = (uint8_t)cpv;
-              s.pos += cnt;
-              continue;
+#pragma unroll
+            for (int u = 0; u < EU; u++) {
+              uint32_t eu = e0 + 64u * (uint32_t)u;
+              if (eu >= total) break;
+              uint32_t e = eu + (uint32_t)lane, cpv = cv[u];
+              // a step of plain ASCII (nothing to escape): scalar = byte, lane = output position — no scan, no byte loop
+              if (!lmw::ballot(cpv < 0x20 || cpv >= 0x80 || cpv == '"' || cpv == '\\')) {
+                uint32_t cnt = total - eu < 64 ? total - eu : 64;
+                if (s.out && s.pos + cnt <= s.cap && e < total) s.out[s.pos + (uint32_t)lane] = (uint8_t)cpv;
+                s.pos += cnt;
+              } else {
+                uint64_t bytes = 0;
+                uint32_t nb = 0;
+                if (e < total) {
+                  if (cpv == TB_WIDE) cpv = d.cp[elem0 + gv[u]]; else if (cpv == TB_ANCHOR) cpv = 0xFFFFFFFFu;
+                  cp_bytes(cpv, bytes, nb);
+                }
+                sink_lanes(s, bytes, nb);
+              }
             }
-            if (e < total) cp_bytes(cpv, bytes, nb);
-            sink_lanes(s, bytes, nb);
           }
         }
         sink_byte(s, '"');

@@ -94,37 +94,46 @@ LM_DEV uint64_t sp_hit(const SpanRegs& R, uint32_t x) { return lmw::ballot(x - R
 #endif
 static constexpr uint32_t LOC_SHORT = LM_LOC_SHORT;
 // loc[] layout.  Default (LM_LOC16): loc[] is kept only for the HEAD of every item and for the elements whose counter is a
-// multiple of 16; -DLM_LOC_FULL builds the per-element layout of rounds 1-2 instead (kept as the A/B and parity counterpart).
+// multiple of LOC_W (64; 16 in round 2); -DLM_LOC_FULL builds the per-element layout of rounds 1-2 instead (kept as the A/B and parity counterpart).
 // Measured on configs[1], 5,000 documents per launch (profiles/r02_ab_prepared.log): 14.95 -> 14.50 ms, 12.98 ms with the
 // PLAIN + SWEEP instantiation on top.
 #if !defined(LM_LOC_FULL) && !defined(LM_LOC16)
 #define LM_LOC16 1
 #endif
 #ifdef LM_LOC16
+// (LOC_W: the window — 16 in round 2.  Typing comes in long runs — 70 % of a configs[1] document's text sits in items longer than
+// 64 elements — and a flush wrote 1 + len / 16 entries per pending item; a lookup reads one window with one wave load whatever
+// its width up to 64, and lookups are rare: ≈170 per document against ≈2,900 flushes)
+#ifndef LM_LOC_W
+#define LM_LOC_W 64
+#endif
+static constexpr uint32_t LOC_W = LM_LOC_W;   // a power of two <= 64
 // loc[] is kept only for the HEAD of every item and for the elements whose
-// counter is a multiple of 16 — everything else stays NONE.  Items are only ever cut or appended to, never joined, so a head
-// stays a head; the nearest kept entry at or below an element of an item, inside its 16-aligned counter window, is therefore an
+// counter is a multiple of LOC_W — everything else stays NONE.  Items are only ever cut or appended to, never joined, so a head
+// stays a head; the nearest kept entry at or below an element of an item, inside its LOC_W-aligned counter window, is therefore an
 // element of the same item (ts_loc_find).  A flush writes 1 + len/16 entries per pending item instead of len.
 LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
   uint32_t len = pend ? R.len : 0u;
   uint32_t c0 = pid_ctr(R.id);
   uint32_t g = pend ? t.ebase[pid_peer(R.id)] + c0 : 0u;
   if (pend) t.loc[g] = L;
-  uint32_t k = 16u - (c0 & 15u);                       // offset of the first multiple of 16 beyond the head
-  for (uint32_t i = 0; i < 4; i++, k += 16) if (k < len) t.loc[g + k] = L;
+  uint32_t k = LOC_W - (c0 & (LOC_W - 1));             // offset of the first multiple of LOC_W beyond the head
+  // (most pending items are short: the trips are taken only while some item still has such an element — four masked trips
+  // for every call were 4.5 % of the kernel)
+  for (uint32_t i = 0; i < 4 && lmw::any(k < len); i++, k += LOC_W) if (k < len) t.loc[g + k] = L;
   uint64_t m = lmw::ballot(k < len);                   // items with more than four such elements
   while (m) {
     int j = lmw::ffs64(m);
     m &= m - 1;
     uint32_t gj = lmw::bcast(g, j), lj = lmw::bcast(len, j), kj = lmw::bcast(k, j);
-    for (uint32_t kk = kj + 16u * (uint32_t)lmw::lane(); kk < lj; kk += 1024) t.loc[gj + kk] = L;
+    for (uint32_t kk = kj + LOC_W * (uint32_t)lmw::lane(); kk < lj; kk += 64 * LOC_W) t.loc[gj + kk] = L;
   }
 }
 // leaf of element `pid` (wave-uniform), NONE when no kept entry lies at or below it in its window
 LM_DEV uint32_t ts_loc_find(const Ts& t, uint32_t pid) {
-  uint32_t ctr = pid_ctr(pid), lo = ctr & ~15u, eb = t.ebase[pid_peer(pid)];
+  uint32_t ctr = pid_ctr(pid), lo = ctr & ~(LOC_W - 1), eb = t.ebase[pid_peer(pid)];
   uint32_t lane = (uint32_t)lmw::lane();
-  uint32_t v = (lane < 16 && lo + lane <= ctr) ? t.loc[eb + lo + lane] : NONE;
+  uint32_t v = (lane < LOC_W && lo + lane <= ctr) ? t.loc[eb + lo + lane] : NONE;
   uint64_t m = lmw::ballot(v != NONE);
   if (!m) return NONE;
   int top = 63 - __builtin_clzll((unsigned long long)m);
@@ -390,8 +399,29 @@ LM_DEV void sp_insert_item(Ts& t, uint32_t& p, SpanRegs& R, uint32_t& idx, const
 // inside an active run) — no directory search, no leaf traffic, no sibling scan; the directory entry is patched in place.
 // Returns false without touching anything when the general path is needed.
 LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
-  if (t.cr.n > 62 || pos <= t.cache_pre) return false;   // no cached leaf: n = 255; unknown prefix: cache_pre = NONE
   int lane = lmw::lane();
+  if (t.cr.n > 62 || pos <= t.cache_pre) {   // no cached leaf: n = 255; unknown prefix: cache_pre = NONE
+#ifndef LM_NO_POS0_FAST
+    // the very start of the sequence while its first leaf is cached (edits at the top of a document: ≈120 of a configs[1]
+    // document's 1,800 insert rows, ≈870 instructions each on the general path): no origin_left, origin_right = item 0 when
+    // that one is not future — nothing lies in between, nothing to merge with
+    if ((pos | t.cache_p) != 0 || t.cr.n > 62) return false;
+    if (!(lmw::ballot(!(t.cr.st & ST_FUT)) & 1)) return false;
+    SpanItem A;
+    A.id = pid0; A.len = len; A.ol = NONE; A.orr = lmw::bcast(t.cr.id, 0); A.st = 0;
+    uint32_t n0 = t.cr.n;
+    t.cr = sp_shift_in(t.cr, t.loc_pend, 0, A, A, 1, true, false);
+    t.dirty = true;
+    t.cache_pre = 0;
+    lmw::wave_sync();
+    if (lane == 0) { t.da[0] = sa_make(t.cache_leaf, n0 + 1, true); lmw::lds_add(&t.db[0], len); }
+    t.tot_active += len;
+    lmw::wave_sync();
+    return true;
+#else
+    return false;
+#endif
+  }
   uint32_t p = t.cache_p, k = pos - t.cache_pre;
   lmw::wave_sync();
   if (k > lmw::first(t.db[p])) return false;
@@ -965,7 +995,7 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
         nf |= !(st & ST_FUT);
         for (uint32_t k = 0; k < ln; k++) {
 #ifdef LM_LOC16
-          uint32_t expect = (k == 0 || ((id0 + k) & 15u) == 0) ? L : NONE;   // kept entries only: heads and multiples of 16
+          uint32_t expect = (k == 0 || ((id0 + k) & (LOC_W - 1)) == 0) ? L : NONE;   // kept entries only: heads and multiples of LOC_W
 #else
           uint32_t expect = L;
 #endif
@@ -1238,6 +1268,22 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
         uint32_t pe = PLAIN ? ch.ctr + ch.len : s_end[node_peer];   // (PLAIN: every applied change lies inside the rendered version)
         uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
         if (RES && ch.ctr + ch.len <= (PLAIN ? s_app[node_peer] : skip_to)) n_rows = 0;   // (PLAIN: the applied end lies on a change boundary — no sliced change)
+        if (PLAIN && !RES && n_rows && !checked_out) {
+          // the tracker moves to the node's dependencies before its first row.  A plain document has no sliced change: a change
+          // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
+          // carries no test for it (7 instructions per op row, 4 of them register moves in front of the branch)
+          checked_out = true;
+          for (uint32_t p = 0; p < P && !t.err; p++) {
+            uint32_t cur = s_cur[p], tgt = vv[p];
+            if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
+            else if (cur < tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, cur, tgt, +1);
+          }
+          lmw::block_sync();
+          for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = vv[p];
+          lmw::block_sync();
+          PROF_ADD(t, PF_CHECKOUT);
+          TS_CHECK("checkout", ch.op0);
+        }
         for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
           OpRow r = rw_get(w, op_w, row);
@@ -1248,7 +1294,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           touched = true;
           if (!PLAIN && r.ctr + a >= pe) continue;
           uint32_t b = PLAIN ? r.len : (r.ctr + r.len <= pe ? r.len : pe - r.ctr);
-          if (!checked_out) {
+          if (!(PLAIN && !RES) && !checked_out) {
             checked_out = true;
             for (uint32_t p = 0; p < P && !t.err; p++) {
               uint32_t cur = s_cur[p], tgt = vv[p];

@@ -72,7 +72,7 @@ struct Engine {
   DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
   DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
-  DBuf b_cp, b_loc;
+  DBuf b_cp, b_loc, b_tb;
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_pfx, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
@@ -161,7 +161,7 @@ struct Engine {
                    &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
-                   &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_it,
+                   &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
                    &b_dir_out, &b_lf_chunk,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_elem_cap, &b_old_blobs, &b_prev_doc, &b_prev_uniq, &b_prev_end, &b_lca_out, &b_lca_scratch, &b_lca_off};
@@ -638,7 +638,7 @@ struct Engine {
         // (k_res_layout gives every peer a region of extent x 1.5 + 64 slots: a fresh layout needs at most 1.5 x atoms + 68 per peer)
         uint64_t need = (uint64_t)m.atoms + m.atoms / 2 + 68ull * (m.n_peers + 1) + 8;
         if (ok && need > tk_elem_cap[i]) {
-          uint64_t cap = ((need + need / 2 + 80ull * 8) + 3) & ~3ull;
+          uint64_t cap = ((need + need / 2 + 80ull * 8) + 15) & ~15ull;   // (slices start at multiples of 16 element slots)
           if (cap > 0xfffffff0ull) throw std::runtime_error("resident element slice beyond 32-bit indices");
           tk_elem0[i] = elem_top; tk_elem_cap[i] = (uint32_t)cap; elem_top += cap;
         }
@@ -667,7 +667,7 @@ struct Engine {
         if (ok && (tk_pcap[i] == 0 || m.n_peers > tk_pcap[i] || m.n_cont > tk_ccap[i])) tk_grow(i, m.n_peers, m.n_cont);   // (a record for every document that runs, an empty one included)
       }
       m.vvh0_lo = (uint32_t)vvh; m.vvh0_hi = (uint32_t)(vvh >> 32);
-      if (ok) { elem += ((uint64_t)m.atoms + 3) & ~3ull; leaves += lc; vvh += (uint64_t)m.n_nodes * m.n_peers; }   // element slices start 16-byte aligned (k_integrate_span clears loc[] four entries per store)
+      if (ok) { elem += ((uint64_t)m.atoms + 15) & ~15ull; leaves += lc; vvh += (uint64_t)m.n_nodes * m.n_peers; }   // element slices start at multiples of 16 slots (k_integrate_span clears loc[] four entries per store; tb[] slices start 16-byte aligned)
       if (lc > dir_cap) dir_cap = lc;
       // optimistic LDS directory: leaves are ≈3/4 full in practice (≈48 elements); sized for 40 per leaf
       uint32_t lo = ok ? m.n_elems / 40 + 2 * m.n_cont + 16 : 0;
@@ -697,11 +697,11 @@ struct Engine {
     if (resident) {
       // arenas that outlive the run: element payloads (a MovableList move keeps the id of the item it deleted in its own slot),
       // the leaf pool and the two generations of the leaf directories
-      b_cp.ensure_keep((elem_top + 1) * 4, b_cp.cap); b_loc.ensure_keep((elem_top + 1) * 4, b_loc.cap);
+      b_cp.ensure_keep((elem_top + 1) * 4, b_cp.cap); b_loc.ensure_keep((elem_top + 1) * 4, b_loc.cap); b_tb.ensure_keep(elem_top + 16, b_tb.cap);
       b_it.ensure_keep(((size_t)leaf_top + 1) * SP_REC * 4, b_it.cap);
       for (DBuf* b : {&b_dir_out, &b_dir_out2, &b_dir_b, &b_dir_b2}) b->ensure_keep(((size_t)leaf_top + 1) * 4, b->cap);
     } else {
-      b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4);
+      b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4); b_tb.ensure(elem + 16);
       b_it.ensure((leaves + 1) * (span ? (size_t)SP_REC : 256) * 4);
       b_dir_out.ensure((leaves + 1) * 4);
     }
@@ -714,7 +714,7 @@ struct Engine {
     b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4); b_ht_cnt.ensure((size_t)n_docs * 4 + 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
-    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>();
+    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>(); d.tb = b_tb.as<uint8_t>();
     d.it = b_it.as<uint32_t>();
     d.dir_out = b_dir_out.as<uint32_t>();
     d.lf_chunk = b_lf_chunk.as<uint8_t>();
