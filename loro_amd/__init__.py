@@ -16,7 +16,7 @@ from ._cabi import Binding, Context
 
 _ROOT = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_ROOT, "csrc")
-LIB_PATH = os.path.join(_CSRC, "libloromerge.so")
+LIB_PATH = os.environ.get("LORO_AMD_LIB") or os.path.join(_CSRC, "libloromerge.so")   # (LORO_AMD_LIB: an experiment build, tests/tools only)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 __all__ = ["build_library", "MergeEngine", "LIB_PATH", "merge_batch"]

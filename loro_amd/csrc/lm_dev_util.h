@@ -12,14 +12,36 @@ struct Rd {                 // bounded reader over global memory; `bad` latches 
   bool bad;
 };
 LM_DEV Rd rd_make(const uint8_t* p, uint64_t n) { Rd r; r.p = p; r.end = p + n; r.bad = false; return r; }
-LM_DEV uint64_t rd_left(const Rd& r) { return (uint64_t)(r.end - r.p); }
+template <class R> LM_DEV uint64_t rd_left(const R& r) { return (uint64_t)(r.end - r.p); }
 // byte loads: consecutive reads of a lane stay inside one cache line, so they are L1 hits; buffering eight
 // bytes in registers was measured slower (more VALU per byte than the load it saves).
 LM_DEV uint32_t rd_u8(Rd& r) {
   if (r.p >= r.end) { r.bad = true; return 0; }
   return *r.p++;
 }
-LM_DEV uint64_t rd_uleb(Rd& r) {
+// The value walker of k_block_decode_wave reads through a WINDOW: the next DEC_VW bytes behind its cursor, fetched by the
+// block's eight lanes with one coalesced load and kept in LDS — a byte inside it is an LDS read, anything else the plain load.
+// (Every byte used to be a dependent HBM / L2 round trip of one lane: 31 % of the decoder's time on text blocks, 62 % on blocks
+// of Map values — profiles/r03_decoder_phases.log.)  Same fields and the same `bad` latch as Rd, so the templated readers
+// below serve both.
+static constexpr uint32_t DEC_VW = 64;    // (LDS decides the decoder's occupancy: 15,616 bytes per wave are 10 waves per CU, 14,848 are 11 — and 10 % of its time)
+struct RdW {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool bad;
+  const uint8_t* wp;      // global address of the window's first byte
+  lm_lds_bytes wl;        // the window in LDS
+};
+LM_DEV uint32_t rd_u8(RdW& r) {
+  if (r.p >= r.end) { r.bad = true; return 0; }
+  uint64_t o = (uint64_t)(r.p - r.wp);
+  uint32_t b = o < DEC_VW ? r.wl[o] : *r.p;
+  r.p++;
+  return b;
+}
+LM_DEV uint32_t rd_peek(const Rd& r) { return *r.p; }   // r.p < r.end
+LM_DEV uint32_t rd_peek(const RdW& r) { uint64_t o = (uint64_t)(r.p - r.wp); return o < DEC_VW ? r.wl[o] : *r.p; }   // r.p < r.end
+template <class R> LM_DEV uint64_t rd_uleb(R& r) {
   uint64_t v = 0;
   for (int i = 0; i < 10; i++) {
     uint32_t b = rd_u8(r);
@@ -52,7 +74,7 @@ LM_DEV int64_t rd_zigzag128(Rd& r) {
   r.bad = true;
   return 0;
 }
-LM_DEV int64_t rd_sleb(Rd& r) {
+template <class R> LM_DEV int64_t rd_sleb(R& r) {
   int64_t result = 0;
   int shift = 0;
   uint32_t b;
@@ -65,7 +87,7 @@ LM_DEV int64_t rd_sleb(Rd& r) {
   if (shift < 64 && (b & 0x40)) result |= -((int64_t)1 << shift);
   return result;
 }
-LM_DEV void rd_skip(Rd& r, uint64_t n) {
+template <class R> LM_DEV void rd_skip(R& r, uint64_t n) {
   if (n > rd_left(r)) { r.bad = true; r.p = r.end; return; }
   r.p += n;
 }
@@ -140,6 +162,60 @@ LM_DEV int64_t rle_next_any(RleCur& c, uint32_t mode) {   // the run value lives
   if (need) c.runv = rd_any(c.r, mode);
   if (mode != 2) return c.runv;
   if (__builtin_add_overflow(c.val, c.runv, &c.val)) c.r.bad = true;   // the reference sums in i128 and fails the narrowing
+  return c.val;
+}
+// The same cursor over a column of a block STAGED IN LDS (k_block_decode_wave): byte offsets into the slot instead of 64-bit
+// pointers, LDS loads instead of flat ones, and a varint of up to three bytes — nearly all of them — is read with three
+// independent loads and no per-byte bounds test, whenever three bytes are left in the column (the generic reader above spends
+// ≈12 instructions per byte on the bounds test, the latch and the pointer; 80 % of the decoder's instructions were inside it).
+// Anything else — the last bytes of a column, a longer varint — goes through the generic reader on the same bytes, so the
+// values, the `bad` latch and the position after every call are those of rle_next_any.
+struct ColCur { lm_lds_bytes base; uint32_t p, end; bool bad; int64_t rem; bool run; int64_t val, runv; };
+LM_DEV ColCur col_make(lm_lds_bytes base, uint32_t p, uint32_t end, bool bad) {
+  ColCur c; c.base = base; c.p = p; c.end = end; c.bad = bad; c.rem = 0; c.run = false; c.val = 0; c.runv = 0; return c;
+}
+LM_DEV bool col_var3(ColCur& c, uint32_t& v) {   // a uleb128 that ends within three bytes, all inside the column; false: nothing consumed
+  if (c.end - c.p < 3) return false;
+  uint32_t b0 = c.base[c.p], b1 = c.base[c.p + 1], b2 = c.base[c.p + 2];
+  if (b0 & b1 & b2 & 0x80) return false;
+  uint32_t c0 = b0 >> 7, c1 = c0 & (b1 >> 7);
+  v = (b0 & 0x7f) | (c0 ? (b1 & 0x7f) << 7 : 0u) | (c1 ? (b2 & 0x7f) << 14 : 0u);
+  c.p += 1 + c0 + c1;
+  return true;
+}
+LM_DEV int64_t col_any(ColCur& c, uint32_t mode) {   // == rd_any on the column's reader
+  uint32_t v;
+  if (mode == 0) { if (c.p < c.end) return c.base[c.p++]; }
+  else if (col_var3(c, v)) return mode == 1 ? (int64_t)v : (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+  Rd r = rd_make((const uint8_t*)c.base + c.p, c.end - c.p);
+  int64_t w = rd_any(r, mode);
+  c.p = (uint32_t)(r.p - (const uint8_t*)c.base);
+  if (r.bad) c.bad = true;
+  return w;
+}
+LM_DEV int64_t col_next_any(ColCur& c, uint32_t mode) {   // == rle_next_any
+  bool need = !c.run;
+  if (c.rem == 0) {
+    // == rle_head
+    if (c.p >= c.end) { c.bad = true; return mode == 2 ? c.val : 0; }
+    int64_t k;
+    uint32_t v;
+    if (col_var3(c, v)) k = (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+    else {
+      Rd r = rd_make((const uint8_t*)c.base + c.p, c.end - c.p);
+      k = rd_zigzag(r);
+      c.p = (uint32_t)(r.p - (const uint8_t*)c.base);
+      if (r.bad) c.bad = true;
+    }
+    if (k == 0) { c.bad = true; return mode == 2 ? c.val : 0; }
+    c.run = k > 0;
+    c.rem = k > 0 ? k : -k;
+    need = true;
+  }
+  c.rem--;
+  if (need) c.runv = col_any(c, mode);
+  if (mode != 2) return c.runv;
+  if (__builtin_add_overflow(c.val, c.runv, &c.val)) c.bad = true;   // the reference sums in i128 and fails the narrowing
   return c.val;
 }
 // number of values in a whole AnyRle payload whose literals are single bytes (Rle<u8>)

@@ -259,7 +259,17 @@ LM_KERNEL void k_block_count(Dev d) {
 // container (tag 9 + kind byte) is accepted down to nesting depth `cdepth`: 0 for a Map value, 1 for the items of a List
 // insert; -1 nowhere.  Children of a kind outside Map / List / Text are accepted here: they render as null and flag the
 // document DF_SOFT_UNSUPPORTED when met by the emitter (or when one of their ops is applied).
-LM_DEV void skip_loro_value_fs(Rd& r, bool& unsupported, int cdepth, uint32_t* f_cnt) {   // f_cnt: 16 words of frame stack
+// (a scalar at the top level — what a Map set or a list of numbers carries — is stepped over right here: the frame machinery below
+// is for lists, maps and child containers)
+template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt);
+template <class R> LM_DEV void skip_loro_value_top(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt, uint32_t tag_peek) {
+  if (tag_peek > 6 || r.bad) { skip_loro_value_fs(r, unsupported, cdepth, f_cnt); return; }   // (a latched reader consumes nothing there)
+  (void)rd_u8(r);
+  if (tag_peek == 3) (void)rd_sleb(r);
+  else if (tag_peek == 4) rd_skip(r, 8);
+  else if (tag_peek >= 5) { uint64_t l = rd_uleb(r); rd_skip(r, l); }
+}
+template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt) {   // f_cnt: 16 words of frame stack
   uint32_t f_map = 0;  // bit i: frame i is a map (each item is preceded by a key index)
   int sp = 0;
   uint32_t cnt = 1;

@@ -31,24 +31,34 @@ namespace lm {
 static constexpr uint32_t DEC_G = LM_DEC_G;     // blocks per wave (8 lanes each; -DLM_DEC_G=4: half the lanes idle, half the LDS per wave — twice the waves per CU)
 static constexpr uint32_t DEC_R = 8;            // rows per chunk (one lane per row in the assembly phase)
 static constexpr uint32_t DEC_WW = 6;           // words the walker hands over per row: value offset lo/hi, aux, flags, counter, change
-static constexpr uint32_t DEC_LDS_FIXED = DEC_G * 16 * 4 + DEC_G * DEC_R * 8 * 4 + DEC_G * DEC_R * DEC_WW * 4;   // frame stacks + s_x + s_w
-static constexpr uint32_t DEC_KINDS = 32;       // container kinds of a block cached in LDS (more: read back from cid_raw)
+static constexpr uint32_t DEC_LDS_FIXED = DEC_G * 16 * 4 + DEC_G * DEC_R * 8 * 4 + DEC_G * DEC_R * DEC_WW * 4 + DEC_G * DEC_VW;   // frame stacks + s_x + s_w + value windows
+static constexpr uint32_t DEC_KINDS = 16;       // container kinds of a block cached in LDS (more: read back from cid_raw)
 // error bookkeeping of the row loop: the earliest row wins, then the role order of the sequential decoder
 LM_DEV void dec_err(uint32_t& key, uint32_t row, uint32_t prio, int32_t code) {
   uint32_t k = (row << 8) | (prio << 4) | (uint32_t)code;
   if (k < key) key = k;
 }
 
-LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
+#ifdef LM_PROF_DEC
+#define DEC_PH(i) do { uint64_t n_ = lmw::clock(); pacc[i] += n_ - ptp; ptp = n_; } while (0)
+#else
+#define DEC_PH(i) do {} while (0)
+#endif
+// (the LDS slots bound the occupancy at ≈2.5 waves per SIMD: a register budget for three — 168 VGPRs — costs nothing and keeps everything out of scratch)
+LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d, uint32_t slot_cap) {
   int lane = lmw::lane();
+#ifdef LM_PROF_DEC
+  uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptp = lmw::clock();   // 0 stage, 1 head (role 0), 2 cursors, 3 A1, 4 T + A2, 5 W, 6 B, 7 close
+#endif
   uint32_t g0 = (uint32_t)lmw::bid() * DEC_G;
   uint32_t b = (uint32_t)lane >> 3, r = (uint32_t)lane & 7;
   uint32_t bi = g0 + b;
-  LM_DYN_SHARED(uint32_t, s_mem);   // DEC_G slots of slot_cap staged bytes | DEC_G x 16 frame-stack words | s_x | s_w | DEC_G x DEC_KINDS kind bytes
+  LM_DYN_SHARED(uint32_t, s_mem);   // DEC_G slots of slot_cap staged bytes | DEC_G x 16 frame-stack words | s_x | s_w | DEC_G value windows | DEC_G x DEC_KINDS kind bytes
   uint32_t* s_fs = s_mem + DEC_G * (slot_cap / 4);
   uint32_t* s_x = s_fs + DEC_G * 16;                  // DEC_G x DEC_R rows x 8 column words
   uint32_t* s_w = s_x + DEC_G * DEC_R * 8;            // DEC_G x DEC_R rows x DEC_WW walker words
-  uint8_t* s_kinds = (uint8_t*)(s_w + DEC_G * DEC_R * DEC_WW);
+  uint8_t* s_vw = (uint8_t*)(s_w + DEC_G * DEC_R * DEC_WW);   // DEC_G value windows of DEC_VW bytes (16-byte aligned: slot_cap and every table in front are multiples of 16)
+  uint8_t* s_kinds = s_vw + DEC_G * DEC_VW;
   bool have = b < DEC_G && bi < d.n_blocks;
   // only the scalar fields of the descriptor stay in registers; section extents are read where a section is opened
   struct { uint64_t base; uint32_t counter_start, counter_len, n_changes; } bd = {0, 0, 0, 0};
@@ -71,6 +81,7 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
     for (uint32_t i = r; i < nv; i += 8) ldst[i] = gsrc[i];   // `data` carries 64 bytes of slack behind the last blob
   }
   lmw::block_sync();
+  DEC_PH(0);
   if (!lmw::any(ok)) return;   // no decodable block in the group
   const uint8_t* blk_p = staged ? (const uint8_t*)slot + (bd.base - org) : d.data + bd.base;   // first byte of the block
   auto sec = [&](int s_) { return rd_make(blk_p + bdp->sec_rel[s_], bdp->sec_len[s_]); };
@@ -213,8 +224,10 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
     }
   }
   lmw::block_sync();   // kinds (LDS) and the change rows (HBM, read back by role 7 of the same block) are in place
+  DEC_PH(1);
   // ---- column cursors (roles 0-6) and the per-role parameters that let ONE code path decode all seven columns
   RleCur col = rle_make(rd_make(blk_p, 0));
+  ColCur fcol = col_make((lm_lds_bytes)slot, 0, 0, false);   // the same cursor for a staged block (LDS offsets, lean varints)
   bool has_del = false;
   uint32_t errk = 0xffffffffu;   // earliest row error of this lane
   bool shape_bad = false;        // ops / delete section framing
@@ -232,6 +245,7 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
       for (uint32_t c = 4; c < 7; c++) { Rd cc = rd_bytes(ds); if (r == c) mine = cc; }
     }
     col = rle_make(mine);
+    if (staged) fcol = col_make((lm_lds_bytes)slot, (uint32_t)(mine.p - (const uint8_t*)slot), (uint32_t)(mine.end - (const uint8_t*)slot), mine.bad);
   }
   // value domain of each column: [v_lo, v_lo + v_span) (v_nz: zero is invalid too); a value outside it records the
   // row error (v_prio orders the findings of one row like the sequential decoder) and is replaced by v_repl
@@ -250,6 +264,7 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
   else if (r == 6) { v_lo = -(int64_t)MAX_COUNTER; v_span = 2ull * MAX_COUNTER + 1; v_nz = true; v_repl = 1; v_prio = 7; }   //   signed len
   // ---- role 7: value walker + row→change bookkeeping
   Rd v = rd_make(blk_p, 0);
+  const uint64_t v_end_abs = ok ? bd.base + bdp->sec_rel[SEC_VALUES] + bdp->sec_len[SEC_VALUES] : 0ull;   // end of the block's values section
   uint64_t counter = bd.counter_start;
   uint32_t change_index = 0, rows_in_change = 0;
   uint64_t next_boundary = 0;
@@ -267,17 +282,19 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
   //   B  lane = (block, row): decode_op mapping, the 32-byte OpRow and its side tables, 64 rows per store
   uint32_t* sx = s_x + (size_t)b * (DEC_R * 8);       // this block's rows: 8 words each (columns 0-6, word 7 = container kind)
   uint32_t* sw = s_w + (size_t)b * (DEC_R * DEC_WW);
+  DEC_PH(2);
   for (uint32_t c0 = 0; c0 < max_rows; c0 += DEC_R) {
     // A1. op columns
     for (uint32_t k = 0; k < DEC_R; k++) {
       uint32_t row = c0 + k;
       if (ok && row < n_ops && r < 4) {
-        int64_t w = rle_next_any(col, mode);
+        int64_t w = staged ? col_next_any(fcol, mode) : rle_next_any(col, mode);
         if ((uint64_t)(w - v_lo) >= v_span) { dec_err(errk, row, v_prio, v_code); w = v_repl; }
         sx[k * 8 + r] = (uint32_t)w & v_mask;
       }
     }
     lmw::wave_sync();
+    DEC_PH(3);
     // T. lane = (block, row r): which rows are DeleteSeq ops of a sequence container
     uint32_t row = c0 + r;
     bool act = ok && row < n_ops;
@@ -294,17 +311,20 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
       if (todo) {
         uint32_t k = (uint32_t)__builtin_ctz(todo);
         todo &= todo - 1;
-        int64_t w = rle_next_any(col, 2);
+        int64_t w = staged ? col_next_any(fcol, 2) : rle_next_any(col, 2);
         if ((uint64_t)(w - v_lo) >= v_span || (v_nz && w == 0)) { dec_err(errk, c0 + k, v_prio, v_code); w = v_repl; }
-        if (col.r.bad) dec_err(errk, c0 + k, 9, ST_DATA_CORRUPTION);
+        if (staged ? fcol.bad : col.r.bad) dec_err(errk, c0 + k, 9, ST_DATA_CORRUPTION);
         sx[k * 8 + r] = (uint32_t)w;
       }
     }
     lmw::wave_sync();
+    DEC_PH(4);
     // W. role 7: value payloads (docs/encoding.md §10) and the row → change bookkeeping
-    if (ok && r == 7) {
+    {
+      const uint32_t wn = (ok && r == 7 && c0 < n_ops) ? (n_ops - c0 < DEC_R ? n_ops - c0 : DEC_R) : 0u;
       uint32_t* fs = s_fs + b * 16;
-      for (uint32_t k = 0; k < DEC_R && c0 + k < n_ops; k++) {
+      // one value (row k of the chunk), through either reader
+      auto walk = [&](auto& v, const uint32_t k) {
         uint32_t wvt = sx[k * 8 + 2], wlen = sx[k * 8 + 3], wkind = sx[k * 8 + 7];
         uint64_t val_at = (uint64_t)(v.p - d.data);
         uint32_t aux = 0, flags = 0;   // aux: element count of a list value | mark length; flags bit 0: the value is a list
@@ -316,10 +336,11 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
           case 7: (void)rd_uleb(v); break;
           case 10: (void)rd_sleb(v); break;
           case 11: {
-            bool is_list_value = v.p < v.end && *v.p == 7;
-            if (is_list_value) { Rd t = v; (void)rd_u8(t); aux = (uint32_t)rd_uleb(t); flags = 1; }
+            uint32_t tag0 = v.p < v.end ? rd_peek(v) : 0xffu;   // (an empty reader goes through the general routine, which latches `bad`)
+            bool is_list_value = tag0 == 7;
+            if (is_list_value) { auto t = v; (void)rd_u8(t); aux = (uint32_t)rd_uleb(t); flags = 1; }
             // (values of containers outside the device scope are never rendered: any shape is accepted)
-            skip_loro_value_fs(v, unsupported, wkind == CK_MAP ? 0 : (is_list_value && (wkind == CK_LIST || wkind == CK_MOVABLE) ? 1 : (wkind > CK_TEXT && wkind != CK_MOVABLE ? 16 : -1)), fs);
+            skip_loro_value_top(v, unsupported, wkind == CK_MAP ? 0 : (is_list_value && (wkind == CK_LIST || wkind == CK_MOVABLE) ? 1 : (wkind > CK_TEXT && wkind != CK_MOVABLE ? 16 : -1)), fs, tag0);
             break;
           }
           case 12: {
@@ -370,9 +391,44 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
           d.chg[chg0 + change_index].op0 = op0 + c0 + k + 1;
           next_boundary = change_index + 1 < N ? d.chg[chg0 + change_index + 1].ctr : (uint64_t)bd.counter_start + bd.counter_len;
         }
+      };
+      // A chunk whose payloads are scalars or nested values — blocks of Map sets, list items — is walked through a WINDOW: the
+      // block's eight lanes fetch the DEC_VW bytes behind the walker's cursor into LDS (one coalesced load for all such blocks of
+      // the wave) and the walker passes over the values that begin inside it, trip by trip; every byte was a dependent HBM / L2
+      // round trip of one lane before (62 % of the decoder's time on configs[2], profiles/r03_decoder_phases.log).  A chunk with
+      // a string or binary payload — a length prefix, then a jump — reads straight from HBM: with windows a text block's walk took
+      // 17 % longer.  A wave without a dense chunk runs the plain loop.
+      bool dense = false, jumps = false;   // (a chunk of delete rows has no payload at all: nothing to fetch)
+      for (uint32_t k = 0; k < wn; k++) { uint32_t t_ = sx[k * 8 + 2]; jumps |= t_ == 5 || t_ == 6 || t_ > 16; dense |= t_ == 3 || t_ == 4 || (t_ >= 10 && t_ <= 16); }
+      dense &= !jumps;
+      if (!lmw::any(dense)) {
+        for (uint32_t k = 0; k < wn; k++) walk(v, k);
+      } else {
+        RdW w;
+        w.p = v.p; w.end = v.end; w.bad = v.bad; w.wl = (lm_lds_bytes)(s_vw + (size_t)b * DEC_VW);
+        uint32_t wk = 0;
+        while (lmw::any(wk < wn)) {
+          uint64_t vp = (uint64_t)(w.p - d.data);
+          int wl_ = (int)(b * 8 + 7);
+          uint64_t wpos = ((uint64_t)lmw::shfl((uint32_t)(vp >> 32), wl_) << 32) | lmw::shfl((uint32_t)vp, wl_);
+          bool more = lmw::shfl((dense && wk < wn) ? 1u : 0u, wl_) != 0;
+          if (more && wpos + 8ull * r < v_end_abs) {   // (an 8-byte piece that starts inside the section: `data` carries 64 bytes of slack)
+            struct V8 { uint32_t x, y; } pc;
+            __builtin_memcpy(&pc, d.data + wpos + 8ull * r, 8);
+            *(V8*)(s_vw + (size_t)b * DEC_VW + 8u * r) = pc;
+          }
+          lmw::wave_sync();
+          if (wk < wn) {
+            w.wp = dense ? w.p : w.p - DEC_VW;   // (not dense: nothing lies inside the window)
+            for (bool first = true; wk < wn && (first || !dense || (uint64_t)(w.p - w.wp) + 12 <= DEC_VW); wk++, first = false) walk(w, wk);
+          }
+          lmw::wave_sync();
+        }
+        v.p = w.p; v.bad = w.bad;
       }
     }
     lmw::wave_sync();
+    DEC_PH(5);
     // B. lane = (block, row): decode_op mapping (outdated_encode_reordered.rs:215-476) and the row itself
     if (act) {
       const uint32_t* o = sw + r * DEC_WW;
@@ -420,6 +476,7 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
       d.op_blk[op0 + row] = bi;
     }
     lmw::wave_sync();   // the next chunk overwrites s_x / s_w
+    DEC_PH(6);
   }
   // ---- close the block: remaining change rows, the reader flags, the block status
   uint32_t tail = 0;   // low-priority findings (bit 0: a reader ran off its column, bit 1: counter does not add up, bit 2: unsupported shape)
@@ -431,7 +488,7 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
     if (counter != (uint64_t)bd.counter_start + bd.counter_len) tail |= 2;
     if (unsupported) tail |= 4;
   }
-  if (ok && r < 4 && col.r.bad) tail |= 1;
+  if (ok && r < 4 && (staged ? fcol.bad : col.r.bad)) tail |= 1;
   if (ok && shape_bad) tail |= 8;
   // combine over the 8 lanes of the block
   for (int m = 1; m < 8; m <<= 1) {
@@ -447,6 +504,10 @@ LM_KERNEL void k_block_decode_wave(Dev d, uint32_t slot_cap) {
     if (st == ST_OK && (tail & 4)) st = ST_UNSUPPORTED;
     d.blk[bi].status = st;
   }
+#ifdef LM_PROF_DEC
+  DEC_PH(7);
+  if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&d.prof[i], (unsigned long long)pacc[i]);
+#endif
 }
 
 }  // namespace lm

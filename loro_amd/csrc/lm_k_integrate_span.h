@@ -757,7 +757,12 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   bool tried = true;   // the in-leaf path has just declined this very element
   if (ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); if (c >= c1) return; tried = false; }
   uint32_t eb = t.ebase[peer];
-  if (c1 > t.end[peer]) c1 = t.end[peer];   // a damaged target range cannot make the walk longer than the peer's history
+  if (c1 > t.end[peer]) {   // a damaged target range cannot make the walk longer than the peer's history
+    // a delete row whose targets lie beyond what its peer has inserted (a damaged peer table, ...): the reference deletes whatever sits
+    // at the row's position (crdt_rope.rs:256-335) — not a value this engine reproduces (see ts_del_pos_ok)
+    if (hint_k) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+    c1 = t.end[peer];
+  }
   for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
     lmw::wave_sync();
     if (!tried && ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); continue; }
@@ -1465,7 +1470,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_ml(Dev d, 
 }
 // Resident documents (DevRes above): the common body with PLAIN = false (sliced rows: the applied prefix), SWEEP, RES.
 // (128 VGPRs: the prologue / epilogue state of a resident document does not fit the 96 of five waves per SIMD without scratch)
-LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+#ifndef LM_RES_WAVES
+#define LM_RES_WAVES 4
+#endif
+LM_KERNEL LM_WAVES_PER_SIMD(LM_RES_WAVES) LM_ONE_WAVE_GROUPS void k_integrate_span_res(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count, DevRes rs) {
@@ -1475,13 +1483,13 @@ LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res(Dev d, DevDag g, uint32
 #ifndef LM_RES_PLAIN_WAVES
 #define LM_RES_PLAIN_WAVES LM_INTEGRATE_WAVES
 #endif
-LM_KERNEL LM_WAVES_PER_SIMD(LM_RES_PLAIN_WAVES) void k_integrate_span_res_plain(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+LM_KERNEL LM_WAVES_PER_SIMD(LM_RES_PLAIN_WAVES) LM_ONE_WAVE_GROUPS void k_integrate_span_res_plain(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count, DevRes rs) {
   integrate_span_body<false, true, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count, rs);
 }
-LM_KERNEL LM_WAVES_PER_SIMD(4) void k_integrate_span_res_ml(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+LM_KERNEL LM_WAVES_PER_SIMD(LM_RES_WAVES) LM_ONE_WAVE_GROUPS void k_integrate_span_res_ml(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count, DevRes rs) {

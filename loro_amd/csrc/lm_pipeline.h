@@ -135,7 +135,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1280, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -597,6 +597,9 @@ struct Engine {
     // one wave per group of DEC_G blocks, staged through LDS (lm_k_decode_wave.h); LM_DECODE=0 selects the one-lane-per-block
     // decoder (kept as the second, independently structured implementation the parity suites also run)
     if (NB) {
+#ifdef LM_PROF_DEC   // experiment build: cycle accounting of the decoder's phases (tests/tools/gpu_prof_dec.py)
+      b_prof.ensure((size_t)n_docs * 16 * 8); d.prof = b_prof.as<unsigned long long>(); lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
+#endif
       if (!kn.decode_wave) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
       else {
         uint32_t slot_cap = kn.dec_slot;
@@ -709,7 +712,9 @@ struct Engine {
     b_vvh.ensure((vvh + 1) * 4);
     b_prof.ensure((size_t)n_docs * 16 * 8);
     d.prof = b_prof.as<unsigned long long>();
+#ifndef LM_PROF_DEC
     lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
+#endif
     b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_pfx.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 8);   // per doc 2·cap entries: claimed slots [0, cap/2) + sort scratch
     b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4); b_ht_cnt.ensure((size_t)n_docs * 4 + 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
@@ -997,7 +1002,7 @@ struct Engine {
     }
     payload_bytes = 0;
     for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) payload_bytes += (uint64_t)h_doc[i].out_len + h_doc[i].vv_len;
-#ifdef LM_PROF
+#if defined(LM_PROF) || defined(LM_PROF_DEC)
     h_prof.resize((size_t)n_docs * 16);
     lmbe::d2h(h_prof.data(), d.prof, (size_t)n_docs * 16 * 8);
 #endif

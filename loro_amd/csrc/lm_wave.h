@@ -15,8 +15,10 @@
 #define LM_DEV_NOINLINE __device__ __noinline__
 #define LM_KERNEL extern "C" __global__
 #define LM_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget: 512 / n VGPRs
+#define LM_ONE_WAVE_GROUPS __launch_bounds__(64)   // launched with 64-thread workgroups only: lifts the 128-VGPR cap of a 1,024-thread group
 #define LM_SHARED(type, name, n) __shared__ type name[n]
 #define LM_DYN_SHARED(type, name) extern __shared__ type name[]
+typedef const __attribute__((address_space(3))) uint8_t* lm_lds_bytes;   // bytes known to sit in LDS (ds_read_u8 instead of a flat load)
 
 namespace lmw {
 static constexpr int WAVE = 64;
@@ -67,8 +69,10 @@ LM_DEV uint64_t clock() { return __builtin_readcyclecounter(); }
 #define LM_DEV_NOINLINE inline
 #define LM_KERNEL inline
 #define LM_WAVES_PER_SIMD(n)
+#define LM_ONE_WAVE_GROUPS
 #define LM_SHARED(type, name, n) static type name[n]
 #define LM_DYN_SHARED(type, name) type* name = (type*)lmw::emu_dyn_shared()
+typedef const uint8_t* lm_lds_bytes;
 
 namespace lmw {
 static constexpr int WAVE = 64;

@@ -366,6 +366,17 @@ def test_damaged_blobs_never_take_the_batch_down():
     assert n_both_ok > 0 and n_same == n_both_ok
 
 
+def test_delete_rows_that_name_elements_nobody_inserted():
+    """tests/golden/damaged_peer_table.json: a flipped PeerID byte in one blob's peer table leaves the other blobs' delete rows
+    pointing at elements of a peer without any — the reference deletes by position and accepts the document (the oracle too);
+    the kernel deletes by id, so the document is LM_DATA_CORRUPTION, never a different rendering."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "damaged_peer_table.json")))
+    doc = [bytes.fromhex(h) for h in fx["blobs_hex"]]
+    assert _oracle.merge_batch([doc])[0][0] == 0
+    assert _emu.merge_batch([doc])[0][0] == 3
+
+
 def test_run_async_and_wait_with_two_contexts():
     """lm_run_async / lm_wait: two contexts alternate (the double-buffered serving loop of bench.py)."""
     from loro_amd._cabi import Context

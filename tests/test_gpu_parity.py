@@ -263,6 +263,11 @@ def test_damaged_blobs_never_take_the_batch_down(engine):
     # kernel by id) or whose span length differs from its op length is LM_DATA_CORRUPTION since round 3 (ts_del_pos_ok,
     # lm_k_integrate_span.h): what both sides accept, they render alike
     assert n_both_ok > 0 and n_same == n_both_ok
+    # delete rows that name elements nobody inserted (a flipped PeerID byte in another blob's peer table): accepted by the
+    # reference, which deletes by position — LM_DATA_CORRUPTION here (tests/golden/damaged_peer_table.json)
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "damaged_peer_table.json")))
+    doc = [bytes.fromhex(h) for h in fx["blobs_hex"]]
+    assert _oracle.merge_batch([doc])[0][0] == 0 and engine.merge_batch([doc])[0][0] == 3
 
 
 def test_two_contexts_in_flight(engine):
