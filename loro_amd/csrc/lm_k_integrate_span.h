@@ -566,10 +566,19 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
       // continuation items: origin_left = last element of the item right before them in this leaf, which the scan has
       // already passed (a run cut by deletes or by an insertion stays a chain of such items).  They are visited
       // non-siblings by construction — one ballot finds them all, and the scan hops over whole chains
+      // (the same holds two to four items back — the right part of a run that an insertion cut follows what was inserted: an
+      // item whose origin_left is the last element of one of the eight items in front of it, all inside the range, is passed like
+      // a continuation; one at a time these were most of the ≈28 items a colliding edit of the other peer puts in the way)
       uint64_t contm;
       {
-        uint32_t prev_last = lmw::shift_up(C.id + C.len - 1, 1);
-        contm = lmw::ballot(((uint32_t)lane > ci) & ((uint32_t)lane < limit) & (C.ol == prev_last));
+        uint32_t last = C.id + C.len - 1;
+        uint32_t back = (uint32_t)lane - ci;   // items of the range in front of this one (huge for lanes in front of the range)
+        bool inr = ((uint32_t)lane > ci) & ((uint32_t)lane < limit) & (C.ol != origin_left) & (C.ol != NONE);
+        uint32_t l1 = lmw::shift_up(last, 1), l2 = lmw::shift_up(l1, 1), l3 = lmw::shift_up(l2, 1), l4 = lmw::shift_up(l3, 1);
+        uint32_t l5 = lmw::shift_up(l4, 1), l6 = lmw::shift_up(l5, 1), l7 = lmw::shift_up(l6, 1), l8 = lmw::shift_up(l7, 1);
+        bool found = (C.ol == l1) | ((back >= 2) & (C.ol == l2)) | ((back >= 3) & (C.ol == l3)) | ((back >= 4) & (C.ol == l4)) |
+                     ((back >= 5) & (C.ol == l5)) | ((back >= 6) & (C.ol == l6)) | ((back >= 7) & (C.ol == l7)) | ((back >= 8) & (C.ol == l8));
+        contm = lmw::ballot(inr & found);
       }
       for (uint32_t h = ci; h < limit; h++) {   // (every `stop` / error leaves through a break)
         if ((contm >> h) & 1) {
