@@ -283,17 +283,20 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
   uint32_t* sx = s_x + (size_t)b * (DEC_R * 8);       // this block's rows: 8 words each (columns 0-6, word 7 = container kind)
   uint32_t* sw = s_w + (size_t)b * (DEC_R * DEC_WW);
   DEC_PH(2);
-  for (uint32_t c0 = 0; c0 < max_rows; c0 += DEC_R) {
-    // A1. op columns
-    for (uint32_t k = 0; k < DEC_R; k++) {
-      uint32_t row = c0 + k;
-      if (ok && row < n_ops && r < 4) {
-        int64_t w = staged ? col_next_any(fcol, mode) : rle_next_any(col, mode);
-        if ((uint64_t)(w - v_lo) >= v_span) { dec_err(errk, row, v_prio, v_code); w = v_repl; }
-        sx[k * 8 + r] = (uint32_t)w & v_mask;
-      }
+  // (the chunk's delete-start columns — one value per DeleteSeq row — advance in the SAME trips as the next chunk's op columns:
+  // roles 0-3 and roles 4-6 run one cursor code path on different lanes.  The order inside a chunk is therefore T (which rows
+  // are DeleteSeq rows; the op columns go to registers), W (reads value type / length / kind), then the column trips — the next
+  // chunk's op columns overwrite words 0-3 of s_x, which nobody reads any more, while this chunk's delete-start values land in
+  // words 4-6 — then B.  As a phase of their own the delete columns were 25 % of the decoder's time on text blocks.)
+  for (uint32_t k = 0; k < DEC_R; k++) {   // op columns of the first chunk
+    if (ok && k < n_ops && r < 4) {
+      int64_t w = staged ? col_next_any(fcol, mode) : rle_next_any(col, mode);
+      if ((uint64_t)(w - v_lo) >= v_span) { dec_err(errk, k, v_prio, v_code); w = v_repl; }
+      sx[k * 8 + r] = (uint32_t)w & v_mask;
     }
-    lmw::wave_sync();
+  }
+  lmw::wave_sync();
+  for (uint32_t c0 = 0; c0 < max_rows; c0 += DEC_R) {
     DEC_PH(3);
     // T. lane = (block, row r): which rows are DeleteSeq ops of a sequence container
     uint32_t row = c0 + r;
@@ -305,19 +308,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
     bool take_del = act && vt == 9 && (ckind == CK_TEXT || ckind == CK_LIST || ckind == CK_MOVABLE);
     if (act) sx[r * 8 + 7] = ckind;
     uint64_t tdm = lmw::ballot(take_del && has_del);
-    // A2. delete-start columns: one value per DeleteSeq row, in row order
-    uint32_t todo = (r >= 4 && r < 7) ? (uint32_t)(tdm >> (b * 8)) & 0xffu : 0u;
-    while (lmw::any(todo != 0)) {
-      if (todo) {
-        uint32_t k = (uint32_t)__builtin_ctz(todo);
-        todo &= todo - 1;
-        int64_t w = staged ? col_next_any(fcol, 2) : rle_next_any(col, 2);
-        if ((uint64_t)(w - v_lo) >= v_span || (v_nz && w == 0)) { dec_err(errk, c0 + k, v_prio, v_code); w = v_repl; }
-        if (staged ? fcol.bad : col.r.bad) dec_err(errk, c0 + k, 9, ST_DATA_CORRUPTION);
-        sx[k * 8 + r] = (uint32_t)w;
-      }
-    }
-    lmw::wave_sync();
+    uint32_t todo = (r >= 4 && r < 7) ? (uint32_t)(tdm >> (b * 8)) & 0xffu : 0u;   // delete-start columns: one value per DeleteSeq row, in row order
     DEC_PH(4);
     // W. role 7: value payloads (docs/encoding.md §10) and the row → change bookkeeping
     {
@@ -429,6 +420,21 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
     }
     lmw::wave_sync();
     DEC_PH(5);
+    // A. the column trips: this chunk's delete-start values (roles 4-6 → words 4-6) beside the next chunk's op columns (roles 0-3 → words 0-3)
+    for (uint32_t k = 0; k < DEC_R; k++) {
+      const bool a1 = ok && r < 4 && c0 + DEC_R + k < n_ops, a2 = todo != 0;
+      if (!lmw::any(a1 | a2)) break;
+      if (a1 | a2) {
+        uint32_t kk = a2 ? (uint32_t)__builtin_ctz(todo) : k;
+        uint32_t rowx = a2 ? c0 + kk : c0 + DEC_R + k;
+        todo &= todo - 1;   // (0 stays 0)
+        int64_t w = staged ? col_next_any(fcol, mode) : rle_next_any(col, mode);
+        if ((uint64_t)(w - v_lo) >= v_span || (v_nz && w == 0)) { dec_err(errk, rowx, v_prio, v_code); w = v_repl; }
+        if (a2 && (staged ? fcol.bad : col.r.bad)) dec_err(errk, rowx, 9, ST_DATA_CORRUPTION);
+        sx[kk * 8 + r] = (uint32_t)w & v_mask;
+      }
+    }
+    lmw::wave_sync();
     // B. lane = (block, row): decode_op mapping (outdated_encode_reordered.rs:215-476) and the row itself
     if (act) {
       const uint32_t* o = sw + r * DEC_WW;

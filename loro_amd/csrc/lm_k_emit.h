@@ -671,7 +671,10 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
         // (one wave renders a document, so every HBM round trip is on its critical path: the leaf records are requested one
         // leaf ahead, the directory entries two, and the byte gathers of four steps go out together — a step-at-a-time loop
         // took ≈1,200 dependent round trips per configs[1] document)
-        static constexpr int EU = 4;
+        #ifndef LM_EMIT_EU
+#define LM_EMIT_EU 4
+#endif
+        static constexpr int EU = LM_EMIT_EU;
         uint32_t de1 = nr > 0 ? dirp[0] : 0u, de2 = nr > 1 ? dirp[1] : 0u;
         uint32_t p_id = NONE, p_ln = 0, p_st = ST_EVER;
         if (nr > 0 && (uint32_t)lane < de_n(de1)) {
