@@ -308,6 +308,10 @@ LM_DEV void dod_finish(DodCur& c, Rd& r, uint64_t n) {
   rd_skip(r, (c.pos + 7) / 8);
 }
 
+// unaligned 32-bit access (gfx950 global memory takes it in one instruction)
+LM_DEV uint32_t ld32u(const uint8_t* p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+LM_DEV void st32u(uint8_t* p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
+
 LM_DEV uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 LM_DEV uint32_t ld32le(const uint8_t* p) {
   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);

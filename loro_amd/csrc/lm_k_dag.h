@@ -528,10 +528,6 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
   }
 }
 
-// unaligned 32-bit access (gfx950 global memory takes it in one instruction)
-LM_DEV uint32_t ld32u(const uint8_t* p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
-LM_DEV void st32u(uint8_t* p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
-
 // cooperative UTF-8 → scalars of ONE long string with coalesced loads: 64 bytes per step while the text is ASCII (byte =
 // scalar, no lane traffic), otherwise 61 — a scalar spans at most 4 bytes, so a lead byte below lane 61 has its tail loaded;
 // scalar boundaries come from a ballot over the lead bytes and each lead lane assembles its scalar from the following lanes.

@@ -312,8 +312,63 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
     DEC_PH(4);
     // W. role 7: value payloads (docs/encoding.md §10) and the row → change bookkeeping
     {
-      const uint32_t wn = (ok && r == 7 && c0 < n_ops) ? (n_ops - c0 < DEC_R ? n_ops - c0 : DEC_R) : 0u;
+      uint32_t wn = (ok && r == 7 && c0 < n_ops) ? (n_ops - c0 < DEC_R ? n_ops - c0 : DEC_R) : 0u;
       uint32_t* fs = s_fs + b * 16;
+      // S. A chunk of plain typing — every row a string insert or a row without payload — needs no walk through memory: if the
+      // strings are ASCII, string k begins where the lengths of the rows in front of it say (length prefix + as many bytes as
+      // the row has elements).  The block's eight lanes (lane = row here, as in T) compute those positions with one scan and check
+      // all eight prefixes with one load each; only if every prefix holds exactly its row's length does the walker advance by
+      // arithmetic.  (The prefix of string k+1 sits behind string k: read one after the other they were a chain of dependent
+      // HBM / L2 round trips of one lane — 40 % of the decoder's time on text blocks.)
+      bool spec = false;
+      {
+        const bool str_r = act && vt == 5;
+        const uint32_t hdr_r = len < 128u ? 1u : (len < 16384u ? 2u : (len < 2097152u ? 3u : 4u));
+        const uint32_t pay_r = str_r ? hdr_r + len : 0u;
+        bool ok_r = !act || str_r || vt <= 2 || vt == 8 || vt == 9;
+        if (lmw::any(str_r)) {
+          uint32_t inc = lmw::scan_incl_add(pay_r);
+          uint32_t base = lmw::shfl(inc, (int)(b ? b * 8 - 1 : 0));   // (every lane takes part in a lane permute: a lane that sat it out would read as 0)
+          if (!b) base = 0;
+          int wl_ = (int)(b * 8 + 7);
+          uint64_t vp = (uint64_t)(v.p - d.data);
+          uint64_t wpos = ((uint64_t)lmw::shfl((uint32_t)(vp >> 32), wl_) << 32) | lmw::shfl((uint32_t)vp, wl_);
+          if (str_r) {
+            uint64_t pos = wpos + (inc - pay_r - base);
+            ok_r = pos + pay_r <= v_end_abs;
+            if (ok_r) {
+              uint32_t w4 = ld32u(d.data + pos);   // (the prefix; `data` carries 64 bytes of slack behind the last blob)
+              uint32_t b0 = w4 & 0xff, b1 = (w4 >> 8) & 0xff, b2 = (w4 >> 16) & 0xff, b3 = w4 >> 24;
+              uint32_t val, used;
+              if (!(b0 & 0x80)) { val = b0; used = 1; }
+              else if (!(b1 & 0x80)) { val = (b0 & 0x7f) | (b1 << 7); used = 2; }
+              else if (!(b2 & 0x80)) { val = (b0 & 0x7f) | ((b1 & 0x7f) << 7) | (b2 << 14); used = 3; }
+              else { val = (b0 & 0x7f) | ((b1 & 0x7f) << 7) | ((b2 & 0x7f) << 14) | ((b3 & 0x7f) << 21); used = (b3 & 0x80) ? 0u : 4u; }
+              ok_r = val == len && used == hdr_r;
+            }
+          }
+          uint64_t okm = lmw::ballot(ok_r);
+          spec = ((okm >> (b * 8)) & 0xffull) == 0xffull;
+          // … and when no change of the block ends inside the chunk, the rows' bookkeeping words (value offset, counter, change) are
+          // a scan away too: every row lane writes its own s_w entry and the walker only moves its state on — eight rows one after
+          // the other on ONE lane were what was left of this phase
+          uint32_t cinc = lmw::scan_incl_add(act ? len : 0u);
+          uint32_t cbase = lmw::shfl(cinc, (int)(b ? b * 8 - 1 : 0));
+          if (!b) cbase = 0;
+          uint32_t tot_len = lmw::shfl(cinc, wl_) - cbase, tot_pay = lmw::shfl(inc, wl_) - base;
+          uint32_t ctr7 = lmw::shfl((uint32_t)counter, wl_), ci7 = lmw::shfl(change_index, wl_);
+          uint32_t nb7 = lmw::shfl((uint32_t)(next_boundary > 0xffffffffull ? 0xffffffffull : next_boundary), wl_);
+          const bool whole = spec && ci7 < N && (uint64_t)ctr7 + tot_len <= MAX_COUNTER && ((uint64_t)ctr7 + tot_len < nb7 || ci7 + 1 >= N);
+          if (whole) {
+            if (act) {
+              uint64_t va = wpos + (inc - pay_r - base);
+              uint32_t* o = sw + r * DEC_WW;
+              o[0] = (uint32_t)va; o[1] = (uint32_t)(va >> 32); o[2] = 0; o[3] = 0; o[4] = ctr7 + (cinc - len - cbase); o[5] = chg0 + ci7;
+            }
+            if (wn) { v.p += tot_pay; counter += tot_len; rows_in_change += wn; wn = 0; }
+          }
+        }
+      }
       // one value (row k of the chunk), through either reader
       auto walk = [&](auto& v, const uint32_t k) {
         uint32_t wvt = sx[k * 8 + 2], wlen = sx[k * 8 + 3], wkind = sx[k * 8 + 7];
@@ -323,7 +378,9 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
           case 0: case 1: case 2: case 8: case 9: break;
           case 3: (void)rd_sleb(v); break;
           case 4: rd_skip(v, 8); break;
-          case 5: case 6: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
+          case 5: if (spec) { v.p += (wlen < 128u ? 1u : (wlen < 16384u ? 2u : (wlen < 2097152u ? 3u : 4u))) + wlen; break; }   // (checked above: S)
+            [[fallthrough]];
+          case 6: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
           case 7: (void)rd_uleb(v); break;
           case 10: (void)rd_sleb(v); break;
           case 11: {
