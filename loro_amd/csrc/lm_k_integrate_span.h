@@ -311,16 +311,15 @@ LM_DEV SpanRegs sp_shift_in(const SpanRegs& R, uint32_t& lp, uint32_t idx, const
   SpanRegs N;
   N.n = R.n + cnt;
   uint32_t pid, pln, pol, por, pst, plp;
-  // (no branch on cnt: both shifts are computed and a select picks — vector work instead of scalar control)
+  // (the second shift and the second item under a branch on cnt: the kernel runs at the machine's issue rate, where a wave-wide
+  // VALU operation costs what a scalar one costs — twelve shifts and selects saved for cnt == 1 beat the three scalar instructions of the branch)
   pid = lmw::shift_up0(R.id, 1); pln = lmw::shift_up0(R.len, 1); pol = lmw::shift_up0(R.ol, 1); por = lmw::shift_up0(R.orr, 1); pst = lmw::shift_up0(R.st, 1); plp = lmw::shift_up0(lp, 1);
-  {
-    bool two = cnt == 2;
-    uint32_t q;
-    q = lmw::shift_up0(pid, 1); pid = two ? q : pid;  q = lmw::shift_up0(pln, 1); pln = two ? q : pln;  q = lmw::shift_up0(pol, 1); pol = two ? q : pol;
-    q = lmw::shift_up0(por, 1); por = two ? q : por;  q = lmw::shift_up0(pst, 1); pst = two ? q : pst;  q = lmw::shift_up0(plp, 1); plp = two ? q : plp;
+  if (cnt == 2) {
+    pid = lmw::shift_up0(pid, 1); pln = lmw::shift_up0(pln, 1); pol = lmw::shift_up0(pol, 1);
+    por = lmw::shift_up0(por, 1); pst = lmw::shift_up0(pst, 1); plp = lmw::shift_up0(plp, 1);
   }
   uint32_t inh = idx ? lmw::bcast(lp, (int)idx - 1) : 0u;
-  bool sh = lane >= idx + cnt, isA = lane == idx, isB = (cnt == 2) & (lane == idx + 1);
+  bool sh = lane >= idx + cnt, isA = lane == idx;
   N.id = sh ? pid : R.id; N.len = sh ? pln : R.len; N.ol = sh ? pol : R.ol; N.orr = sh ? por : R.orr; N.st = sh ? pst : R.st;
   uint32_t nlp = sh ? plp : lp;
   N.id = isA ? A.id : N.id; N.len = isA ? A.len : N.len; N.ol = isA ? A.ol : N.ol; N.orr = isA ? A.orr : N.orr; N.st = isA ? A.st : N.st;
@@ -329,12 +328,15 @@ LM_DEV SpanRegs sp_shift_in(const SpanRegs& R, uint32_t& lp, uint32_t idx, const
 #else
   nlp = isA ? ((setA ? 1u : 0u) | inh) : nlp;
 #endif
-  N.id = isB ? B.id : N.id; N.len = isB ? B.len : N.len; N.ol = isB ? B.ol : N.ol; N.orr = isB ? B.orr : N.orr; N.st = isB ? B.st : N.st;
+  if (cnt == 2) {
+    bool isB = lane == idx + 1;
+    N.id = isB ? B.id : N.id; N.len = isB ? B.len : N.len; N.ol = isB ? B.ol : N.ol; N.orr = isB ? B.orr : N.orr; N.st = isB ? B.st : N.st;
 #ifdef LM_LOC16
-  nlp = isB ? 1u : nlp;
+    nlp = isB ? 1u : nlp;
 #else
-  nlp = isB ? ((setB ? 1u : 0u) | inh) : nlp;
+    nlp = isB ? ((setB ? 1u : 0u) | inh) : nlp;
 #endif
+  }
   lp = nlp;
   return N;
 }
