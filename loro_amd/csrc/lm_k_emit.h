@@ -29,7 +29,11 @@ LM_DEV int bytes_cmp(const uint8_t* a, uint32_t na, const uint8_t* b, uint32_t n
 }
 
 // K10: one lane per op row — running LWW maximum per (container, key) in the doc's hash table.
-LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
+// The table of a document is sized OPTIMISTICALLY (lm_pipeline.h: a few thousand slots, however many Map rows it has — an LWW
+// history writes few keys many times, and a table sized for the rows is megabytes per document that every probe misses the caches
+// in); a document that claims more than half of its slots is flagged DF_LWW_RETRY and counted in retry_count[2]: the host gives it
+// a table sized for its rows and launches the kernel again for those documents only (`only_retry`).
+LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops, uint32_t* retry_count, uint32_t only_retry) {
   uint32_t t = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
   if (t >= n_ops) return;
   OpRow r = d.op[t];
@@ -54,6 +58,11 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
     return;
   }
   if (r.ctr < ch.ctr + d.chg_skip[r.chg]) return;  // already-known prefix of a sliced change
+  if (((m.flags & DF_LWW_RETRY) != 0) != (only_retry != 0)) return;   // (first pass: a document already found too big is not worth more work)
+  auto overflow = [&]() {
+    if (only_retry) { LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }   // (the second table holds every row's key)
+    if (!(lmw::atomic_or(&d.doc[doc].flags, DF_LWW_RETRY) & DF_LWW_RETRY)) lmw::atomic_add(retry_count + 2, 1u);
+  };
   uint32_t cap = d.ht_cap[doc];
   if (cap == 0) { LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }
   uint32_t cidx = r.cidx_kind & 0xffff;
@@ -74,7 +83,9 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
       cur = lmw::atomic_cas64(&keys[slot], HT_EMPTY, mine);
       if (cur == HT_EMPTY) {   // this thread claimed the slot: one list entry per distinct (container, key)
         cur = mine;
-        d.ht_list[2 * d.ht0[doc] + lmw::atomic_add(&d.ht_cnt[doc], 1u)] = slot;
+        uint32_t at = lmw::atomic_add(&d.ht_cnt[doc], 1u);
+        if (at >= cap / 2) { overflow(); return; }
+        d.ht_list[2 * d.ht0[doc] + at] = slot;
       }
     }
     bool same = cur == mine;
@@ -94,7 +105,7 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops) {
       return;
     }
   }
-  LM_SETERR(d.doc[doc].status, ST_INTERNAL);
+  overflow();
 }
 
 // K9b: documents rendered at a checked-out version only, one wave per document, after the integrate stage.

@@ -78,7 +78,8 @@ struct Engine {
   DBuf b_ht_key, b_ht_pfx, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
   DBuf b_out, b_out_off, b_vv_out, b_vv_off, b_hash, b_order, b_prof, b_slab, b_vslab, b_slab_off, b_vslab_off, b_slab2, b_slab2_off;
   uint64_t payload_bytes = 0;   // Σ json_len + Σ vv_len of the last run (without alignment padding)
-  std::vector<uint64_t> h_prof, h_hash;
+  std::vector<uint64_t> h_prof, h_hash, h_ht0;
+  std::vector<uint32_t> h_ht_cap, h_ht_full;   // LWW tables of the run: first slot, slots, slots of a table sized for the document's Map rows
   // results
   std::vector<DocMeta> h_doc;
   std::vector<DocResult> results;
@@ -135,7 +136,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 8192; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -147,6 +148,7 @@ struct Engine {
     if (const char* e = getenv("LM_LOC_MEMSET")) k.loc_memset = atoi(e) != 0;
     if (const char* e = getenv("LM_DIR_OPT_MAX")) k.dir_opt_max = (uint32_t)atoi(e);             // tests: force the retry launch
     if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
+    if (const char* e = getenv("LM_HT_OPT")) k.ht_opt = (uint32_t)atoi(e);                       // slots of a document's optimistic LWW table (a power of two; 0: sized for its Map rows at once; tests: 64 forces the second pass)
     kn = k;
   }
 
@@ -626,8 +628,7 @@ struct Engine {
     d.span = span ? 1u : 0u;
     d.res_vis = resident ? 1u : 0u;
     uint64_t elem = 0, leaves = 0, vvh = 0;
-    std::vector<uint64_t> h_ht0(n_docs);
-    std::vector<uint32_t> h_ht_cap(n_docs);
+    h_ht0.assign(n_docs, 0); h_ht_cap.assign(n_docs, 0); h_ht_full.assign(n_docs, 0);
     for (uint32_t i = 0; i < n_docs; i++) {
       DocMeta& m = h_doc[i];
       bool ok = m.status == ST_OK;
@@ -681,6 +682,11 @@ struct Engine {
       // LWW table: 2× the doc's Map op rows rounded up to a power of two
       uint32_t cap = 0;
       if (ok && m.n_mapop) { cap = 64; while (cap < 2 * m.n_mapop) cap <<= 1; }
+      h_ht_full[i] = cap;
+      // … optimistically capped (k_map_lww): an LWW history writes few keys many times — 1,024 keys in 160,000 rows on configs[2],
+      // 8 MB of table per document against 128 KB; a document with more keys than half the cap gets the full table in a second pass.
+      // (Not for resident documents, whose tables outlive the run, nor for MovableLists, whose elements enter after the integrate stage.)
+      if (kn.ht_opt && !resident && !(m.flags & DF_MOVABLE) && cap > kn.ht_opt) cap = kn.ht_opt;
       h_ht0[i] = ht; h_ht_cap[i] = cap;
       ht += cap;
     }
@@ -787,7 +793,10 @@ struct Engine {
     if (NB && !reuse) LM_LAUNCH(k_elem_fill, NB, 64, d);
     lmbe::toc("k_elem_fill", times, profiling);
     lmbe::tic(profiling);
-    if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO);   // (ht == 0: no document holds a Map / MovableList-LWW / out-of-scope row, k_dag_a)
+    b_tot.ensure(64 * 4);
+    uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
+    lmbe::dmemset(retry_cnt, 0, 12);   // [0] documents to re-run with the worst-case directory, [1] resident documents replayed from the empty version, [2] documents whose optimistic LWW table filled up
+    if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO, retry_cnt, 0u);   // (ht == 0: no document holds a Map / MovableList-LWW / out-of-scope row, k_dag_a)
     lmbe::toc("k_map_lww", times, profiling);
     lmbe::tic(profiling);
     dir_cap = (dir_cap + 3) & ~3u;
@@ -796,9 +805,6 @@ struct Engine {
     size_t lds_pad = kn.lds_pad;
     if (kn.no_opt_dir) dir_opt = dir_cap;
     if (kn.dir_opt_max) { uint32_t mx = kn.dir_opt_max; if (mx >= 4 && mx < dir_opt) dir_opt = mx & ~3u; }
-    b_tot.ensure(64 * 4);
-    uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
-    lmbe::dmemset(retry_cnt, 0, 8);   // [0] documents to re-run with the worst-case directory, [1] resident documents replayed from the empty version
     const size_t dir_words = span ? 2 : 1;   // LDS words per directory entry
     // documents that hold a MovableList are replayed by the kernel that knows move rows (k_integrate_span_ml), the others by
     // the common one; each kernel's waves leave the other's documents at once
@@ -842,12 +848,31 @@ struct Engine {
       LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                     (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
     }
-    uint32_t n_retry = 0;
+    uint32_t n_retry = 0, n_lww = 0;
     {
-      uint32_t two[2] = {0, 0};
-      lmbe::d2h(two, retry_cnt, 8);
-      n_retry = two[0];
-      if (resident) last_fresh = two[1];
+      uint32_t three[3] = {0, 0, 0};
+      lmbe::d2h(three, retry_cnt, 12);
+      n_retry = three[0]; n_lww = three[2];
+      if (resident) last_fresh = three[1];
+    }
+    if (n_lww) {
+      // documents with more keys than their optimistic LWW table holds: full-size tables behind the others', their Map rows again
+      std::vector<DocMeta> hd(n_docs);
+      lmbe::d2h(hd.data(), d.doc, (size_t)n_docs * sizeof(DocMeta));
+      std::vector<uint32_t> h_cnt(n_docs);
+      lmbe::d2h(h_cnt.data(), d.ht_cnt, (size_t)n_docs * 4);
+      const uint64_t ht_old = ht;
+      for (uint32_t i = 0; i < n_docs; i++) if (hd[i].flags & DF_LWW_RETRY) { h_ht0[i] = ht; h_ht_cap[i] = h_ht_full[i]; ht += h_ht_full[i]; h_cnt[i] = 0; }
+      b_ht_key.ensure_keep((ht + 1) * 8, (ht_old + 1) * 8); b_ht_best.ensure_keep((ht + 1) * 8, (ht_old + 1) * 8);
+      b_ht_pfx.ensure_keep((ht + 1) * 8, 0); b_ht_list.ensure_keep((ht + 1) * 8, (ht_old + 1) * 8);
+      d.ht_key = b_ht_key.as<unsigned long long>(); d.ht_best = b_ht_best.as<unsigned long long>(); d.ht_pfx = b_ht_pfx.as<unsigned long long>();
+      d.ht_list = b_ht_list.as<uint32_t>();
+      lmbe::dmemset((uint8_t*)b_ht_key.p + ht_old * 8, 0xff, (ht - ht_old) * 8);
+      lmbe::dmemset((uint8_t*)b_ht_best.p + ht_old * 8, 0, (ht - ht_old) * 8);
+      lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
+      lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
+      lmbe::h2d(b_ht_cnt.p, h_cnt.data(), (size_t)n_docs * 4);
+      LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO, retry_cnt, 1u);
     }
     if (n_retry) {  // rare: re-run the overflowed documents with the worst-case directory
       if (resident) {

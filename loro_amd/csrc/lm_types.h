@@ -114,6 +114,8 @@ enum : uint32_t {
   DF_LAYOUT_SAME = 32u,      // resident documents (k_res_layout): the element slots of everything the stored tracker holds are where they were —
                              // loc[] is still right (only the new slots are cleared) and k_elem_fill skips the blocks of earlier runs
   DF_FILL_KEPT = 64u,        // … and that run left nothing pending: every payload slot of its blocks was filled then (k_elem_fill fills applied rows only)
+  DF_LWW_RETRY = 128u,       // k_map_lww: the document's optimistic LWW table (sized for a few thousand keys) filled up: its Map rows are resolved
+                             // again in a table sized for as many keys as it has Map rows (lm_pipeline.h)
   DF_PLAIN = 8u,             // no sliced change, no style anchor, no MovableList (k_dag_a); the host clears it for checked-out documents
                              // and under LM_PLAIN=0: such a document is replayed by k_integrate_span_plain_sweep (lm_pipeline.h)
 };

@@ -4,7 +4,7 @@ GPU parity tests proper are in test_gpu_parity.py (-m gpu)."""
 import pytest
 
 import _oracle, _emu, _cases
-from loro_amd import wire
+from loro_amd import wire, workload
 
 
 DEVICE_SCOPE_GAPS = set()   # every edge-case document is rendered by the device path
@@ -375,6 +375,16 @@ def test_delete_rows_that_name_elements_nobody_inserted():
     doc = [bytes.fromhex(h) for h in fx["blobs_hex"]]
     assert _oracle.merge_batch([doc])[0][0] == 0
     assert _emu.merge_batch([doc])[0][0] == 3
+
+
+def test_optimistic_lww_table_overflow_takes_the_second_pass(monkeypatch):
+    """LM_HT_OPT=64: every document with more than 32 distinct (container, key) pairs — or more Map rows than 32 — fills its
+    optimistic LWW table, is flagged DF_LWW_RETRY and resolved again in a table sized for its rows; documents next to it keep
+    their small tables."""
+    monkeypatch.setenv("LM_HT_OPT", "64")
+    docs = [workload.cfg3_doc(d, n_peers=4, n_writes=300, n_keys=k, combined=(d % 2 == 0), per_change=50) for d, k in enumerate([8, 200, 31, 33, 120, 16])]
+    docs += _cases.cfg4_docs(6, first=4100, n_steps=150)
+    _check(docs, ["lww %d" % i for i in range(len(docs))])
 
 
 def test_run_async_and_wait_with_two_contexts():

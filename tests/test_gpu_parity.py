@@ -96,6 +96,15 @@ def test_config3_lww_map_variants_agree(engine):
         assert got[k][1] == got[k + 1][1] and got[k][2] == got[k + 1][2]
 
 
+def test_optimistic_lww_table_overflow_takes_the_second_pass(engine, monkeypatch):
+    """LM_HT_OPT=64 (read when the batch is staged): documents with more than 32 distinct keys fill their optimistic LWW table,
+    are flagged and resolved again in a table sized for their Map rows; the documents next to them keep their small tables."""
+    monkeypatch.setenv("LM_HT_OPT", "64")
+    docs = [workload.cfg3_doc(d, n_peers=4, n_writes=300, n_keys=k, combined=(d % 2 == 0), per_change=50) for d, k in enumerate([8, 200, 31, 33, 120, 16] * 8)]
+    docs += _cases.cfg4_docs(24, first=4100, n_steps=150)
+    _same(engine, docs)
+
+
 def test_full_size_config2_properties(engine):
     """configs[1] documents at full size (100k ops): bit-exact on a sample, and size-independent properties on
     the whole batch — both import orders converge, re-importing a blob is idempotent, VV = all ops applied."""
