@@ -67,7 +67,11 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
       if (neg) out[n++] = '-';
       char tmp[20];
       int tn = 0;
-      do { tmp[tn++] = (char)('0' + iv % 10); iv /= 10; } while (iv);
+      // (two chunks in 32-bit arithmetic: a 64-bit division per digit is a software routine on this target, see sink_i64)
+      uint64_t q1 = iv / 1000000000ull;
+      uint32_t c0 = (uint32_t)(iv - q1 * 1000000000ull), c1 = (uint32_t)q1;
+      if (c1) { for (int i = 0; i < 9; i++) { tmp[tn++] = (char)('0' + c0 % 10u); c0 /= 10u; } c0 = c1; }
+      do { tmp[tn++] = (char)('0' + c0 % 10u); c0 /= 10u; } while (c0);
       while (tn) out[n++] = tmp[--tn];
       out[n++] = '.'; out[n++] = '0';
       return n;

@@ -350,11 +350,21 @@ LM_DEV void sink_string(Sink& s, const uint8_t* p, uint32_t len) {
   sink_escaped(s, p, len);
   sink_byte(s, '"');
 }
+// (digits from three 9-digit chunks in 32-bit arithmetic: a 64-bit `% 10` / `/ 10` per digit is a ≈150-instruction software
+// division each on this target — ≈4,000 instructions for a 13-digit Map value, 90 % of the renderer's time on configs[2] and
+// most of the List renderer's on configs[3], tests/tools/gpu_prof_emit.py)
 LM_DEV void sink_i64(Sink& s, int64_t v) {
   char buf[24];
   int n = 0;
   uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
-  do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+  uint64_t q1 = u / 1000000000ull, q2 = q1 / 1000000000ull;
+  uint32_t c0 = (uint32_t)(u - q1 * 1000000000ull), c1 = (uint32_t)(q1 - q2 * 1000000000ull), c2 = (uint32_t)q2;
+  const int top = c2 ? 2 : (c1 ? 1 : 0);
+  for (int ci = 0; ci <= top; ci++) {
+    uint32_t c = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
+    if (ci < top) for (int i = 0; i < 9; i++) { buf[n++] = (char)('0' + c % 10u); c /= 10u; }
+    else do { buf[n++] = (char)('0' + c % 10u); c /= 10u; } while (c);
+  }
   if (v < 0) buf[n++] = '-';
   if (s.out && s.pos + (uint32_t)n <= s.cap && lmw::lane() == 0) for (int i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)buf[n - 1 - i];
   s.pos += (uint32_t)n;
@@ -515,6 +525,11 @@ static constexpr uint32_t EMIT_MAX_DEPTH = 16;   // nesting depth of child conta
 // `pass` 0 renders every document into its optimistic slab [out_off[doc], out_off[doc+1]); a document whose JSON does not fit
 // is left flagged DF_REEMIT with its exact size in out_len.  `pass` 1 re-renders only those documents (the host has moved
 // their slabs to exactly-sized ones).
+#ifdef LM_PROF_EMIT   // experiment build: where the renderer's time goes (tests/tools/gpu_prof_emit.py) — ticks per kind of container
+#define EMIT_PH(i) do { uint64_t n_ = lmw::clock(); epacc[i] += n_ - eptp; eptp = n_; } while (0)
+#else
+#define EMIT_PH(i) do {} while (0)
+#endif
 template <bool TEXT_ONLY>
 LM_DEV void emit_doc(Dev d, int mode, int pass) {
   uint32_t doc = (uint32_t)lmw::bid();
@@ -653,7 +668,11 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
   uint32_t scratch_top = 0;
   uint64_t doc_end = 0;   // list item values are bounded by the end of the document's last blob
   if (d.doc_blob[doc + 1] > d.doc_blob[doc]) doc_end = d.blob_off[d.doc_blob[doc + 1] - 1] + d.blob_len[d.doc_blob[doc + 1] - 1];
+#ifdef LM_PROF_EMIT
+  uint64_t epacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, eptp = lmw::clock();   // 0 set-up (roots, order) | 1 text | 2 list | 3 map sort | 4 map entries | 5 version vector | 6 root names
+#endif
   sink_byte(s, '{');
+  EMIT_PH(0);
   for (uint32_t oi = 0; oi < n_roots && !err; oi++) {
     {
       const uint8_t* np = d.data;
@@ -665,6 +684,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
       if (s_order[oi] & GHOST) { empty_child(gk); continue; }
     }
     int sp = 1;
+    EMIT_PH(6);
     frame_set(0, s_order[oi], 0, 0, 0x3);   // c bit 1 = frame not entered yet
     while (sp > 0 && !err) {
       lmw::block_sync();
@@ -745,6 +765,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
         }
         sink_byte(s, '"');
         sp--;
+        EMIT_PH(1);
       } else if (kind == CK_TEXT) {
         sink_byte(s, '"');
         uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
@@ -848,6 +869,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
           }
         }
         if (!pushed && !err) { sink_byte(s, ']'); sp--; }
+        EMIT_PH(2);
       } else if (!TEXT_ONLY && kind == CK_MAP) {
         if (fc & 2) {
           // first visit: this container's winning SET entries out of the document's claimed slots, bitonic-sorted by key
@@ -912,6 +934,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
           sink_byte(s, '{');
           fa = 0; fb = scratch_top; fc = K << 2;
           scratch_top += Kp;
+          EMIT_PH(3);
         }
         uint32_t K = fc >> 2;
         const uint32_t* sorted = scratch + fb;
@@ -968,6 +991,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
           scratch_top = fb;   // lists of deeper maps were released when those frames closed
           sp--;
         }
+        EMIT_PH(4);
       } else {
         sink_lit(s, "null", 4);
         sp--;
@@ -994,6 +1018,10 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
       put_uleb((uint64_t)e << 1);  // zigzag of a non-negative i32
     }
   }
+#ifdef LM_PROF_EMIT
+  EMIT_PH(5);
+  if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&d.prof[8 + i], (unsigned long long)epacc[i]);
+#endif
   if (s.pos > 0xfffffff0ull) err = ST_UNSUPPORTED;   // a document's JSON is addressed with 32 bits
   if (lane == 0) {
     if (err) { d.doc[doc].status = err; d.doc[doc].out_len = 0; d.doc[doc].vv_len = 0; d.doc[doc].flags = m.flags & ~DF_REEMIT; }

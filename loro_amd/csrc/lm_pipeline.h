@@ -1027,7 +1027,7 @@ struct Engine {
     }
     payload_bytes = 0;
     for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) payload_bytes += (uint64_t)h_doc[i].out_len + h_doc[i].vv_len;
-#if defined(LM_PROF) || defined(LM_PROF_DEC)
+#if defined(LM_PROF) || defined(LM_PROF_DEC) || defined(LM_PROF_EMIT)
     h_prof.resize((size_t)n_docs * 16);
     lmbe::d2h(h_prof.data(), d.prof, (size_t)n_docs * 16 * 8);
 #endif
