@@ -864,7 +864,9 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
                 pushed = true;
                 break;
               }
+              EMIT_PH(2);
               sink_value(s, r, err, d, vblk, m.blk0, m.n_blk);   // NONE: the item's block is found only if its key table is needed
+              EMIT_PH(7);
             }
           }
         }

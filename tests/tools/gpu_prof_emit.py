@@ -18,7 +18,7 @@ else:
     tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
     base = [tpl.stamp(d) for d in range(64)]
 docs = [base[i % len(base)] for i in range(n_docs)]
-names = ["set-up (roots, order)", "text", "list", "map: key sort", "map: entries", "version vector + close", "root names", "-"]
+names = ["set-up (roots, order)", "text", "list: everything around the values", "map: key sort", "map: entries", "version vector + close", "root names", "list: the items' values (sink_value)"]
 with Context(b, 0) as e:
     e.stage(docs)
     e.run(); e.run()
