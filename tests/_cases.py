@@ -271,3 +271,18 @@ def corrupted_docs(n, seed=1):
         d[j] = corrupt(d[j])
         docs.append(d)
     return docs
+
+
+def ascii_paste_docs():
+    """Plain-ASCII pastes whose length prefixes take 1, 2, 3 and 4 bytes (the decoder's arithmetic walk of plain-text chunks and
+    k_elem_fill's flat copy see every prefix width), next to ordinary typing; two peers, both import orders."""
+    from loro_amd import wire
+    docs = []
+    for n in (100, 200, 20000, 2200000):
+        a, b = wire.Replica(21), wire.Replica(22)
+        a.text_insert("text", 0, "head "); a.commit()
+        b.merge_from(a); b.set_visible("text", wire.KIND_TEXT, _oracle.visible_ids([a.export()], "text", wire.KIND_TEXT))
+        a.text_insert("text", 2, "".join("abcdefghijklmnopqrstuvwxyz \n"[(i * 7 + i // 31) % 28] for i in range(n))); a.text_insert("text", 1, "xy"); a.text_delete("text", 4, 3); a.commit()
+        b.text_insert("text", 5, "tail"); b.text_delete("text", 0, 1); b.commit()
+        docs.append([a.export(), b.export()]); docs.append([b.export(), a.export()])
+    return docs

@@ -387,6 +387,12 @@ def test_optimistic_lww_table_overflow_takes_the_second_pass(monkeypatch):
     _check(docs, ["lww %d" % i for i in range(len(docs))])
 
 
+def test_ascii_pastes_with_every_length_prefix_width():
+    docs = _cases.ascii_paste_docs()
+    got, _ = _check(docs, ["paste %d" % i for i in range(len(docs))])
+    assert all(g[0] == 0 for g in got) and got[0][1] == got[1][1] and got[6][1] == got[7][1] and len(got[6][1]) > 2200000
+
+
 def test_run_async_and_wait_with_two_contexts():
     """lm_run_async / lm_wait: two contexts alternate (the double-buffered serving loop of bench.py)."""
     from loro_amd._cabi import Context

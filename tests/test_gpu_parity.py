@@ -105,6 +105,13 @@ def test_optimistic_lww_table_overflow_takes_the_second_pass(engine, monkeypatch
     _same(engine, docs)
 
 
+def test_ascii_pastes_with_every_length_prefix_width(engine):
+    """length prefixes of 1, 2, 3 and 4 bytes through the decoder's arithmetic walk and the flat payload copy"""
+    docs = _cases.ascii_paste_docs()
+    got = _same(engine, docs)
+    assert got[6][1] == got[7][1] and len(got[6][1]) > 2200000
+
+
 def test_full_size_config2_properties(engine):
     """configs[1] documents at full size (100k ops): bit-exact on a sample, and size-independent properties on
     the whole batch — both import orders converge, re-importing a blob is idempotent, VV = all ops applied."""
