@@ -12,6 +12,10 @@
 
 namespace lm {
 
+#ifndef LM_NO_NODE_CUT
+#define LM_NO_NODE_CUT 0   // 1: nodes are whole self-dependent runs and ready nodes replay in ascending peer order (rounds 1-3; A/B builds)
+#endif
+
 struct DevDag {            // extra scratch of the DAG stage
   uint32_t* blk_sorted;    // [blk0 + i] blocks of a doc ordered by (peer, counter_start)
   uint32_t* chg_node;      // [chg0 + i] node id of the i-th sorted applied change
@@ -329,7 +333,26 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     }
     if (run > m.atoms && lane == 0) LM_SETERR(d.doc[doc].status, ST_INTERNAL);
   }
-  // ---- 5. DAG nodes: maximal runs linked only by a dependency on the peer's previous op
+  // ---- 5. DAG nodes: maximal runs linked only by a dependency on the peer's previous op — cut behind every change another
+  // peer's change depends on (AppDagNode::has_succ and the lazy node split of the reference, loro_dag.rs:302-367,995-1019):
+  // what follows such a change is concurrent with the dependent branch, and k_dag_b is then free to replay that branch FIRST
+  // (a node is its scheduling unit: uncut, a peer's whole run — configs[1]: the base AND its own branch — had to precede
+  // everything that depends on any part of it).
+  lmw::mem_fence();
+  lmw::block_sync();   // peer_chg0/1 (find_change) are complete
+  for (uint32_t i = (uint32_t)lane; i < n_valid; i += 64) {
+    uint32_t row = d.chg_sorted[m.chg0 + i];
+    const ChangeRow& ch = d.chg[row];
+    if (d.chg_skip[row] != 0) continue;   // sliced change: its only dependency is the known prefix
+    for (uint32_t k = ch.dep0; k < ch.dep0 + ch.n_dep; k++) {
+      uint32_t q = d.dep_peer[k];
+      if (q == ch.peer || q >= P) continue;
+      uint32_t ci = find_change(d, m, q, d.dep_ctr[k]);
+      if (ci != NONE) lmw::atomic_or(&d.chg_flag[d.chg_sorted[m.chg0 + ci]], 2u);   // (chg_flag: bit 0 applied, bit 1 has a successor of another peer)
+    }
+  }
+  lmw::mem_fence();
+  lmw::block_sync();
   uint32_t n_nodes = 0;
   for (uint32_t i0 = 0; i0 < n_valid; i0 += 64) {
     uint32_t i = i0 + (uint32_t)lane;
@@ -343,6 +366,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
       else if (ch.n_dep == 1 && d.dep_peer[ch.dep0] == ch.peer && ch.ctr > 0 && d.dep_ctr[ch.dep0] == ch.ctr - 1) cont = true;
       // a continuation needs a predecessor of the same peer right before it in the sorted order
       if (cont && (i == 0 || d.chg[d.chg_sorted[m.chg0 + i - 1]].peer != ch.peer)) cont = false;
+      if (cont && !LM_NO_NODE_CUT && d.chg_skip[row] == 0 && (d.chg_flag[d.chg_sorted[m.chg0 + i - 1]] & 2u)) cont = false;
       head = !cont;
     }
     uint64_t hm = lmw::ballot(head);
@@ -427,6 +451,41 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
   lmw::block_sync();
   for (uint32_t pass = 0; pass <= N && n_done < N; pass++) {
     uint32_t batch0 = n_done;
+#if !LM_NO_NODE_CUT
+    // ONE node per pass: of the peers' first unfinished nodes whose dependencies are all done, the one of the LARGEST peer.
+    // Any causal order gives the same sequence (Fugue converges; the reference's own order depends on a hash map,
+    // dag/iter.rs:268-274) — but not at the same price: integrating a run next to concurrent runs of other peers walks over
+    // every sibling of a SMALLER peer and stops at the first one of a larger peer (crdt_rope.rs:187,217: `other.peer >
+    // new.peer → break`).  Concurrent branches replayed in descending peer order meet only larger peers' items: the scan ends
+    // at its first sibling.  Staying with one peer as long as its next node is ready also keeps the tracker from moving
+    // between branches more often than the graph demands.
+    {
+      uint32_t pick = NONE;
+      for (uint32_t p0 = ((P - 1) >> 6) << 6;; p0 -= 64) {
+        uint32_t pr = p0 + (uint32_t)lane;
+        uint32_t n = pr < P ? s_next[pr] : NONE;
+        bool ready = false;
+        if (pr < P && n < s_pend[pr] && !g.node_done[m.chg0 + n]) {
+          ready = true;
+          const ChangeRow& ch = d.chg[d.chg_sorted[m.chg0 + d.node_first[m.chg0 + n]]];
+          for (uint32_t k = ch.dep0; k < ch.dep0 + ch.n_dep; k++) {
+            uint32_t ci = find_change(d, m, d.dep_peer[k], d.dep_ctr[k]);
+            if (ci == NONE || !g.node_done[m.chg0 + g.chg_node[m.chg0 + ci]]) ready = false;
+          }
+        }
+        uint64_t rm = lmw::ballot(ready);
+        if (rm) { pick = p0 + (uint32_t)(63 - __builtin_clzll((unsigned long long)rm)); break; }
+        if (p0 == 0) break;
+      }
+      if (pick != NONE) {
+        lmw::block_sync();
+        uint32_t n = s_next[pick];
+        lmw::block_sync();
+        if (lane == 0) { d.node_order[m.chg0 + n_done] = n; s_next[pick] = n + 1; }
+        n_done++;
+      }
+    }
+#else
     // collect the peers' first unfinished nodes whose dependencies are all done (ascending peer = ascending node index)
     for (uint32_t p0 = 0; p0 < P; p0 += 64) {
       uint32_t pr = p0 + (uint32_t)lane;
@@ -444,6 +503,8 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
       if (ready) { d.node_order[m.chg0 + n_done + (uint32_t)lmw::popc64(rm & ((1ull << lane) - 1))] = n; s_next[pr] = n + 1; }
       n_done += (uint32_t)lmw::popc64(rm);
     }
+#endif
+    lmw::mem_fence();
     lmw::block_sync();
     if (n_done == batch0) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }  // cycle: malformed deps
     // finish the batch: lamport + vv at the head, lamports of every change of the node
@@ -472,6 +533,37 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
         d.chg_lamport[row] = lam + (d.chg[row].ctr - hc.ctr);
       }
       if (lane == 0) { g.node_done[m.chg0 + n] = 1; g.node_lam[m.chg0 + n] = lam; }
+      lmw::block_sync();
+    }
+  }
+  // ---- critical versions (integrate stage: ts_goto / ts_convert_base, lm_k_integrate_span.h).  The version in front of the
+  // i-th node of the replay order is CRITICAL when every node from i on depends on all of it: vv_head(node j) >= everything the
+  // nodes in front of i hold, for all j >= i (Eg-walker's critical versions; what lets the reference start a tracker at the
+  // common ancestors with the history before them collapsed, tracker.rs:40-60).  Walked backwards with a running minimum of the
+  // vv_heads and the version "everything in front of node i" (a peer's nodes are replayed in counter order, so taking node i
+  // away sets its peer back to the node's first counter).  Flag (node_done bit 1): critical in front of node i but not in front
+  // of node i+1 — a concurrent section begins with node i, the tracker gets its base there.  A history that is one chain
+  // (critical everywhere) gets no flag at all, and neither does its last node.
+  if (res_mode != 2 && N) {
+    uint32_t* s_min = s_next;
+    uint32_t* s_tot = s_pend;
+    lmw::block_sync();
+    for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_min[p] = NONE; s_tot[p] = d.peer_end[m.praw0 + p]; }
+    lmw::block_sync();
+    bool crit_next = true;
+    for (uint32_t i = N; i-- > 0;) {
+      uint32_t n = d.node_order[m.chg0 + i];
+      uint32_t row = d.chg_sorted[m.chg0 + d.node_first[m.chg0 + n]];
+      const ChangeRow& hc = d.chg[row];
+      const uint32_t* vv = d.vvh + vvh0 + (uint64_t)n * P;
+      if (lane == 0) s_tot[hc.peer] = hc.ctr + d.chg_skip[row];
+      for (uint32_t p = (uint32_t)lane; p < P; p += 64) { uint32_t v = vv[p]; if (v < s_min[p]) s_min[p] = v; }
+      lmw::block_sync();
+      bool below = false;
+      for (uint32_t p = (uint32_t)lane; p < P; p += 64) below |= s_min[p] < s_tot[p];
+      bool crit = !lmw::any(below);
+      if (lane == 0) g.node_done[m.chg0 + n] = 1u | ((crit && !crit_next) ? 2u : 0u);
+      crit_next = crit;
       lmw::block_sync();
     }
   }

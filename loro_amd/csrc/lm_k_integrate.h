@@ -20,6 +20,9 @@
 namespace lm {
 
 static constexpr uint32_t ST_FUT = 1u, ST_EVER = 2u, ST_DEL1 = 0x100u, ST_DELMASK = 0x00FFFF00u;
+// span-granular kernel: deleted at the tracker's base version (a critical version of the history, ts_convert_base) — the top bit
+// of the delete count, so every "is it active" test sees it; the counted part below it then holds deletes applied since
+static constexpr uint32_t ST_DEAD = 0x00800000u;
 LM_DEV bool st_active(uint32_t st) { return (st & (ST_FUT | ST_DELMASK)) == 0; }
 
 // directory entry: leaf id (17 bits) | "holds a non-future element" (1 bit) | element count (7 bits) | active count (7 bits)

@@ -408,9 +408,23 @@ LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     // document's 1,800 insert rows, ≈870 instructions each on the general path): no origin_left, origin_right = item 0 when
     // that one is not future — nothing lies in between, nothing to merge with
     if ((pos | t.cache_p) != 0 || t.cr.n > 62) return false;
-    if (!(lmw::ballot(!(t.cr.st & ST_FUT)) & 1)) return false;
     SpanItem A;
-    A.id = pid0; A.len = len; A.ol = NONE; A.orr = lmw::bcast(t.cr.id, 0); A.st = 0;
+#ifdef LM_NO_COLLIDE_FAST
+    if (!(lmw::ballot(!(t.cr.st & ST_FUT)) & 1)) return false;
+    A.orr = lmw::bcast(t.cr.id, 0);
+#else
+    {
+      uint64_t nf0 = lmw::ballot(!(t.cr.st & ST_FUT));
+      if (!nf0) return false;
+      int rs = lmw::ffs64(nf0);
+      A.orr = lmw::bcast(t.cr.id, rs);
+      if (rs != 0) {   // future items in front of origin_right: see the in-leaf case below
+        uint32_t o_id = lmw::bcast(t.cr.id, 0), o_ol = lmw::bcast(t.cr.ol, 0), o_or = lmw::bcast(t.cr.orr, 0);
+        if (o_ol == NONE && (o_or != A.orr || pid_peer(o_id) <= pid_peer(pid0))) return false;
+      }
+    }
+#endif
+    A.id = pid0; A.len = len; A.ol = NONE; A.st = 0;
     uint32_t n0 = t.cr.n;
     t.cr = sp_shift_in(t.cr, t.loc_pend, 0, A, A, 1, true, false);
     t.dirty = true;
@@ -447,8 +461,23 @@ LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
     cnt = 2;
   } else {
     uint64_t nf = lmw::ballot(((uint32_t)lane >= idx) & !(t.cr.st & ST_FUT));
+#ifdef LM_NO_COLLIDE_FAST
     if (!((nf >> idx) & 1)) return false;   // origin_right in another leaf, or future items in between (nf has no bit below idx)
     A.orr = lmw::bcast(t.cr.id, (int)idx);
+#else
+    if (!nf) return false;                  // origin_right in another leaf
+    int rs = lmw::ffs64(nf);
+    A.orr = lmw::bcast(t.cr.id, rs);
+    if ((uint32_t)rs != idx) {
+      // future items lie between the cursor and origin_right — concurrent runs of other peers at this very place.  The sibling scan
+      // (crdt_rope.rs:156-237) ends at its FIRST item when that item is not a sibling (its origin_left is not ours: nothing has
+      // been passed yet, so it cannot be a descendant of a passed item) or is a sibling with our origin_right and a larger peer:
+      // the new run goes right here.  With concurrent branches replayed in descending peer order (k_dag_b) this is what every
+      // colliding insert meets; anything else takes the general path.
+      uint32_t o_id = lmw::bcast(t.cr.id, (int)idx), o_ol = lmw::bcast(t.cr.ol, (int)idx), o_or = lmw::bcast(t.cr.orr, (int)idx);
+      if (o_ol == A.ol && (o_or != A.orr || pid_peer(o_id) <= pid_peer(pid0))) return false;
+    }
+#endif
     if ((v_st | (sid + sln - pid0) | ((sid ^ pid0) >> 24) | (v_or ^ A.orr)) == 0) {
       // run merging (FugueSpan::is_mergeable): the item grows
       t.cr.len = (uint32_t)lane == slot ? sln + len : t.cr.len;
@@ -711,7 +740,7 @@ LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int m
   if (mode == UPD_SET_FUT) st1 |= ST_FUT;
   else if (mode == UPD_CLR_FUT) st1 &= ~ST_FUT;
   else if (mode == UPD_DEL_INC) st1 = (st1 + ST_DEL1) | ST_EVER;
-  else if (st1 & ST_DELMASK) st1 -= ST_DEL1;
+  else if (st1 & (ST_DELMASK & ~ST_DEAD)) st1 -= ST_DEL1;
   uint32_t s_off = x - id0;
   uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
   uint32_t tail = pid_ctr(id0) + ln - endc, mid = endc - c;
@@ -827,7 +856,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     if (mode == UPD_SET_FUT) st1 |= ST_FUT;
     else if (mode == UPD_CLR_FUT) st1 &= ~ST_FUT;
     else if (mode == UPD_DEL_INC) st1 = (st1 + ST_DEL1) | ST_EVER;
-    else if (st1 & ST_DELMASK) st1 -= ST_DEL1;
+    else if (st1 & (ST_DELMASK & ~ST_DEAD)) st1 -= ST_DEL1;
     uint32_t s_off = x - id0;                                   // elements of the run before the range
     uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
     uint32_t tail = pid_ctr(id0) + ln - endc;                   // elements of the run beyond the range
@@ -992,6 +1021,91 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
   }
 }
 
+// ---- the tracker's BASE version (batch replays only; resident trackers keep no base — a later import may be concurrent with
+// anything they hold).  k_dag_b flags the node in front of which the replayed history is a CRITICAL version — every node still to
+// come depends on all of it — and behind which a concurrent section begins (the reference starts its tracker at such a version
+// with everything before it collapsed into one unknown span, tracker.rs:40-60 `new_with_unknown`; Eg-walker's "critical
+// versions").  The tracker will never be moved below it again, so when it stands exactly there
+//   * ts_convert_base: every item deleted by then becomes ST_DEAD (the counted part of the status returns to zero): one pass over
+//     the status words;
+//   * ts_reset_to_base: a later move BACK to exactly that version — the replay switches to a concurrent branch — undoes
+//     everything applied since in ONE pass over the leaves: items of ops beyond the base become future, every counted delete is
+//     dropped (all of them were applied beyond the base).  Row by row this was the retreat of a whole branch: one by-id update
+//     per delete row and a sweep for the insert rows (configs[1]: ≈9 % of the kernel).
+LM_DEV void ts_convert_base(Ts& t) {
+  int lane = lmw::lane();
+  lmw::wave_sync();
+  for (uint32_t q = 0; q < t.n_dir; q++) {
+    uint32_t a = lmw::first(t.da[q]);
+    uint32_t L = sa_leaf(a), n = sa_n(a);
+    if (L == t.cache_leaf) {
+      uint32_t st = t.cr.st;
+      t.cr.st = (st & ST_DELMASK) ? ((st & ~ST_DELMASK) | ST_DEAD) : st;
+      t.dirty = true;
+      continue;
+    }
+    uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+    if ((uint32_t)lane < n) {
+      uint32_t st = rec[256 + lane];
+      if (st & ST_DELMASK) rec[256 + lane] = (st & ~ST_DELMASK) | ST_DEAD;
+    }
+  }
+}
+LM_DEV void ts_reset_to_base(Ts& t, const uint32_t* s_base) {
+  int lane = lmw::lane();
+  sp_flush(t);                                                     // the pass works on the leaf records in HBM
+  sd_sync_cached(t);
+  t.cache_leaf = NONE; t.cr.n = 255; t.cache_pre = NONE; t.dirty = false; t.loc_pend = 0;
+  lmw::wave_sync();
+  for (uint32_t q = 0; q < t.n_dir; q++) {
+    uint32_t a = lmw::first(t.da[q]);
+    uint32_t L = sa_leaf(a), n = sa_n(a);
+    uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+    bool in = (uint32_t)lane < n;
+    uint32_t id = in ? rec[lane] : 0u, ln = in ? rec[64 + lane] : 0u, st = in ? rec[256 + lane] : ST_FUT;
+    bool post = in && pid_ctr(id) >= s_base[pid_peer(id)];
+    uint32_t st1 = (st & ~(ST_DELMASK & ~ST_DEAD)) | (post ? ST_FUT : 0u);
+    if (!lmw::any(in && st1 != st)) continue;
+    if (in && st1 != st) rec[256 + lane] = st1;
+    uint32_t act = lmw::reduce_add((in && st_active(st1)) ? ln : 0u);
+    bool nf = lmw::ballot(in && !(st1 & ST_FUT)) != 0;
+    sd_set(t, q, sa_make(L, n, nf), act);
+  }
+}
+// The tracker moves from s_cur to the version vv (the dependencies of the node about to be replayed): Tracker::checkout
+// (tracker.rs:354-461), peer by peer — or in one pass when vv is the tracker's base (above).  `conv`: k_dag_b flagged this node.
+template <bool ML, bool SWEEP>
+LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t P, const uint32_t* vv, uint32_t* s_cur, uint32_t* s_base,
+                    bool& base_on, bool conv) {
+  int lane = lmw::lane();
+  bool reset = false;
+  if (base_on) {
+    bool same = true;
+    uint32_t back = 0;
+    for (uint32_t p = (uint32_t)lane; p < P; p += 64) { uint32_t v = vv[p], c = s_cur[p]; same &= v == s_base[p]; back += c > v ? c - v : 0u; }
+    back = lmw::reduce_add(back);
+#ifdef LM_SWEEP_EAGER   // tests: every move back to the base takes the pass
+    reset = !lmw::any(!same) && back > 0;
+#else
+    reset = !lmw::any(!same) && back > 4 * t.n_dir + 32;   // (a short way back is cheaper row by row than a pass over every leaf)
+#endif
+  }
+#ifdef LM_EMU_TRACE
+  if (getenv("LM_EMU_BASE") && lane == 0) fprintf(stderr, "BASE cont %u: %s%s (n_dir %u)\n", cidx, reset ? "reset" : "move", conv ? " +convert" : "", t.n_dir);
+#endif
+  if (reset) ts_reset_to_base(t, s_base);
+  else
+    for (uint32_t p = 0; p < P && !t.err; p++) {
+      uint32_t cur = s_cur[p], tgt = vv[p];
+      if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
+      else if (cur < tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, cur, tgt, +1);
+    }
+  lmw::block_sync();
+  for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_cur[p] = vv[p]; if (conv) s_base[p] = vv[p]; }
+  if (conv && !t.err) { ts_convert_base(t); base_on = true; }
+  lmw::block_sync();
+}
+
 #ifdef LM_EMU_CHECK
 // debug-only (kernel-logic harness built with -DLM_EMU_CHECK): the directory against the leaves and loc[] against both
 inline bool ts_check(Ts& t, const char* what, uint32_t row) {
@@ -1084,6 +1198,9 @@ LM_DEV uint32_t* tk_cont(uint32_t* tk, uint32_t pcap, uint32_t c) { return tk + 
 // never occur there.
 #ifndef LM_INTEGRATE_WAVES
 #define LM_INTEGRATE_WAVES 5
+#endif
+#ifndef LM_BASE_RESET
+#define LM_BASE_RESET 1   // 0: no base version — every move of the tracker goes row by row / by the insert sweep (rounds 1-3; A/B builds)
 #endif
 // PLAIN = true (k_integrate_span_plain_sweep by default, k_integrate_span_plain under LM_PLAIN=1; LM_PLAIN=0 = common kernel): the
 // documents flagged DF_PLAIN — no checkout, no sliced change, no style anchor — whose row loop needs neither the slicing of a row
@@ -1263,11 +1380,15 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     }
     lmw::block_sync();
     bool touched = false;
+    bool base_on = false;              // the tracker has a base version (s_base), ts_goto
+    uint32_t* s_base = s_tgt;          // (not RES: the slot of the resident kernels' rendered version)
     for (uint32_t oi = 0; oi < m.n_nodes && !t.err; oi++) {
       uint32_t n = d.node_order[m.chg0 + oi];
       uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
       const uint32_t* vv = vvh_ro + vvh0 + (uint64_t)n * P;
       uint32_t node_peer = chg_ro[sorted_ro[m.chg0 + first]].peer;
+      // (k_dag_b: the replayed history in front of this node is a critical version and a concurrent section begins behind it)
+      const bool conv_node = !RES && LM_BASE_RESET && (lmw::first(g.node_done[m.chg0 + n]) & 2u) != 0;
       if (RES) {   // a node the stored tracker has applied to its end
         const ChangeRow lc = chg_ro[sorted_ro[m.chg0 + last]];
         if (lc.ctr + lc.len <= s_app[node_peer]) continue;
@@ -1289,14 +1410,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
           // carries no test for it (7 instructions per op row, 4 of them register moves in front of the branch)
           checked_out = true;
-          for (uint32_t p = 0; p < P && !t.err; p++) {
-            uint32_t cur = s_cur[p], tgt = vv[p];
-            if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
-            else if (cur < tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, cur, tgt, +1);
-          }
-          lmw::block_sync();
-          for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = vv[p];
-          lmw::block_sync();
+          ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node);
           PROF_ADD(t, PF_CHECKOUT);
           TS_CHECK("checkout", ch.op0);
         }
@@ -1312,6 +1426,8 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           uint32_t b = PLAIN ? r.len : (r.ctr + r.len <= pe ? r.len : pe - r.ctr);
           if (!(PLAIN && !RES) && !checked_out) {
             checked_out = true;
+            if (!RES) ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node);
+            else {
             for (uint32_t p = 0; p < P && !t.err; p++) {
               uint32_t cur = s_cur[p], tgt = vv[p];
               // RES: the stored tracker may stand below this peer's own earlier ops (a previous run left it at an older
@@ -1323,6 +1439,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
             lmw::block_sync();
             for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_cur[p] = (RES && p == node_peer) ? r.ctr + a : vv[p];
             lmw::block_sync();
+            }
             PROF_ADD(t, PF_CHECKOUT);
             TS_CHECK("checkout", row);
           }
