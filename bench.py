@@ -247,6 +247,8 @@ def _gen(args):
         import random, _fuzz
         reps = _fuzz.movable_session(7000 + d, n_peers=3, n_steps=500, sync_prob=0.08, nested=True, bulk=300)
         return _fuzz.blobs_of(reps, random.Random(d)), None
+    if kind == "trace":        # configs[1] at its stated size from ANOTHER synthetic trace (seed d)
+        return workload.Cfg2Template(50000, 25000, seed=d, commit_every=10, fuse=True), None
     if kind == "tpl":          # a configs[1]-shaped template of another size / commit granularity
         n_base, n_branch, every, fuse = d
         return workload.Cfg2Template(n_base, n_branch, seed=n_base % 97, commit_every=every, fuse=fuse), None
@@ -268,10 +270,12 @@ def other_configs(device, cores):
         shapes = [(2000, 1000, 10, True), (10000, 5000, 10, True), (25000, 12500, 10, True), (50000, 25000, 10, True),
                   (100000, 50000, 10, True), (5000, 2500, 1, False), (20000, 10000, 1, False)]
         gh = pool.map_async(_gen, [("tpl", sh) for sh in shapes])
+        # configs[1] with 128 DIFFERENT traces (the headline batch stamps ONE trace 10,000 times: identical control flow in every wave)
+        gt = pool.map_async(_gen, [("trace", sd) for sd in range(1, 129)])
         gm = pool.map_async(_gen, [("movable", d) for d in range(16)])
         cfg1 = [workload.cfg1_doc(d) for d in range(100)]
         cfg4_base = _cases.cfg4_docs(96)
-        g3, g5, gh = g3.get(), g5.get(), gh.get()
+        g3, g5, gh, gt = g3.get(), g5.get(), gh.get(), gt.get()
         try:
             gm = gm.get()
         except Exception as ex:   # (not a BASELINE config: its generator must not take the bench line down)
@@ -288,12 +292,14 @@ def other_configs(device, cores):
             note(f"other configs: {name} FAILED: {type(ex).__name__}: {ex}"[:200])
 
     def _run(name, docs, fronts, distinct, desc, reps):
+        t_cpu = time.perf_counter()
         want = _oracle.merge_batch(docs[:distinct], threads=min(32, cores), frontiers=None if fronts is None else fronts[:distinct])
+        t_cpu = time.perf_counter() - t_cpu
         with loro_amd.MergeEngine(device) as e:
             e.stage(docs, fronts)
             e.run()
             got = e.fetch()
-            if name.endswith("heterogeneous"):   # every document is its own: the first `distinct` against the oracle, all must succeed
+            if name.endswith(("heterogeneous", "traces")):   # every document is its own: the first `distinct` against the oracle, all must succeed
                 assert got[:distinct] == want and all(g[0] == 0 for g in got), f"{name}: device results differ from the CPU oracle"
             else:
                 assert all(got[i] == want[i % distinct] for i in range(len(docs))), f"{name}: device results differ from the CPU oracle"
@@ -317,7 +323,11 @@ def other_configs(device, cores):
                      "roofline": None if not dom else {"bound": "hbm", "kernel": dom, "kernel_ms": stage_ms[dom], "achieved": round(alg / (stage_ms[dom] * 1e-3) / 1e9, 2),
                                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                                                        "what": "algorithmic bytes of the batch over the dominant stage's time for the whole batch (streams serialized); per stage: algorithmic bytes / stage_ms"},
-                     "parity": (f"first {distinct} results equal to the oracle's, all {len(docs)} succeeded" if name.endswith("heterogeneous") else f"all {len(docs)} results equal to the oracle's"),
+                     "cpu_baseline": {"value": round(distinct / t_cpu, 1), "unit": "docs/s", "cores": min(32, cores, distinct), "kind": "port",
+                                      "sample": f"the {distinct} distinct documents of this entry through oracle/liblorooracle.so, one pass, {min(32, cores, distinct)} threads of one process "
+                                                "(the pass that produced the expected results; threads of one process share a heap and scale worse than the headline's one process per core)"},
+                     "gpu_over_cpu": round(len(docs) / best / (distinct / t_cpu), 2),
+                     "parity": (f"first {distinct} results equal to the oracle's, all {len(docs)} succeeded" if name.endswith(("heterogeneous", "traces")) else f"all {len(docs)} results equal to the oracle's"),
                      "workload": desc}
 
     run("configs[0]", cfg1, None, 100, "100 docs x 2 peers x 1,000 sequential inserts, 2 blobs/doc")
@@ -332,6 +342,10 @@ def other_configs(device, cores):
     run("configs[1]-heterogeneous", mix, None, 64,
         "10,000 two-peer concurrent text documents of seven shapes interleaved (4k, 20k, 50k, 100k, 200k ops with fused changes; 10k and "
         f"40k ops with one change per keystroke): {sum(t.n_ops for t in tpls) // len(tpls)} ops/doc on average — per-wave load imbalance and divergent control flow")
+    ttr = [g[0] for g in gt]
+    run("configs[1]-128-traces", [ttr[(d * 7919) % len(ttr)].stamp(d) for d in range(10000)], None, 64,
+        "configs[1] at its stated size (10,000 docs x 100k ops, 2 concurrent peers, 3 blobs) from 128 DIFFERENT synthetic traces interleaved "
+        "pseudo-randomly, letters stamped per document: neighbouring waves replay different histories (the headline batch stamps one trace)")
     docs5, fr5 = [], []
     for blobs, fr in g5:
         docs5 += [blobs] * len(fr); fr5 += fr
@@ -584,7 +598,7 @@ def main():
             assert e.fetch() == got, "contexts disagree"
         if world == 1:
             import _oracle
-            n_chk = min(256, len(docs))
+            n_chk = min(2048, len(docs))   # (every document of the batch differs: B's letters are stamped per document)
             want = _oracle.merge_batch(docs[:n_chk], threads=min(32, os.cpu_count() or 1))
             assert got[:n_chk] == want, "device results differ from the CPU oracle"
         n_total = args.docs * world

@@ -4,6 +4,7 @@
 #include <memory>
 #include <thread>
 #include <map>
+#include <mutex>
 #include "lm_pipeline.h"
 #include "lm_encode.h"
 
@@ -145,11 +146,7 @@ int LM_API(import)(void* c, const lm_doc_in_c* docs, size_t n) {
 // computed: no resident run yet, a failed document, more than 16 common-ancestor ids), computed on the device by k_import_lca
 int LM_API(import_modes)(void* c, int32_t* modes) {
   auto* x = (lm_ctx_impl*)c;
-  x->for_docs([&](uint32_t i, lm::Engine& e, const lm::DocResult&) {
-    uint32_t k = i - 0;
-    (void)k;
-    modes[i] = -1;
-  });
+  for (size_t i = 0; i < x->n_docs; i++) modes[i] = -1;
   for (uint32_t p = 0; p < x->n_parts(); p++) {
     lm::Engine& e = *x->parts[p];
     for (uint32_t i = 0; i < e.n_docs; i++)
@@ -378,6 +375,7 @@ inline Api& api() {
 #endif
 struct lm_comm_state { int rank = 0, world = 1; void* comm = nullptr; };
 static std::map<void*, lm_comm_state>& lm_comms() { static std::map<void*, lm_comm_state> m; return m; }
+static std::mutex& lm_comms_mu() { static std::mutex m; return m; }   // contexts may be created / destroyed from several threads
 
 // rank 0 creates the id and hands it to the other ranks out of band (128 bytes)
 int LM_API(comm_unique_id)(uint8_t* out128) {
@@ -411,7 +409,7 @@ int LM_API(comm_init)(void* c, int rank, int world, const uint8_t* id128) {
     x->err = "the kernel-logic harness has no collective"; return -1;
 #endif
   }
-  lm_comms()[c] = st;
+  { std::lock_guard<std::mutex> lk(lm_comms_mu()); lm_comms()[c] = st; }
   return 0;
 }
 // doc_ids[n_docs] = the global ids of this context's documents; table receives rows of 6 int64 (layout above = loro_amd/dist.py
@@ -420,8 +418,8 @@ long LM_API(summary_allgather)(void* c, const int64_t* doc_ids, int64_t* table, 
   auto* x = (lm_ctx_impl*)c;
   try {
     if (!x->ran) throw std::runtime_error("lm_summary_allgather before lm_run");
-    auto it = lm_comms().find(c);
-    lm_comm_state st = it == lm_comms().end() ? lm_comm_state() : it->second;
+    lm_comm_state st;
+    { std::lock_guard<std::mutex> lk(lm_comms_mu()); auto it = lm_comms().find(c); if (it != lm_comms().end()) st = it->second; }
     size_t n = x->n_docs;
     std::vector<int64_t> local(n * 6);
     x->for_docs([&](uint32_t i, lm::Engine&, const lm::DocResult& r) {
@@ -467,13 +465,15 @@ long LM_API(summary_allgather)(void* c, const int64_t* doc_ids, int64_t* table, 
 }
 
 void LM_API(destroy)(void* c) {
-  auto it = lm_comms().find(c);
-  if (it != lm_comms().end()) {
-#ifndef LM_EMU
-    if (it->second.comm && lmcomm::api().destroy) (void)lmcomm::api().destroy(it->second.comm);
-#endif
-    lm_comms().erase(it);
+  lm_comm_state st;
+  {
+    std::lock_guard<std::mutex> lk(lm_comms_mu());
+    auto it = lm_comms().find(c);
+    if (it != lm_comms().end()) { st = it->second; lm_comms().erase(it); }
   }
+#ifndef LM_EMU
+  if (st.comm && lmcomm::api().destroy) (void)lmcomm::api().destroy(st.comm);
+#endif
   delete (lm_ctx_impl*)c;
 }
 // number of engine parts (HIP streams) the last staged batch was split into

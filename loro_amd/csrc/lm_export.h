@@ -69,7 +69,10 @@ inline std::vector<T> dec_any_rle_all(Rd r, F&& rv) {
   while (r.left()) {
     int64_t c = r.zigzag();
     if (c > 0) { T v = rv(r); if (c > (1 << 28)) throw std::runtime_error("Rle run too long"); out.insert(out.end(), (size_t)c, v); }
-    else if (c < 0) { for (int64_t i = 0; i < -c; i++) out.push_back(rv(r)); }
+    else if (c < 0) {   // literal run: every literal takes at least one byte (and -INT64_MIN does not exist)
+      if (c < -(int64_t)r.left()) throw std::runtime_error("Rle literal run longer than its bytes");
+      for (int64_t i = 0; i < -c; i++) out.push_back(rv(r));
+    }
     else throw std::runtime_error("Rle zero-length segment");
   }
   return out;
@@ -291,6 +294,7 @@ inline void cut_block(Block& b, uint32_t from, uint32_t to) {
       n_lam.push_back(b.lamport[i] + (sliced ? co : 0));
       n_self.push_back(sliced ? 1 : b.dep_on_self[i]);
       n_dc.push_back(sliced ? 0 : (uint32_t)nd);
+      if (dep_at + nd > b.dep_peer_idx.size() || dep_at + nd > b.dep_counter.size()) throw std::runtime_error("block: dependency rows do not match the dependency counts");
       if (!sliced) for (size_t d = 0; d < nd; d++) { n_dp.push_back(b.dep_peer_idx[dep_at + d]); n_dctr.push_back(b.dep_counter[dep_at + d]); }
       n_ts.push_back(b.timestamp[i]);
       n_ml.push_back((uint32_t)ml);

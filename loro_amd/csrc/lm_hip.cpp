@@ -8,6 +8,7 @@
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
+#include <map>
 #include "lm_wave.h"
 
 namespace lm { struct KernelTime; }
@@ -112,10 +113,12 @@ inline void check_launch(const char* name) {
 // launch: hipFuncSetAttribute is a driver round trip.  Per kernel function, whatever site launches it.)
 namespace lmbe {
 inline bool dyn_lds_needs_raise(const void* fn, size_t bytes) {
+  // (keyed by (device, function): the attribute belongs to the function as loaded on ONE device — a context on a second device
+  // of the same process must raise it again)
   static std::mutex mu;
-  static std::unordered_map<const void*, size_t> set;
+  static std::map<std::pair<int, const void*>, size_t> set;
   std::lock_guard<std::mutex> g(mu);
-  size_t& cur_max = set[fn];
+  size_t& cur_max = set[std::make_pair(cur ? cur->device : 0, fn)];
   if (bytes <= cur_max) return false;
   cur_max = bytes;
   return true;

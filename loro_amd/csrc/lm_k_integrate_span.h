@@ -113,6 +113,7 @@ static constexpr uint32_t LOC_W = LM_LOC_W;   // a power of two <= 64
 // stays a head; the nearest kept entry at or below an element of an item, inside its LOC_W-aligned counter window, is therefore an
 // element of the same item (ts_loc_find).  A flush writes 1 + len/16 entries per pending item instead of len.
 LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
+  if (!t.loc) return;   // loc[] is not kept yet (ts_build_loc): nothing can ask for an element by id while the replay is one chain
   uint32_t len = pend ? R.len : 0u;
   uint32_t c0 = pid_ctr(R.id);
   uint32_t g = pend ? t.ebase[pid_peer(R.id)] + c0 : 0u;
@@ -131,6 +132,7 @@ LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
 }
 // leaf of element `pid` (wave-uniform), NONE when no kept entry lies at or below it in its window
 LM_DEV uint32_t ts_loc_find(const Ts& t, uint32_t pid) {
+  if (!t.loc) return NONE;
   uint32_t ctr = pid_ctr(pid), lo = ctr & ~(LOC_W - 1), eb = t.ebase[pid_peer(pid)];
   uint32_t lane = (uint32_t)lmw::lane();
   uint32_t v = (lane < LOC_W && lo + lane <= ctr) ? t.loc[eb + lo + lane] : NONE;
@@ -827,13 +829,13 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       }
     }
     if (!hm) {
+      if (hint_k) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }   // the element at the row's position is not the row's target (see ts_del_pos_ok)
 #ifdef LM_LOC16
       uint32_t lf = ts_loc_find(t, x);
 #else
       uint32_t lf = lmw::first(t.loc[eb + c]);
 #endif
       PROF_CNT(t, 15, 1);   // status updates that went through loc[] (the target was not in the cached leaf)
-      if (hint_k) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }   // the element at the row's position is not the row's target (see ts_del_pos_ok)
       if (lf >= t.n_leaf || lf == t.cache_leaf) { c++; continue; }   // not an element of this container (malformed target): ignored
       // all five arrays are requested for all 64 slots right away; the directory lookup (LDS) runs while they are in
       // flight, and the item count then masks the unused slots.  The leaf becomes the cached leaf: a delete run arrives
@@ -1074,10 +1076,35 @@ LM_DEV void ts_reset_to_base(Ts& t, const uint32_t* s_base) {
 }
 // The tracker moves from s_cur to the version vv (the dependencies of the node about to be replayed): Tracker::checkout
 // (tracker.rs:354-461), peer by peer — or in one pass when vv is the tracker's base (above).  `conv`: k_dag_b flagged this node.
+// loc[] of every item the tracker holds, in one pass over its leaves.  A plain document's replay starts WITHOUT loc[]: while
+// its history is one chain nothing is ever looked up by id — delete rows carry their position, there is no future item for a
+// sibling scan to resolve, no op to retreat — so the flushes of the cached leaf write no loc[] entry (configs[1]: the 50k-op
+// base, 60 % of its rows; a document imported sequentially never pays for loc[] at all).  The first move of the tracker
+// (ts_goto) brings it up to date; from then on it is maintained as always.
+LM_DEV void ts_build_loc(Ts& t, uint32_t* loc_real) {
+  int lane = lmw::lane();
+  t.loc = loc_real;
+  lmw::wave_sync();
+  for (uint32_t q = 0; q < t.n_dir; q++) {
+    uint32_t a = lmw::first(t.da[q]);
+    uint32_t L = sa_leaf(a), n = sa_n(a);
+    if (L == t.cache_leaf) { t.loc_pend = (uint32_t)lane < t.cr.n ? 1u : 0u; continue; }   // (written with the leaf's next flush)
+    const uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+    bool in = (uint32_t)lane < n;
+    SpanRegs R;
+    R.n = n; R.id = in ? rec[lane] : NONE; R.len = in ? rec[64 + lane] : 0u; R.ol = NONE; R.orr = NONE; R.st = 0;
+    sp_set_loc_lanes(t, R, in, L);
+  }
+}
 template <bool ML, bool SWEEP>
 LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t P, const uint32_t* vv, uint32_t* s_cur, uint32_t* s_base,
-                    bool& base_on, bool conv) {
+                    bool& base_on, bool conv, uint32_t* loc_real) {
   int lane = lmw::lane();
+  if (!t.loc) {
+    bool mv = false;
+    for (uint32_t p = (uint32_t)lane; p < P; p += 64) mv |= s_cur[p] != vv[p];
+    if (conv || lmw::any(mv)) ts_build_loc(t, loc_real);
+  }
   bool reset = false;
   if (base_on) {
     bool same = true;
@@ -1123,7 +1150,7 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
         if (ln == 0) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u item %u has length 0\n", what, row, q, L, i); ok = false; }
         if (st_active(st)) act += ln;
         nf |= !(st & ST_FUT);
-        for (uint32_t k = 0; k < ln; k++) {
+        for (uint32_t k = 0; k < ln && t.loc; k++) {
 #ifdef LM_LOC16
           uint32_t expect = (k == 0 || ((id0 + k) & (LOC_W - 1)) == 0) ? L : NONE;   // kept entries only: heads and multiples of LOC_W
 #else
@@ -1198,6 +1225,12 @@ LM_DEV uint32_t* tk_cont(uint32_t* tk, uint32_t pcap, uint32_t c) { return tk + 
 // never occur there.
 #ifndef LM_INTEGRATE_WAVES
 #define LM_INTEGRATE_WAVES 5
+#endif
+#if defined(LM_LOC_FULL) && !defined(LM_LAZY_LOC)
+#define LM_LAZY_LOC 0     // (the per-element layout reads loc[] without going through ts_loc_find)
+#endif
+#ifndef LM_LAZY_LOC
+#define LM_LAZY_LOC 1     // 0: loc[] is kept from the first op on (rounds 1-3; A/B builds)
 #endif
 #ifndef LM_BASE_RESET
 #define LM_BASE_RESET 1   // 0: no base version — every move of the tracker goes row by row / by the insert sweep (rounds 1-3; A/B builds)
@@ -1380,6 +1413,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     }
     lmw::block_sync();
     bool touched = false;
+    t.loc = (PLAIN && !RES && LM_LAZY_LOC) ? nullptr : d.loc + elem0;   // (ts_build_loc)
     bool base_on = false;              // the tracker has a base version (s_base), ts_goto
     uint32_t* s_base = s_tgt;          // (not RES: the slot of the resident kernels' rendered version)
     for (uint32_t oi = 0; oi < m.n_nodes && !t.err; oi++) {
@@ -1410,7 +1444,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
           // carries no test for it (7 instructions per op row, 4 of them register moves in front of the branch)
           checked_out = true;
-          ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node);
+          ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0);
           PROF_ADD(t, PF_CHECKOUT);
           TS_CHECK("checkout", ch.op0);
         }
@@ -1426,7 +1460,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           uint32_t b = PLAIN ? r.len : (r.ctr + r.len <= pe ? r.len : pe - r.ctr);
           if (!(PLAIN && !RES) && !checked_out) {
             checked_out = true;
-            if (!RES) ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node);
+            if (!RES) ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0);
             else {
             for (uint32_t p = 0; p < P && !t.err; p++) {
               uint32_t cur = s_cur[p], tgt = vv[p];

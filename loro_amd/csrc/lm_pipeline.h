@@ -310,6 +310,7 @@ struct Engine {
     lmbe::sync();
     ran = fetched = false;
     resident = false; tables_valid = false;   // a new batch: whatever was resident is gone
+    have_prev = false; h_lca.clear();         // (lm_import_modes / lm_import_lca: nothing is known about the new batch's imports)
   }
 
   // ---- lm_import: more blobs (and / or other checkouts) for the documents of the resident batch
@@ -398,11 +399,32 @@ struct Engine {
   void import_more(const DocIn* docs, size_t nd) {
     lmbe::bind(sc);
     if (nd != n_docs) throw std::runtime_error("lm_import: the document count differs from the resident batch");
+    for (size_t i = 0; i < nd; i++)
+      if (docs[i].front && docs[i].front_len == 0) throw std::runtime_error("checkout_frontiers with zero length (the empty version is the byte 00)");
     read_knobs();
-    if (!resident) adopt_resident();
+    if (!resident) {
+      // The staged batch becomes the first generation of the resident documents — as ITS OWN import: `lm_stage; [lm_run;]
+      // lm_import(b); lm_run` is import_batch(staged) followed by import(b), two diffs for the state store (a root whose text the
+      // second import deletes stays, empty; loro.rs:568-649, state.rs:621-849), not one import_batch of everything.  A batch run
+      // (lm_run straight after lm_stage) records neither trackers nor the "state store holds this container" words, so the
+      // staged blobs are run once more here as the resident documents' first step.
+      // (lm_import straight after lm_stage, with no lm_run in between, asks for no state in between: staged and imported blobs
+      // then form the documents' first step together — one import_batch.)
+      const bool was_run = ran;
+      adopt_resident();
+      if (was_run && n_blobs) {
+        for (uint32_t i = 0; i < n_docs; i++) r_step[i] = (uint32_t)r_blobs[i].size();   // a document whose batch import failed is empty again afterwards (loro.rs:780-838)
+        run();
+        lmbe::bind(sc);
+      }
+    }
+    // Everything that can fail happens on temporaries: a rejected lm_import leaves the documents' blob lists, their checkouts and
+    // the arena exactly as they were (a half-recorded one handed the next import arena offsets that other documents' bytes
+    // already occupied).
     std::vector<std::vector<uint8_t>> conv;
     struct Src { const uint8_t* p; size_t l; uint64_t off; };
     std::vector<Src> src;
+    std::vector<std::vector<BlobRef>> add_refs(nd);
     uint64_t top = arena_top;
     for (size_t i = 0; i < nd; i++) {
       for (size_t k = 0; k < docs[i].n; k++) {
@@ -410,22 +432,23 @@ struct Engine {
         const uint8_t* p = snapshot_or_same(docs[i].blobs[k], l, conv);
         if (l > 0xfffffff0ull) throw std::runtime_error("blob larger than 4 GiB");
         src.push_back(Src{p, l, top});
-        r_blobs[i].push_back(BlobRef{top, (uint32_t)l});
-        r_step[i]++;
+        add_refs[i].push_back(BlobRef{top, (uint32_t)l});
         top += (l + 15) & ~(uint64_t)15;
       }
-      if (docs[i].front && docs[i].front_len == 0) throw std::runtime_error("checkout_frontiers with zero length (the empty version is the byte 00)");
-      std::vector<uint8_t> f;
-      if (docs[i].front) f.assign(docs[i].front, docs[i].front + docs[i].front_len);
-      r_front[i].swap(f);
+      // list values are addressed by 32-bit offsets from the document's first blob (cp[], lm_k_dag.h k_elem_fill)
+      if (!add_refs[i].empty()) {
+        uint64_t first = r_blobs[i].empty() ? add_refs[i].front().off : r_blobs[i].front().off;
+        if (add_refs[i].back().off + add_refs[i].back().len - first >= 0xfffffff0ull)
+          throw std::runtime_error("lm_import: a resident document's blobs span more than 4 GiB of the arena (stage the batch again)");
+      }
     }
     uint64_t add = top - arena_top;
     if (add) {
       if (add + 64 > h_stage_cap) {
+        uint8_t* nh = (uint8_t*)lmbe::halloc(add + add / 4 + 4096);
+        if (!nh) throw std::runtime_error("host staging allocation failed");
         if (h_stage) lmbe::hfree(h_stage);
-        h_stage_cap = add + add / 4 + 4096;
-        h_stage = (uint8_t*)lmbe::halloc(h_stage_cap);
-        if (!h_stage) { h_stage_cap = 0; throw std::runtime_error("host staging allocation failed"); }
+        h_stage = nh; h_stage_cap = add + add / 4 + 4096;
       }
       for (const Src& x : src) {
         uint64_t o = x.off - arena_top, pad = ((x.l + 15) & ~(uint64_t)15) - x.l;
@@ -435,9 +458,16 @@ struct Engine {
       memset(h_stage + add, 0, 64);
       b_data.ensure_keep(top + 64, arena_top);
       lmbe::h2d_async((uint8_t*)b_data.p + arena_top, h_stage, add + 64);
-      arena_top = top;
-      tables_valid = false;
     }
+    // commit
+    for (size_t i = 0; i < nd; i++) {
+      r_blobs[i].insert(r_blobs[i].end(), add_refs[i].begin(), add_refs[i].end());
+      r_step[i] += (uint32_t)add_refs[i].size();
+      std::vector<uint8_t> f;
+      if (docs[i].front) f.assign(docs[i].front, docs[i].front + docs[i].front_len);
+      r_front[i].swap(f);
+    }
+    if (add) { arena_top = top; tables_valid = false; }
     rebuild_blob_tables();
     lmbe::sync();
     ran = fetched = false;

@@ -205,3 +205,63 @@ def test_import_mode_and_common_ancestors_on_the_device():
         assert c.import_info() == [o.import_info()] == [("Import", wire.encode_frontiers([]))]
         c.import_more([[]]); c.run()
         assert c.import_info()[0][0] == "Linear"                                   # nothing imported: diff_calc.rs:150-152
+
+
+def test_stage_run_import_run_is_import_batch_then_import():
+    """The call order include/loro_merge.h documents: lm_stage([[a]]) + lm_run, then lm_import([[b]]) + lm_run = import_batch([a])
+    followed by import(b) — two diffs for the state store (the batch run records no tracker and no `exists` words, so the
+    staged blobs are run once more as the resident documents' first step when lm_import arrives)."""
+    a = wire.Replica(1)
+    a.text_insert("text", 0, "ab"); a.list_insert("list", 0, [1, 2]); a.map_set("map", "k", 1); a.commit()
+    first = a.export()
+    a.text_delete("text", 0, 2); a.list_delete("list", 0, 2); a.map_delete("map", "k"); a.commit()
+    second = a.export({1: a.changes[1][0].ctr_end})
+    b = wire.Replica(2)
+    b.text_insert("text", 0, "xyz"); b.commit()
+    other = b.export()
+    sess = _oracle.Session()
+    want = [sess.step([first], None), sess.step([second], None), sess.step([other], None)]
+    sess.close()
+    with Context(_emu.binding()) as c:
+        c.stage([[first], [first]])
+        c.run()
+        assert c.fetch()[0] == want[0]
+        c.import_more([[second], [second]])
+        c.run()
+        got1 = c.fetch()
+        c.import_more([[other], []])
+        c.run()
+        got2 = c.fetch()
+    assert got1[0] == want[1] and got1[1] == want[1]
+    assert got1[0][1] == b'{"list":[],"map":{},"text":""}'
+    assert got2[0] == want[2] and got2[1] == want[1]
+
+
+def test_rejected_import_leaves_the_documents_as_they_were():
+    """lm_import validates everything before it records anything: after a refused call (zero-length checkout frontiers for the LAST
+    document) the blob lists, checkouts and arena offsets are those of the last accepted call (the refused call's
+    BlobRefs stayed behind and the next import's bytes landed under them)."""
+    docs = []
+    for seed in (3, 4, 5):
+        r = wire.Replica(10 + seed)
+        r.text_insert("text", 0, "doc%d" % seed); r.commit()
+        docs.append(r)
+    firsts = [[r.export()] for r in docs]
+    for r in docs:
+        r.text_insert("text", 0, "more "); r.commit()
+    seconds = [[r.export({r.peer: r.changes[r.peer][0].ctr_end})] for r in docs]
+    want = []
+    for f, s in zip(firsts, seconds):
+        o = _oracle.Session(); o.step(f, None); want.append(o.step(s, None)); o.close()
+    with Context(_emu.binding()) as c:
+        c.stage(firsts)
+        c.run()
+        with pytest.raises(RuntimeError):
+            c.import_more(seconds, [None, None, b""])
+        c.import_more([[], seconds[1], []])
+        c.run()
+        mid = c.fetch()
+        assert mid[1] == want[1] and mid[0][3] == 0 and mid[2][3] == 0 and all(m[0] == 0 for m in mid)
+        c.import_more([seconds[0], [], seconds[2]])
+        c.run()
+        assert c.fetch() == want
