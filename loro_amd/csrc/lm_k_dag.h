@@ -163,6 +163,7 @@ LM_KERNEL void k_remap(Dev d, uint32_t n_ops, uint32_t n_chg) {
       uint32_t ci = d.cid_map[bo[BC_CID] + local];
       r.cidx_kind = ci | (kind << 16);
       if (kind == OK_DEL || kind == OK_LIST_MOVE || kind == OK_LIST_SET) r.a0 = d.peer_map[bo[BC_PEER] + r.a0];
+      else if (kind == OK_MAP_SET || kind == OK_MAP_DEL) r.a0 = bo[BC_KEY] + (uint32_t)r.prop;   // the row's key row (the LWW kernels: no trip through op_blk → boff)
       d.op[t] = r;
       m_chg = r.chg; m_bit = ci & 63;
     }
@@ -383,16 +384,14 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     g.node_done[m.chg0 + n] = 0;
   }
   // number of Map op rows (sizes the doc's LWW hash table)
+  // (from the blocks' descriptors: the decoders count their rows by kind as they write them — lm_k_decode.h kc_add.  MovableList
+  // move / set rows compete per element in the same LWW table, a move also places a new list item; rows of containers outside the
+  // device scope count too: the LWW stage is what marks their containers, and a batch without any such row skips it)
   uint32_t n_map = 0, n_el = 0, n_style = 0;
-  for (uint32_t i = (uint32_t)lane; i < m.n_op; i += 64) {
-    const OpRow& r = d.op[m.op0 + i];
-    uint32_t k = (r.cidx_kind >> 16) & 0xff;
-    // (MovableList move / set rows compete per element in the same LWW table; a move also places a new list item)
-    // (rows of containers outside the device scope count too: k_map_lww is what marks their containers, and a batch without any
-    // such row skips that kernel — it reads every op row of the batch, 0.75 GB per configs[1] launch)
-    n_map += (k == OK_MAP_SET || k == OK_MAP_DEL || k == OK_LIST_MOVE || k == OK_LIST_SET || k == OK_OTHER) ? 1u : 0u;
-    n_el += (k == OK_TEXT_INS || k == OK_LIST_INS || k == OK_STYLE_START || k == OK_STYLE_END) ? r.len : (k == OK_LIST_MOVE ? 1u : 0u);
-    n_style += (k == OK_STYLE_START || k == OK_STYLE_END) ? 1u : 0u;
+  for (uint32_t i = (uint32_t)lane; i < m.n_blk; i += 64) {
+    const BlockDesc& kb = d.blk[m.blk0 + i];
+    if (kb.status != ST_OK) continue;
+    n_map += kb.flags & 0x7fffffffu; n_el += kb.pad; n_style += kb.flags >> 31;
   }
   bool has_ml = false;
   for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) has_ml |= (d.cont[m.cid0 + c].kind_root & 0xff) == CK_MOVABLE;

@@ -92,6 +92,8 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* ht_list;            // per doc [ht0, ht0+cap): lower half = slots claimed (one per distinct key), upper half = sort scratch
   uint32_t* ht_cnt;             // per doc number of claimed slots
   unsigned long long* prof;     // [doc*16 + slot] cycle accounting (LM_PROF builds)
+  uint32_t* dec_stat;           // [0] blocks whose head (everything before the value payloads) exceeds dec_slot bytes, [1] the largest such head, [2] the largest span of such a block's op / delete-start columns
+  uint32_t dec_slot;            // the decoder's default LDS slot (k_block_count compares against it)
   // outputs
   uint8_t* out;          // JSON bytes
   uint64_t* out_off;     // per doc offset (n_docs+1)
@@ -151,7 +153,9 @@ LM_KERNEL void k_frame_count(Dev d) {
   d.blob_nblk[b] = nblk;
 }
 
-// K2: one lane per blob — write a BlockDesc per block (postcard struct head + section extents).
+// K2a: one lane per blob — where every block of the blob begins (the frames are a chain: `uleb len + block`, fast_snapshot.rs:372-400).
+// Only the chain is walked here; the blocks' descriptors are filled in parallel by k_block_desc (a 2.4 MB blob holds 400 blocks:
+// parsed one after the other by this one lane they were 7 ms of a configs[2] batch).
 LM_KERNEL void k_frame_fill(Dev d) {
   uint32_t b = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
   if (b >= d.n_blobs) return;
@@ -162,30 +166,39 @@ LM_KERNEL void k_frame_fill(Dev d) {
   Rd r = rd_make(p + 22, len - 22);
   uint32_t bi = d.blob_blk0[b];
   uint32_t nblk = d.blob_nblk[b];
+  uint32_t doc = d.blob_doc[b];
   for (uint32_t k = 0; k < nblk; k++, bi++) {
     uint64_t bl = rd_uleb(r);
-    Rd q = rd_make(r.p, bl);
-    BlockDesc bd;
-    bd.base = (uint64_t)(r.p - d.data);
-    bd.blob = b;
-    bd.doc = d.blob_doc[b];
-    uint64_t cs = rd_uleb(q), cl = rd_uleb(q), ls = rd_uleb(q), ll = rd_uleb(q), nc = rd_uleb(q);
-    bd.status = ST_OK;
-    bd.flags = 0; bd.pad = 0;
-    if (cs > 0x7fffffffull || cl > 0x7fffffffull || ls > 0xffffffffull || ll > 0xffffffffull || nc > 0x7fffffffull || nc == 0)
-      bd.status = ST_DECODE_ERROR;
-    if (cs + cl > MAX_COUNTER) bd.status = bd.status ? bd.status : ST_UNSUPPORTED;
-    bd.counter_start = (uint32_t)cs; bd.counter_len = (uint32_t)cl;
-    bd.lamport_start = (uint32_t)ls; bd.lamport_len = (uint32_t)ll; bd.n_changes = (uint32_t)nc;
-    for (int s = 0; s < (int)SEC_N; s++) {
-      Rd sec = rd_bytes(q);
-      bd.sec_rel[s] = (uint32_t)(sec.p - r.p);
-      bd.sec_len[s] = (uint32_t)rd_left(sec);
-    }
-    if (q.bad) bd.status = ST_DECODE_ERROR;
-    d.blk[bi] = bd;
-    r.p += bl;
+    BlockDesc* o = d.blk + bi;
+    o->base = (uint64_t)(r.p - d.data);
+    o->blob = b;
+    o->doc = doc;
+    o->pad = (uint32_t)bl;     // (the block's length, for k_block_desc; a frame is shorter than its blob, a blob shorter than 4 GiB)
+    r.p += bl;                 // (k_frame_count checked every frame against the blob's end)
   }
+}
+// K2b: one lane per block — the postcard struct head and the section extents (block_encode.rs:94-119).
+LM_KERNEL void k_block_desc(Dev d) {
+  uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (bi >= d.n_blocks) return;
+  BlockDesc bd = d.blk[bi];
+  const uint8_t* p0 = d.data + bd.base;
+  Rd q = rd_make(p0, bd.pad);
+  uint64_t cs = rd_uleb(q), cl = rd_uleb(q), ls = rd_uleb(q), ll = rd_uleb(q), nc = rd_uleb(q);
+  bd.status = ST_OK;
+  bd.flags = 0; bd.pad = 0;
+  if (cs > 0x7fffffffull || cl > 0x7fffffffull || ls > 0xffffffffull || ll > 0xffffffffull || nc > 0x7fffffffull || nc == 0)
+    bd.status = ST_DECODE_ERROR;
+  if (cs + cl > MAX_COUNTER) bd.status = bd.status ? bd.status : ST_UNSUPPORTED;
+  bd.counter_start = (uint32_t)cs; bd.counter_len = (uint32_t)cl;
+  bd.lamport_start = (uint32_t)ls; bd.lamport_len = (uint32_t)ll; bd.n_changes = (uint32_t)nc;
+  for (int s = 0; s < (int)SEC_N; s++) {
+    Rd sec = rd_bytes(q);
+    bd.sec_rel[s] = (uint32_t)(sec.p - p0);
+    bd.sec_len[s] = (uint32_t)rd_left(sec);
+  }
+  if (q.bad) bd.status = ST_DECODE_ERROR;
+  d.blk[bi] = bd;
 }
 
 LM_DEV Rd blk_sec(const Dev& d, const BlockDesc& bd, int s) {
@@ -244,6 +257,14 @@ LM_KERNEL void k_block_count(Dev d) {
   }
   if (bad) { d.blk[bi].status = ST_DECODE_ERROR; return; }
   (void)nmap;
+  {   // heads beyond the decoder's default LDS slot (Map blocks with hundreds of keys, blocks of thousands of changes): the host
+      // launches the decoder a second time, with larger slots, for the groups that hold one (lm_pipeline.h)
+    uint32_t span = (uint32_t)(bd.base & 15) + bd.sec_rel[SEC_VALUES];
+    if (d.dec_stat && span > d.dec_slot) {
+      lmw::atomic_add(&d.dec_stat[0], 1u); lmw::atomic_max32(&d.dec_stat[1], span);
+      lmw::atomic_max32(&d.dec_stat[2], (uint32_t)((bd.base + bd.sec_rel[SEC_OPS]) & 15) + bd.sec_rel[SEC_VALUES] - bd.sec_rel[SEC_OPS]);   // … and of its op / delete-start columns alone
+    }
+  }
   c[BC_CHG] = N;
   c[BC_DEP] = (uint32_t)ndep;
   c[BC_OP] = (uint32_t)nops;
@@ -312,6 +333,17 @@ LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
 }
 
 // K4: one lane per block — full decode into the row tables (block-local indices; K6 remaps them).
+// Per-block row statistics both decoders leave in the block's descriptor for k_dag_a (which used to read every op row of the
+// document again just to count them — 10 GB per configs[2] batch): BlockDesc.flags = rows that compete in the LWW table (Map
+// sets / deletes, MovableList moves / sets, rows of containers outside the device scope) | bit 31: the block holds a style
+// anchor; BlockDesc.pad = elements its rows insert (the length of insert / anchor rows, one per move).
+LM_DEV void kc_add(uint32_t& n_map, uint32_t& n_el, uint32_t& n_style, uint32_t k, uint32_t len) {
+  n_map += (k == OK_MAP_SET || k == OK_MAP_DEL || k == OK_LIST_MOVE || k == OK_LIST_SET || k == OK_OTHER) ? 1u : 0u;
+  n_el += (k == OK_TEXT_INS || k == OK_LIST_INS || k == OK_STYLE_START || k == OK_STYLE_END) ? len : (k == OK_LIST_MOVE ? 1u : 0u);
+  n_style += (k == OK_STYLE_START || k == OK_STYLE_END) ? 1u : 0u;
+}
+LM_DEV uint32_t kc_pack(uint32_t n_map, uint32_t n_style) { return (n_map & 0x7fffffffu) | (n_style ? 0x80000000u : 0u); }
+
 LM_KERNEL void k_block_decode(Dev d) {
   uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
   if (bi >= d.n_blocks) return;
@@ -324,6 +356,7 @@ LM_KERNEL void k_block_decode(Dev d) {
   uint32_t n_peers = cnt[BC_PEER], n_ops = cnt[BC_OP], n_keys = cnt[BC_KEY], n_cids = cnt[BC_CID];
   int32_t st = ST_OK;
   bool unsupported = false;
+  uint32_t kc_map = 0, kc_el = 0, kc_style = 0;   // (kc_add)
   // ---- header
   Rd h = blk_sec(d, bd, SEC_HEADER);
   (void)rd_uleb(h);
@@ -572,6 +605,7 @@ LM_KERNEL void k_block_decode(Dev d) {
         }
       }
       r.cidx_kind |= kind << 16;
+      kc_add(kc_map, kc_el, kc_style, kind, (uint32_t)len);
       d.op[op0 + row] = r;
       d.op_val[op0 + row] = val_at;
       d.op_blk[op0 + row] = bi;
@@ -592,6 +626,7 @@ LM_KERNEL void k_block_decode(Dev d) {
   }
   if (st == ST_OK && unsupported) st = ST_UNSUPPORTED;
   d.blk[bi].status = st;
+  d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = kc_el;
 }
 
 }  // namespace lm

@@ -18,7 +18,8 @@
 //    Header, change meta, keys and container ids (small, sequential by format) are parsed by role 0 of every block
 //    before the row loop.
 //  * nothing lives in scratch: the nested-value frame stack of role 7 is in LDS.
-// A block whose head exceeds the slot (thousands of changes or keys) is decoded by the same code straight from HBM.
+// A block whose head exceeds the slot (thousands of changes or keys) has its op / delete-start columns staged alone; one whose
+// columns do not fit either is decoded by the same code straight from HBM.
 // Reference: decode_block block_encode.rs:535-706, decode_changes_header block_meta_encode.rs:90-242,
 // decode_op outdated_encode_reordered.rs:215-476.  Output tables are identical to k_block_decode's.
 #pragma once
@@ -27,6 +28,9 @@ namespace lm {
 
 #ifndef LM_DEC_G
 #define LM_DEC_G 8
+#endif
+#ifndef LM_NO_PARTIAL_STAGE
+#define LM_NO_PARTIAL_STAGE 0   // 1: a block whose head exceeds the LDS slot is not staged at all (rounds 2-3; A/B builds)
 #endif
 static constexpr uint32_t DEC_G = LM_DEC_G;     // blocks per wave (8 lanes each; -DLM_DEC_G=4: half the lanes idle, half the LDS per wave — twice the waves per CU)
 static constexpr uint32_t DEC_R = 8;            // rows per chunk (one lane per row in the assembly phase)
@@ -45,7 +49,11 @@ LM_DEV void dec_err(uint32_t& key, uint32_t row, uint32_t prio, int32_t code) {
 #define DEC_PH(i) do {} while (0)
 #endif
 // (the LDS slots bound the occupancy at ≈2.5 waves per SIMD: a register budget for three — 168 VGPRs — costs nothing and keeps everything out of scratch)
-LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d, uint32_t slot_cap) {
+// (head_lo, head_hi]: the launch takes the groups whose largest head span lies in that range — the host launches the kernel once
+// for every batch and a second time, with larger slots, when k_block_count met heads beyond the default slot (a batch of Map
+// documents: every block carries a key table of a few KB; parsed from HBM by one lane, key after key, those tables were half of
+// configs[2]'s decode).  Each group is decoded by exactly one of the launches; the other's wave leaves at once.
+LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d, uint32_t slot_cap, uint32_t head_lo, uint32_t head_hi) {
   int lane = lmw::lane();
 #ifdef LM_PROF_DEC
   uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptp = lmw::clock();   // 0 stage, 1 head (role 0), 2 cursors, 3 A1, 4 T + A2, 5 W, 6 B, 7 close
@@ -68,11 +76,28 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
   // ---- stage the block up to its value payloads: header | change_meta | cids | keys | positions | ops | delete_start_ids.
   // The payload bytes (mostly text) are not needed here — the walker only reads each value's length prefix, straight from
   // HBM (one monotonic cursor per block: 8 hot lines per wave) — so a slot of `slot_cap` bytes per block is enough.
-  uint64_t org = bd.base & ~(uint64_t)15;
+  // A head that does not fit the slot — a block of Map writes carries its own key table, hundreds of keys — still has its op and
+  // delete-start COLUMNS staged when those fit (they are the last two sections of the head): header / meta / cids / keys are then
+  // parsed from HBM by role 0, once, and the row loop's cursors read LDS as for any other block.  (Unstaged, every cursor of the
+  // block chases bytes through HBM — and slows the trips of all eight blocks of its wave: configs[2] spent 57 of its 118 ms here.)
+  // Every LDS address is formed as slot + (non-negative offset): a generic pointer rebased to the block's first byte would lie
+  // BELOW the LDS aperture for a block staged from its ops section on, and a flat access whose base register is outside the
+  // aperture goes to global memory whatever its immediate offset adds (the round-3 attempt died on the GPU this way).
   uint32_t head_len = ok ? bdp->sec_rel[SEC_VALUES] : 0u;          // bytes of the block before the values section
-  uint32_t span = ok ? (uint32_t)(bd.base - org) + head_len : 0u;  // staged bytes, from the 16-byte boundary below the block
-  bool staged = ok && span <= slot_cap;
+  {
+    uint32_t gmax = lmw::reduce_max(ok ? (uint32_t)(bd.base & 15) + head_len : 0u);
+    if (!(gmax > head_lo && gmax <= head_hi) && !(gmax == 0 && head_lo == 0)) return;   // the other launch's group
+  }
+  const bool head_fits = ok && (uint32_t)(bd.base & 15) + head_len <= slot_cap;
+  const uint32_t from = (!ok || head_fits || LM_NO_PARTIAL_STAGE) ? 0u : bdp->sec_rel[SEC_OPS];   // first staged byte of the block
+  const uint64_t org = (bd.base + from) & ~(uint64_t)15;           // staged bytes start at the 16-byte boundary below it
+  uint32_t span = ok ? (uint32_t)(bd.base + head_len - org) : 0u;
+  bool staged = ok && span <= slot_cap;                            // the op / delete-start columns sit in LDS
+  const bool head_lds = staged && from == 0;                       // … and so does the rest of the head
   uint8_t* slot = (uint8_t*)s_mem + (size_t)b * slot_cap;
+#ifdef LM_EMU_TRACE
+  if (getenv("LM_EMU_STAGE") && ok && r == 0) fprintf(stderr, "STAGE %s head %u cols %u slot %u\n", head_lds ? "whole" : staged ? "columns" : "none", head_len, head_len - bdp->sec_rel[SEC_OPS], slot_cap);
+#endif
   if (staged) {
     struct V16 { uint32_t x, y, z, w; };
     const V16* gsrc = (const V16*)(d.data + org);
@@ -83,9 +108,13 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
   lmw::block_sync();
   DEC_PH(0);
   if (!lmw::any(ok)) return;   // no decodable block in the group
-  const uint8_t* blk_p = staged ? (const uint8_t*)slot + (bd.base - org) : d.data + bd.base;   // first byte of the block
-  auto sec = [&](int s_) { return rd_make(blk_p + bdp->sec_rel[s_], bdp->sec_len[s_]); };
-  auto abs_of = [&](const uint8_t* p) { return (uint64_t)(p - blk_p) + bd.base; };
+  auto sec = [&](int s_) {
+    const uint64_t at = bd.base + bdp->sec_rel[s_];   // absolute offset of the section
+    const bool lds = head_lds || (staged && (s_ == (int)SEC_OPS || s_ == (int)SEC_DEL));
+    return rd_make(lds ? (const uint8_t*)slot + (uint32_t)(at - org) : d.data + at, bdp->sec_len[s_]);
+  };
+  auto abs_of = [&](const uint8_t* p) { return head_lds ? (uint64_t)(p - (const uint8_t*)slot) + org : (uint64_t)(p - d.data); };   // (head sections only)
+  const uint8_t* const blk_p = d.data;   // (start value of readers that are set later)
 
   const uint32_t* off = d.boff + (uint64_t)(have ? bi : 0) * BCN;
   const uint32_t* cnt = d.bcnt + (uint64_t)(have ? bi : 0) * BCN;
@@ -230,6 +259,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
   ColCur fcol = col_make((lm_lds_bytes)slot, 0, 0, false);   // the same cursor for a staged block (LDS offsets, lean varints)
   bool has_del = false;
   uint32_t errk = 0xffffffffu;   // earliest row error of this lane
+  uint32_t kc_map = 0, kc_el = 0, kc_style = 0;   // this lane's rows (phase B: lane = (block, row of the chunk)), lm_k_decode.h kc_add
   bool shape_bad = false;        // ops / delete section framing
   if (ok) {
     Rd o = sec(SEC_OPS);
@@ -534,6 +564,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
         else { orow.a0 = sx[r * 8 + 4]; orow.a1 = sx[r * 8 + 5]; orow.a2 = (int32_t)sx[r * 8 + 6]; }
       }
       orow.cidx_kind |= kind << 16;
+      kc_add(kc_map, kc_el, kc_style, kind, len);
       d.op[op0 + row] = orow;
       d.op_val[op0 + row] = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
       d.op_blk[op0 + row] = bi;
@@ -558,6 +589,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
     uint32_t oe = lmw::shfl_xor(errk, m), ot = lmw::shfl_xor(tail, m);
     errk = oe < errk ? oe : errk;
     tail |= ot;
+    kc_map += lmw::shfl_xor(kc_map, m); kc_el += lmw::shfl_xor(kc_el, m); kc_style += lmw::shfl_xor(kc_style, m);
   }
   if (ok && r == 0) {
     if (st == ST_OK && (tail & 8)) st = ST_DECODE_ERROR;
@@ -566,6 +598,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
     if (st == ST_OK && (tail & 2)) st = ST_DATA_CORRUPTION;
     if (st == ST_OK && (tail & 4)) st = ST_UNSUPPORTED;
     d.blk[bi].status = st;
+    d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = kc_el;
   }
 #ifdef LM_PROF_DEC
   DEC_PH(7);

@@ -33,7 +33,7 @@ LM_DEV int bytes_cmp(const uint8_t* a, uint32_t na, const uint8_t* b, uint32_t n
 // history writes few keys many times, and a table sized for the rows is megabytes per document that every probe misses the caches
 // in); a document that claims more than half of its slots is flagged DF_LWW_RETRY and counted in retry_count[2]: the host gives it
 // a table sized for its rows and launches the kernel again for those documents only (`only_retry`).
-LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops, uint32_t* retry_count, uint32_t only_retry) {
+LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops, uint32_t* retry_count, uint32_t only_retry, uint32_t skip_lds) {
   uint32_t t = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
   if (t >= n_ops) return;
   OpRow r = d.op[t];
@@ -44,6 +44,8 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops, uint32_t* retry_count, uint32_t 
   uint32_t doc = d.blk[blk].doc;
   const DocMeta& m = d.doc[doc];
   if (status_fatal(m.status)) return;
+  // (skip_lds: the documents whose table fits LDS were resolved by k_map_lww_doc, lm_k_lww_doc.h — 2,048 = its LWW_LDS_CAP)
+  if (skip_lds && !only_retry && d.ht_cap[doc] <= 2048u && !(m.flags & DF_MOVABLE)) return;
   const ChangeRow& ch = d.chg[r.chg];
   if (kind == OK_OTHER) {
     // an applied op of a container outside the device scope (Tree / Counter): the container is known to
@@ -69,7 +71,7 @@ LM_KERNEL void k_map_lww(Dev d, uint32_t n_ops, uint32_t* retry_count, uint32_t 
   // checked-out documents: writes after the version do not compete (MapHistoryCache::get_container_latest_op_at_vv,
   // history_cache.rs:630-703); the container itself stays known to the state store
   if (r.ctr >= d.peer_end[m.praw0 + ch.peer]) { d.cont[m.cid0 + cidx].touched = 1; return; }
-  uint32_t krow = d.boff[(uint64_t)blk * BCN + BC_KEY] + (uint32_t)r.prop;
+  uint32_t krow = r.a0;   // (k_remap: the block's first key row + prop)
   const uint8_t* ks = d.data + d.key_off[krow];
   uint32_t kl = d.key_len[krow];
   uint64_t h = fnv1a(ks, kl, 0xcbf29ce484222325ull ^ cidx);
@@ -962,6 +964,80 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
               g_lim_lo = (uint32_t)lim_o; g_lim_hi = (uint32_t)(lim_o >> 32); g_voff_lo = (uint32_t)vo; g_voff_hi = (uint32_t)(vo >> 32);
             }
           }
+#ifndef LM_NO_EMIT_MAP_FAST
+          if (e == g_base) {
+            // 64 entries at once, one per lane, when every one of them is PLAIN: a key of at most 24 bytes that needs no escape and
+            // an integer / bool / null value — what an LWW map of counters, flags and ids holds.  Each lane formats its own entry
+            // and the wave writes them side by side (one scan of the lengths).  Entry by entry the wave spent ≈30 single-byte
+            // stores of lane 0 and a handful of dependent loads on each of a configs[2] document's 1,024 entries.  Anything else in
+            // the group — a long or escaped key, a string / float / nested value, a child container — and the group is rendered
+            // entry by entry below.
+            const uint32_t ge = e + (uint32_t)lane;
+            const bool act = ge < K;
+            bool plain = true;
+            uint32_t vlen = 0, lit = 0, nd = 0;
+            uint64_t dg0 = 0, dg1 = 0, dg2 = 0;   // decimal digits, least significant first, one per byte
+            bool neg = false;
+            const uint8_t* kp = d.data + (((uint64_t)g_koff_hi << 32) | g_koff_lo);
+            if (act) {
+              if (g_klen > 24) plain = false;
+              else for (uint32_t i = 0; i < g_klen; i++) { uint32_t c = kp[i]; if (c < 0x20 || c == '"' || c == '\\') plain = false; }
+              const uint8_t* vp = d.data + (((uint64_t)g_voff_hi << 32) | g_voff_lo);
+              const uint8_t* vl = d.data + (((uint64_t)g_lim_hi << 32) | g_lim_lo);
+              if (vp >= vl) plain = false;
+              else {
+                uint32_t tag = *vp;
+                if (tag == 0) { lit = 1; vlen = 4; }
+                else if (tag == 1) { lit = 2; vlen = 4; }
+                else if (tag == 2) { lit = 3; vlen = 5; }
+                else if (tag == 3) {
+                  Rd vr = rd_make(vp + 1, (uint64_t)(vl - (vp + 1)));
+                  int64_t v = rd_sleb(vr);
+                  if (vr.bad) plain = false;
+                  neg = v < 0;
+                  uint64_t u = neg ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+                  uint64_t q1 = u / 1000000000ull, q2 = q1 / 1000000000ull;
+                  uint32_t c0 = (uint32_t)(u - q1 * 1000000000ull), c1 = (uint32_t)(q1 - q2 * 1000000000ull), c2 = (uint32_t)q2;
+                  const int top = c2 ? 2 : (c1 ? 1 : 0);
+                  for (int ci = 0; ci <= top; ci++) {
+                    uint32_t c = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
+                    for (int i = 0; i < 9 && (ci < top || c || i == 0); i++) {
+                      uint64_t dgt = '0' + c % 10u;
+                      c /= 10u;
+                      if (nd < 8) dg0 |= dgt << (8 * nd); else if (nd < 16) dg1 |= dgt << (8 * (nd - 8)); else dg2 |= dgt << (8 * (nd - 16));
+                      nd++;
+                    }
+                  }
+                  vlen = nd + (neg ? 1u : 0u);
+                } else plain = false;
+              }
+            }
+            if (!lmw::any(act && !plain)) {
+              uint32_t len = act ? (ge ? 1u : 0u) + 2u + g_klen + 1u + vlen : 0u;
+              uint32_t inc = lmw::scan_incl_add(len);
+              uint32_t tot = lmw::bcast(inc, 63);
+              if (s.out && s.pos + tot <= s.cap && act) {
+                uint8_t* o = s.out + s.pos + (inc - len);
+                if (ge) *o++ = ',';
+                *o++ = '"';
+                for (uint32_t i = 0; i < g_klen; i++) *o++ = kp[i];
+                *o++ = '"'; *o++ = ':';
+                if (lit == 1) { o[0] = 'n'; o[1] = 'u'; o[2] = 'l'; o[3] = 'l'; }
+                else if (lit == 2) { o[0] = 't'; o[1] = 'r'; o[2] = 'u'; o[3] = 'e'; }
+                else if (lit == 3) { o[0] = 'f'; o[1] = 'a'; o[2] = 'l'; o[3] = 's'; o[4] = 'e'; }
+                else {
+                  if (neg) *o++ = '-';
+                  for (uint32_t j = nd; j-- > 0;) *o++ = (uint8_t)(j < 8 ? dg0 >> (8 * j) : (j < 16 ? dg1 >> (8 * (j - 8)) : dg2 >> (8 * (j - 16))));
+                }
+              }
+              s.pos += tot;
+              uint32_t n_grp = K - e < 64 ? K - e : 64u;
+              e += n_grp - 1;       // (the loop's own increment takes the last step)
+              g_base = NONE;
+              continue;
+            }
+          }
+#endif
           int gj = (int)(e - g_base);
           uint32_t row = lmw::bcast(g_row, gj), vblk = lmw::bcast(g_blk, gj);
           uint64_t koff = ((uint64_t)lmw::bcast(g_koff_hi, gj) << 32) | lmw::bcast(g_koff_lo, gj);

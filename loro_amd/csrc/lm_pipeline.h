@@ -17,6 +17,7 @@
 #include <stdexcept>
 #include "lm_k_scan.h"
 #include "lm_k_emit.h"
+#include "lm_k_lww_doc.h"
 #include "lm_k_lca.h"
 #include "lm_snapshot.h"
 #include "lm_export.h"
@@ -136,19 +137,22 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 8192; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048; bool lww_lds = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
     if (const char* e = getenv("LM_PLAIN")) k.plain = atoi(e);
     if (const char* e = getenv("LM_DECODE")) k.decode_wave = atoi(e) != 0;
     if (const char* e = getenv("LM_DEC_SLOT")) k.dec_slot = ((uint32_t)atoi(e) + 15u) & ~15u;   // LDS bytes per block for everything before its value payloads (per 5k configs[1] documents: 512 5.4 ms, 1024 4.5, 1280 4.2, 1536 4.9, 2048 5.7 — occupancy against the share of heads that fit; larger heads are read from HBM)
+    if (const char* e = getenv("LM_DEC_SLOT_BIG")) k.dec_slot_big = ((uint32_t)atoi(e) + 15u) & ~15u;   // slot of the second decoder launch (groups with a head beyond LM_DEC_SLOT); 0: one launch, as in rounds 2-3
+    if (const char* e = getenv("LM_DEC_BIG_MODE")) k.dec_big_mode = (uint32_t)atoi(e);
     if (const char* e = getenv("LM_LDS_PAD")) k.lds_pad = (size_t)atoi(e);                       // occupancy experiments only
     k.no_opt_dir = getenv("LM_NO_OPT_DIR") != nullptr;
     if (const char* e = getenv("LM_LOC_MEMSET")) k.loc_memset = atoi(e) != 0;
     if (const char* e = getenv("LM_DIR_OPT_MAX")) k.dir_opt_max = (uint32_t)atoi(e);             // tests: force the retry launch
     if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
     if (const char* e = getenv("LM_HT_OPT")) k.ht_opt = (uint32_t)atoi(e);                       // slots of a document's optimistic LWW table (a power of two; 0: sized for its Map rows at once; tests: 64 forces the second pass)
+    if (const char* e = getenv("LM_LWW_LDS")) k.lww_lds = atoi(e) != 0;                          // 0: every document's Map rows go through the HBM tables (k_map_lww), as in rounds 1-3
     kn = k;
   }
 
@@ -560,6 +564,8 @@ struct Engine {
     {
       std::vector<uint32_t> big;
       for (uint32_t i = 0; i < n_blobs; i++) if (h_blob_len[i] >= BIG_BLOB) big.push_back(i);
+      // longest first: xxh32 is a serial chain per blob (≈2 ms for 2.4 MB) — a long one that starts last IS the stage's duration
+      std::stable_sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) { return h_blob_len[a] > h_blob_len[b]; });
       b_blob_hash.ensure((size_t)n_blobs * 4 + 4);
       d.blob_hash = b_blob_hash.as<uint32_t>();
       if (!big.empty()) {
@@ -582,11 +588,17 @@ struct Engine {
     d.boff = b_boff.as<uint32_t>();
     lmbe::tic(profiling);
     if (n_blobs) LM_LAUNCH(k_frame_fill, cdiv(n_blobs, 64), 64, d);
+    if (NB) LM_LAUNCH(k_block_desc, cdiv(NB, 64), 64, d);
+    b_tot.ensure(64 * 4);
+    d.dec_stat = b_tot.as<uint32_t>() + 48; d.dec_slot = kn.dec_slot;
+    lmbe::dmemset(d.dec_stat, 0, 12);
     if (NB) LM_LAUNCH(k_block_count, cdiv(NB, 64), 64, d);
     lmbe::toc("k_frame_fill+k_block_count", times, profiling);
     scan(d.bcnt, d.boff, NB, BCN);
     uint32_t tot[BCN];
     lmbe::d2h(tot, d.boff + (uint64_t)NB * BCN, sizeof tot);
+    uint32_t dec_stat[3] = {0, 0, 0};
+    lmbe::d2h(dec_stat, d.dec_stat, 12);
     uint32_t ND = tot[BC_DEP], NK = tot[BC_KEY];
     NC = tot[BC_CHG]; NO = tot[BC_OP]; NCID = tot[BC_CID]; NP = tot[BC_PEER];
     // 3. row tables
@@ -635,7 +647,18 @@ struct Engine {
       if (!kn.decode_wave) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
       else {
         uint32_t slot_cap = kn.dec_slot;
-        LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_cap);
+        // heads beyond the default slot: those groups get a launch of their own.  LM_DEC_BIG_MODE=1 (default): slots sized for their
+        // op / delete-start COLUMNS (the head is parsed from HBM by role 0) — the decoder is bound by its dependent round trips at
+        // the occupancy its LDS allows, and a Map block's columns (≈650 bytes) need half the default slot: measured on configs[2],
+        // 2,048 documents: one launch 50.7 ms; slots of 4 KB for the whole heads 116 ms (4 waves per CU).  =2: slots sized for the
+        // largest head, capped by LM_DEC_SLOT_BIG
+        uint32_t slot_big = 0;
+        if (dec_stat[0] && kn.dec_slot_big) {
+          if (kn.dec_big_mode == 2) { slot_big = (dec_stat[1] + 15u) & ~15u; if (slot_big > kn.dec_slot_big) slot_big = kn.dec_slot_big; }
+          else { slot_big = (dec_stat[2] + 15u) & ~15u; if (slot_big < 64) slot_big = 64; if (slot_big >= slot_cap) slot_big = 0; }
+        }
+        LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_cap, 0u, slot_big ? slot_cap : 0xffffffffu);
+        if (slot_big) LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_big + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_big, slot_cap, 0xffffffffu);
       }
     }
     lmbe::toc("k_block_decode", times, profiling);
@@ -826,7 +849,16 @@ struct Engine {
     b_tot.ensure(64 * 4);
     uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
     lmbe::dmemset(retry_cnt, 0, 12);   // [0] documents to re-run with the worst-case directory, [1] resident documents replayed from the empty version, [2] documents whose optimistic LWW table filled up
-    if (NO && ht) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO, retry_cnt, 0u);   // (ht == 0: no document holds a Map / MovableList-LWW / out-of-scope row, k_dag_a)
+    if (NO && ht) {   // (ht == 0: no document holds a Map / MovableList-LWW / out-of-scope row, k_dag_a)
+      // documents whose (optimistic) table fits LDS are resolved by a workgroup each (lm_k_lww_doc.h); the others — resident
+      // documents, MovableLists, tables sized for every row — one row per lane in their HBM tables
+      bool any_lds = false, any_hbm = false;
+      for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK && h_doc[i].n_mapop) {
+        if (kn.lww_lds && !resident && h_ht_cap[i] <= LWW_LDS_CAP && !(h_doc[i].flags & DF_MOVABLE)) any_lds = true; else any_hbm = true;
+      }
+      if (any_lds) LM_LAUNCH_DYN(k_map_lww_doc, n_docs, LWW_WG, (size_t)LWW_LDS_CAP * 24 + (MAX_PEERS + MAX_CONTAINERS / 32 + 8) * 4, d, retry_cnt);
+      if (any_hbm) LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO, retry_cnt, 0u, any_lds ? 1u : 0u);
+    }
     lmbe::toc("k_map_lww", times, profiling);
     lmbe::tic(profiling);
     dir_cap = (dir_cap + 3) & ~3u;
@@ -902,7 +934,7 @@ struct Engine {
       lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
       lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
       lmbe::h2d(b_ht_cnt.p, h_cnt.data(), (size_t)n_docs * 4);
-      LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO, retry_cnt, 1u);
+      LM_LAUNCH(k_map_lww, cdiv(NO, 256), 256, d, NO, retry_cnt, 1u, 0u);
     }
     if (n_retry) {  // rare: re-run the overflowed documents with the worst-case directory
       if (resident) {

@@ -41,6 +41,7 @@ LM_DEV uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_r
 LM_DEV uint32_t first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 LM_DEV uint32_t atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 LM_DEV uint32_t atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+LM_DEV uint32_t atomic_max32(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 // LDS word += v, no value returned (ds_add_u32: no round trip to wait for)
 LM_DEV void lds_add(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 LM_DEV uint64_t atomic_max64(unsigned long long* p, uint64_t v) { return atomicMax(p, (unsigned long long)v); }
@@ -228,6 +229,7 @@ inline uint32_t first(uint32_t v) {
 }
 inline uint32_t atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 inline uint32_t atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+inline uint32_t atomic_max32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 inline void lds_add(uint32_t* p, uint32_t v) { *p += v; }
 inline uint64_t atomic_max64(unsigned long long* p, uint64_t v) { uint64_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }

@@ -286,3 +286,48 @@ def ascii_paste_docs():
         b.text_insert("text", 5, "tail"); b.text_delete("text", 0, 1); b.commit()
         docs.append([a.export(), b.export()]); docs.append([b.export(), a.export()])
     return docs
+
+
+def map_render_docs():
+    """Maps of hundreds of entries for the renderer's two paths (lm_k_emit.h): 64 entries at once, one per lane, when every entry of
+    the group is plain (a short key without escapes, an integer / bool / null value), entry by entry otherwise.  Integers at the
+    edges of i64, groups that are plain throughout, groups with one string / float / nested / escaped-key / long-key / child entry in
+    the middle, deleted keys, two peers writing the same keys."""
+    from loro_amd import wire
+    docs = []
+    edge = [0, 1, -1, 9, 10, -10, 999999999, 1000000000, -1000000000, 10**18, -(10**18), 2**63 - 1, -(2**63), 123456789012345678, 42]
+    a = wire.Replica(71)
+    for i in range(300):
+        a.map_set("plain", "k%03d" % i, edge[i % len(edge)] if i % 7 else (None if i % 14 else (i % 4 == 0)))
+        if i % 40 == 39:
+            a.commit()
+    a.commit()
+    docs.append([a.export()])
+    b = wire.Replica(72)
+    for i in range(260):
+        if i in (5, 70, 130, 200, 259):
+            v = ["s", 1.5, {"x": [1, 2]}, 'str"q', b"\x01\x02"][(i // 60) % 5]
+        else:
+            v = i * 1000003 - 77
+        key = "key-%d" % i
+        if i == 100:
+            key = "quote\"d"
+        if i == 150:
+            key = "a-key-that-is-longer-than-twenty-four-bytes-%d" % i
+        if i == 180:
+            key = "tab\tkey"
+        b.map_set("mixed", key, v)
+        if i % 50 == 49:
+            b.commit()
+    b.map_set_container("mixed", "child-190", 2)
+    b.commit()
+    for i in range(0, 260, 9):
+        b.map_delete("mixed", "key-%d" % i)
+    b.commit()
+    c = wire.Replica(70)
+    c.merge_from(b)
+    for i in range(0, 260, 5):
+        c.map_set("mixed", "key-%d" % i, -i)
+    c.commit()
+    docs.append([b.export(), c.export()])
+    return docs

@@ -85,6 +85,10 @@ def test_leaf_sweep_on_every_range(monkeypatch):
         assert c.merge_batch(docs) == _oracle.merge_batch(docs)
 
 
+def test_map_rendering_plain_groups_and_entry_by_entry():
+    _check(_cases.map_render_docs())
+
+
 def test_concurrent_sibling_scans():
     # many peers typing long runs at the same spots: stresses the run-head sibling scan
     _check(_cases.fuzz_docs(12, base=1000, steps=120, peers=4, max_ins=30, sync_prob=0.08))
@@ -559,13 +563,23 @@ def test_reference_fixtures_with_out_of_scope_containers_render_the_rest():
     check(_emu.merge_batch(docs))
 
 
-@pytest.mark.parametrize("variant", ["wave", "wave-unstaged", "lane"])
+@pytest.mark.parametrize("variant", ["wave", "wave-unstaged", "wave-slot-64", "wave-slot-160", "wave-slot-320", "wave-two-launches-64-320", "wave-two-launches-160-4096", "wave-columns-launch-320", "lane"])
 def test_block_decoders_agree(monkeypatch, variant):
     """The wave-per-block-group decoder (default; LDS-staged, lane = block x column), the same kernel with slots too
     small to stage anything (every parser reads HBM) and the one-lane-per-block decoder (LM_DECODE=0) must all give the
     oracle's results — including WHICH error a damaged block is rejected with."""
     if variant == "wave-unstaged":
         monkeypatch.setenv("LM_DEC_SLOT", "16")
+        monkeypatch.setenv("LM_DEC_SLOT_BIG", "0")   # (no second launch with larger slots for the groups whose heads exceed the slot)
+    if variant.startswith("wave-slot-"):   # slots between the blocks' column bytes and their heads: some blocks staged whole, some with their op / delete-start columns only, some not at all
+        monkeypatch.setenv("LM_DEC_SLOT", variant.rsplit("-", 1)[1])
+        monkeypatch.setenv("LM_DEC_SLOT_BIG", "0")
+    if variant.startswith("wave-two-launches-"):   # groups with a head beyond the first slot are decoded by a second launch with the larger one
+        monkeypatch.setenv("LM_DEC_SLOT", variant.split("-")[3])
+        monkeypatch.setenv("LM_DEC_SLOT_BIG", variant.split("-")[4])
+        monkeypatch.setenv("LM_DEC_BIG_MODE", "2")   # slots of the second launch sized for the heads (capped by LM_DEC_SLOT_BIG)
+    if variant.startswith("wave-columns-launch-"):   # the default mode: the second launch's slots are sized for the op / delete-start columns of those groups
+        monkeypatch.setenv("LM_DEC_SLOT", variant.rsplit("-", 1)[1])
     if variant == "lane":
         monkeypatch.setenv("LM_DECODE", "0")
     names, docs = _cases.edge_case_docs()
@@ -576,6 +590,8 @@ def test_block_decoders_agree(monkeypatch, variant):
     bad = _cases.corrupted_docs(120, seed=11)
     got = _emu.merge_batch(bad)
     monkeypatch.delenv("LM_DEC_SLOT", raising=False)
+    monkeypatch.delenv("LM_DEC_SLOT_BIG", raising=False)
+    monkeypatch.delenv("LM_DEC_BIG_MODE", raising=False)
     monkeypatch.setenv("LM_DECODE", "0")
     ref = _emu.merge_batch(bad)          # the sequential decoder's verdicts
     assert [g[0] for g in got] == [x[0] for x in ref]

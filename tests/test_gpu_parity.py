@@ -105,6 +105,54 @@ def test_optimistic_lww_table_overflow_takes_the_second_pass(engine, monkeypatch
     _same(engine, docs)
 
 
+@pytest.mark.parametrize("slot", ["16", "64", "160", "320", "640", "1136", "64+320", "160+4096", "1264+2048", "320+cols", "1264+cols"])
+def test_decoder_slots_below_the_block_heads(engine, monkeypatch, slot):
+    """LM_DEC_SLOT (read when the batch is staged) below the blocks' heads: blocks staged whole, blocks with their op / delete-start
+    columns staged alone (a head with a large key table: Map blocks of many keys) and blocks decoded straight from HBM side by side
+    in one wave.  (Round 3's first attempt at staging the columns alone passed the kernel-logic harness and died on hardware: a
+    generic pointer rebased below the LDS aperture — what the fiber harness cannot model needs a GPU test of its own.)"""
+    # "a+b": groups with a head beyond `a` bytes are decoded by a second launch with slots of `b` bytes (LM_DEC_BIG_MODE=2);
+    # a single number: one launch, everything beyond the slot takes the partial / unstaged paths
+    monkeypatch.setenv("LM_DEC_SLOT", slot.split("+")[0])
+    if slot.endswith("+cols"):   # the default mode: the second launch's slots are sized for the op / delete-start columns of its groups
+        pass
+    else:
+        monkeypatch.setenv("LM_DEC_SLOT_BIG", slot.split("+")[1] if "+" in slot else "0")
+        monkeypatch.setenv("LM_DEC_BIG_MODE", "2")
+    docs = [workload.cfg3_doc(d, n_peers=4, n_writes=700, n_keys=k, combined=(d % 2 == 0), per_change=c) for d, (k, c) in enumerate([(16, 10), (300, 100), (1024, 100), (64, 700)] * 3)]
+    names, edge = _cases.edge_case_docs()
+    docs += edge + _cases.fuzz_docs(24, base=15100) + _cases.cfg4_docs(12, first=5200, n_steps=200)
+    tpl = workload.Cfg2Template(3000, 1500, seed=9, commit_every=10, fuse=True)
+    docs += [tpl.stamp(d) for d in range(4)]
+    _same(engine, docs)
+
+
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_map_lww_in_lds_and_in_hbm_tables(engine, monkeypatch, lds):
+    """k_map_lww_doc (a workgroup per document, the table in LDS — the default for batches) and k_map_lww (one row per lane, the
+    table in HBM: LM_LWW_LDS=0) on the same documents: many writers per key, keys longer than the eight prefix bytes an LDS entry
+    identifies a key by, equal prefixes, several Map containers per document, nested children, checkouts."""
+    monkeypatch.setenv("LM_LWW_LDS", lds)
+    docs = [workload.cfg3_doc(d, n_peers=16, n_writes=500, n_keys=k, combined=(d % 2 == 0)) for d, k in enumerate([1, 7, 128, 900, 1024, 1100])]
+    reps = []
+    for p in range(5):
+        r = wire.Replica(900 + p)
+        for i in range(300):
+            r.map_set("m%d" % (i % 3), "a-long-key-with-a-shared-prefix-%03d" % ((i * 7 + p) % 40), i * 10 + p)
+            r.map_set("m0", "k%d" % (i % 11), "v%d" % i)
+            if i % 50 == 49:
+                r.commit()
+        r.commit()
+        reps.append(r)
+    docs.append([r.export() for r in reps])
+    docs += _cases.cfg4_docs(16, first=6100, n_steps=250) + _cases.fuzz_docs(16, base=16100)
+    _same(engine, docs)
+
+
+def test_map_rendering_plain_groups_and_entry_by_entry(engine):
+    _same(engine, _cases.map_render_docs() * 40)
+
+
 def test_ascii_pastes_with_every_length_prefix_width(engine):
     """length prefixes of 1, 2, 3 and 4 bytes through the decoder's arithmetic walk and the flat payload copy"""
     docs = _cases.ascii_paste_docs()

@@ -132,3 +132,30 @@ def test_import_mode_and_common_ancestors_on_the_device():
     for mode in ("flat", "text", "movable"):
         modes |= T._import_info_matches(_engine, T._sessions(mode, range(6000, 6064)))
     assert {"Linear", "Import", "ImportGreaterUpdates"} <= modes
+
+
+def test_stage_run_import_run_and_a_rejected_import():
+    """the documented call order lm_stage + lm_run, lm_import + lm_run (= import_batch, then import) and a rejected lm_import that
+    must leave nothing behind — the device twins of tests/test_emu_resident.py's two tests"""
+    a = wire.Replica(1)
+    a.text_insert("text", 0, "ab"); a.list_insert("list", 0, [1, 2]); a.map_set("map", "k", 1); a.commit()
+    first = a.export()
+    a.text_delete("text", 0, 2); a.list_delete("list", 0, 2); a.map_delete("map", "k"); a.commit()
+    second = a.export({1: a.changes[1][0].ctr_end})
+    sess = _oracle.Session()
+    want = [sess.step([first], None), sess.step([second], None)]
+    sess.close()
+    with _engine() as c:
+        c.stage([[first]] * 300)
+        c.run()
+        assert all(g == want[0] for g in c.fetch())
+        with pytest.raises(RuntimeError):
+            c.import_more([[second]] * 300, [None] * 299 + [b""])
+        c.import_more([[second]] * 150 + [[]] * 150)
+        c.run()
+        got = c.fetch()
+        assert all(g == want[1] for g in got[:150]) and all(g == want[0] for g in got[150:])
+        assert got[0][1] == b'{"list":[],"map":{},"text":""}'
+        c.import_more([[]] * 150 + [[second]] * 150)
+        c.run()
+        assert all(g == want[1] for g in c.fetch())
