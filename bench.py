@@ -170,6 +170,21 @@ class StepLoop:
         self.engs, self.doc_ids, self.world, self.dev = engs, doc_ids, world, dev
         self.busy = [False] * len(engs)
         self.timing = {"on": False, "k": {}}
+        # The exchange step as ONE collective on device memory (lm_summary_layout): every run writes this rank's summary rows
+        # with a kernel, the all-gather sends that buffer as it is (equal counts: rows per rank are computed, not exchanged)
+        # and the gathered table stays on the device until host_table() is asked for it.  Document ids must be an arithmetic
+        # progression (first + i * stride) — bench.py's and the `doc % world` dealing of loro_amd.dist both are.
+        self.dev_rows = False
+        self.gather_out = [None] * len(engs)
+        n = len(doc_ids)
+        stride = (doc_ids[1] - doc_ids[0]) if n > 1 else 1
+        if n and all(doc_ids[i] == doc_ids[0] + i * stride for i in range(n)):
+            try:
+                for e in engs:
+                    e.summary_layout(doc_ids[0], stride, n)
+                self.dev_rows = True
+            except Exception as ex:   # (an older library: the host-table exchange below)
+                note(f"summary rows on the device unavailable ({ex}): host-table exchange")
 
     def finish(self, k):
         from loro_amd import dist as lmdist
@@ -179,11 +194,34 @@ class StepLoop:
         if self.timing["on"]:
             for name, ms in e.kernel_times():       # HIP events of this step, recorded without host syncs
                 self.timing["k"].setdefault(name, []).append(ms)
+        if self.world > 1 and self.dev_rows:
+            ptr, rows = e.summary_rows_ptr()
+            send = lmdist.rows_tensor(ptr, rows, self.dev)
+            self.gather_out[k] = lmdist.all_gather_rows(send, self.gather_out[k])   # the single collective; result left on the device
+            return self.gather_out[k]
         st, jl, vl, pe = e.result_meta()
         local = lmdist.summarize_device(self.doc_ids, st, pe, jl, vl, e.result_hashes())
         if self.world > 1:
             return lmdist.all_gather_summaries(local, device=self.dev)
         return local
+
+    @staticmethod
+    def host_table(out):
+        """the summary table on the host, ordered by document id (a gathered device tensor is read back here, when asked)"""
+        from loro_amd import dist as lmdist
+        return out if not hasattr(out, "cpu") else lmdist.table_of(out)
+
+    def device_rows_check(self, k=0):
+        """the rows the last run of context k wrote on the device (through the tensor view the collective sends) against the
+        host-side summary of the same run — run at N=1 too, so the device path is exercised wherever bench.py runs"""
+        from loro_amd import dist as lmdist
+        e = self.engs[k]
+        st, jl, vl, pe = e.result_meta()
+        want = lmdist.summarize_device(self.doc_ids, st, pe, jl, vl, e.result_hashes())
+        ptr, rows = e.summary_rows_ptr()
+        got = lmdist.table_of(lmdist.rows_tensor(ptr, rows, self.dev))
+        want = want[want[:, 0].argsort(kind="stable")]
+        return got.shape == want.shape and bool((got == want).all())
 
     def run_steps(self, n):
         """n steps; step i runs on context i % inflight, which is first drained of its previous step"""
@@ -642,8 +680,11 @@ def main():
             line["cpu_baseline"] = cpu
             line["gpu_over_cpu"] = {"measured_on_available_cores": round(line["value"] / cpu["value"], 2),
                                     "vs_linear_extrapolation_to_physical_cores": round(line["value"] / cpu["linear_extrapolation_to_physical_cores"]["value"], 2)}
-        table = out
+        table = StepLoop.host_table(out)
         assert table.shape[0] == n_total and (table[:, 1] == 0).all() and (table[:, 5] != 0).all()
+        if loop.dev_rows:
+            assert loop.device_rows_check(0), "summary rows written on the device differ from the host-side summary"
+            line["config"]["summary_exchange"] = "rows written by k_summary_rows into the send buffer; one all_gather_into_tensor of equal counts per step, result left on the device"
         import xxhash
         hashes = np.ascontiguousarray(table[:, 5]).view(np.uint64)
         for i in (0, len(got) // 2, len(got) - 1):   # the summary's content word is the hash of what lm_fetch returns

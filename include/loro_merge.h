@@ -155,6 +155,16 @@ int lm_result_hashes(lm_ctx* ctx, uint64_t* json_xxh64);
 int lm_comm_unique_id(uint8_t out128[128]);
 int lm_comm_init(lm_ctx* ctx, int rank, int world, const uint8_t id128[128]);
 long lm_summary_allgather(lm_ctx* ctx, const int64_t* doc_ids, int64_t* table, size_t cap_rows);
+/* The same exchange as ONE collective on device memory.  lm_summary_layout (after lm_stage): document i of this context has the
+ * global id first_id + i * stride and every rank contributes rows_padded rows (>= its document count; with documents dealt
+ * `doc % world` that is ceil(total / world): computed, never exchanged).  Every lm_run then writes the rows ON THE DEVICE (rows
+ * beyond the context's documents are -1): lm_summary_rows_device is that buffer — a host that drives its own collective sends it
+ * as it is (bench.py: torch.distributed over RCCL) — and lm_summary_allgather_device issues the single ncclAllGather of
+ * rows_padded x 6 int64 per rank and returns the gathered table (world x rows_padded rows, rank-major), which stays in device
+ * memory until it is read.  lm_stage drops the layout. */
+int lm_summary_layout(lm_ctx* ctx, int64_t first_id, int64_t stride, size_t rows_padded);
+const int64_t* lm_summary_rows_device(lm_ctx* ctx);
+long lm_summary_allgather_device(lm_ctx* ctx, const int64_t** table_dev);
 
 /* ---- Export / encode side (host only, no device needed): the inverse of the decode stage.
  * lm_block_tables = the tables of ONE change block — the changes of one peer, counter-contiguous — exactly what the decode

@@ -19,7 +19,8 @@ class RunStats(ctypes.Structure):
 
 
 SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
-           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca", "export", "comm_unique_id", "comm_init", "summary_allgather"]
+           "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca", "export", "comm_unique_id", "comm_init", "summary_allgather",
+           "summary_layout", "summary_rows_device", "summary_allgather_device"]
 
 
 class Binding:
@@ -44,6 +45,11 @@ class Binding:
         self.comm_init = g("comm_init"); self.comm_init.restype = ctypes.c_int; self.comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
         self.summary_allgather = g("summary_allgather"); self.summary_allgather.restype = ctypes.c_long
         self.summary_allgather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self.summary_layout = g("summary_layout"); self.summary_layout.restype = ctypes.c_int
+        self.summary_layout.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_size_t]
+        self.summary_rows_device = g("summary_rows_device"); self.summary_rows_device.restype = ctypes.c_void_p; self.summary_rows_device.argtypes = [ctypes.c_void_p]
+        self.summary_allgather_device = g("summary_allgather_device"); self.summary_allgather_device.restype = ctypes.c_long
+        self.summary_allgather_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
         self.resident_fresh = g("resident_fresh"); self.resident_fresh.restype = ctypes.c_int; self.resident_fresh.argtypes = [ctypes.c_void_p]
         self.run = g("run"); self.run.restype = ctypes.c_int; self.run.argtypes = [ctypes.c_void_p]
         self.run_async = g("run_async"); self.run_async.restype = ctypes.c_int; self.run_async.argtypes = [ctypes.c_void_p]
@@ -173,6 +179,17 @@ class Context:
         if n < 0:
             raise RuntimeError(self.b.last_error(self.h).decode())
         return table[:n]
+
+    def summary_layout(self, first_id, stride, rows_padded):
+        """lm_summary_layout: from now on every run writes this context's summary rows on the device (ids first_id + i * stride,
+        rows_padded rows, the ones beyond the staged documents -1)"""
+        if self.b.summary_layout(self.h, first_id, stride, rows_padded) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        self._sum_rows = rows_padded
+
+    def summary_rows_ptr(self):
+        """(device address, rows) of the summary rows the last run wrote (lm_summary_rows_device)"""
+        return self.b.summary_rows_device(self.h), getattr(self, "_sum_rows", 0)
 
     def import_info(self):
         """[(DiffMode name or None, encoded LCA Frontiers or None)] of the last run's import, per resident document"""

@@ -26,6 +26,16 @@ struct lm_ctx_impl {
   bool in_flight = false;
 
   int device = 0;                  // HIP device of this context: every engine (stream, buffers) is created on it
+  // lm_summary_layout: the summary rows of this context's documents, written on the device by every run (k_summary_rows)
+  lm::DBuf sum_buf, sum_all;       // rows_padded x 6 int64 (this rank's), world x rows_padded x 6 (gathered)
+  size_t sum_rows_padded = 0;
+  long long sum_first = 0, sum_stride = 1;
+  void sum_bind() {                // every part writes its own documents' rows
+    for (uint32_t p = 0; p < n_parts() && p < parts.size(); p++) {
+      parts[p]->sum_rows = sum_rows_padded ? sum_buf.as<long long>() + (size_t)first[p] * 6 : nullptr;
+      parts[p]->sum_id0 = sum_first + (long long)first[p] * sum_stride; parts[p]->sum_stride = sum_stride;
+    }
+  }
 
   explicit lm_ctx_impl(int dev) : device(dev) {
     if (const char* e = getenv("LM_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= (int)LM_MAX_PARTS) want_parts = (uint32_t)v; }
@@ -39,6 +49,8 @@ struct lm_ctx_impl {
   void stage(const lm::Engine::DocIn* docs, size_t n) {
     n_docs = (uint32_t)n;
     ran = false;
+    sum_rows_padded = 0;             // (a new batch: lm_summary_layout is called again for it)
+    for (auto& pt : parts) pt->sum_rows = nullptr;
     // split into contiguous ranges of about equal blob bytes; small batches stay in one part
     uint64_t total = 0;
     for (size_t i = 0; i < n; i++) for (size_t b = 0; b < docs[i].n; b++) total += docs[i].lens[b];
@@ -412,8 +424,58 @@ int LM_API(comm_init)(void* c, int rank, int world, const uint8_t* id128) {
   { std::lock_guard<std::mutex> lk(lm_comms_mu()); lm_comms()[c] = st; }
   return 0;
 }
+// ---- the exchange as ONE collective on device memory.  lm_summary_layout (after lm_stage): this context's
+// document i has the global id first_id + i * stride, and every rank contributes `rows_padded` rows (>= its document count; with
+// documents dealt `doc % world` that is ceil(total / world) — computed, not exchanged).  From then on every lm_run writes the rows
+// on the device (k_summary_rows; rows beyond the context's documents stay -1); lm_summary_rows_device is that buffer (a host that
+// drives its own collective — torch.distributed in bench.py — sends it as it is), lm_summary_allgather_device issues the single
+// ncclAllGather of rows_padded x 6 int64 per rank and leaves the gathered table (world x rows_padded rows, rank-major, -1 rows =
+// padding) on the device until somebody asks for it.
+int LM_API(summary_layout)(void* c, int64_t first_id, int64_t stride, size_t rows_padded) {
+  auto* x = (lm_ctx_impl*)c;
+  try {
+    if (rows_padded < x->n_docs) throw std::runtime_error("lm_summary_layout: fewer rows than staged documents");
+    if (x->in_flight) throw std::runtime_error("lm_summary_layout while a run is in flight");
+    lm::Engine& e = *x->parts[0];
+    lmbe::bind(e.sc);
+    x->sum_buf.ensure((rows_padded ? rows_padded : 1) * 48);
+    lmbe::dmemset(x->sum_buf.p, 0xff, (rows_padded ? rows_padded : 1) * 48);   // every word -1
+    lmbe::sync();
+    x->sum_rows_padded = rows_padded; x->sum_first = first_id; x->sum_stride = stride;
+    x->sum_bind();
+    return 0;
+  } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
+const int64_t* LM_API(summary_rows_device)(void* c) {
+  auto* x = (lm_ctx_impl*)c;
+  return x->sum_rows_padded ? (const int64_t*)x->sum_buf.p : nullptr;
+}
+long LM_API(summary_allgather_device)(void* c, const int64_t** table_dev) {
+  auto* x = (lm_ctx_impl*)c;
+  try {
+    if (!x->ran) throw std::runtime_error("lm_summary_allgather_device before lm_run");
+    if (!x->sum_rows_padded) throw std::runtime_error("lm_summary_allgather_device before lm_summary_layout");
+    lm_comm_state st;
+    { std::lock_guard<std::mutex> lk(lm_comms_mu()); auto it = lm_comms().find(c); if (it != lm_comms().end()) st = it->second; }
+    if (st.world == 1) { *table_dev = (const int64_t*)x->sum_buf.p; return (long)x->sum_rows_padded; }
+#ifndef LM_EMU
+    auto& a = lmcomm::api();
+    lm::Engine& e = *x->parts[0];
+    lmbe::bind(e.sc);
+    x->sum_all.ensure((size_t)st.world * x->sum_rows_padded * 48);
+    if (a.all_gather(x->sum_buf.p, x->sum_all.p, x->sum_rows_padded * 6, /*ncclInt64*/ 4, st.comm, lmbe::cur->s) != 0) throw std::runtime_error("ncclAllGather (summaries) failed");
+    lmbe::sync();
+    *table_dev = (const int64_t*)x->sum_all.p;
+    return (long)((size_t)st.world * x->sum_rows_padded);
+#else
+    throw std::runtime_error("the kernel-logic harness has no collective");
+#endif
+  } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
 // doc_ids[n_docs] = the global ids of this context's documents; table receives rows of 6 int64 (layout above = loro_amd/dist.py
 // SUMMARY_WORDS) for the documents of ALL ranks, sorted by document id; returns the number of rows, -1 on error
+// (the host-table form: shard sizes are exchanged first, the rows pass through host memory; lm_summary_layout +
+// lm_summary_allgather_device is the one-collective form)
 long LM_API(summary_allgather)(void* c, const int64_t* doc_ids, int64_t* table, size_t cap_rows) {
   auto* x = (lm_ctx_impl*)c;
   try {

@@ -12,6 +12,9 @@
 
 namespace lm {
 
+#ifndef LM_FUSE_ROWS
+#define LM_FUSE_ROWS 1     // 0: no row fusion (rounds 1-3; A/B builds)
+#endif
 #ifndef LM_NO_NODE_CUT
 #define LM_NO_NODE_CUT 0   // 1: nodes are whole self-dependent runs and ready nodes replay in ascending peer order (rounds 1-3; A/B builds)
 #endif
@@ -408,7 +411,8 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     d.doc[doc].n_mapop = n_map;
     d.doc[doc].n_elems = n_el;
     if (has_ml) d.doc[doc].flags |= DF_MOVABLE;
-    else if (!any_skip_doc && n_style == 0) d.doc[doc].flags |= DF_PLAIN;
+    // (DF_FUSED: few rows per change — one change per keystroke — k_fuse_rows chains the rows into runs, lm_k_fuse.h)
+    else if (!any_skip_doc && n_style == 0) d.doc[doc].flags |= DF_PLAIN | ((LM_FUSE_ROWS && (uint64_t)n_valid * 8 > m.n_op) ? DF_FUSED : 0u);
   }
 }
 

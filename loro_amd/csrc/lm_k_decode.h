@@ -92,6 +92,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* ht_list;            // per doc [ht0, ht0+cap): lower half = slots claimed (one per distinct key), upper half = sort scratch
   uint32_t* ht_cnt;             // per doc number of claimed slots
   unsigned long long* prof;     // [doc*16 + slot] cycle accounting (LM_PROF builds)
+  uint32_t* fuse;               // [2 x op row] k_fuse_rows: a run head's leftmost delete target counter | signed total length (nullptr: no run was chained)
   uint32_t* dec_stat;           // [0] blocks whose head (everything before the value payloads) exceeds dec_slot bytes, [1] the largest such head, [2] the largest span of such a block's op / delete-start columns
   uint32_t dec_slot;            // the decoder's default LDS slot (k_block_count compares against it)
   // outputs

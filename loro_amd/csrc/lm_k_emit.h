@@ -1173,4 +1173,25 @@ LM_KERNEL void k_hash_json(Dev d, uint64_t* out_hash) {
   if (lane == 0) out_hash[doc] = h;
 }
 
+// The per-document row of the merged-state summary a sharded deployment exchanges (layout = loro_amd/dist.py
+// SUMMARY_WORDS): document id, status, pending ops, JSON length, VV length, xxh64 of the JSON — written on the device straight
+// into the buffer the all-gather sends (lm_summary_layout): no host copy of the table, no D2H → pack → H2D in front of the
+// collective.  Statuses as lm_result_meta reports them.  One lane per document.
+LM_KERNEL void k_summary_rows(Dev d, const uint64_t* hashes, long long* rows, long long id0, long long stride) {
+  uint32_t i = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (i >= d.n_docs) return;
+  const DocMeta m = d.doc[i];
+  bool ok = m.status == ST_OK;
+  int32_t st = m.status;
+  if (ok && (m.flags & DF_SOFT_UNSUPPORTED)) st = ST_UNSUPPORTED;               // rendered, with the out-of-scope containers as null
+  if (ok && (m.flags & DF_FRONT_ERR)) { st = m.front_err; ok = false; }          // resident: the import went through, the checkout was refused
+  long long* w = rows + (uint64_t)i * 6;
+  w[0] = id0 + (long long)i * stride;
+  w[1] = st;
+  w[2] = ok ? (long long)(((uint64_t)m.pending_hi << 32) | m.pending_lo) : 0;
+  w[3] = ok ? (long long)m.out_len : 0;
+  w[4] = ok ? (long long)m.vv_len : 0;
+  w[5] = ok ? (long long)hashes[i] : 0;
+}
+
 }  // namespace lm

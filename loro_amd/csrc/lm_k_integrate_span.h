@@ -1238,7 +1238,7 @@ LM_DEV uint32_t* tk_cont(uint32_t* tk, uint32_t pcap, uint32_t c) { return tk + 
 // PLAIN = true (k_integrate_span_plain_sweep by default, k_integrate_span_plain under LM_PLAIN=1; LM_PLAIN=0 = common kernel): the
 // documents flagged DF_PLAIN — no checkout, no sliced change, no style anchor — whose row loop needs neither the slicing of a row
 // against the known prefix / the rendered version nor the style branches.
-template <bool ML, bool PLAIN, bool SWEEP = false, bool RES = false>
+template <bool ML, bool PLAIN, bool SWEEP = false, bool RES = false, bool FUSE = false>
 LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
@@ -1267,6 +1267,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     uint32_t fl = m.flags;
     if (RES && (fl & DF_PLAIN) && d.front_off[doc + 1] > d.front_off[doc]) fl &= ~DF_PLAIN;   // resident, rendered at a checked-out version: the general instantiation's
     if ((fl & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
+    if (PLAIN && !RES && ((fl & DF_FUSED) != 0 && d.fuse != nullptr) != FUSE) return;                      // (k_integrate_span_plain_fuse's / the plain kernel's)
   }
   (void)SWEEP;
   if (retry_pass && m.status != ST_RETRY) return;
@@ -1431,6 +1432,25 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       const uint32_t* op_w = (const uint32_t*)op_ro;
       RowWin w;
       w.base = NONE - 64; w.lim = m.op0 + m.n_op; w.cur = 0; w.nxt = 0;   // opened by the first row; stays open across the node's changes
+      // FUSE (one change per keystroke): when the rows of the node's changes lie back to back in the op table — consecutive changes of
+      // consecutive blocks — the node is ONE row range: the per-change work (two dependent gathers and ≈60 instructions for each of a
+      // 40,000-change document's changes, most of which hold one continuation row that is skipped anyway) is paid once per node
+      bool node_contig = false;
+      uint32_t node_row_hi = 0, node_end_ctr = 0;
+      if (FUSE && last > first) {
+        bool bad = false, mine = false;
+        for (uint32_t i = first + (uint32_t)lane; i <= last; i += 64) {
+          uint32_t cr0 = sorted_ro[m.chg0 + i];
+          if (i < last) { const ChangeRow c0 = chg_ro[cr0], c1 = chg_ro[sorted_ro[m.chg0 + i + 1]]; bad |= c0.op0 + c0.n_op != c1.op0; }
+          mine |= ((d.chg_mask[2 * (uint64_t)cr0 + ((cidx >> 5) & 1)] >> (cidx & 31)) & 1) != 0;
+        }
+        node_contig = !lmw::any(bad);
+        if (node_contig) {
+          if (!lmw::any(mine)) continue;   // no change of the node holds a row of this container
+          const ChangeRow lc = chg_ro[sorted_ro[m.chg0 + last]];
+          node_row_hi = lc.op0 + lc.n_op; node_end_ctr = lc.ctr + lc.len;
+        }
+      }
       for (uint32_t ci = first; ci <= last && !t.err; ci++) {
         uint32_t crow = sorted_ro[m.chg0 + ci];
         const ChangeRow ch = chg_ro[crow];
@@ -1439,6 +1459,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
         uint32_t pe = PLAIN ? ch.ctr + ch.len : s_end[node_peer];   // (PLAIN: every applied change lies inside the rendered version)
         uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
         if (RES && ch.ctr + ch.len <= (PLAIN ? s_app[node_peer] : skip_to)) n_rows = 0;   // (PLAIN: the applied end lies on a change boundary — no sliced change)
+        if (FUSE && node_contig) { n_rows = node_row_hi - ch.op0; pe = node_end_ctr; ci = last; }   // the whole node in this trip
         if (PLAIN && !RES && n_rows && !checked_out) {
           // the tracker moves to the node's dependencies before its first row.  A plain document has no sliced change: a change
           // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
@@ -1452,6 +1473,18 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           PROF_T0();
           OpRow r = rw_get(w, op_w, row);
           if ((r.cidx_kind & 0xffff) != cidx) continue;
+          if (FUSE) {
+            // k_fuse_rows (lm_k_fuse.h): a row that continues the run of the row in front of it was replayed with its head; a head
+            // carries its run's extent (inserts: the total length; deletes: the leftmost target and the signed total)
+            if (r.cidx_kind & OPF_CONT) continue;
+            if (r.cidx_kind & OPF_HEAD) {
+              lmw::wave_sync();
+              uint32_t fa1 = lmw::first(d.fuse[2 * (uint64_t)row]);
+              int32_t fa2 = (int32_t)lmw::first(d.fuse[2 * (uint64_t)row + 1]);
+              r.len = (uint32_t)(fa2 < 0 ? -fa2 : fa2);
+              if (((r.cidx_kind >> 16) & 0xff) == OK_DEL) { r.a1 = fa1; r.a2 = fa2; }
+            }
+          }
           if (!PLAIN && r.ctr + r.len <= skip_to) continue;
           uint32_t kind = (r.cidx_kind >> 16) & 0xff;
           uint32_t a = PLAIN ? 0u : (skip_to > r.ctr ? skip_to - r.ctr : 0);
@@ -1535,7 +1568,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
             r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
           }
         }
-        if (checked_out && lane == 0) s_cur[node_peer] = ch.ctr + ch.len < pe ? ch.ctr + ch.len : pe;
+        if (checked_out && lane == 0) s_cur[node_peer] = (FUSE && node_contig) ? pe : (ch.ctr + ch.len < pe ? ch.ctr + ch.len : pe);
       }
       lmw::block_sync();
     }
@@ -1623,6 +1656,13 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_plain_swee
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {
   integrate_span_body<false, true, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
+}
+// the plain documents k_dag_a flagged DF_FUSED: one change per keystroke, rows chained into runs by k_fuse_rows
+LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_plain_fuse(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count) {
+  integrate_span_body<false, true, true, false, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
 }
 LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_ml(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,

@@ -18,6 +18,7 @@
 #include "lm_k_scan.h"
 #include "lm_k_emit.h"
 #include "lm_k_lww_doc.h"
+#include "lm_k_fuse.h"
 #include "lm_k_lca.h"
 #include "lm_snapshot.h"
 #include "lm_export.h"
@@ -73,7 +74,7 @@ struct Engine {
   DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
   DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
-  DBuf b_cp, b_loc, b_tb;
+  DBuf b_cp, b_loc, b_tb, b_fuse;
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_pfx, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
@@ -94,6 +95,8 @@ struct Engine {
   uint64_t device_bytes = 0;
   uint32_t last_retries = 0, last_reemits = 0;
   lmbe::StreamCtx* sc = nullptr;   // this engine's HIP stream + timing events
+  long long* sum_rows = nullptr;   // lm_summary_layout: where this engine's documents' summary rows go (device), first id, stride
+  long long sum_id0 = 0, sum_stride = 1;
 
   // ---- resident documents (lm_import; SURVEY §8f N2 — diff_calc.rs:62-68 DiffCalculatorRetainMode::Persist, loro.rs:568-649
   // import on a document that already holds history).  The blobs stay in `b_data`, used as an append-only arena; every
@@ -137,7 +140,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048; bool lww_lds = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048; bool lww_lds = true, fuse_rows = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -152,6 +155,7 @@ struct Engine {
     if (const char* e = getenv("LM_DIR_OPT_MAX")) k.dir_opt_max = (uint32_t)atoi(e);             // tests: force the retry launch
     if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
     if (const char* e = getenv("LM_HT_OPT")) k.ht_opt = (uint32_t)atoi(e);                       // slots of a document's optimistic LWW table (a power of two; 0: sized for its Map rows at once; tests: 64 forces the second pass)
+    if (const char* e = getenv("LM_FUSE_ROWS")) k.fuse_rows = atoi(e) != 0;                      // 0: one-change-per-keystroke documents are replayed row by row, as in rounds 1-3
     if (const char* e = getenv("LM_LWW_LDS")) k.lww_lds = atoi(e) != 0;                          // 0: every document's Map rows go through the HBM tables (k_map_lww), as in rounds 1-3
     kn = k;
   }
@@ -168,7 +172,7 @@ struct Engine {
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
-                   &b_dir_out, &b_lf_chunk,
+                   &b_dir_out, &b_lf_chunk, &b_fuse,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_elem_cap, &b_old_blobs, &b_prev_doc, &b_prev_uniq, &b_prev_end, &b_lca_out, &b_lca_scratch, &b_lca_off};
     for (DBuf* b : all) b->release();
@@ -541,7 +545,7 @@ struct Engine {
     // profiles/r02_ab_prepared.log); LM_PLAIN=1 selects k_integrate_span_plain, LM_PLAIN=0 the common kernel for every document
     const int plain_mode = !span ? 0 : kn.plain;   // (resident documents: 0 = the general kernel for all, otherwise k_integrate_span_res_plain for the DF_PLAIN ones)
     const bool plain_on = plain_mode == 1 || plain_mode == 2;
-    bool any_plain = false;
+    bool any_plain = false, any_fused = false;
     if (reuse) {
       d = sv.d; g = sv.g;
       d.front = b_front.as<uint8_t>(); d.front_off = b_front_off.as<uint64_t>();
@@ -686,8 +690,10 @@ struct Engine {
       DocMeta& m = h_doc[i];
       bool ok = m.status == ST_OK;
       // (resident documents keep the flag: which version is rendered changes from run to run — the kernels look at the frontiers)
-      if (!plain_on || !ok || (!resident && h_front_off.size() > i + 1 && h_front_off[i + 1] > h_front_off[i])) m.flags &= ~DF_PLAIN;
+      if (!plain_on || !ok || (!resident && h_front_off.size() > i + 1 && h_front_off[i + 1] > h_front_off[i])) m.flags &= ~(DF_PLAIN | DF_FUSED);
+      if (resident || plain_mode != 2 || !kn.fuse_rows) m.flags &= ~DF_FUSED;
       any_plain |= (m.flags & DF_PLAIN) != 0;
+      any_fused |= (m.flags & DF_FUSED) != 0;
       m.elem0_lo = (uint32_t)elem; m.elem0_hi = (uint32_t)(elem >> 32);
       if (resident) {
         // the document's slice of the element arena stays where it is while it is large enough (loc[] and the payload slots of
@@ -819,6 +825,13 @@ struct Engine {
       LM_LAUNCH(k_res_layout, n_docs, 64, d, rs);   // (a run that reuses its tables: the layout is the previous run's, unless that run failed for the document)
     }
     lmbe::tic(profiling);
+    d.fuse = nullptr;
+    if (!resident && any_fused && NO) {
+      // one-change-per-keystroke documents: rows of one node chained into runs (lm_k_fuse.h); their replay is k_integrate_span_plain_fuse's
+      b_fuse.ensure(((size_t)NO + 1) * 8);
+      d.fuse = b_fuse.as<uint32_t>();
+      LM_LAUNCH(k_fuse_rows, cdiv(NO, 256), 256, d, NO);
+    }
     if (!resident) LM_LAUNCH(k_dag_b, n_docs, 64, d, g, 0u);
     else {
       if (!reuse) {
@@ -894,9 +907,13 @@ struct Engine {
         LM_LAUNCH_DYN(k_integrate_span_res_ml, n_docs, 64, lds, d, g, dir_opt, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                       (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
     } else if (span) {
-      if (any_plain && plain_mode == 2)
+      if (any_plain && plain_mode == 2) {
         LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+        if (d.fuse)
+          LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                        (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
+      }
       else if (any_plain)
         LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
@@ -954,9 +971,13 @@ struct Engine {
         if (any_ml)
           LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
-        if (any_plain && plain_mode == 2)
+        if (any_plain && plain_mode == 2) {
           LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
+          if (d.fuse)
+            LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                          (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
+        }
         else if (any_plain)
           LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
@@ -1084,6 +1105,7 @@ struct Engine {
       lmbe::toc("k_compact", times, profiling);
       b_hash.ensure((size_t)n_docs * 8 + 8);
       LM_LAUNCH(k_hash_json, n_docs, 64, d, b_hash.as<uint64_t>());
+      if (sum_rows) LM_LAUNCH(k_summary_rows, cdiv(n_docs, 256), 256, d, (const uint64_t*)b_hash.as<uint64_t>(), sum_rows, sum_id0, sum_stride);
       h_hash.resize(n_docs);
       lmbe::d2h(h_hash.data(), b_hash.p, (size_t)n_docs * 8);
     }

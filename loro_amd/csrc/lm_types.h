@@ -58,6 +58,9 @@ struct OpRow {               // 32 B, read with scalar loads by the integrate ke
   uint32_t chg;              // global change row
 };
 
+// OpRow.cidx_kind flag bits (k_fuse_rows): the row continues the run of the row in front of it / heads a run whose extent is in Dev::fuse
+enum : uint32_t { OPF_CONT = 1u << 24, OPF_HEAD = 1u << 25 };
+
 struct ChangeRow {           // 32 B
   uint32_t peer;             // block-local 0 → doc peer idx after remap
   uint32_t ctr, len;
@@ -116,6 +119,8 @@ enum : uint32_t {
   DF_FILL_KEPT = 64u,        // … and that run left nothing pending: every payload slot of its blocks was filled then (k_elem_fill fills applied rows only)
   DF_LWW_RETRY = 128u,       // k_map_lww: the document's optimistic LWW table (sized for a few thousand keys) filled up: its Map rows are resolved
                              // again in a table sized for as many keys as it has Map rows (lm_pipeline.h)
+  DF_FUSED = 256u,           // a plain document whose changes hold few rows each (one change per keystroke): k_fuse_rows chained its rows into runs
+                             // across change boundaries, k_integrate_span_plain_fuse replays the runs (lm_k_fuse.h)
   DF_PLAIN = 8u,             // no sliced change, no style anchor, no MovableList (k_dag_a); the host clears it for checked-out documents
                              // and under LM_PLAIN=0: such a document is replayed by k_integrate_span_plain_sweep (lm_pipeline.h)
 };

@@ -55,3 +55,51 @@ def all_gather_summaries(local: np.ndarray, device=None):
     dist.all_gather(gathered, buf)             # THE all-gather of the merged-state summary
     table = torch.cat([g[: int(s.item())] for g, s in zip(gathered, sizes)], dim=0).cpu().numpy()
     return table[np.argsort(table[:, 0], kind="stable")]
+
+
+# ---- the exchange as ONE collective on device memory (lm_summary_layout: the rows are written by a kernel of every run)
+
+def rows_padded(n_total: int, world: int) -> int:
+    """rows every rank contributes when documents are dealt `doc % world`: the largest shard — computed, never exchanged"""
+    return (n_total + world - 1) // world
+
+
+class _DevRows:
+    """a device buffer of the library seen through __cuda_array_interface__ (no copy): rows x SUMMARY_WORDS int64"""
+
+    def __init__(self, ptr, rows):
+        self.__cuda_array_interface__ = {"shape": (rows, SUMMARY_WORDS), "typestr": "<i8", "data": (int(ptr), False), "version": 2}   # (torch refuses read-only views; nobody writes through this one)
+
+
+def rows_tensor(ptr: int, rows: int, device=None):
+    """the library's summary rows as a tensor that aliases them: a device tensor on a GPU, a CPU tensor under the kernel-logic
+    harness (whose "device" memory is host memory)"""
+    import ctypes
+    import torch
+    if device is not None and getattr(device, "type", str(device)).startswith("cuda"):
+        return torch.as_tensor(_DevRows(ptr, rows), device=device)
+    buf = (ctypes.c_int64 * (rows * SUMMARY_WORDS)).from_address(ptr)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np.int64).reshape(rows, SUMMARY_WORDS))
+
+
+def all_gather_rows(send, out=None):
+    """THE all-gather of the merged-state summary: one collective, equal counts, device memory in and out.  `send` = this rank's
+    [rows_padded, SUMMARY_WORDS] rows; returns the gathered [world * rows_padded, SUMMARY_WORDS] tensor (rank-major; rows of -1
+    are padding), which stays where it is until table_of() is asked for the host table."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty((world * send.shape[0], SUMMARY_WORDS), dtype=torch.int64, device=send.device)
+    try:
+        dist.all_gather_into_tensor(out, send)
+    except (RuntimeError, NotImplementedError, AttributeError):   # a backend without the flat form
+        dist.all_gather(list(out.view(world, send.shape[0], SUMMARY_WORDS).unbind(0)), send)
+    return out
+
+
+def table_of(gathered) -> np.ndarray:
+    """host table of a gathered tensor: padding dropped, ordered by document id"""
+    t = gathered.cpu().numpy()
+    t = t[t[:, 0] >= 0]
+    return t[np.argsort(t[:, 0], kind="stable")]

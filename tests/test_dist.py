@@ -65,7 +65,8 @@ def _bench_worker(rank, world, port, per_rank, out_dir):
         e.run()
     loop = bench.StepLoop(engs, doc_ids, world, None)
     loop.run_steps(1)
-    table = loop.run_steps(3)
+    table = bench.StepLoop.host_table(loop.run_steps(3))
+    assert loop.dev_rows and loop.device_rows_check(0) and loop.device_rows_check(1)   # the one-collective path ran, on rows a kernel wrote
     np.save(os.path.join(out_dir, f"bench_table{rank}.npy"), table)
     for e in engs:
         e.close()
@@ -107,3 +108,29 @@ def test_c_abi_summary_matches_the_python_exchange():
         got = c.summary_allgather(ids, len(docs))
         assert got.shape == want.shape and (got == want).all()
         assert (got == lmdist.summarize(sorted(ids), [c.fetch()[len(docs) - 1 - k] for k in range(len(docs))])).all()
+
+
+def test_summary_rows_written_on_the_device_match_the_host_summary():
+    """lm_summary_layout: every run writes the context's summary rows with a kernel (k_summary_rows) — ids first + i * stride,
+    padding rows -1, statuses as lm_result_meta reports them (failed documents, out-of-scope containers) — and
+    lm_summary_allgather_device with one rank hands that table back without a copy"""
+    import ctypes
+    import _emu
+    from loro_amd._cabi import Context
+    names, docs = _cases.edge_case_docs()
+    docs = docs + _cases.corrupted_docs(12, seed=3)
+    with Context(_emu.binding()) as c:
+        c.stage(docs)
+        c.summary_layout(500, 3, len(docs) + 5)
+        c.run()
+        st, jl, vl, pe = c.result_meta()
+        want = lmdist.summarize_device([500 + 3 * i for i in range(len(docs))], st, pe, jl, vl, c.result_hashes())
+        ptr, rows = c.summary_rows_ptr()
+        t = lmdist.rows_tensor(ptr, rows).numpy()
+        assert rows == len(docs) + 5 and (t[len(docs):] == -1).all() and (t[:len(docs)] == want).all()
+        assert (lmdist.table_of(lmdist.rows_tensor(ptr, rows)) == want).all()
+        c.comm_init(0, 1)
+        out = ctypes.c_void_p()
+        assert c.b.summary_allgather_device(c.h, ctypes.byref(out)) == rows and out.value == ptr
+        c.run()   # the rows are rewritten by every run
+        assert (lmdist.rows_tensor(ptr, rows).numpy()[:len(docs)] == want).all()
