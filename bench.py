@@ -370,9 +370,9 @@ def other_configs(device, cores):
 
     run("configs[0]", cfg1, None, 100, "100 docs x 2 peers x 1,000 sequential inserts, 2 blobs/doc")
     d3 = [g[0] for g in g3]
-    run("configs[2]", [d3[i % 16] for i in range(2048)], None, 16,
-        "LWW Map, 16 peers x 10,000 writes on 1,024 keys per doc (160k ops/doc); 2,048 docs (of the config's 10,000): 8 distinct "
-        "histories x {one combined blob, 16 per-peer blobs}")
+    run("configs[2]", [d3[i % 16] for i in range(10000)], None, 16,
+        "LWW Map, 16 peers x 10,000 writes on 1,024 keys per doc (160k ops/doc); the config's 10,000 docs (24 GB of blobs): 8 distinct "
+        "histories x {one combined blob, 16 per-peer blobs}", reps=2)
     run("configs[3]", [cfg4_base[i % 96] for i in range(12500)], None, 96,
         "mixed List/Map/Text roots, 4 peers x ~1k ops with pairwise syncs; 12,500 docs = one GPU's share of the config's 100k over 8")
     tpls = [g[0] for g in gh]

@@ -344,19 +344,32 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   // everything that depends on any part of it).
   lmw::mem_fence();
   lmw::block_sync();   // peer_chg0/1 (find_change) are complete
+  // (every dependency is resolved to its change HERE, once — dep_ci — so that k_dag_b's passes, one per node, test readiness and
+  // merge version vectors with two loads per dependency instead of a binary search each.  A dependency on the peer's own previous
+  // op — nearly all of them — is the change right in front, no search.)
   for (uint32_t i = (uint32_t)lane; i < n_valid; i += 64) {
     uint32_t row = d.chg_sorted[m.chg0 + i];
     const ChangeRow& ch = d.chg[row];
-    if (d.chg_skip[row] != 0) continue;   // sliced change: its only dependency is the known prefix
     for (uint32_t k = ch.dep0; k < ch.dep0 + ch.n_dep; k++) {
-      uint32_t q = d.dep_peer[k];
-      if (q == ch.peer || q >= P) continue;
-      uint32_t ci = find_change(d, m, q, d.dep_ctr[k]);
-      if (ci != NONE) lmw::atomic_or(&d.chg_flag[d.chg_sorted[m.chg0 + ci]], 2u);   // (chg_flag: bit 0 applied, bit 1 has a successor of another peer)
+      uint32_t q = d.dep_peer[k], c = d.dep_ctr[k];
+      uint32_t ci = NONE;
+      if (q == ch.peer && i > 0 && c + 1 == ch.ctr) {
+        const ChangeRow& pv = d.chg[d.chg_sorted[m.chg0 + i - 1]];
+        if (pv.peer == q && pv.ctr <= c && c < pv.ctr + pv.len) ci = i - 1;
+      }
+      if (ci == NONE && q < P) ci = find_change(d, m, q, c);
+      d.dep_ci[k] = ci;
+      if (q != ch.peer && ci != NONE && d.chg_skip[row] == 0)   // (a sliced change's only dependency is the known prefix)
+        lmw::atomic_or(&d.chg_flag[d.chg_sorted[m.chg0 + ci]], 2u);   // (chg_flag: bit 0 applied, bit 1 has a successor of another peer)
     }
   }
   lmw::mem_fence();
   lmw::block_sync();
+  // The cut and the one-node-per-pass, largest-peer-first order of k_dag_b pay where concurrent branches are LONG (configs[1]: 27 %
+  // of the integrate stage); a small document of many peers that sync every few ops only gets more nodes out of it — more passes
+  // here, more tracker moves in the replay (measured, tests/tools/gpu_other.py: MovableList batch integrate 15.1 -> 20.6 ms, k_dag_b
+  // 2.9 -> 6.8 ms; configs[3] k_dag_b 5.1 -> 13.7 ms).  So: documents of at least LM_CUT_MIN_ROWS op rows (an environment knob, 2,048 by default; the parity suites also run with 0).
+  const bool cut_doc = !LM_NO_NODE_CUT && m.n_op >= d.cut_min_rows;
   uint32_t n_nodes = 0;
   for (uint32_t i0 = 0; i0 < n_valid; i0 += 64) {
     uint32_t i = i0 + (uint32_t)lane;
@@ -370,7 +383,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
       else if (ch.n_dep == 1 && d.dep_peer[ch.dep0] == ch.peer && ch.ctr > 0 && d.dep_ctr[ch.dep0] == ch.ctr - 1) cont = true;
       // a continuation needs a predecessor of the same peer right before it in the sorted order
       if (cont && (i == 0 || d.chg[d.chg_sorted[m.chg0 + i - 1]].peer != ch.peer)) cont = false;
-      if (cont && !LM_NO_NODE_CUT && d.chg_skip[row] == 0 && (d.chg_flag[d.chg_sorted[m.chg0 + i - 1]] & 2u)) cont = false;
+      if (cont && cut_doc && d.chg_skip[row] == 0 && (d.chg_flag[d.chg_sorted[m.chg0 + i - 1]] & 2u)) cont = false;
       head = !cont;
     }
     uint64_t hm = lmw::ballot(head);
@@ -410,6 +423,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     d.doc[doc].pending_hi = 0;
     d.doc[doc].n_mapop = n_map;
     d.doc[doc].n_elems = n_el;
+    if (cut_doc) d.doc[doc].flags |= DF_CUT;
     if (has_ml) d.doc[doc].flags |= DF_MOVABLE;
     // (DF_FUSED: few rows per change — one change per keystroke — k_fuse_rows chains the rows into runs, lm_k_fuse.h)
     else if (!any_skip_doc && n_style == 0) d.doc[doc].flags |= DF_PLAIN | ((LM_FUSE_ROWS && (uint64_t)n_valid * 8 > m.n_op) ? DF_FUSED : 0u);
@@ -454,7 +468,7 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
   lmw::block_sync();
   for (uint32_t pass = 0; pass <= N && n_done < N; pass++) {
     uint32_t batch0 = n_done;
-#if !LM_NO_NODE_CUT
+    if (m.flags & DF_CUT) {
     // ONE node per pass: of the peers' first unfinished nodes whose dependencies are all done, the one of the LARGEST peer.
     // Any causal order gives the same sequence (Fugue converges; the reference's own order depends on a hash map,
     // dag/iter.rs:268-274) — but not at the same price: integrating a run next to concurrent runs of other peers walks over
@@ -472,7 +486,7 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
           ready = true;
           const ChangeRow& ch = d.chg[d.chg_sorted[m.chg0 + d.node_first[m.chg0 + n]]];
           for (uint32_t k = ch.dep0; k < ch.dep0 + ch.n_dep; k++) {
-            uint32_t ci = find_change(d, m, d.dep_peer[k], d.dep_ctr[k]);
+            uint32_t ci = d.dep_ci[k];
             if (ci == NONE || !g.node_done[m.chg0 + g.chg_node[m.chg0 + ci]]) ready = false;
           }
         }
@@ -488,8 +502,8 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
         n_done++;
       }
     }
-#else
-    // collect the peers' first unfinished nodes whose dependencies are all done (ascending peer = ascending node index)
+    } else {
+    // small documents: every peer's first unfinished node whose dependencies are all done, in one pass (ascending peer = ascending node index)
     for (uint32_t p0 = 0; p0 < P; p0 += 64) {
       uint32_t pr = p0 + (uint32_t)lane;
       uint32_t n = pr < P ? s_next[pr] : NONE;
@@ -498,7 +512,7 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
         ready = true;
         const ChangeRow& ch = d.chg[d.chg_sorted[m.chg0 + d.node_first[m.chg0 + n]]];
         for (uint32_t k = ch.dep0; k < ch.dep0 + ch.n_dep; k++) {
-          uint32_t ci = find_change(d, m, d.dep_peer[k], d.dep_ctr[k]);
+          uint32_t ci = d.dep_ci[k];
           if (ci == NONE || !g.node_done[m.chg0 + g.chg_node[m.chg0 + ci]]) ready = false;
         }
       }
@@ -506,9 +520,8 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
       if (ready) { d.node_order[m.chg0 + n_done + (uint32_t)lmw::popc64(rm & ((1ull << lane) - 1))] = n; s_next[pr] = n + 1; }
       n_done += (uint32_t)lmw::popc64(rm);
     }
-#endif
-    lmw::mem_fence();
-    lmw::block_sync();
+    }
+    lmw::block_sync();   // (node_order is written and read by lanes of this one wave: program order is enough, as in rounds 1-3)
     if (n_done == batch0) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_INTERNAL); return; }  // cycle: malformed deps
     // finish the batch: lamport + vv at the head, lamports of every change of the node
     for (uint32_t bi = batch0; bi < n_done; bi++) {
@@ -520,7 +533,7 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
       uint32_t lam = 0;
       for (uint32_t k = hc.dep0; k < hc.dep0 + hc.n_dep; k++) {
         uint32_t q = d.dep_peer[k], c = d.dep_ctr[k];
-        uint32_t ci = find_change(d, m, q, c);
+        uint32_t ci = d.dep_ci[k];
         uint32_t drow = d.chg_sorted[m.chg0 + ci];
         uint32_t dl = d.chg_lamport[drow] + (c - d.chg[drow].ctr) + 1;
         lam = dl > lam ? dl : lam;
@@ -547,7 +560,7 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
   // away sets its peer back to the node's first counter).  Flag (node_done bit 1): critical in front of node i but not in front
   // of node i+1 — a concurrent section begins with node i, the tracker gets its base there.  A history that is one chain
   // (critical everywhere) gets no flag at all, and neither does its last node.
-  if (res_mode != 2 && N) {
+  if (res_mode != 2 && N && (m.flags & DF_CUT)) {
     uint32_t* s_min = s_next;
     uint32_t* s_tot = s_pend;
     lmw::block_sync();

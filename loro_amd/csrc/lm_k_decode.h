@@ -42,6 +42,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   ChangeRow* chg;
   uint32_t* dep_peer;
   uint32_t* dep_ctr;
+  uint32_t* dep_ci;      // per dep row: the sorted applied change (doc-relative index into chg_sorted) that holds the dependency, NONE if none — resolved once by k_dag_a, read by k_dag_b
   OpRow* op;
   uint64_t* op_val;
   uint32_t* op_blk;
@@ -95,6 +96,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* fuse;               // [2 x op row] k_fuse_rows: a run head's leftmost delete target counter | signed total length (nullptr: no run was chained)
   uint32_t* dec_stat;           // [0] blocks whose head (everything before the value payloads) exceeds dec_slot bytes, [1] the largest such head, [2] the largest span of such a block's op / delete-start columns
   uint32_t dec_slot;            // the decoder's default LDS slot (k_block_count compares against it)
+  uint32_t cut_min_rows;        // k_dag_a: documents of at least this many op rows get the node cut + descending-peer replay order (DF_CUT)
   // outputs
   uint8_t* out;          // JSON bytes
   uint64_t* out_off;     // per doc offset (n_docs+1)

@@ -135,7 +135,12 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
       d.peer_raw[peer0 + i] = v;
     }
     {
-      // change lens → counters
+      // change lens → counters.  The passes below never read a ChangeRow back: what a later pass needs of an earlier one (a
+      // change's counter, its dep_on_self bit, its dependency count) comes from walking the same columns again — LDS reads for a
+      // staged head.  (Each pass used to load every ChangeRow it had stored: three dependent global round trips per change for
+      // ONE lane per block — with one change per keystroke, ≈200 changes per block, that was most of the decoder's time on such
+      // blocks: 52 ms of the heterogeneous batch's decode.)
+      const Rd h_lens = h;              // the N-1 change lengths start here
       uint64_t known = 0;
       uint32_t ctr = bd.counter_start;
       for (uint32_t i = 0; i < N; i++) {
@@ -148,57 +153,91 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
         ctr += (uint32_t)l;
       }
       // dep_on_self BoolRle[N] and other-dep counts AnyRle<usize>[N] advance together: one pass over the changes
-      BoolCur bc = bool_make(h);
+      const BoolCur bc0 = bool_make(h);
       // the dep-count column starts where the BoolRle ends: run the bool cursor to its end first (N values)
       Rd after_bool = h;
       {
-        BoolCur t = bc;
+        BoolCur t = bc0;
         for (uint32_t i = 0; i < N; i++) (void)bool_next(t);
         if (t.rem != 0) t.r.bad = true;
         after_bool = t.r;
       }
-      RleCur dc = rle_make(after_bool);
+      const RleCur dc0 = rle_make(after_bool);
+      // one change's (dep_on_self, other dependencies) and where its dependency rows begin — the same walk in every pass, the
+      // clamp of a damaged count included
+      const uint32_t dep_lim = dep0 + cnt[BC_DEP];
+      auto next_deps = [&](BoolCur& bc, RleCur& dc, uint32_t& dcur, uint32_t& ds, uint32_t& others, bool& clamp) {
+        ds = bool_next(bc) ? 1u : 0u;
+        uint64_t o = rle_next_uvar(dc);
+        clamp = (uint64_t)dcur + ds + o > dep_lim;
+        if (clamp) { o = 0; ds = 0; }
+        others = (uint32_t)o;
+      };
+      BoolCur bc = bc0;
+      RleCur dc = dc0;
       uint32_t dcur = dep0;
-      for (uint32_t i = 0; i < N; i++) {
-        uint32_t ds = bool_next(bc) ? 1u : 0u;
-        uint64_t others = rle_next_uvar(dc);
-        ChangeRow c = d.chg[chg0 + i];
-        if (dcur + ds + others > dep0 + cnt[BC_DEP]) { st = ST_DECODE_ERROR; others = 0; ds = 0; }
-        c.dep0 = dcur;
-        c.n_dep = ds + (uint32_t)others;
-        c.op0 = ds;   // kept until the dep columns are read
-        if (ds) {
-          if (c.ctr == 0) st = ST_DECODE_ERROR;
-          d.dep_peer[dcur] = 0;
-          d.dep_ctr[dcur] = c.ctr ? c.ctr - 1 : 0;
+      {
+        Rd hl = h_lens;               // the changes' counters again, from their lengths
+        uint64_t kn = 0;
+        uint32_t cctr = bd.counter_start;
+        for (uint32_t i = 0; i < N; i++) {
+          uint32_t ds, others;
+          bool clamp;
+          next_deps(bc, dc, dcur, ds, others, clamp);
+          if (clamp) st = ST_DECODE_ERROR;
+          d.chg[chg0 + i].dep0 = dcur;
+          d.chg[chg0 + i].n_dep = ds + others;
+          if (ds) {
+            if (cctr == 0) st = ST_DECODE_ERROR;
+            d.dep_peer[dcur] = 0;
+            d.dep_ctr[dcur] = cctr ? cctr - 1 : 0;
+          }
+          dcur += ds + others;
+          uint64_t l = 0;
+          if (i + 1 < N) { l = rd_uleb(hl); kn += l; if (kn > bd.counter_len) l = 0; }
+          cctr += (uint32_t)l;
         }
-        dcur += c.n_dep;
-        d.chg[chg0 + i] = c;
       }
       if (dc.rem != 0) dc.r.bad = true;
       if (dcur - dep0 != cnt[BC_DEP]) st = ST_DECODE_ERROR;
       // dep peer idx AnyRle<u32>[D]
       RleCur pc = rle_make(dc.r);
       uint64_t D = 0;
-      for (uint32_t i = 0; i < N; i++) {
-        ChangeRow c = d.chg[chg0 + i];
-        for (uint32_t k = c.dep0 + c.op0; k < c.dep0 + c.n_dep; k++) {
-          uint64_t pi = rle_next_uvar(pc);
-          if (pi >= n_peers) { st = ST_DECODE_ERROR; pi = 0; }
-          d.dep_peer[k] = (uint32_t)pi;
-          D++;
+      {
+        BoolCur b2 = bc0;
+        RleCur d2 = dc0;
+        uint32_t cur2 = dep0;
+        for (uint32_t i = 0; i < N; i++) {
+          uint32_t ds, others;
+          bool clamp;
+          next_deps(b2, d2, cur2, ds, others, clamp);
+          for (uint32_t k = cur2 + ds; k < cur2 + ds + others; k++) {
+            uint64_t pi = rle_next_uvar(pc);
+            if (pi >= n_peers) { st = ST_DECODE_ERROR; pi = 0; }
+            d.dep_peer[k] = (uint32_t)pi;
+            D++;
+          }
+          cur2 += ds + others;
         }
       }
       if (pc.rem != 0) pc.r.bad = true;
       // dep counters DeltaOfDelta[D]
       Rd hr = pc.r;
       DodCur dd = dod_make(hr);
-      for (uint32_t i = 0; i < N && D; i++) {
-        ChangeRow c = d.chg[chg0 + i];
-        for (uint32_t k = c.dep0 + c.op0; k < c.dep0 + c.n_dep; k++) {
-          int64_t v = dod_next(dd);
-          if (v < 0 || v >= (int64_t)MAX_COUNTER) { st = st ? st : ST_DECODE_ERROR; v = 0; }
-          d.dep_ctr[k] = (uint32_t)v;
+      if (D) {
+        BoolCur b3 = bc0;
+        RleCur d3 = dc0;
+        uint32_t cur3 = dep0;
+        for (uint32_t i = 0; i < N; i++) {
+          uint32_t ds, others;
+          bool clamp;
+          next_deps(b3, d3, cur3, ds, others, clamp);
+          for (uint32_t k = cur3 + ds; k < cur3 + ds + others; k++) {
+            int64_t v = dod_next(dd);
+            if (v < 0 || v >= (int64_t)MAX_COUNTER) { st = st ? st : ST_DECODE_ERROR; v = 0; }
+            d.dep_ctr[k] = (uint32_t)v;
+          }
+          cur3 += ds + others;
         }
       }
       dod_finish(dd, hr, D);
@@ -208,7 +247,6 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
       for (uint32_t i = 0; i + 1 < N; i++) (void)dod_next(ld);
       dod_finish(ld, hr, N - 1);
       if (h.bad || bc.r.bad || after_bool.bad || dc.r.bad || pc.r.bad || hr.bad) st = st ? st : ST_DECODE_ERROR;
-      for (uint32_t i = 0; i < N; i++) d.chg[chg0 + i].op0 = 0;
     }
     {  // change_meta: timestamps + message lengths, shape only (block_encode.rs:563-571)
       Rd m = sec(SEC_META);
@@ -298,10 +336,18 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
   uint64_t counter = bd.counter_start;
   uint32_t change_index = 0, rows_in_change = 0;
   uint64_t next_boundary = 0;
+  Rd hl7 = rd_make(d.data, 0);   // role 7: the header's change lengths (N - 1 of them)
+  uint64_t kn7 = 0;
+  auto next_len7 = [&]() -> uint64_t { uint64_t l = rd_uleb(hl7); kn7 += l; return kn7 > bd.counter_len ? 0ull : l; };
   bool unsupported = false;
   if (ok && r == 7) {
     v = rd_make(d.data + bd.base + bdp->sec_rel[SEC_VALUES], bdp->sec_len[SEC_VALUES]);
-    next_boundary = N > 1 ? d.chg[chg0 + 1].ctr : (uint64_t)bd.counter_start + bd.counter_len;
+    // (the changes' first counters come from the header's length column — LDS for a staged head — not from the ChangeRows role 0
+    // stored: one dependent global load per change boundary was a third of the walker's time on one-change-per-keystroke blocks)
+    hl7 = sec(SEC_HEADER);
+    (void)rd_uleb(hl7);
+    rd_skip(hl7, (uint64_t)n_peers * 8);
+    next_boundary = N > 1 ? (uint64_t)bd.counter_start + next_len7() : (uint64_t)bd.counter_start + bd.counter_len;
     d.chg[chg0].op0 = op0;
   }
   uint32_t max_rows = lmw::reduce_max(ok ? n_ops : 0u);
@@ -467,7 +513,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
           rows_in_change = 0;
           change_index++;
           d.chg[chg0 + change_index].op0 = op0 + c0 + k + 1;
-          next_boundary = change_index + 1 < N ? d.chg[chg0 + change_index + 1].ctr : (uint64_t)bd.counter_start + bd.counter_len;
+          next_boundary = change_index + 1 < N ? next_boundary + next_len7() : (uint64_t)bd.counter_start + bd.counter_len;
         }
       };
       // A chunk whose payloads are scalars or nested values — blocks of Map sets, list items — is walked through a WINDOW: the

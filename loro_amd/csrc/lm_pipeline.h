@@ -70,7 +70,7 @@ struct Engine {
   // work buffers
   DBuf b_blob_status, b_blob_nblk, b_blob_blk0, b_tile, b_tot;
   DBuf b_blk, b_bcnt, b_boff;
-  DBuf b_chg, b_dep_peer, b_dep_ctr, b_op, b_op_val, b_op_blk, b_key_off, b_key_len, b_cid_raw, b_cid_map, b_peer_raw, b_peer_map;
+  DBuf b_chg, b_dep_peer, b_dep_ctr, b_dep_ci, b_op, b_op_val, b_op_blk, b_key_off, b_key_len, b_cid_raw, b_cid_map, b_peer_raw, b_peer_map;
   DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
   DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
@@ -140,7 +140,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048; bool lww_lds = true, fuse_rows = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048; bool lww_lds = true, fuse_rows = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -155,6 +155,7 @@ struct Engine {
     if (const char* e = getenv("LM_DIR_OPT_MAX")) k.dir_opt_max = (uint32_t)atoi(e);             // tests: force the retry launch
     if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
     if (const char* e = getenv("LM_HT_OPT")) k.ht_opt = (uint32_t)atoi(e);                       // slots of a document's optimistic LWW table (a power of two; 0: sized for its Map rows at once; tests: 64 forces the second pass)
+    if (const char* e = getenv("LM_CUT_MIN_ROWS")) k.cut_min_rows = (uint32_t)atoll(e);           // op rows from which a document's nodes are cut at cross-peer dependency targets and replayed largest peer first (tests: 0)
     if (const char* e = getenv("LM_FUSE_ROWS")) k.fuse_rows = atoi(e) != 0;                      // 0: one-change-per-keystroke documents are replayed row by row, as in rounds 1-3
     if (const char* e = getenv("LM_LWW_LDS")) k.lww_lds = atoi(e) != 0;                          // 0: every document's Map rows go through the HBM tables (k_map_lww), as in rounds 1-3
     kn = k;
@@ -168,7 +169,7 @@ struct Engine {
   ~Engine() { release_all(); if (h_stage) lmbe::hfree(h_stage); lmbe::stream_destroy(sc); }
   void release_all() {
     DBuf* all[] = {&b_front, &b_front_off, &b_froot, &b_froot_off, &b_blob_hash, &b_big, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
-                   &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
+                   &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_dep_ci, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
@@ -594,7 +595,7 @@ struct Engine {
     if (n_blobs) LM_LAUNCH(k_frame_fill, cdiv(n_blobs, 64), 64, d);
     if (NB) LM_LAUNCH(k_block_desc, cdiv(NB, 64), 64, d);
     b_tot.ensure(64 * 4);
-    d.dec_stat = b_tot.as<uint32_t>() + 48; d.dec_slot = kn.dec_slot;
+    d.dec_stat = b_tot.as<uint32_t>() + 48; d.dec_slot = kn.dec_slot; d.cut_min_rows = kn.cut_min_rows;
     lmbe::dmemset(d.dec_stat, 0, 12);
     if (NB) LM_LAUNCH(k_block_count, cdiv(NB, 64), 64, d);
     lmbe::toc("k_frame_fill+k_block_count", times, profiling);
@@ -607,7 +608,7 @@ struct Engine {
     NC = tot[BC_CHG]; NO = tot[BC_OP]; NCID = tot[BC_CID]; NP = tot[BC_PEER];
     // 3. row tables
     b_chg.ensure((size_t)(NC + 1) * sizeof(ChangeRow));
-    b_dep_peer.ensure((size_t)(ND + 1) * 4); b_dep_ctr.ensure((size_t)(ND + 1) * 4);
+    b_dep_peer.ensure((size_t)(ND + 1) * 4); b_dep_ctr.ensure((size_t)(ND + 1) * 4); b_dep_ci.ensure((size_t)(ND + 1) * 4);
     b_op.ensure((size_t)(NO + 1) * sizeof(OpRow)); b_op_val.ensure((size_t)(NO + 1) * 8); b_op_blk.ensure((size_t)(NO + 1) * 4);
     b_key_off.ensure((size_t)(NK + 1) * 8); b_key_len.ensure((size_t)(NK + 1) * 4);
     b_cid_raw.ensure((size_t)(NCID + 1) * 16); b_cid_map.ensure((size_t)(NCID + 1) * 4);
@@ -622,7 +623,7 @@ struct Engine {
     b_blk_sorted.ensure((size_t)(NB + 1) * 4);
     b_chg_mask.ensure((size_t)(NC + 1) * 8);
     b_cont_root0.ensure((size_t)(NCID + 1) * 4); b_cont_nroot.ensure((size_t)(NCID + 1) * 4);
-    d.chg = b_chg.as<ChangeRow>(); d.dep_peer = b_dep_peer.as<uint32_t>(); d.dep_ctr = b_dep_ctr.as<uint32_t>();
+    d.chg = b_chg.as<ChangeRow>(); d.dep_peer = b_dep_peer.as<uint32_t>(); d.dep_ctr = b_dep_ctr.as<uint32_t>(); d.dep_ci = b_dep_ci.as<uint32_t>();
     d.op = b_op.as<OpRow>(); d.op_val = b_op_val.as<uint64_t>(); d.op_blk = b_op_blk.as<uint32_t>();
     d.key_off = b_key_off.as<uint64_t>(); d.key_len = b_key_len.as<uint32_t>();
     d.cid_raw = b_cid_raw.as<uint32_t>(); d.cid_map = b_cid_map.as<uint32_t>();
@@ -657,7 +658,9 @@ struct Engine {
         // 2,048 documents: one launch 50.7 ms; slots of 4 KB for the whole heads 116 ms (4 waves per CU).  =2: slots sized for the
         // largest head, capped by LM_DEC_SLOT_BIG
         uint32_t slot_big = 0;
-        if (dec_stat[0] && kn.dec_slot_big) {
+        // (only when the batch is MADE of such blocks: a group that mixes one of them with ordinary blocks needs the ordinary slot —
+        // the MovableList batch, where a few blocks carry a 300-item insert, decoded in 7.7 ms with the second launch and 3.9 without)
+        if (dec_stat[0] && kn.dec_slot_big && (kn.dec_big_mode == 2 || (uint64_t)dec_stat[0] * 10 >= (uint64_t)NB * 9)) {
           if (kn.dec_big_mode == 2) { slot_big = (dec_stat[1] + 15u) & ~15u; if (slot_big > kn.dec_slot_big) slot_big = kn.dec_slot_big; }
           else { slot_big = (dec_stat[2] + 15u) & ~15u; if (slot_big < 64) slot_big = 64; if (slot_big >= slot_cap) slot_big = 0; }
         }

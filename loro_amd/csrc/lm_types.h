@@ -121,6 +121,7 @@ enum : uint32_t {
                              // again in a table sized for as many keys as it has Map rows (lm_pipeline.h)
   DF_FUSED = 256u,           // a plain document whose changes hold few rows each (one change per keystroke): k_fuse_rows chained its rows into runs
                              // across change boundaries, k_integrate_span_plain_fuse replays the runs (lm_k_fuse.h)
+  DF_CUT = 512u,             // k_dag_a: the document is large enough for the node cut + descending-peer replay order to pay (k_dag_a / k_dag_b)
   DF_PLAIN = 8u,             // no sliced change, no style anchor, no MovableList (k_dag_a); the host clears it for checked-out documents
                              // and under LM_PLAIN=0: such a document is replayed by k_integrate_span_plain_sweep (lm_pipeline.h)
 };

@@ -89,6 +89,25 @@ def test_map_rendering_plain_groups_and_entry_by_entry():
     _check(_cases.map_render_docs())
 
 
+def test_node_cut_replay_order_and_tracker_base_on_small_documents(monkeypatch):
+    """LM_CUT_MIN_ROWS=0: every document — not only those of 2,048 op rows and more — gets its nodes cut at cross-peer dependency
+    targets, replayed one node per pass with the largest ready peer first, and its trackers a base version at critical versions
+    (conversion + one-pass reset; LM_SWEEP_EAGER: every move back to the base takes the pass), under the structural checker."""
+    monkeypatch.setenv("LM_CUT_MIN_ROWS", "0")
+    b = _emu.variant(["LM_SWEEP_EAGER", "LM_EMU_CHECK"])
+    import _fuzz
+    from loro_amd._cabi import Context
+    docs = _cases.fuzz_docs(40, base=21000) + _cases.cfg4_docs(8, first=7300, n_steps=250) + _nested_docs(6, n_peers=4, n_steps=160)
+    for seed in range(4):
+        tpl = workload.Cfg2Template(1200 + 300 * seed, 600, seed=seed, commit_every=(1 if seed % 2 else 10), fuse=bool(seed % 2 == 0))
+        docs += [tpl.stamp(seed), list(reversed(tpl.stamp(seed + 20)))]
+    docs += [_fuzz.blobs_of(_fuzz.movable_session(8800 + d, n_peers=3, n_steps=120, nested=True)) for d in range(6)]
+    with Context(b) as c:
+        got = c.merge_batch(docs)
+    want = _oracle.merge_batch(docs)
+    assert got == want
+
+
 def test_concurrent_sibling_scans():
     # many peers typing long runs at the same spots: stresses the run-head sibling scan
     _check(_cases.fuzz_docs(12, base=1000, steps=120, peers=4, max_ins=30, sync_prob=0.08))

@@ -149,6 +149,19 @@ def test_map_lww_in_lds_and_in_hbm_tables(engine, monkeypatch, lds):
     _same(engine, docs)
 
 
+def test_node_cut_replay_order_and_tracker_base_on_small_documents(engine, monkeypatch):
+    """LM_CUT_MIN_ROWS=0 (read when the batch is staged): the node cut, the largest-peer-first replay order and the trackers' base
+    version for documents of every size (by default from 2,048 op rows on)"""
+    import _fuzz
+    monkeypatch.setenv("LM_CUT_MIN_ROWS", "0")
+    docs = _cases.fuzz_docs(200, base=23000) + _cases.cfg4_docs(48, first=7400, n_steps=300)
+    for seed in range(6):
+        tpl = workload.Cfg2Template(3000 + 500 * seed, 1500, seed=seed, commit_every=(1 if seed % 2 else 10), fuse=bool(seed % 2 == 0))
+        docs += [tpl.stamp(seed), list(reversed(tpl.stamp(seed + 20)))]
+    docs += [_fuzz.blobs_of(_fuzz.movable_session(8900 + d, n_peers=3, n_steps=150, nested=True)) for d in range(16)]
+    _same(engine, docs)
+
+
 def test_map_rendering_plain_groups_and_entry_by_entry(engine):
     _same(engine, _cases.map_render_docs() * 40)
 

@@ -12,6 +12,9 @@ which = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 if which == "cfg3":
     base = [workload.cfg3_doc(d, combined=(d % 2 == 0)) for d in range(4)]
     docs = [base[i % 4] for i in range(n_docs)]
+elif which == "key":   # one change per keystroke: ~200 changes per block
+    tpl = workload.Cfg2Template(20000, 10000, seed=0, commit_every=1, fuse=False)
+    docs = [tpl.stamp(d) for d in range(n_docs)]
 else:
     tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
     docs = [tpl.stamp(d) for d in range(n_docs)]
