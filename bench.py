@@ -354,12 +354,29 @@ def other_configs(device, cores):
             e.set_profiling(0)
         alg = float(st.in_bytes + st.out_bytes)
         dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
+        # HBM traffic of the dominant stage: only where a committed rocprofv3 --pmc record of this config names the same kernel
+        # (profiles/collect_cfg3.sh: 2,048 documents; the counters scale with the documents)
+        traffic, traffic_src = None, None
+        if name == "configs[2]" and dom:
+            for tag in sorted({f.split("_pmc_configs2.json")[0] for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_configs2.json")}, reverse=True):
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_configs2.json")))
+                except Exception:
+                    continue
+                kk = pj.get("kernels", {}).get(pj.get("dominant_kernel", ""), {})
+                if not pj.get("dominant_kernel", "").startswith(dom) or "FETCH_SIZE_KiB_per_launch" not in kk:
+                    continue
+                per_doc = (2 * kk["FETCH_SIZE_KiB_per_launch"] + kk["WRITE_SIZE_KiB_per_launch"]) * 1024 * kk["calls"] / pj.get("runs_of_the_pipeline", 1) / pj["docs"]
+                traffic = int(per_doc * len(docs))
+                traffic_src = (f"profiles/{tag}_pmc_configs2.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{pj.get('command')}` (not this run), "
+                               f"(2 x FETCH_SIZE + WRITE_SIZE) KiB summed over {pj['dominant_kernel']}'s dispatches of one pipeline run, per document x {len(docs)} documents")
+                break
         note(f"other configs: {name} done")
         out[name] = {"docs": len(docs), "distinct_docs": distinct, "docs_per_s": round(len(docs) / best, 1), "ms_per_batch": round(best * 1e3, 2),
                      "algorithmic_bytes": int(alg), "algorithmic_GBps": round(alg / best / 1e9, 2), "frac_of_hbm_peak": round(alg / best / 1e9 / HBM_PEAK_GBS, 5),
                      "stage_ms": stage_ms,
                      "roofline": None if not dom else {"bound": "hbm", "kernel": dom, "kernel_ms": stage_ms[dom], "achieved": round(alg / (stage_ms[dom] * 1e-3) / 1e9, 2),
-                                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                                                        "what": "algorithmic bytes of the batch over the dominant stage's time for the whole batch (streams serialized); per stage: algorithmic bytes / stage_ms"},
                      "cpu_baseline": {"value": round(distinct / t_cpu, 1), "unit": "docs/s", "cores": min(32, cores, distinct), "kind": "port",
                                       "sample": f"the {distinct} distinct documents of this entry through oracle/liblorooracle.so, one pass, {min(32, cores, distinct)} threads of one process "

@@ -164,6 +164,16 @@ LM_DEV int64_t rle_next_any(RleCur& c, uint32_t mode) {   // the run value lives
   if (__builtin_add_overflow(c.val, c.runv, &c.val)) c.r.bad = true;   // the reference sums in i128 and fails the narrowing
   return c.val;
 }
+// The reference decodes every column of a block IN FULL before it looks at a row (serde_columnar: each column into its own vector,
+// block_encode.rs:587-595, outdated_encode_reordered.rs:480-489), so a column that does not decode, or that holds more or fewer
+// values than the rows need, fails the block with DecodeError whatever the rows say.  The decoders read columns row by row; these
+// two give them the same verdict afterwards: is the column used up exactly, and how many values does the rest hold.
+LM_DEV bool rle_exhausted(const RleCur& c) { return c.rem == 0 && c.r.p >= c.r.end; }
+LM_DEV uint32_t rle_drain(RleCur& c, uint32_t mode) {   // values left in the column (c.r.bad: the rest does not decode)
+  uint32_t n = 0;
+  while (!c.r.bad && !rle_exhausted(c) && n < (1u << 28)) { (void)rle_next_any(c, mode); if (!c.r.bad) n++; }
+  return n;
+}
 // The same cursor over a column of a block STAGED IN LDS (k_block_decode_wave): byte offsets into the slot instead of 64-bit
 // pointers, LDS loads instead of flat ones, and a varint of up to three bytes — nearly all of them — is read with three
 // independent loads and no per-byte bounds test, whenever three bytes are left in the column (the generic reader above spends
@@ -217,6 +227,12 @@ LM_DEV int64_t col_next_any(ColCur& c, uint32_t mode) {   // == rle_next_any
   if (mode != 2) return c.runv;
   if (__builtin_add_overflow(c.val, c.runv, &c.val)) c.bad = true;   // the reference sums in i128 and fails the narrowing
   return c.val;
+}
+LM_DEV bool col_exhausted(const ColCur& c) { return c.rem == 0 && c.p >= c.end; }
+LM_DEV uint32_t col_drain(ColCur& c, uint32_t mode) {
+  uint32_t n = 0;
+  while (!c.bad && !col_exhausted(c) && n < (1u << 28)) { (void)col_next_any(c, mode); if (!c.bad) n++; }
+  return n;
 }
 // number of values in a whole AnyRle payload whose literals are single bytes (Rle<u8>)
 LM_DEV uint64_t rle_count_u8(Rd r) {

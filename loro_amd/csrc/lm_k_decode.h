@@ -285,15 +285,19 @@ LM_KERNEL void k_block_count(Dev d) {
 // document DF_SOFT_UNSUPPORTED when met by the emitter (or when one of their ops is applied).
 // (a scalar at the top level — what a Map set or a list of numbers carries — is stepped over right here: the frame machinery below
 // is for lists, maps and child containers)
-template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt);
-template <class R> LM_DEV void skip_loro_value_top(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt, uint32_t tag_peek) {
-  if (tag_peek > 6 || r.bad) { skip_loro_value_fs(r, unsupported, cdepth, f_cnt); return; }   // (a latched reader consumes nothing there)
+// n_keys / corrupt: the reference decodes EVERY value in full when it decodes the block — a nested map whose key index lies beyond
+// the block's key table, a value tag nobody defined, a collection of more than 2^28 items are DecodeDataCorruptionError there
+// whether or not the value ever reaches the state (value.rs:342-459) — so the walk reports them (*corrupt) instead of leaving them to
+// the renderer, which only ever parses the values that won.
+template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt, uint32_t n_keys = 0xffffffffu, bool* corrupt = nullptr);
+template <class R> LM_DEV void skip_loro_value_top(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt, uint32_t tag_peek, uint32_t n_keys = 0xffffffffu, bool* corrupt = nullptr) {
+  if (tag_peek > 6 || r.bad) { skip_loro_value_fs(r, unsupported, cdepth, f_cnt, n_keys, corrupt); return; }   // (a latched reader consumes nothing there)
   (void)rd_u8(r);
   if (tag_peek == 3) (void)rd_sleb(r);
   else if (tag_peek == 4) rd_skip(r, 8);
   else if (tag_peek >= 5) { uint64_t l = rd_uleb(r); rd_skip(r, l); }
 }
-template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt) {   // f_cnt: 16 words of frame stack
+template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt, uint32_t n_keys, bool* corrupt) {   // f_cnt: 16 words of frame stack
   uint32_t f_map = 0;  // bit i: frame i is a map (each item is preceded by a key index)
   int sp = 0;
   uint32_t cnt = 1;
@@ -307,7 +311,7 @@ template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int c
     }
     if (r.bad) return;
     cnt--;
-    if (in_map) (void)rd_uleb(r);
+    if (in_map) { uint64_t kidx = rd_uleb(r); if (kidx >= n_keys && !r.bad && corrupt) { *corrupt = true; r.bad = true; return; } }
     uint32_t tag = rd_u8(r);
     switch (tag) {
       case 0: case 1: case 2: break;
@@ -316,6 +320,7 @@ template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int c
       case 5: case 6: { uint64_t l = rd_uleb(r); rd_skip(r, l); break; }
       case 7: case 8: {
         uint64_t n = rd_uleb(r);
+        if (n > (1u << 28) && !r.bad && corrupt) *corrupt = true;
         if (n > (1u << 28) || sp >= 16) { r.bad = true; return; }
         f_cnt[sp] = cnt;
         f_map = (f_map & ~(1u << sp)) | ((in_map ? 1u : 0u) << sp);
@@ -324,15 +329,15 @@ template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int c
         in_map = tag == 8;
         break;
       }
-      case 9: { uint32_t ck = rd_u8(r); if (ck > CK_COUNTER) { r.bad = true; return; } if (sp > cdepth) unsupported = true; break; }
-      default: r.bad = true; return;
+      case 9: { (void)rd_u8(r); if (sp > cdepth) unsupported = true; break; }   // (any kind byte: ContainerType::Unknown, lib.rs:793-804)
+      default: if (!r.bad && corrupt) *corrupt = true; r.bad = true; return;
     }
   }
   r.bad = true;
 }
-LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {
+LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1, uint32_t n_keys = 0xffffffffu, bool* corrupt = nullptr) {
   uint32_t f_cnt[16];
-  skip_loro_value_fs(r, unsupported, cdepth, f_cnt);
+  skip_loro_value_fs(r, unsupported, cdepth, f_cnt, n_keys, corrupt);
 }
 
 // K4: one lane per block — full decode into the row tables (block-local indices; K6 remaps them).
@@ -477,7 +482,7 @@ LM_KERNEL void k_block_decode(Dev d) {
       w[1] = (uint32_t)pidx;
       w[2] = (uint32_t)koc;
       w[3] = bi;
-      if (kind > CK_COUNTER) st = st ? st : ST_DECODE_ERROR;   // ContainerType::try_from_u8 fails (loro-common/src/lib.rs:748-793)
+      // (a kind beyond Counter is ContainerType::Unknown(kind), loro-common/src/lib.rs:793-804 — try_from_u8 never fails: the container is outside the device scope like Tree / Counter)
     }
     if (k.bad) st = st ? st : ST_DECODE_ERROR;
   }
@@ -498,6 +503,20 @@ LM_KERNEL void k_block_decode(Dev d) {
       d_peer = rle_make(rd_bytes(dsec));
       d_ctr = rle_make(rd_bytes(dsec));
       d_len = rle_make(rd_bytes(dsec));
+    }
+    {
+      // every column decodes, the op columns to one value per row, the delete-start columns to equally many (lm_dev_util.h rle_drain)
+      bool colbad = false;
+      { RleCur t = c_cont; uint32_t n = rle_drain(t, 2); colbad |= t.r.bad || n != n_ops; }
+      { RleCur t = c_prop; uint32_t n = rle_drain(t, 2); colbad |= t.r.bad || n != n_ops; }
+      { RleCur t = c_vt; uint32_t n = rle_drain(t, 0); colbad |= t.r.bad || n != n_ops; }
+      { RleCur t = c_len; uint32_t n = rle_drain(t, 1); colbad |= t.r.bad || n != n_ops; }
+      if (has_del) {
+        RleCur t1 = d_peer, t2 = d_ctr, t3 = d_len;
+        uint32_t n1 = rle_drain(t1, 2), n2 = rle_drain(t2, 2), n3 = rle_drain(t3, 2);
+        colbad |= t1.r.bad || t2.r.bad || t3.r.bad || n1 != n2 || n1 != n3;
+      }
+      if (colbad) st = st ? st : ST_DECODE_ERROR;
     }
     Rd v = blk_sec(d, bd, SEC_VALUES);
     uint64_t counter = bd.counter_start;
@@ -523,6 +542,7 @@ LM_KERNEL void k_block_decode(Dev d) {
       uint32_t kind = OK_OTHER;
       uint32_t mark_len = 0;
       uint64_t mv_from = 0, mv_peer = 0, mv_lam = 0;
+      bool vcorrupt = false;   // (skip_loro_value: a nested key index beyond the key table, an undefined value tag)
       bool is_list_value = false;
       // value payload (docs/encoding.md §10)
       switch (vt) {
@@ -541,7 +561,7 @@ LM_KERNEL void k_block_decode(Dev d) {
             r.a0 = (uint32_t)rd_uleb(t);
           }
           // (values of containers outside the device scope are never rendered: any shape is accepted)
-          skip_loro_value(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && (ckind == CK_LIST || ckind == CK_MOVABLE) ? 1 : (ckind > CK_TEXT && ckind != CK_MOVABLE ? 16 : -1)));
+          skip_loro_value(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && (ckind == CK_LIST || ckind == CK_MOVABLE) ? 1 : (ckind > CK_TEXT && ckind != CK_MOVABLE ? 16 : -1)), n_keys, &vcorrupt);
           break;
         }
         case 12: {
@@ -550,7 +570,7 @@ LM_KERNEL void k_block_decode(Dev d) {
           uint64_t key_idx = rd_uleb(v);
           if (key_idx >= n_keys) st = st ? st : ST_DATA_CORRUPTION;
           bool u = false;
-          skip_loro_value(v, u);
+          skip_loro_value(v, u, -1, n_keys, &vcorrupt);
           break;
         }
         case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
@@ -558,8 +578,8 @@ LM_KERNEL void k_block_decode(Dev d) {
         case 15: {   // ListSet: element peer idx, element lamport, then the nested value (op_val points at it)
           mv_peer = rd_uleb(v); mv_lam = rd_uleb(v);
           val_at = (uint64_t)(v.p - d.data);
-          if (ckind == CK_MOVABLE) skip_loro_value(v, unsupported, 0);
-          else { bool u = false; skip_loro_value(v, u); }
+          if (ckind == CK_MOVABLE) skip_loro_value(v, unsupported, 0, n_keys, &vcorrupt);
+          else { bool u = false; skip_loro_value(v, u, -1, n_keys, &vcorrupt); }
           break;
         }
         case 16: {
@@ -570,6 +590,7 @@ LM_KERNEL void k_block_decode(Dev d) {
         }
         default: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
       }
+      if (vcorrupt) st = st ? st : ST_DATA_CORRUPTION;
       // decode_op mapping (outdated_encode_reordered.rs:215-476)
       bool take_del = false;
       if (ckind == CK_TEXT) {
@@ -616,6 +637,7 @@ LM_KERNEL void k_block_decode(Dev d) {
       if (counter > MAX_COUNTER) { st = st ? st : ST_UNSUPPORTED; counter = MAX_COUNTER; }
       if (change_index >= N) { st = st ? st : ST_DATA_CORRUPTION; change_index = N - 1; }
       d.chg[chg0 + change_index].n_op++;
+      if (counter > next_boundary && change_index + 1 < N) st = st ? st : ST_DATA_CORRUPTION;   // an op crosses a change boundary (docs/encoding.md §10.6)
       if (counter >= next_boundary && change_index + 1 < N) {
         change_index++;
         d.chg[chg0 + change_index].op0 = op0 + row + 1;

@@ -35,7 +35,8 @@ namespace lm {
 static constexpr uint32_t DEC_G = LM_DEC_G;     // blocks per wave (8 lanes each; -DLM_DEC_G=4: half the lanes idle, half the LDS per wave — twice the waves per CU)
 static constexpr uint32_t DEC_R = 8;            // rows per chunk (one lane per row in the assembly phase)
 static constexpr uint32_t DEC_WW = 6;           // words the walker hands over per row: value offset lo/hi, aux, flags, counter, change
-static constexpr uint32_t DEC_LDS_FIXED = DEC_G * 16 * 4 + DEC_G * DEC_R * 8 * 4 + DEC_G * DEC_R * DEC_WW * 4 + DEC_G * DEC_VW;   // frame stacks + s_x + s_w + value windows
+static constexpr uint32_t DEC_VW2 = 128;        // window of the integer-values fast path (8 values of up to 11 bytes, rounded to 16-byte loads)
+static constexpr uint32_t DEC_LDS_FIXED = DEC_G * 16 * 4 + DEC_G * DEC_R * 8 * 4 + DEC_G * DEC_R * DEC_WW * 4 + DEC_G * DEC_VW + DEC_G * DEC_VW2;   // frame stacks + s_x + s_w + value windows
 static constexpr uint32_t DEC_KINDS = 16;       // container kinds of a block cached in LDS (more: read back from cid_raw)
 // error bookkeeping of the row loop: the earliest row wins, then the role order of the sequential decoder
 LM_DEV void dec_err(uint32_t& key, uint32_t row, uint32_t prio, int32_t code) {
@@ -66,7 +67,8 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
   uint32_t* s_x = s_fs + DEC_G * 16;                  // DEC_G x DEC_R rows x 8 column words
   uint32_t* s_w = s_x + DEC_G * DEC_R * 8;            // DEC_G x DEC_R rows x DEC_WW walker words
   uint8_t* s_vw = (uint8_t*)(s_w + DEC_G * DEC_R * DEC_WW);   // DEC_G value windows of DEC_VW bytes (16-byte aligned: slot_cap and every table in front are multiples of 16)
-  uint8_t* s_kinds = s_vw + DEC_G * DEC_VW;
+  uint8_t* s_vw2 = s_vw + DEC_G * DEC_VW;             // DEC_G windows of DEC_VW2 bytes (the integer-values fast path)
+  uint8_t* s_kinds = s_vw2 + DEC_G * DEC_VW2;
   bool have = b < DEC_G && bi < d.n_blocks;
   // only the scalar fields of the descriptor stay in registers; section extents are read where a section is opened
   struct { uint64_t base; uint32_t counter_start, counter_len, n_changes; } bd = {0, 0, 0, 0};
@@ -284,7 +286,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
         w[1] = (uint32_t)pidx;
         w[2] = (uint32_t)koc;
         w[3] = bi;
-        if (kind > CK_COUNTER) st = st ? st : ST_DECODE_ERROR;   // ContainerType::try_from_u8 fails (loro-common/src/lib.rs:748-793)
+        // (a kind beyond Counter is ContainerType::Unknown(kind), loro-common/src/lib.rs:793-804 — try_from_u8 never fails: the container is outside the device scope like Tree / Counter)
         if (i < DEC_KINDS) s_kinds[b * DEC_KINDS + i] = (uint8_t)kind;
       }
       if (k.bad) st = st ? st : ST_DECODE_ERROR;
@@ -298,6 +300,8 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
   bool has_del = false;
   uint32_t errk = 0xffffffffu;   // earliest row error of this lane
   uint32_t kc_map = 0, kc_el = 0, kc_style = 0;   // this lane's rows (phase B: lane = (block, row of the chunk)), lm_k_decode.h kc_add
+  bool colbad = false;           // this lane's column does not decode (lm_dev_util.h rle_drain)
+  uint32_t n_del_read = 0;       // delete-start columns: values read for the block's DeleteSeq rows
   bool shape_bad = false;        // ops / delete section framing
   if (ok) {
     Rd o = sec(SEC_OPS);
@@ -445,11 +449,102 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
           }
         }
       }
+#ifndef LM_NO_I64_FAST
+      // I. A chunk of Map writes whose values are integers — `set(key, i64)`: counters, timestamps, ids — needs no walk either.  Each
+      // value is a tag byte (3) and a signed LEB128: bytes with a clear top bit ALTERNATE tag, last LEB byte, tag, last LEB byte …
+      // The block's eight lanes fetch the 128 bytes behind the walker's cursor with one 16-byte load each; every row lane then reads
+      // the window, finds its value between the (2k)-th and the (2k+1)-th such byte, and checks its tag; when all eight hold and no
+      // change ends inside the chunk the rows' bookkeeping words come from a scan, as for plain typing above.  (One lane stepped
+      // through the eight values byte by byte before: 55 % of the decoder's time on configs[2], profiles/r04_decoder_phases.log.)
+      {
+        const bool int_r = act && vt == 11 && ckind == CK_MAP;
+        const uint64_t cand_m = lmw::ballot(int_r || !act);
+        const bool blk_cand = ((cand_m >> (b * 8)) & 0xffull) == 0xffull;
+        const uint32_t wn_blk = lmw::shfl(wn, (int)(b * 8 + 7));
+        if (lmw::any(blk_cand && wn_blk != 0)) {
+          int wl_ = (int)(b * 8 + 7);
+          uint64_t vp = (uint64_t)(v.p - d.data);
+          uint64_t wpos = ((uint64_t)lmw::shfl((uint32_t)(vp >> 32), wl_) << 32) | lmw::shfl((uint32_t)vp, wl_);
+          const bool go = blk_cand && wn_blk != 0;
+          uint8_t* win = s_vw2 + (size_t)b * DEC_VW2;
+          if (go && wpos + 16ull * r < v_end_abs) {   // (a 16-byte piece that starts inside the section: `data` carries 64 bytes of slack)
+            struct V16b { uint32_t x, y, z, w; } pc;
+            __builtin_memcpy(&pc, d.data + wpos + 16ull * r, 16);
+            *(V16b*)(win + 16u * r) = pc;
+          }
+          lmw::wave_sync();
+          bool ok_r = true;
+          uint32_t st_k = 0, en_k = 0;
+          if (go && act) {
+            // bytes of the window with a clear top bit, as two 64-bit masks (only bytes inside the values section count)
+            uint64_t left = v_end_abs - wpos;
+            uint64_t t0 = 0, t1 = 0;
+            const uint32_t* w32 = (const uint32_t*)win;
+            for (uint32_t q = 0; q < 16; q++) {
+              uint32_t x = ~w32[q] & 0x80808080u;                                       // bit 7 of each byte: set where the byte terminates
+              uint64_t nib = ((x >> 7) & 1u) | ((x >> 14) & 2u) | ((x >> 21) & 4u) | ((x >> 28) & 8u);
+              t0 |= nib << (4 * q);
+            }
+            for (uint32_t q = 16; q < 32; q++) {
+              uint32_t x = ~w32[q] & 0x80808080u;
+              uint64_t nib = ((x >> 7) & 1u) | ((x >> 14) & 2u) | ((x >> 21) & 4u) | ((x >> 28) & 8u);
+              t1 |= nib << (4 * (q - 16));
+            }
+            if (left < 64) { t0 &= (1ull << left) - 1; t1 = 0; }
+            else if (left < 128) t1 &= (1ull << (left - 64)) - 1;
+            // the (2r)-th and (2r+1)-th set bits (r = this lane's row of the chunk)
+            auto nth = [&](uint32_t n, uint32_t& pos) -> bool {
+              uint64_t a = t0, bq = t1;
+              uint32_t c0 = (uint32_t)lmw::popc64(a);
+              if (n < c0) { for (uint32_t i = 0; i < n; i++) a &= a - 1; pos = (uint32_t)lmw::ffs64(a); return true; }
+              n -= c0;
+              if (n >= (uint32_t)lmw::popc64(bq)) return false;
+              for (uint32_t i = 0; i < n; i++) bq &= bq - 1;
+              pos = 64u + (uint32_t)lmw::ffs64(bq);
+              return true;
+            };
+            ok_r = nth(2 * r, st_k) && nth(2 * r + 1, en_k);
+            // the tag is an I64's, the LEB128 is at most ten bytes (the bytes between two set bits all carry the continuation bit by
+            // construction), and the value begins right behind the one in front of it
+            if (ok_r) ok_r = win[st_k] == 3 && en_k - st_k <= 10;
+            if (ok_r) {
+              uint32_t pen = 0;
+              if (r == 0) ok_r = st_k == 0;
+              else ok_r = nth(2 * r - 1, pen) && st_k == pen + 1;
+            }
+          }
+          uint64_t okm = lmw::ballot(!go || !act || ok_r);
+          const bool all_ok = go && ((okm >> (b * 8)) & 0xffull) == 0xffull;
+          // end of the chunk's last value = where the walker continues; the rows' counters / change as in S
+          uint32_t n_act = (uint32_t)lmw::popc64((lmw::ballot(act) >> (b * 8)) & 0xffull);
+          uint32_t last_en = lmw::shfl(en_k, (int)(b * 8 + (n_act ? n_act - 1 : 0)));
+          uint32_t cinc = lmw::scan_incl_add(act ? len : 0u);
+          uint32_t cbase = lmw::shfl(cinc, (int)(b ? b * 8 - 1 : 0));
+          if (!b) cbase = 0;
+          uint32_t tot_len = lmw::shfl(cinc, wl_) - cbase;
+          uint32_t ctr7 = lmw::shfl((uint32_t)counter, wl_), ci7 = lmw::shfl(change_index, wl_);
+          uint32_t nb7 = lmw::shfl((uint32_t)(next_boundary > 0xffffffffull ? 0xffffffffull : next_boundary), wl_);
+          const bool whole = all_ok && n_act == wn_blk && ci7 < N && (uint64_t)ctr7 + tot_len <= MAX_COUNTER && ((uint64_t)ctr7 + tot_len < nb7 || ci7 + 1 >= N);
+#ifdef LM_EMU_TRACE
+          if (getenv("LM_EMU_I64") && go && r == 7) fprintf(stderr, "I64 %s\n", whole ? "fast" : (all_ok ? "boundary" : "declined"));
+#endif
+          if (whole) {
+            if (act) {
+              uint64_t va = wpos + st_k;
+              uint32_t* o = sw + r * DEC_WW;
+              o[0] = (uint32_t)va; o[1] = (uint32_t)(va >> 32); o[2] = 0; o[3] = 0; o[4] = ctr7 + (cinc - len - cbase); o[5] = chg0 + ci7;
+            }
+            if (wn) { v.p += last_en + 1; counter += tot_len; rows_in_change += wn; wn = 0; }
+          }
+        }
+      }
+#endif
       // one value (row k of the chunk), through either reader
       auto walk = [&](auto& v, const uint32_t k) {
         uint32_t wvt = sx[k * 8 + 2], wlen = sx[k * 8 + 3], wkind = sx[k * 8 + 7];
         uint64_t val_at = (uint64_t)(v.p - d.data);
         uint32_t aux = 0, flags = 0;   // aux: element count of a list value | mark length; flags bit 0: the value is a list
+        bool vcorrupt = false;         // (skip_loro_value: a nested key index beyond the key table, an undefined value tag)
         switch (wvt) {
           case 0: case 1: case 2: case 8: case 9: break;
           case 3: (void)rd_sleb(v); break;
@@ -464,7 +559,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
             bool is_list_value = tag0 == 7;
             if (is_list_value) { auto t = v; (void)rd_u8(t); aux = (uint32_t)rd_uleb(t); flags = 1; }
             // (values of containers outside the device scope are never rendered: any shape is accepted)
-            skip_loro_value_top(v, unsupported, wkind == CK_MAP ? 0 : (is_list_value && (wkind == CK_LIST || wkind == CK_MOVABLE) ? 1 : (wkind > CK_TEXT && wkind != CK_MOVABLE ? 16 : -1)), fs, tag0);
+            skip_loro_value_top(v, unsupported, wkind == CK_MAP ? 0 : (is_list_value && (wkind == CK_LIST || wkind == CK_MOVABLE) ? 1 : (wkind > CK_TEXT && wkind != CK_MOVABLE ? 16 : -1)), fs, tag0, n_keys, &vcorrupt);
             break;
           }
           case 12: {
@@ -473,7 +568,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
             uint64_t key_idx = rd_uleb(v);
             if (key_idx >= n_keys) dec_err(errk, c0 + k, 2, ST_DATA_CORRUPTION);
             bool u = false;
-            skip_loro_value_fs(v, u, -1, fs);
+            skip_loro_value_fs(v, u, -1, fs, n_keys, &vcorrupt);
             break;
           }
           case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
@@ -489,8 +584,8 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
             if (pi >= n_peers || lm_ > 0xFFFFFFFFull) flags |= 2;
             sx[k * 8 + 4] = (uint32_t)pi; sx[k * 8 + 5] = (uint32_t)lm_; sx[k * 8 + 6] = 0;
             val_at = (uint64_t)(v.p - d.data);   // op_val of a set row points at the nested value
-            if (wkind == CK_MOVABLE) skip_loro_value_fs(v, unsupported, 0, fs);
-            else { bool u = false; skip_loro_value_fs(v, u, -1, fs); }
+            if (wkind == CK_MOVABLE) skip_loro_value_fs(v, unsupported, 0, fs, n_keys, &vcorrupt);
+            else { bool u = false; skip_loro_value_fs(v, u, -1, fs, n_keys, &vcorrupt); }
             break;
           }
           case 16: {
@@ -501,6 +596,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
           }
           default: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
         }
+        if (vcorrupt) dec_err(errk, c0 + k, 2, ST_DATA_CORRUPTION);
         uint32_t* o = sw + k * DEC_WW;
         o[0] = (uint32_t)val_at; o[1] = (uint32_t)(val_at >> 32); o[2] = aux; o[3] = flags;
         o[4] = (uint32_t)counter; o[5] = chg0 + change_index;
@@ -508,6 +604,9 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
         if (counter > MAX_COUNTER) { dec_err(errk, c0 + k, 10, ST_UNSUPPORTED); counter = MAX_COUNTER; }
         if (change_index >= N) { dec_err(errk, c0 + k, 11, ST_DATA_CORRUPTION); change_index = N - 1; }
         rows_in_change++;
+        // (an op that crosses a change boundary — or any op of a change whose header length is zero: docs/encoding.md §10.6, "independent
+        // validators should reject these inputs"; the oracle does the same)
+        if (counter > next_boundary && change_index + 1 < N) dec_err(errk, c0 + k, 12, ST_DATA_CORRUPTION);
         if (counter >= next_boundary && change_index + 1 < N) {
           d.chg[chg0 + change_index].n_op = rows_in_change;
           rows_in_change = 0;
@@ -561,9 +660,12 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
         uint32_t kk = a2 ? (uint32_t)__builtin_ctz(todo) : k;
         uint32_t rowx = a2 ? c0 + kk : c0 + DEC_R + k;
         todo &= todo - 1;   // (0 stays 0)
-        int64_t w = staged ? col_next_any(fcol, mode) : rle_next_any(col, mode);
-        if ((uint64_t)(w - v_lo) >= v_span || (v_nz && w == 0)) { dec_err(errk, rowx, v_prio, v_code); w = v_repl; }
-        if (a2 && (staged ? fcol.bad : col.r.bad)) dec_err(errk, rowx, 9, ST_DATA_CORRUPTION);
+        // (a delete-start column that is used up has no id for this row: the row's finding; one that does not decode is the column's)
+        const bool used_up = a2 && (staged ? col_exhausted(fcol) : rle_exhausted(col));
+        int64_t w = used_up ? v_repl : (staged ? col_next_any(fcol, mode) : rle_next_any(col, mode));
+        if (a2 && !used_up) { if (staged ? fcol.bad : col.r.bad) colbad = true; else n_del_read++; }
+        if (!used_up && ((uint64_t)(w - v_lo) >= v_span || (v_nz && w == 0))) { dec_err(errk, rowx, v_prio, v_code); w = v_repl; }
+        if (a2 && (used_up || (staged ? fcol.bad : col.r.bad))) dec_err(errk, rowx, 9, ST_DATA_CORRUPTION);
         sx[kk * 8 + r] = (uint32_t)w & v_mask;
       }
     }
@@ -628,7 +730,19 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
     if (counter != (uint64_t)bd.counter_start + bd.counter_len) tail |= 2;
     if (unsupported) tail |= 4;
   }
-  if (ok && r < 4 && (staged ? fcol.bad : col.r.bad)) tail |= 1;
+  // every column decodes in full: the op columns to exactly one value per row, the delete-start columns to equally many values each
+  // (what is left of them is counted here) — the reference decodes the columns before it looks at a row, so this finding precedes
+  // every row's (bit 4)
+  if (ok && r < 4 && ((staged ? fcol.bad : col.r.bad) || !(staged ? col_exhausted(fcol) : rle_exhausted(col)))) tail |= 16;
+  {
+    uint32_t tot = n_del_read;
+    if (ok && has_del && r >= 4 && r < 7) {
+      tot += staged ? col_drain(fcol, mode) : rle_drain(col, mode);
+      if (colbad || (staged ? fcol.bad : col.r.bad)) tail |= 16;
+    }
+    uint32_t t4 = lmw::shfl(tot, (int)(b * 8 + 4)), t5 = lmw::shfl(tot, (int)(b * 8 + 5)), t6 = lmw::shfl(tot, (int)(b * 8 + 6));
+    if (ok && has_del && (t4 != t5 || t4 != t6)) tail |= 16;
+  }
   if (ok && shape_bad) tail |= 8;
   // combine over the 8 lanes of the block
   for (int m = 1; m < 8; m <<= 1) {
@@ -638,7 +752,11 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
     kc_map += lmw::shfl_xor(kc_map, m); kc_el += lmw::shfl_xor(kc_el, m); kc_style += lmw::shfl_xor(kc_style, m);
   }
   if (ok && r == 0) {
+#ifdef LM_EMU_TRACE
+    if (getenv("LM_EMU_DECERR") && (st != ST_OK || errk != 0xffffffffu || tail)) fprintf(stderr, "DECERR blk %u st %d errk %x tail %x\n", bi, st, errk, tail);
+#endif
     if (st == ST_OK && (tail & 8)) st = ST_DECODE_ERROR;
+    if (st == ST_OK && (tail & 16)) st = ST_DECODE_ERROR;
     if (st == ST_OK && errk != 0xffffffffu) st = (int32_t)(errk & 0xf);
     if (st == ST_OK && (tail & 1)) st = ST_DECODE_ERROR;
     if (st == ST_OK && (tail & 2)) st = ST_DATA_CORRUPTION;

@@ -795,6 +795,12 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
     counter += (int64_t)col_len[row];
     if (counter > INT32_MAX) fail(ST_DATA_CORRUPTION, "counter overflow");
     if (change_index + 1 >= counters.size()) fail(ST_DATA_CORRUPTION, "change index");
+    // canonical invariant (docs/encoding.md §10.6: "operation atom lengths partition the reconstructed change counter ranges
+    // exactly, without crossing a boundary … independent validators should reject these inputs"): the Rust reader advances at
+    // most one change on `counter >= next_counter` (block_encode.rs:697-703) and lets an op that crosses a boundary — or a change of
+    // length zero — through; what the oplog then makes of overlapping changes is not a value anybody specified.  Rejected here, and by
+    // the device decoders (lm_k_decode_wave.h / lm_k_decode.h), like the other canonical invariants above.
+    if (counter > counters[change_index + 1]) fail(ST_DATA_CORRUPTION, "op crosses a change boundary");
     if (counter >= counters[change_index + 1]) change_index++;
   }
 }

@@ -330,4 +330,21 @@ def map_render_docs():
         c.map_set("mixed", "key-%d" % i, -i)
     c.commit()
     docs.append([b.export(), c.export()])
+    # integers of every LEB128 width (the decoder's integer-values fast path finds eight values at once in a 128-byte window), chunks
+    # with a string / null among them, change boundaries every 100 rows
+    vals = [0, 1, -1, 63, 64, -64, -65, 8191, 8192, -8192, -8193, 2**20, -(2**20) - 1, 2**27 - 1, 2**27, 2**34, -(2**34) - 1, 2**41, 2**48,
+            -(2**48) - 1, 2**55, 2**62, -(2**62), 2**63 - 1, -(2**63)]
+    for rep in range(3):
+        r = wire.Replica(50 + rep)
+        for i in range(400):
+            v = vals[(i * 7 + rep) % len(vals)]
+            if rep == 1 and i % 37 == 0:
+                v = "s%d" % i
+            if rep == 2 and i % 41 == 0:
+                v = None
+            r.map_set("m", "k%d" % (i % 97), v)
+            if i % 100 == 99:
+                r.commit()
+        r.commit()
+        docs.append([r.export()])
     return docs

@@ -366,7 +366,7 @@ def test_damaged_blobs_never_take_the_batch_down():
     — when the oracle accepts it too — rendered alike (a delete row whose position and target ids disagree, or whose span
     length differs from its op length, is LM_DATA_CORRUPTION: the reference deletes by position, the kernel by id —
     ts_del_pos_ok, lm_k_integrate_span.h)."""
-    bad = _cases.corrupted_docs(150, seed=7)
+    bad = _cases.corrupted_docs(150, seed=7) + _cases.corrupted_docs(100, seed=8) + _cases.corrupted_docs(100, seed=11)
     good = _cases.fuzz_docs(8, base=6000)
     docs = []
     for i, b in enumerate(bad):
@@ -375,18 +375,20 @@ def test_damaged_blobs_never_take_the_batch_down():
             docs.append(good[(i // 8) % len(good)])
     want = _oracle.merge_batch(docs, threads=8)
     got = _emu.merge_batch(docs)
-    n_same = n_both_ok = 0
+    n_same = n_both_ok = n_dev_only = 0
     k = 0
     for i in range(len(bad)):
         g, w = got[k], want[k]
         if g[0] == 0 and w[0] == 0:
             n_both_ok += 1
             n_same += g == w
+        n_dev_only += g[0] == 0 and w[0] not in (0, 4)
         k += 1
         if i % 8 == 0:
             assert got[k] == want[k] and want[k][0] == 0      # the healthy neighbour
             k += 1
     assert n_both_ok > 0 and n_same == n_both_ok
+    assert n_dev_only == 0   # the device never renders a document the oracle rejects (surplus column values, nested key indices, ops across change boundaries)
 
 
 def test_delete_rows_that_name_elements_nobody_inserted():

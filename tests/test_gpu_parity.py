@@ -312,11 +312,16 @@ def test_container_limit_is_reported(engine):
 
 
 def test_damaged_blobs_never_take_the_batch_down(engine):
-    """1200 documents with one damaged blob each (checksum re-fitted), interleaved with healthy documents: every healthy
-    document still comes back exact, no damaged document crashes the batch, and a damaged document is either rejected or
-    — when the oracle accepts it too — mostly rendered alike (the device applies deletes by target id and checks a few
-    things the oracle does not, DESIGN.md §7, so a handful of damaged-but-accepted documents may differ)."""
-    bad = _cases.corrupted_docs(1200, seed=7)
+    """2,400 documents with one damaged blob each (checksum re-fitted; eight seeds), interleaved with healthy documents: every
+    healthy document still comes back exact, no damaged document crashes the batch, what both sides accept is rendered alike, and
+    the device never renders a document the oracle rejects (the converse — the reference deletes by position and accepts a few
+    documents whose delete rows the device refuses by id — is DESIGN.md §7's documented deviation)."""
+    # eight seeds (VERDICT r3: seed 7 alone hid three documents per ≈1,500 that both sides accepted and rendered differently —
+    # zero-length changes — and a dozen the device accepted where the reference fails: columns with surplus values, nested key
+    # indices beyond the key table; all aligned in round 4, see DESIGN §7)
+    bad = []
+    for seed in (7, 1, 2, 3, 5, 6, 8, 11):
+        bad += _cases.corrupted_docs(300, seed=seed)
     good = _cases.fuzz_docs(8, base=6000)
     docs = []
     for i, b in enumerate(bad):
@@ -325,17 +330,19 @@ def test_damaged_blobs_never_take_the_batch_down(engine):
             docs.append(good[(i // 8) % len(good)])
     want = _oracle.merge_batch(docs, threads=8)
     got = engine.merge_batch(docs)
-    n_same = n_both_ok = 0
+    n_same = n_both_ok = n_dev_only = 0
     k = 0
     for i in range(len(bad)):
         g, w = got[k], want[k]
         if g[0] == 0 and w[0] == 0:
             n_both_ok += 1
             n_same += g == w
+        n_dev_only += g[0] == 0 and w[0] not in (0, 4)
         k += 1
         if i % 8 == 0:
             assert got[k] == want[k] and want[k][0] == 0      # the healthy neighbour
             k += 1
+    assert n_dev_only == 0, "the device rendered a damaged document the reference algorithm rejects"
     # a damaged delete row whose position and target ids disagree (the reference deletes by position, crdt_rope.rs:256-335, the
     # kernel by id) or whose span length differs from its op length is LM_DATA_CORRUPTION since round 3 (ts_del_pos_ok,
     # lm_k_integrate_span.h): what both sides accept, they render alike
