@@ -511,9 +511,17 @@ def resident_configs(device, cores, n_docs=10000, full=True):
                         assert all(got[i] == want[(i % 4) * 16 + k] for i in range(n5)), "configs[4]-resident: device results differ from the CPU oracle"
                 if rep:
                     best = min(best, time.perf_counter() - t0)
+            # one more move (from the last version back to the eighth) with the stages timed on their own
+            e.set_profiling(1)
+            e.import_more([[] for _ in docs5], [g5[i % 4][1][7] for i in range(n5)]); e.run()
+            kt_move = {}
+            for name, ms in e.kernel_times():
+                kt_move[name] = round(kt_move.get(name, 0.0) + ms, 3)
+            e.set_profiling(0)
         out["configs[4]-resident"] = {
             "renderings": n5 * 16, "renderings_per_s": round(n5 * 16 / best, 1), "ms_total": round(best * 1e3, 2), "ms_replay_incl_staging": round(t_replay * 1e3, 2),
             "parity": f"all {n5 * 16} renderings equal to the oracle's",
+            "stage_ms_of_one_move_and_rendering_streams_serialized": kt_move,
             "workload": f"{n5} 1M-op rich-text documents (4 distinct) — the config's stated size — each staged and replayed ONCE, then rendered at 16 versions by moving "
                         "the resident trackers (lm_import with frontiers only + lm_run, 16 times); the time includes staging (host to device), the replay and all 16 runs. "
                         "One wave per document: 1,000 documents keep 1,000 waves busy, where the batch entry above replays every rendering from the empty version"}

@@ -164,6 +164,18 @@ LM_KERNEL void k_remap(Dev d, uint32_t n_ops, uint32_t n_chg) {
       OpRow r = d.op[t];
       uint32_t local = r.cidx_kind & 0xffff, kind = (r.cidx_kind >> 16) & 0xff;
       uint32_t ci = d.cid_map[bo[BC_CID] + local];
+      if (r.cidx_kind & OPF_NESTED) {
+        // the reference decodes every value in full with the block: a nested map whose key index lies beyond the block's key table is
+        // DataCorruption (value.rs read_value: `keys.get(key_idx).ok_or(DataCorruption)`). The decoders' walkers skip nested values
+        // without the key table in hand (it costs them registers on every row); the few rows that hold a list / map come back here.
+        const uint8_t* vend = d.data + bd.base + bd.sec_rel[SEC_VALUES] + bd.sec_len[SEC_VALUES];
+        Rd v{d.data + d.op_val[t], vend, false};
+        uint32_t n_keys = d.bcnt[(uint64_t)blk * BCN + BC_KEY];
+        if (kind == OK_STYLE_START) { (void)rd_u8(v); (void)rd_uleb(v); (void)rd_uleb(v); }   // (mark: info, len, key idx — checked by the decoder)
+        uint32_t vf = 0;
+        skip_loro_value_keys(v, vf, n_keys);
+        if ((vf & VF_CORRUPT) && !v.bad) LM_SETERR(d.doc[bd.doc].status, ST_DATA_CORRUPTION);
+      }
       r.cidx_kind = ci | (kind << 16);
       if (kind == OK_DEL || kind == OK_LIST_MOVE || kind == OK_LIST_SET) r.a0 = d.peer_map[bo[BC_PEER] + r.a0];
       else if (kind == OK_MAP_SET || kind == OK_MAP_DEL) r.a0 = bo[BC_KEY] + (uint32_t)r.prop;   // the row's key row (the LWW kernels: no trip through op_blk → boff)

@@ -77,6 +77,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   // elements
   uint32_t* cp;          // text: unicode scalar (0xFFFFFFFF = style anchor) | list: value offset rel. to the doc's first byte
   uint32_t* loc;         // element → leaf
+  uint32_t* dcnt;        // resident documents: element → delete ops of the version a tracker is being moved to (ts_sweep_version); nullptr otherwise
   uint8_t* tb;           // span-granular leaves: one byte per Text element — the scalar when it is ASCII, TB_WIDE: cp[] holds it, TB_ANCHOR: a style anchor
   // tracker pools
   uint32_t* it;          // leaf records, 256 dwords each: id[64] | origin_left[64] | origin_right[64] | status[64]
@@ -285,19 +286,24 @@ LM_KERNEL void k_block_count(Dev d) {
 // document DF_SOFT_UNSUPPORTED when met by the emitter (or when one of their ops is applied).
 // (a scalar at the top level — what a Map set or a list of numbers carries — is stepped over right here: the frame machinery below
 // is for lists, maps and child containers)
-// n_keys / corrupt: the reference decodes EVERY value in full when it decodes the block — a nested map whose key index lies beyond
+// corrupt values: the reference decodes EVERY value in full when it decodes the block — a nested map whose key index lies beyond
 // the block's key table, a value tag nobody defined, a collection of more than 2^28 items are DecodeDataCorruptionError there
-// whether or not the value ever reaches the state (value.rs:342-459) — so the walk reports them (*corrupt) instead of leaving them to
-// the renderer, which only ever parses the values that won.
-template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt, uint32_t n_keys = 0xffffffffu, bool* corrupt = nullptr);
-template <class R> LM_DEV void skip_loro_value_top(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt, uint32_t tag_peek, uint32_t n_keys = 0xffffffffu, bool* corrupt = nullptr) {
-  if (tag_peek > 6 || r.bad) { skip_loro_value_fs(r, unsupported, cdepth, f_cnt, n_keys, corrupt); return; }   // (a latched reader consumes nothing there)
+// whether or not the value ever reaches the state (value.rs:342-459).  The decoders' walk (KEYS = false) latches the reader (`bad`)
+// on the last two — the block is rejected — and leaves key indices to k_remap, which walks the rows flagged OPF_NESTED a second
+// time with KEYS = true and reports all three as VF_CORRUPT.
+// (`vf`: bit 0 = a shape the device does not render, bit 1 = corrupt.  Measured with -Rpass-analysis=kernel-resource-usage: every
+// extra write to a caller's flag inside this routine, inlined into the wave decoder's walker, costs that kernel 100-300 spilled
+// scalars and ~20 % of its time — hence the template switch rather than a run-time one)
+static constexpr uint32_t VF_UNSUPPORTED = 1u, VF_CORRUPT = 2u;
+template <bool KEYS = false, class R> LM_DEV void skip_loro_value_fs(R& r, uint32_t& vf, int cdepth, uint32_t* f_cnt, uint32_t n_keys = 0xffffffffu);
+template <class R> LM_DEV void skip_loro_value_top(R& r, uint32_t& vf, int cdepth, uint32_t* f_cnt, uint32_t tag_peek) {
+  if (tag_peek > 6 || r.bad) { skip_loro_value_fs(r, vf, cdepth, f_cnt); return; }   // (a latched reader consumes nothing there)
   (void)rd_u8(r);
   if (tag_peek == 3) (void)rd_sleb(r);
   else if (tag_peek == 4) rd_skip(r, 8);
   else if (tag_peek >= 5) { uint64_t l = rd_uleb(r); rd_skip(r, l); }
 }
-template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int cdepth, uint32_t* f_cnt, uint32_t n_keys, bool* corrupt) {   // f_cnt: 16 words of frame stack
+template <bool KEYS, class R> LM_DEV void skip_loro_value_fs(R& r, uint32_t& vf, int cdepth, uint32_t* f_cnt, uint32_t n_keys) {   // f_cnt: 16 words of frame stack
   uint32_t f_map = 0;  // bit i: frame i is a map (each item is preceded by a key index)
   int sp = 0;
   uint32_t cnt = 1;
@@ -311,7 +317,10 @@ template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int c
     }
     if (r.bad) return;
     cnt--;
-    if (in_map) { uint64_t kidx = rd_uleb(r); if (kidx >= n_keys && !r.bad && corrupt) { *corrupt = true; r.bad = true; return; } }
+    if (in_map) {
+      uint64_t kidx = rd_uleb(r);
+      if (KEYS) vf |= (kidx >= n_keys && !r.bad) ? VF_CORRUPT : 0u;
+    }
     uint32_t tag = rd_u8(r);
     switch (tag) {
       case 0: case 1: case 2: break;
@@ -320,7 +329,7 @@ template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int c
       case 5: case 6: { uint64_t l = rd_uleb(r); rd_skip(r, l); break; }
       case 7: case 8: {
         uint64_t n = rd_uleb(r);
-        if (n > (1u << 28) && !r.bad && corrupt) *corrupt = true;
+        if (KEYS) vf |= (n > (1u << 28) && !r.bad) ? VF_CORRUPT : 0u;
         if (n > (1u << 28) || sp >= 16) { r.bad = true; return; }
         f_cnt[sp] = cnt;
         f_map = (f_map & ~(1u << sp)) | ((in_map ? 1u : 0u) << sp);
@@ -329,15 +338,24 @@ template <class R> LM_DEV void skip_loro_value_fs(R& r, bool& unsupported, int c
         in_map = tag == 8;
         break;
       }
-      case 9: { (void)rd_u8(r); if (sp > cdepth) unsupported = true; break; }   // (any kind byte: ContainerType::Unknown, lib.rs:793-804)
-      default: if (!r.bad && corrupt) *corrupt = true; r.bad = true; return;
+      case 9: { (void)rd_u8(r); if (sp > cdepth) vf |= VF_UNSUPPORTED; break; }   // (any kind byte: ContainerType::Unknown, lib.rs:793-804)
+      default: if (KEYS) vf |= r.bad ? 0u : VF_CORRUPT; r.bad = true; return;
     }
   }
   r.bad = true;
 }
-LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1, uint32_t n_keys = 0xffffffffu, bool* corrupt = nullptr) {
+LM_DEV void skip_loro_value(Rd& r, uint32_t& vf, int cdepth = -1) {
   uint32_t f_cnt[16];
-  skip_loro_value_fs(r, unsupported, cdepth, f_cnt, n_keys, corrupt);
+  skip_loro_value_fs(r, vf, cdepth, f_cnt);
+}
+LM_DEV void skip_loro_value_keys(Rd& r, uint32_t& vf, uint32_t n_keys) {
+  uint32_t f_cnt[16];
+  skip_loro_value_fs<true>(r, vf, -1, f_cnt, n_keys);
+}
+LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {   // (callers that only render: corruption shows as r.bad)
+  uint32_t vf = 0;
+  skip_loro_value(r, vf, cdepth);
+  if (vf & VF_UNSUPPORTED) unsupported = true;
 }
 
 // K4: one lane per block — full decode into the row tables (block-local indices; K6 remaps them).
@@ -542,7 +560,8 @@ LM_KERNEL void k_block_decode(Dev d) {
       uint32_t kind = OK_OTHER;
       uint32_t mark_len = 0;
       uint64_t mv_from = 0, mv_peer = 0, mv_lam = 0;
-      bool vcorrupt = false;   // (skip_loro_value: a nested key index beyond the key table, an undefined value tag)
+      uint32_t vfl = 0;        // (skip_loro_value: VF_UNSUPPORTED | VF_CORRUPT — an undefined value tag, an oversized collection)
+      bool nested = false;     // the value is a list / map, or a payload that may hold one: OPF_NESTED (k_remap checks its key indices)
       bool is_list_value = false;
       // value payload (docs/encoding.md §10)
       switch (vt) {
@@ -555,13 +574,14 @@ LM_KERNEL void k_block_decode(Dev d) {
         case 11: {
           // peek the top-level tag to know whether it is a list (List insert) before skipping
           is_list_value = v.p < v.end && *v.p == 7;
+          nested = v.p < v.end && (*v.p == 7 || *v.p == 8);
           if (is_list_value) {
             Rd t = v;
             (void)rd_u8(t);
             r.a0 = (uint32_t)rd_uleb(t);
           }
           // (values of containers outside the device scope are never rendered: any shape is accepted)
-          skip_loro_value(v, unsupported, ckind == CK_MAP ? 0 : (is_list_value && (ckind == CK_LIST || ckind == CK_MOVABLE) ? 1 : (ckind > CK_TEXT && ckind != CK_MOVABLE ? 16 : -1)), n_keys, &vcorrupt);
+          skip_loro_value(v, vfl, ckind == CK_MAP ? 0 : (is_list_value && (ckind == CK_LIST || ckind == CK_MOVABLE) ? 1 : (ckind > CK_TEXT && ckind != CK_MOVABLE ? 16 : -1)));
           break;
         }
         case 12: {
@@ -569,8 +589,10 @@ LM_KERNEL void k_block_decode(Dev d) {
           mark_len = (uint32_t)rd_uleb(v);
           uint64_t key_idx = rd_uleb(v);
           if (key_idx >= n_keys) st = st ? st : ST_DATA_CORRUPTION;
-          bool u = false;
-          skip_loro_value(v, u, -1, n_keys, &vcorrupt);
+          uint32_t u = 0;
+          skip_loro_value(v, u, -1);
+          vfl |= u & VF_CORRUPT;
+          nested = true;
           break;
         }
         case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
@@ -578,8 +600,9 @@ LM_KERNEL void k_block_decode(Dev d) {
         case 15: {   // ListSet: element peer idx, element lamport, then the nested value (op_val points at it)
           mv_peer = rd_uleb(v); mv_lam = rd_uleb(v);
           val_at = (uint64_t)(v.p - d.data);
-          if (ckind == CK_MOVABLE) skip_loro_value(v, unsupported, 0, n_keys, &vcorrupt);
-          else { bool u = false; skip_loro_value(v, u, -1, n_keys, &vcorrupt); }
+          if (ckind == CK_MOVABLE) skip_loro_value(v, vfl, 0);
+          else { uint32_t u = 0; skip_loro_value(v, u, -1); vfl |= u & VF_CORRUPT; }
+          nested = true;
           break;
         }
         case 16: {
@@ -590,7 +613,8 @@ LM_KERNEL void k_block_decode(Dev d) {
         }
         default: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
       }
-      if (vcorrupt) st = st ? st : ST_DATA_CORRUPTION;
+      if (vfl & VF_UNSUPPORTED) unsupported = true;
+      if (vfl & VF_CORRUPT) st = st ? st : ST_DATA_CORRUPTION;
       // decode_op mapping (outdated_encode_reordered.rs:215-476)
       bool take_del = false;
       if (ckind == CK_TEXT) {
@@ -628,7 +652,7 @@ LM_KERNEL void k_block_decode(Dev d) {
           if (d_peer.r.bad || d_ctr.r.bad || d_len.r.bad) st = st ? st : ST_DATA_CORRUPTION;
         }
       }
-      r.cidx_kind |= kind << 16;
+      r.cidx_kind |= (kind << 16) | ((nested && (vt != 12 || kind == OK_STYLE_START)) ? OPF_NESTED : 0u);
       kc_add(kc_map, kc_el, kc_style, kind, (uint32_t)len);
       d.op[op0 + row] = r;
       d.op_val[op0 + row] = val_at;

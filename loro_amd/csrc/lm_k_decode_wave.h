@@ -54,7 +54,10 @@ LM_DEV void dec_err(uint32_t& key, uint32_t row, uint32_t prio, int32_t code) {
 // for every batch and a second time, with larger slots, when k_block_count met heads beyond the default slot (a batch of Map
 // documents: every block carries a key table of a few KB; parsed from HBM by one lane, key after key, those tables were half of
 // configs[2]'s decode).  Each group is decoded by exactly one of the launches; the other's wave leaves at once.
-LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d, uint32_t slot_cap, uint32_t head_lo, uint32_t head_hi) {
+// I64 = true: the instantiation with the integer-values fast path of the walker (k_block_decode_wave_map: the second launch — batches
+// made of Map blocks); text blocks, which never take it, are decoded by the one without.
+template <bool I64>
+LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, uint32_t head_hi) {
   int lane = lmw::lane();
 #ifdef LM_PROF_DEC
   uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptp = lmw::clock();   // 0 stage, 1 head (role 0), 2 cursors, 3 A1, 4 T + A2, 5 W, 6 B, 7 close
@@ -450,6 +453,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
         }
       }
 #ifndef LM_NO_I64_FAST
+      if (I64)
       // I. A chunk of Map writes whose values are integers — `set(key, i64)`: counters, timestamps, ids — needs no walk either.  Each
       // value is a tag byte (3) and a signed LEB128: bytes with a clear top bit ALTERNATE tag, last LEB byte, tag, last LEB byte …
       // The block's eight lanes fetch the 128 bytes behind the walker's cursor with one 16-byte load each; every row lane then reads
@@ -544,7 +548,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
         uint32_t wvt = sx[k * 8 + 2], wlen = sx[k * 8 + 3], wkind = sx[k * 8 + 7];
         uint64_t val_at = (uint64_t)(v.p - d.data);
         uint32_t aux = 0, flags = 0;   // aux: element count of a list value | mark length; flags bit 0: the value is a list
-        bool vcorrupt = false;         // (skip_loro_value: a nested key index beyond the key table, an undefined value tag)
+        uint32_t vfl = 0;              // (skip_loro_value: VF_UNSUPPORTED | VF_CORRUPT — a nested key index beyond the key table, an undefined value tag)
         switch (wvt) {
           case 0: case 1: case 2: case 8: case 9: break;
           case 3: (void)rd_sleb(v); break;
@@ -558,8 +562,9 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
             uint32_t tag0 = v.p < v.end ? rd_peek(v) : 0xffu;   // (an empty reader goes through the general routine, which latches `bad`)
             bool is_list_value = tag0 == 7;
             if (is_list_value) { auto t = v; (void)rd_u8(t); aux = (uint32_t)rd_uleb(t); flags = 1; }
+            if (tag0 == 7 || tag0 == 8) flags |= 4;   // a list / map value: its nested key indices are checked by k_remap (OPF_NESTED)
             // (values of containers outside the device scope are never rendered: any shape is accepted)
-            skip_loro_value_top(v, unsupported, wkind == CK_MAP ? 0 : (is_list_value && (wkind == CK_LIST || wkind == CK_MOVABLE) ? 1 : (wkind > CK_TEXT && wkind != CK_MOVABLE ? 16 : -1)), fs, tag0, n_keys, &vcorrupt);
+            skip_loro_value_top(v, vfl, wkind == CK_MAP ? 0 : (is_list_value && (wkind == CK_LIST || wkind == CK_MOVABLE) ? 1 : (wkind > CK_TEXT && wkind != CK_MOVABLE ? 16 : -1)), fs, tag0);
             break;
           }
           case 12: {
@@ -567,8 +572,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
             aux = (uint32_t)rd_uleb(v);
             uint64_t key_idx = rd_uleb(v);
             if (key_idx >= n_keys) dec_err(errk, c0 + k, 2, ST_DATA_CORRUPTION);
-            bool u = false;
-            skip_loro_value_fs(v, u, -1, fs, n_keys, &vcorrupt);
+            uint32_t u = 0;
+            skip_loro_value_fs(v, u, -1, fs);
+            vfl |= u & VF_CORRUPT;
+            flags |= 4;
             break;
           }
           case 13: { (void)rd_uleb(v); uint32_t isn = rd_u8(v); (void)rd_uleb(v); if (!isn) (void)rd_uleb(v); break; }
@@ -584,8 +591,9 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
             if (pi >= n_peers || lm_ > 0xFFFFFFFFull) flags |= 2;
             sx[k * 8 + 4] = (uint32_t)pi; sx[k * 8 + 5] = (uint32_t)lm_; sx[k * 8 + 6] = 0;
             val_at = (uint64_t)(v.p - d.data);   // op_val of a set row points at the nested value
-            if (wkind == CK_MOVABLE) skip_loro_value_fs(v, unsupported, 0, fs, n_keys, &vcorrupt);
-            else { bool u = false; skip_loro_value_fs(v, u, -1, fs, n_keys, &vcorrupt); }
+            if (wkind == CK_MOVABLE) skip_loro_value_fs(v, vfl, 0, fs);
+            else { uint32_t u = 0; skip_loro_value_fs(v, u, -1, fs); vfl |= u & VF_CORRUPT; }
+            flags |= 4;
             break;
           }
           case 16: {
@@ -596,7 +604,8 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
           }
           default: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
         }
-        if (vcorrupt) dec_err(errk, c0 + k, 2, ST_DATA_CORRUPTION);
+        if (vfl & VF_UNSUPPORTED) unsupported = true;
+        if (vfl & VF_CORRUPT) dec_err(errk, c0 + k, 2, ST_DATA_CORRUPTION);
         uint32_t* o = sw + k * DEC_WW;
         o[0] = (uint32_t)val_at; o[1] = (uint32_t)(val_at >> 32); o[2] = aux; o[3] = flags;
         o[4] = (uint32_t)counter; o[5] = chg0 + change_index;
@@ -711,7 +720,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
         if (!has_del) dec_err(errk, row, 4, ST_DATA_CORRUPTION);
         else { orow.a0 = sx[r * 8 + 4]; orow.a1 = sx[r * 8 + 5]; orow.a2 = (int32_t)sx[r * 8 + 6]; }
       }
-      orow.cidx_kind |= kind << 16;
+      orow.cidx_kind |= (kind << 16) | (((o[3] & 4) && (vt != 12 || kind == OK_STYLE_START)) ? OPF_NESTED : 0u);
       kc_add(kc_map, kc_el, kc_style, kind, len);
       d.op[op0 + row] = orow;
       d.op_val[op0 + row] = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
@@ -768,6 +777,13 @@ LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d
   DEC_PH(7);
   if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&d.prof[i], (unsigned long long)pacc[i]);
 #endif
+}
+
+LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave(Dev d, uint32_t slot_cap, uint32_t head_lo, uint32_t head_hi) {
+  block_decode_wave_body<false>(d, slot_cap, head_lo, head_hi);
+}
+LM_KERNEL LM_WAVES_PER_SIMD(3) LM_ONE_WAVE_GROUPS void k_block_decode_wave_map(Dev d, uint32_t slot_cap, uint32_t head_lo, uint32_t head_hi) {
+  block_decode_wave_body<true>(d, slot_cap, head_lo, head_hi);
 }
 
 }  // namespace lm

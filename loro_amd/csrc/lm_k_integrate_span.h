@@ -19,6 +19,7 @@ LM_DEV uint32_t sa_leaf(uint32_t a) { return a & DIR_LEAF_MASK; }
 LM_DEV uint32_t sa_n(uint32_t a) { return (a >> 18) & 0x7f; }
 LM_DEV bool sa_nf(uint32_t a) { return (a & DIR_NF) != 0; }
 
+static constexpr uint32_t LOC_OFF = 0x80000000u;   // Ts::n_alive
 struct SpanRegs { uint32_t n, id, len, ol, orr, st; };   // one leaf in registers: lane i holds item i
 struct SpanItem { uint32_t id, len, ol, orr, st; };
 
@@ -36,6 +37,8 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   bool ds_on;
   uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
   uint32_t n_alive;               // elements inserted and never deleted by a replayed op = visible at the rendered version
+                                  // | LOC_OFF (bit 31): loc[] is not kept yet (ts_build_loc) — a flag here costs no register of its own: a
+                                  // nullable `loc` pointer did (two more live scalars: 11 instructions of spill traffic per op row)
   uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); WRITE-BACK: `cr` is the truth, HBM is updated by sp_flush
   uint32_t cache_p;               // its directory position (kept in step with directory inserts)
   uint32_t cache_pre;             // active elements in front of the cached leaf, NONE when not known: an edit at a position
@@ -113,7 +116,7 @@ static constexpr uint32_t LOC_W = LM_LOC_W;   // a power of two <= 64
 // stays a head; the nearest kept entry at or below an element of an item, inside its LOC_W-aligned counter window, is therefore an
 // element of the same item (ts_loc_find).  A flush writes 1 + len/16 entries per pending item instead of len.
 LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
-  if (!t.loc) return;   // loc[] is not kept yet (ts_build_loc): nothing can ask for an element by id while the replay is one chain
+  if (t.n_alive & LOC_OFF) return;   // loc[] is not kept yet (ts_build_loc): nothing can ask for an element by id while the replay is one chain
   uint32_t len = pend ? R.len : 0u;
   uint32_t c0 = pid_ctr(R.id);
   uint32_t g = pend ? t.ebase[pid_peer(R.id)] + c0 : 0u;
@@ -132,7 +135,7 @@ LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
 }
 // leaf of element `pid` (wave-uniform), NONE when no kept entry lies at or below it in its window
 LM_DEV uint32_t ts_loc_find(const Ts& t, uint32_t pid) {
-  if (!t.loc) return NONE;
+  if (t.n_alive & LOC_OFF) return NONE;
   uint32_t ctr = pid_ctr(pid), lo = ctr & ~(LOC_W - 1), eb = t.ebase[pid_peer(pid)];
   uint32_t lane = (uint32_t)lmw::lane();
   uint32_t v = (lane < LOC_W && lo + lane <= ctr) ? t.loc[eb + lo + lane] : NONE;
@@ -1081,9 +1084,9 @@ LM_DEV void ts_reset_to_base(Ts& t, const uint32_t* s_base) {
 // sibling scan to resolve, no op to retreat — so the flushes of the cached leaf write no loc[] entry (configs[1]: the 50k-op
 // base, 60 % of its rows; a document imported sequentially never pays for loc[] at all).  The first move of the tracker
 // (ts_goto) brings it up to date; from then on it is maintained as always.
-LM_DEV void ts_build_loc(Ts& t, uint32_t* loc_real) {
+LM_DEV void ts_build_loc(Ts& t) {
   int lane = lmw::lane();
-  t.loc = loc_real;
+  t.n_alive &= ~LOC_OFF;
   lmw::wave_sync();
   for (uint32_t q = 0; q < t.n_dir; q++) {
     uint32_t a = lmw::first(t.da[q]);
@@ -1096,16 +1099,158 @@ LM_DEV void ts_build_loc(Ts& t, uint32_t* loc_real) {
     sp_set_loc_lanes(t, R, in, L);
   }
 }
+// ---- the tracker moves to ANY version in one pass over the document's delete rows and one over its leaves (resident documents,
+// Tracker::checkout / forward, tracker.rs:354-546).  ts_move_ops undoes / redoes delete rows one by one — a by-id lookup, a leaf
+// switch and a directory update per row: ≈170 ms for a move across a sixteenth of a 1M-op document's history, 17 % of a configs[1]
+// import run (the retreat of the branch the import is concurrent with).  An element's status at a version V is a function of V
+// alone: future unless its insert lies in V, deleted as many times as delete ops of V target it.  So
+//   1. items that straddle the moved ends of V are cut there (two by-id updates per moved peer — as the insert sweep does);
+//   2. dcnt[] (a word per element slot of the document) := 0, then every delete row of the container whose op lies in V adds one
+//      to each of its targets — lane = row, 64 rows per step, global atomics (two rows may target one element);
+//   3. every leaf: status := (kept bits) | future? | count — the count is read at the item's first element: an item never straddles
+//      a delete's range, every delete of V has been applied to this tracker before and cut it there (items are never merged).
+// target(p) = ov for p == ov_peer, vv[p] otherwise (the call sites' override for the replayed node's own peer).
+LM_DEV uint32_t ts_vs_target(const uint32_t* vv, uint32_t ov_peer, uint32_t ov, uint32_t p) { return p == ov_peer ? ov : vv[p]; }
+LM_DEV void ts_sweep_version(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t P, const uint32_t* vv, uint32_t ov_peer, uint32_t ov,
+                             const uint32_t* s_cur, uint32_t* dcnt) {
+  int lane = lmw::lane();
+  // 1. cuts
+  for (uint32_t p = 0; p < P && !t.err; p++) {
+    uint32_t cur = s_cur[p], tgt = ts_vs_target(vv, ov_peer, ov, p);
+    if (cur == tgt) continue;
+    uint32_t lo = cur < tgt ? cur : tgt, hi = cur < tgt ? tgt : cur;
+    int mode = cur > tgt ? UPD_SET_FUT : UPD_CLR_FUT;
+    ts_update_range(t, p, lo, lo + 1, mode);
+    if (!t.err && hi - lo > 1) ts_update_range(t, p, hi - 1, hi, mode);
+    // a version may end INSIDE a delete row (a checkout between two atoms of a run of backspaces): only a part of the row's
+    // targets is deleted there — the item is cut where that part ends (its status is whatever pass 3 decides)
+    uint32_t ci = t.err ? NONE : find_change(d, m, p, tgt);
+    if (ci != NONE) {
+      uint32_t crow = d.chg_sorted[m.chg0 + ci];
+      const ChangeRow ch = d.chg[crow];
+      if (ch.ctr < tgt && ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1)) {
+        uint32_t rl = ch.op0, rh = ch.op0 + ch.n_op;
+        while (rl < rh) { uint32_t mid = (rl + rh) >> 1; if (d.op[mid].ctr + d.op[mid].len <= tgt) rl = mid + 1; else rh = mid; }
+        if (rl < ch.op0 + ch.n_op) {
+          const OpRow r = d.op[rl];
+          if (r.ctr < tgt && (r.cidx_kind & 0xffff) == cidx && ((r.cidx_kind >> 16) & 0xff) == OK_DEL && r.a0 < P) {
+            uint32_t b = tgt - r.ctr, Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+            uint32_t x = r.a2 > 0 ? r.a1 + b : r.a1 + (Ln - b);   // the element whose left edge is the end of the deleted part
+            if (b < Ln && x < t.end[r.a0]) ts_update_range(t, r.a0, x, x + 1, UPD_SET_FUT);
+          }
+        }
+      }
+    }
+  }
+  if (t.err) return;
+  sp_flush(t);                                                     // the passes work on the leaf records in HBM
+  sd_sync_cached(t);
+  t.cache_leaf = NONE; t.cr.n = 255; t.cache_pre = NONE; t.dirty = false; t.loc_pend = 0;
+  lmw::wave_sync();
+  // 2. delete counts at the target version
+  {
+    struct alignas(16) U4 { uint32_t x, y, z, w; };
+    U4* c4 = (U4*)dcnt;
+    const U4 zero4 = {0, 0, 0, 0};
+    for (uint32_t i = (uint32_t)lane; i < (m.atoms + 3) / 4; i += 64) c4[i] = zero4;
+  }
+  lmw::mem_fence();
+  lmw::wave_sync();
+  for (uint32_t i0 = 0; i0 < m.n_op; i0 += 64) {
+    uint32_t i = i0 + (uint32_t)lane;
+    uint32_t g0 = 0, n = 0;
+    if (i < m.n_op) {
+      const OpRow& r = d.op[m.op0 + i];
+      uint32_t ck = r.cidx_kind;
+      if ((ck & 0xffff) == cidx && ((ck >> 16) & 0xff) == OK_DEL && (d.chg_flag[r.chg] & 1u)) {
+        const ChangeRow& ch = d.chg[r.chg];
+        uint32_t peer = ch.peer;
+        uint32_t lo = ch.ctr + d.chg_skip[r.chg], hi = ts_vs_target(vv, ov_peer, ov, peer);
+        if (lo < r.ctr) lo = r.ctr;
+        if (hi > r.ctr + r.len) hi = r.ctr + r.len;
+        if (lo < hi && r.a0 < P) {
+          uint32_t a = lo - r.ctr, b = hi - r.ctr;
+          uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+          uint32_t t0, t1;
+          if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
+          else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
+          uint32_t e = t.end[r.a0];
+          if (t1 > e) t1 = e;                                      // (a damaged target range: what ts_update_range clamps)
+          if (t0 < t1 && b <= Ln) { g0 = t.ebase[r.a0] + t0; n = t1 - t0; }
+        }
+      }
+    }
+    for (uint32_t k = 0; k < n && k < 16; k++) lmw::atomic_add(&dcnt[g0 + k], 1u);
+    // (a long range — a selection deleted at once — is counted by the whole wave)
+    uint64_t lm_ = lmw::ballot(n > 16);
+    while (lm_) {
+      int src = lmw::ffs64(lm_);
+      lm_ &= lm_ - 1;
+      uint32_t bg = lmw::bcast(g0, src), bn = lmw::bcast(n, src);
+      for (uint32_t k = 16 + (uint32_t)lane; k < bn; k += 64) lmw::atomic_add(&dcnt[bg + k], 1u);
+    }
+  }
+  lmw::mem_fence();
+  lmw::wave_sync();
+  // 3. the leaves
+  for (uint32_t q = 0; q < t.n_dir; q++) {
+    uint32_t a = lmw::first(t.da[q]);
+    uint32_t L = sa_leaf(a), n = sa_n(a);
+    uint32_t* rec = t.it + (uint64_t)L * SP_REC;
+    bool in = (uint32_t)lane < n;
+    uint32_t id = in ? rec[lane] : 0u, ln = in ? rec[64 + lane] : 0u, st = in ? rec[256 + lane] : ST_FUT;
+    uint32_t st1 = st;
+    bool over = false, ragged = false;
+    if (in) {
+      uint32_t peer = pid_peer(id), ctr = pid_ctr(id);
+      uint32_t cnt = dcnt[t.ebase[peer] + ctr];
+      over = cnt > 0x7fffu;                                        // (the status word's counter; bit 23 is ST_DEAD)
+      if (over) cnt = 0x7fffu;
+      st1 = (st & ~(ST_FUT | ST_DELMASK)) | (ctr >= ts_vs_target(vv, ov_peer, ov, peer) ? ST_FUT : 0u) | (cnt << 8) | (cnt ? ST_EVER : 0u);
+#ifdef LM_EMU_CHECK
+      for (uint32_t k = 1; k < ln; k++)
+        if (dcnt[t.ebase[peer] + ctr + k] != cnt || ((ctr + k >= ts_vs_target(vv, ov_peer, ov, peer)) != ((st1 & ST_FUT) != 0))) {
+          fprintf(stderr, "CHECK version sweep: item %u:%u+%u is not uniform at element %u (count %u vs %u)\n", peer, ctr, ln, k, dcnt[t.ebase[peer] + ctr + k], cnt);
+          ragged = true;
+        }
+#endif
+    }
+    if (lmw::any(over)) { LM_SETERR(t.err, ST_UNSUPPORTED); return; }
+    if (lmw::any(ragged)) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    if (!lmw::any(in && st1 != st)) continue;
+    if (in && st1 != st) rec[256 + lane] = st1;
+    uint32_t act = lmw::reduce_add((in && st_active(st1)) ? ln : 0u);
+    bool nf = lmw::ballot(in && !(st1 & ST_FUT)) != 0;
+    sd_set(t, q, sa_make(L, n, nf), act);
+  }
+}
+// is the move s_cur → target long enough for the pass?  (its cost: the document's op rows / 64 + its element slots / 256 + its
+// leaves; a row-by-row move costs ≈ a by-id update per row of the moved range)
+LM_DEV bool ts_sweep_pays(const Ts& t, const DocMeta& m, uint32_t P, const uint32_t* vv, uint32_t ov_peer, uint32_t ov, const uint32_t* s_cur) {
+  uint32_t dist = 0;
+  for (uint32_t p = (uint32_t)lmw::lane(); p < P; p += 64) { uint32_t c = s_cur[p], g = ts_vs_target(vv, ov_peer, ov, p); dist += c > g ? c - g : g - c; }
+  dist = lmw::reduce_add(dist);
+#ifdef LM_SWEEP_EAGER   // tests: every move takes the pass
+  return dist > 0;
+#else
+  return dist > 256 && (uint64_t)dist * 16 > (uint64_t)m.atoms / 32 + m.n_op + 40ull * t.n_dir + 2048;
+#endif
+}
 template <bool ML, bool SWEEP>
 LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t P, const uint32_t* vv, uint32_t* s_cur, uint32_t* s_base,
-                    bool& base_on, bool conv, uint32_t* loc_real) {
+                    bool conv) {
   int lane = lmw::lane();
-  if (!t.loc) {
+  if (t.n_alive & LOC_OFF) {
     bool mv = false;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) mv |= s_cur[p] != vv[p];
-    if (conv || lmw::any(mv)) ts_build_loc(t, loc_real);
+    if (conv || lmw::any(mv)) ts_build_loc(t);
   }
   bool reset = false;
+  bool base_on = false;
+  if (m.flags & DF_CUT) {   // (only a document whose nodes were cut ever gets a base, k_dag_b)
+    lmw::block_sync();
+    base_on = lmw::first(s_base[P]) != 0;   // (the word behind the base's P entries: the tracker has a base)
+  }
   if (base_on) {
     bool same = true;
     uint32_t back = 0;
@@ -1129,7 +1274,7 @@ LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32
     }
   lmw::block_sync();
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_cur[p] = vv[p]; if (conv) s_base[p] = vv[p]; }
-  if (conv && !t.err) { ts_convert_base(t); base_on = true; }
+  if (conv && !t.err) { ts_convert_base(t); if (lane == 0) s_base[P] = 1; }
   lmw::block_sync();
 }
 
@@ -1150,7 +1295,7 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
         if (ln == 0) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u item %u has length 0\n", what, row, q, L, i); ok = false; }
         if (st_active(st)) act += ln;
         nf |= !(st & ST_FUT);
-        for (uint32_t k = 0; k < ln && t.loc; k++) {
+        for (uint32_t k = 0; k < ln && !(t.n_alive & LOC_OFF); k++) {
 #ifdef LM_LOC16
           uint32_t expect = (k == 0 || ((id0 + k) & (LOC_W - 1)) == 0) ? L : NONE;   // kept entries only: heads and multiples of LOC_W
 #else
@@ -1350,6 +1495,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   t.loc = d.loc + elem0;
   t.ebase = s_ebase; t.cur = s_cur; t.end = s_end; t.da = s_da; t.db = s_db; t.ds = s_ds; t.ds_on = false;
   t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0;
+  t.n_alive = 0;   // (bit 31 = LOC_OFF is read by sp_set_loc_lanes — the stored leaves' loc[] entries are written before any container sets the count)
 #ifdef LM_PROF
   for (int i = 0; i < PF_N; i++) t.prof[i] = 0;
   uint64_t pf_begin = lmw::clock();
@@ -1414,16 +1560,17 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     }
     lmw::block_sync();
     bool touched = false;
-    t.loc = (PLAIN && !RES && LM_LAZY_LOC) ? nullptr : d.loc + elem0;   // (ts_build_loc)
-    bool base_on = false;              // the tracker has a base version (s_base), ts_goto
-    uint32_t* s_base = s_tgt;          // (not RES: the slot of the resident kernels' rendered version)
+    if (PLAIN && !RES && LM_LAZY_LOC) t.n_alive |= LOC_OFF;   // (ts_build_loc)
+    uint32_t* s_base = s_tgt;          // the tracker's base version, ts_goto (not RES: the slot of the resident kernels' rendered version); [P] != 0: it has one
+    if (!RES && lane == 0) s_base[P] = 0;
+    lmw::block_sync();
     for (uint32_t oi = 0; oi < m.n_nodes && !t.err; oi++) {
       uint32_t n = d.node_order[m.chg0 + oi];
       uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
       const uint32_t* vv = vvh_ro + vvh0 + (uint64_t)n * P;
       uint32_t node_peer = chg_ro[sorted_ro[m.chg0 + first]].peer;
-      // (k_dag_b: the replayed history in front of this node is a critical version and a concurrent section begins behind it)
-      const bool conv_node = !RES && LM_BASE_RESET && (lmw::first(g.node_done[m.chg0 + n]) & 2u) != 0;
+      // (k_dag_b's flag — node_done bit 1: the replayed history in front of this node is a critical version and a concurrent section
+      // begins behind it — is read where the tracker moves, ts_goto's call sites: not a value that lives across the row loop)
       if (RES) {   // a node the stored tracker has applied to its end
         const ChangeRow lc = chg_ro[sorted_ro[m.chg0 + last]];
         if (lc.ctr + lc.len <= s_app[node_peer]) continue;
@@ -1465,7 +1612,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
           // carries no test for it (7 instructions per op row, 4 of them register moves in front of the branch)
           checked_out = true;
-          ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0);
+          ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, !RES && LM_BASE_RESET && (m.flags & DF_CUT) && (lmw::first(g.node_done[m.chg0 + n]) & 2u) != 0);
           PROF_ADD(t, PF_CHECKOUT);
           TS_CHECK("checkout", ch.op0);
         }
@@ -1493,8 +1640,11 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           uint32_t b = PLAIN ? r.len : (r.ctr + r.len <= pe ? r.len : pe - r.ctr);
           if (!(PLAIN && !RES) && !checked_out) {
             checked_out = true;
-            if (!RES) ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0);
+            if (!RES) ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, !RES && LM_BASE_RESET && (m.flags & DF_CUT) && (lmw::first(g.node_done[m.chg0 + n]) & 2u) != 0);
             else {
+            lmw::block_sync();
+            if (RES && !ML && d.dcnt && ts_sweep_pays(t, m, P, vv, node_peer, r.ctr + a, s_cur)) ts_sweep_version(t, d, m, cidx, P, vv, node_peer, r.ctr + a, s_cur, d.dcnt + elem0);
+            else
             for (uint32_t p = 0; p < P && !t.err; p++) {
               uint32_t cur = s_cur[p], tgt = vv[p];
               // RES: the stored tracker may stand below this peer's own earlier ops (a previous run left it at an older
@@ -1576,6 +1726,9 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       // the tracker moves to the version being rendered (Tracker::checkout, tracker.rs:354-461).  A document rendered at the
       // latest version needs no move: every applied op has been replayed, "never deleted" is what shows (as in a batch), and the
       // tracker stays where the last change left it — the next run moves it wherever its first change needs it
+      lmw::block_sync();
+      if (!ML && d.dcnt && ts_sweep_pays(t, m, P, s_tgt, NONE, 0, s_cur)) ts_sweep_version(t, d, m, cidx, P, s_tgt, NONE, 0, s_cur, d.dcnt + elem0);
+      else
       for (uint32_t p = 0; p < P && !t.err; p++) {
         uint32_t cur = s_cur[p], tgt = s_tgt[p];
         if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
@@ -1606,7 +1759,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       // (a MovableList exists once an element was ever inserted — k_mlist_post adds that case after this stage)
       // (RES: visible at the latest version — n_alive counts every applied op — or at the version the tracker was just moved to;
       // earlier runs' verdicts are OR-ed in by k_res_exists)
-      if (touched && (t.n_alive > 0 || (RES && !PLAIN && to_version && t.tot_active > 0))) d.cont[m.cid0 + cidx].touched = 1;
+      if (touched && ((t.n_alive & ~LOC_OFF) > 0 || (RES && !PLAIN && to_version && t.tot_active > 0))) d.cont[m.cid0 + cidx].touched = 1;
     }
     dir_used += t.n_dir;
     lmw::block_sync();

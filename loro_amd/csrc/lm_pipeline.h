@@ -74,7 +74,7 @@ struct Engine {
   DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
   DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
-  DBuf b_cp, b_loc, b_tb, b_fuse;
+  DBuf b_cp, b_loc, b_tb, b_fuse, b_dcnt;
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_pfx, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
@@ -140,7 +140,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048; bool lww_lds = true, fuse_rows = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048; bool lww_lds = true, fuse_rows = true, version_sweep = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -156,6 +156,7 @@ struct Engine {
     if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
     if (const char* e = getenv("LM_HT_OPT")) k.ht_opt = (uint32_t)atoi(e);                       // slots of a document's optimistic LWW table (a power of two; 0: sized for its Map rows at once; tests: 64 forces the second pass)
     if (const char* e = getenv("LM_CUT_MIN_ROWS")) k.cut_min_rows = (uint32_t)atoll(e);           // op rows from which a document's nodes are cut at cross-peer dependency targets and replayed largest peer first (tests: 0)
+    if (const char* e = getenv("LM_VERSION_SWEEP")) k.version_sweep = atoi(e) != 0;              // 0: resident trackers move row by row (rounds 3-4a: delete rows undone / redone one by one)
     if (const char* e = getenv("LM_FUSE_ROWS")) k.fuse_rows = atoi(e) != 0;                      // 0: one-change-per-keystroke documents are replayed row by row, as in rounds 1-3
     if (const char* e = getenv("LM_LWW_LDS")) k.lww_lds = atoi(e) != 0;                          // 0: every document's Map rows go through the HBM tables (k_map_lww), as in rounds 1-3
     kn = k;
@@ -173,7 +174,7 @@ struct Engine {
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
-                   &b_dir_out, &b_lf_chunk, &b_fuse,
+                   &b_dir_out, &b_lf_chunk, &b_fuse, &b_dcnt,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_elem_cap, &b_old_blobs, &b_prev_doc, &b_prev_uniq, &b_prev_end, &b_lca_out, &b_lca_scratch, &b_lca_off};
     for (DBuf* b : all) b->release();
@@ -664,8 +665,9 @@ struct Engine {
           if (kn.dec_big_mode == 2) { slot_big = (dec_stat[1] + 15u) & ~15u; if (slot_big > kn.dec_slot_big) slot_big = kn.dec_slot_big; }
           else { slot_big = (dec_stat[2] + 15u) & ~15u; if (slot_big < 64) slot_big = 64; if (slot_big >= slot_cap) slot_big = 0; }
         }
-        LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_cap, 0u, slot_big ? slot_cap : 0xffffffffu);
-        if (slot_big) LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_big + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_big, slot_cap, 0xffffffffu);
+        if (!(slot_big && dec_stat[0] == NB))   // (a batch in which EVERY block is of the second launch's kind needs no first)
+          LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_cap, 0u, slot_big ? slot_cap : 0xffffffffu);
+        if (slot_big) LM_LAUNCH_DYN(k_block_decode_wave_map, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_big + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_big, slot_cap, 0xffffffffu);
       }
     }
     lmbe::toc("k_block_decode", times, profiling);
@@ -768,7 +770,7 @@ struct Engine {
     if (resident) {
       // arenas that outlive the run: element payloads (a MovableList move keeps the id of the item it deleted in its own slot),
       // the leaf pool and the two generations of the leaf directories
-      b_cp.ensure_keep((elem_top + 1) * 4, b_cp.cap); b_loc.ensure_keep((elem_top + 1) * 4, b_loc.cap); b_tb.ensure_keep(elem_top + 16, b_tb.cap);
+      b_cp.ensure_keep((elem_top + 1) * 4, b_cp.cap); b_loc.ensure_keep((elem_top + 1) * 4, b_loc.cap); b_dcnt.ensure((elem_top + 1) * 4); b_tb.ensure_keep(elem_top + 16, b_tb.cap);
       b_it.ensure_keep(((size_t)leaf_top + 1) * SP_REC * 4, b_it.cap);
       for (DBuf* b : {&b_dir_out, &b_dir_out2, &b_dir_b, &b_dir_b2}) b->ensure_keep(((size_t)leaf_top + 1) * 4, b->cap);
     } else {
@@ -787,7 +789,7 @@ struct Engine {
     b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4); b_ht_cnt.ensure((size_t)n_docs * 4 + 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
-    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>(); d.tb = b_tb.as<uint8_t>();
+    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>(); d.dcnt = (resident && kn.version_sweep) ? b_dcnt.as<uint32_t>() : nullptr; d.tb = b_tb.as<uint8_t>();
     d.it = b_it.as<uint32_t>();
     d.dir_out = b_dir_out.as<uint32_t>();
     d.lf_chunk = b_lf_chunk.as<uint8_t>();
@@ -911,20 +913,20 @@ struct Engine {
                       (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
     } else if (span) {
       if (any_plain && plain_mode == 2) {
-        LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
         if (d.fuse)
-          LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       }
       else if (any_plain)
-        LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       if (any_common || !(any_ml || any_plain))
-        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       if (any_ml)
-        LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
     } else {
       LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
@@ -969,20 +971,20 @@ struct Engine {
           LM_LAUNCH_DYN(k_integrate_span_res_ml, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                         (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
       } else if (span) {
-        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         if (any_ml)
-          LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         if (any_plain && plain_mode == 2) {
-          LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
           if (d.fuse)
-            LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+            LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                           (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         }
         else if (any_plain)
-          LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
       } else {
         LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,

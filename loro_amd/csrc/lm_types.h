@@ -59,7 +59,9 @@ struct OpRow {               // 32 B, read with scalar loads by the integrate ke
 };
 
 // OpRow.cidx_kind flag bits (k_fuse_rows): the row continues the run of the row in front of it / heads a run whose extent is in Dev::fuse
-enum : uint32_t { OPF_CONT = 1u << 24, OPF_HEAD = 1u << 25 };
+// OPF_NESTED (the decoders → k_remap): the row's value is a list / map (or a mark / list-set payload that may hold one): k_remap walks
+// it once more to check nested map key indices against the block's key table, then drops the bit
+enum : uint32_t { OPF_CONT = 1u << 24, OPF_HEAD = 1u << 25, OPF_NESTED = 1u << 26 };
 
 struct ChangeRow {           // 32 B
   uint32_t peer;             // block-local 0 → doc peer idx after remap

@@ -99,6 +99,10 @@ struct EmuBlock {
   uint64_t progress = 0;
   std::function<void()> body;
 };
+inline const char*& emu_kname() {   // the kernel being run (diagnostics of the deadlock report below)
+  static thread_local const char* k = "?";
+  return k;
+}
 inline EmuBlock*& emu_cur() {
   static thread_local EmuBlock* b = nullptr;
   return b;
@@ -147,7 +151,7 @@ inline void emu_run_block(int bid, int bdim, std::function<void()> body) {
   uint64_t last_progress = ~0ull;
   while (remaining > 0) {
     if (blk.progress == last_progress) {
-      fprintf(stderr, "lm emu: deadlock — lanes blocked at different collectives (non-uniform control flow)\n");
+      fprintf(stderr, "lm emu: deadlock in %s, workgroup %d of %d threads — lanes blocked at different collectives (non-uniform control flow)\n", emu_kname(), bid, bdim);
       abort();
     }
     last_progress = blk.progress;

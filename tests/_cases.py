@@ -348,3 +348,46 @@ def map_render_docs():
         r.commit()
         docs.append([r.export()])
     return docs
+
+
+def nested_key_docs():
+    """(good, bad): single-blob documents whose op values hold a nested map — a Map set, a List insert, a MovableList insert and
+    set, a Text mark — and the same blobs with that nested map's key index patched beyond the block's key table (checksum
+    redone).  The reference decodes every value in full with the block (value.rs read_value: keys.get(idx).ok_or(DataCorruption)):
+    all of `bad` are rejected, whether or not the value ever reaches the state."""
+    import struct
+    from loro_amd import wire
+    marker = b"\x03" + wire.sleb(7777)
+
+    def patch(blob):
+        at = blob.index(marker)            # ... 0x08 0x01 <key idx> 0x03 sleb(7777)
+        assert blob[at - 3:at - 1] == b"\x08\x01" and blob[at - 1] < 0x60 and blob.count(marker) == 1
+        tail = bytearray(blob[20:])
+        tail[at - 1 - 20] = 0x63
+        return b"loro" + b"\x00" * 12 + struct.pack("<I", wire.xxh32(bytes(tail))) + bytes(tail)
+
+    good = []
+    for which in range(6):
+        r = wire.Replica(900 + which)
+        r.map_set("m", "first", 1)
+        r.text_insert("t", 0, "hello world")
+        r.list_insert("l", 0, [1, 2, 3])
+        r.mlist_insert("ml", 0, ["a", "b"])
+        r.commit()
+        v = {"inner": 7777}
+        if which == 0:
+            r.map_set("m", "second", v)
+        elif which == 1:
+            r.list_insert("l", 1, ["x", [v], "y"])
+        elif which == 2:
+            r.mlist_insert("ml", 1, [v])
+        elif which == 3:
+            r.mlist_set("ml", 0, v)
+        elif which == 4:
+            r.text_mark("t", 0, 5, "bold", v)
+        else:
+            r.map_set("m", "second", v)
+            r.map_set("m", "second", 5)      # (the corrupt value loses: still rejected)
+        r.commit()
+        good.append([r.export()])
+    return good, [[patch(d[0])] for d in good]

@@ -40,8 +40,8 @@ inline void toc(const char* name, V& times, bool profiling) {
 }
 }  // namespace lmbe
 
-#define LM_LAUNCH(kern, grid, block, ...) lmw::emu_launch((int)(grid), (int)(block), 0, [&]() { lm::kern(__VA_ARGS__); })
-#define LM_LAUNCH_DYN(kern, grid, block, shmem, ...) lmw::emu_launch((int)(grid), (int)(block), (size_t)(shmem), [&]() { lm::kern(__VA_ARGS__); })
+#define LM_LAUNCH(kern, grid, block, ...) do { lmw::emu_kname() = #kern; lmw::emu_launch((int)(grid), (int)(block), 0, [&]() { lm::kern(__VA_ARGS__); }); } while (0)
+#define LM_LAUNCH_DYN(kern, grid, block, shmem, ...) do { lmw::emu_kname() = #kern; lmw::emu_launch((int)(grid), (int)(block), (size_t)(shmem), [&]() { lm::kern(__VA_ARGS__); }); } while (0)
 #define LM_API(name) lmemu_##name
 
 #include "../../loro_amd/csrc/lm_capi_impl.h"

@@ -89,6 +89,19 @@ def test_map_rendering_plain_groups_and_entry_by_entry():
     _check(_cases.map_render_docs())
 
 
+def test_nested_map_key_index_beyond_the_key_table_is_rejected(monkeypatch):
+    """The decoders flag rows whose value holds a list / map (OPF_NESTED) and k_remap walks those values again against the
+    block's key table (lm_k_dag.h) — both decoders, every op shape that carries a nested value."""
+    good, bad = _cases.nested_key_docs()
+    want_good, want_bad = _oracle.merge_batch(good), _oracle.merge_batch(bad)
+    assert all(w[0] == 0 for w in want_good) and all(w[0] != 0 for w in want_bad)
+    for lane in ("1", "0"):
+        monkeypatch.setenv("LM_DECODE", lane)
+        got = _emu.merge_batch(good + bad)
+        assert got[:len(good)] == want_good
+        assert [g[0] for g in got[len(good):]] == [w[0] for w in want_bad]
+
+
 def test_node_cut_replay_order_and_tracker_base_on_small_documents(monkeypatch):
     """LM_CUT_MIN_ROWS=0: every document — not only those of 2,048 op rows and more — gets its nodes cut at cross-peer dependency
     targets, replayed one node per pass with the largest ready peer first, and its trackers a base version at critical versions

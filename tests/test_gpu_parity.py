@@ -166,6 +166,19 @@ def test_map_rendering_plain_groups_and_entry_by_entry(engine):
     _same(engine, _cases.map_render_docs() * 40)
 
 
+@pytest.mark.parametrize("decoder", ["1", "0"])
+def test_nested_map_key_index_beyond_the_key_table_is_rejected(engine, monkeypatch, decoder):
+    """rows whose value holds a list / map are walked again by k_remap against the block's key table (OPF_NESTED): a Map set, a
+    List / MovableList insert, a MovableList set, a Text mark — intact and with the nested key index patched beyond the table,
+    among other documents of the batch (whose results must not move)"""
+    monkeypatch.setenv("LM_DECODE", decoder)
+    good, bad = _cases.nested_key_docs()
+    fill = _cases.fuzz_docs(20, base=15600)
+    docs = fill[:10] + good + fill[10:] + bad
+    got = _same(engine, docs)
+    assert [g[0] for g in got[-len(bad):]] == [3] * len(bad) and all(g[0] == 0 for g in got[10:10 + len(good)])
+
+
 def test_ascii_pastes_with_every_length_prefix_width(engine):
     """length prefixes of 1, 2, 3 and 4 bytes through the decoder's arithmetic walk and the flat payload copy"""
     docs = _cases.ascii_paste_docs()
