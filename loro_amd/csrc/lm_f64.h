@@ -79,12 +79,63 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
   }
   bool even = (f & 1) == 0;                    // round-to-even: the interval ends belong to v
   bool lower_closer = be > 1 && frac == 0;      // v is a power of two: the gap below is half the gap above
-  Big &r = ws[0], &s = ws[1], &mp = ws[2], &mm = ws[3], &hi = ws[4], &r2 = ws[5];
   int bitlen = 64 - __builtin_clzll(f);
   double t = (double)(e2 + bitlen - 1) * 0.30102999566398120;   // log10(2); a lower bound of log10(v)
   int est = (int)t;
   if ((double)est < t - 1e-10) est++;           // ceil(t - 1e-10)
   if (t < 0 && (double)est > t + 1.0) est--;    // (int) truncates toward zero for negative t
+  char dig[20];
+  int nd = 0;
+  int k = est;
+  if (e2 >= -121 && e2 <= 60) {
+    // Everyday magnitudes (≈1.7e-21 … 1e34): the same algorithm, the same numbers — in two 64-bit registers each instead of limb
+    // arrays in LDS.  Every quantity stays below 2^127: for e2 >= 0 the largest is 10·r < 2^(53 + e2 + 2 + 4); for e2 < 0, v >= 1 it
+    // is 10·s <= 2^60; for v < 1 it is 10·s = 10·2^(2 - e2).  (A List of random doubles spent ≈60k cycles per value in the limb
+    // routine — one lane, every limb an LDS round trip; profiles/r03_renderer_phases.log: 97 % of configs[3]'s rendering.)
+    typedef unsigned __int128 u128;
+    u128 r, s, mp, mm;
+    if (e2 >= 0) {
+      r = (u128)f << ((uint32_t)e2 + (lower_closer ? 2u : 1u));
+      s = lower_closer ? 4 : 2;
+      mp = (u128)1 << ((uint32_t)e2 + (lower_closer ? 1u : 0u));
+      mm = (u128)1 << (uint32_t)e2;
+    } else {
+      r = (u128)f << (lower_closer ? 2u : 1u);
+      s = (u128)1 << ((uint32_t)(-e2) + (lower_closer ? 2u : 1u));
+      mp = lower_closer ? 2 : 1;
+      mm = 1;
+    }
+    {
+      uint32_t e = (uint32_t)(est < 0 ? -est : est);
+      u128 p10 = 1;
+      while (e >= 9) { p10 *= 1000000000u; e -= 9; }
+      while (e) { p10 *= 10u; e--; }
+      if (est >= 0) s *= p10; else { r *= p10; mp *= p10; mm *= p10; }
+    }
+    {
+      u128 hi = r + mp;
+      if (even ? hi >= s : hi > s) k++;          // estimate was one too low
+      else { r *= 10u; mp *= 10u; mm *= 10u; }
+    }
+    for (int guard = 0; guard < 19; guard++) {
+      int d = 0;
+      // (no 128-bit division on the device: the digit by compare-and-subtract of 8s, 4s, 2s, s)
+      u128 s2 = s << 1, s4 = s << 2, s8 = s << 3;
+      if (r >= s8) { r -= s8; d += 8; }
+      if (r >= s4) { r -= s4; d += 4; }
+      if (r >= s2) { r -= s2; d += 2; }
+      if (r >= s) { r -= s; d += 1; }
+      bool tc1 = even ? r <= mm : r < mm;
+      u128 hi = r + mp;
+      bool tc2 = even ? hi >= s : hi > s;
+      if (!tc1 && !tc2) { dig[nd++] = (char)('0' + d); r *= 10u; mp *= 10u; mm *= 10u; continue; }
+      if (tc1 && tc2) { u128 r2 = r << 1; if (r2 > s || (r2 == s && (d & 1))) d++; }   // nearer digit; an exact tie goes to the even digit
+      else if (tc2) d++;
+      dig[nd++] = (char)('0' + d);
+      break;
+    }
+  } else {
+  Big &r = ws[0], &s = ws[1], &mp = ws[2], &mm = ws[3], &hi = ws[4], &r2 = ws[5];
   // limbs: the largest value formed is below 2^(57 + |e2| + 3.33·|est| + 8)
   int aest = est < 0 ? -est : est, ae2 = e2 < 0 ? -e2 : e2;
   int nl = (57 + ae2 + (aest * 3322 + 999) / 1000 + 8 + 31) / 32 + 1;
@@ -102,7 +153,6 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
   }
   if (est >= 0) big_mul_pow10(s, (uint32_t)est, nl);
   else { big_mul_pow10(r, (uint32_t)(-est), nl); big_mul_pow10(mp, (uint32_t)(-est), nl); big_mul_pow10(mm, (uint32_t)(-est), nl); }
-  int k = est;
   {
     big_copy(hi, r, nl);
     big_add(hi, mp, nl);
@@ -110,8 +160,6 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
     if (even ? c >= 0 : c > 0) k++;              // estimate was one too low
     else { big_mul_small(r, 10, nl); big_mul_small(mp, 10, nl); big_mul_small(mm, 10, nl); }
   }
-  char dig[20];
-  int nd = 0;
   for (int guard = 0; guard < 19; guard++) {
     int d = 0;
     while (big_cmp(r, s, nl) >= 0) { big_sub(r, s, nl); d++; }
@@ -126,6 +174,7 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
     else if (tc2) d++;
     dig[nd++] = (char)('0' + d);
     break;
+  }
   }
   // v = 0.d1d2…dn × 10^k ; layout rules of ryu's pretty printer (as serde_json prints f64)
   if (neg) out[n++] = '-';

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 #include <atomic>
@@ -23,6 +24,12 @@ struct StreamCtx {
   std::vector<hipEvent_t> ev;            // pairs (start, stop), one pair per timed stage of a run
   std::vector<const char*> names;        // stages recorded since the last flush
   bool open = false;
+  // small host → device copies of a run (sizing tables, offsets): staged in a pinned ring and copied stream-ordered WITHOUT a host
+  // wait — the ring is reused only after the next synchronisation of the stream (rounds 1-4a synchronised after every one of the
+  // ≈10 table uploads of a run)
+  uint8_t* ring = nullptr;
+  size_t ring_cap = 0, ring_top = 0;
+  std::vector<uint8_t*> ring_old;        // outgrown rings: still the source of copies in flight, freed at the next synchronisation
 };
 static thread_local StreamCtx* cur = nullptr;
 static std::atomic<uint64_t> g_alloc{0};
@@ -49,6 +56,9 @@ inline void stream_destroy(StreamCtx* c) {
   if (!c) return;
   if (cur == c) cur = nullptr;
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  (void)hipStreamSynchronize(c->s);
+  for (uint8_t* r : c->ring_old) (void)hipHostFree(r);
+  if (c->ring) (void)hipHostFree(c->ring);
   (void)hipStreamDestroy(c->s);
   delete c;
 }
@@ -62,11 +72,35 @@ inline void* dalloc(size_t n) {
 }
 inline void dfree(void* p) { (void)hipFree(p); }
 inline void dmemset(void* p, int v, size_t n) { LM_HIP_CHECK(hipMemsetAsync(p, v, n, cur->s)); }
-inline void h2d(void* d, const void* h, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, cur->s)); LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
+inline void synced() {   // the stream has just been synchronised: every staged copy has completed
+  cur->ring_top = 0;
+  for (uint8_t* r : cur->ring_old) (void)hipHostFree(r);
+  cur->ring_old.clear();
+}
+inline void sync_stream() { LM_HIP_CHECK(hipStreamSynchronize(cur->s)); synced(); }
+inline void h2d(void* d, const void* h, size_t n) {
+  if (!n) return;
+  if (n > ((size_t)32 << 20)) { LM_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, cur->s)); sync_stream(); return; }
+  size_t at = (cur->ring_top + 63) & ~(size_t)63;
+  if (at + n > cur->ring_cap) {
+    if (n > cur->ring_cap / 2) {           // a larger ring; the old one may still feed copies in flight
+      size_t cap = cur->ring_cap ? cur->ring_cap * 2 : ((size_t)4 << 20);
+      while (cap < 2 * n) cap *= 2;
+      void* nr = nullptr;
+      if (hipHostMalloc(&nr, cap, hipHostMallocDefault) != hipSuccess) throw std::runtime_error("pinned staging ring allocation failed");
+      if (cur->ring) cur->ring_old.push_back(cur->ring);
+      cur->ring = (uint8_t*)nr; cur->ring_cap = cap;
+    } else sync_stream();                  // full: wait once, start over
+    at = 0;
+  }
+  memcpy(cur->ring + at, h, n);
+  LM_HIP_CHECK(hipMemcpyAsync(d, cur->ring + at, n, hipMemcpyHostToDevice, cur->s));
+  cur->ring_top = at + n;
+}
 inline void h2d_async(void* d, const void* h, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, cur->s)); }   // h pinned; completed by the next sync()
-inline void d2h(void* h, const void* d, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, cur->s)); LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
+inline void d2h(void* h, const void* d, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, cur->s)); sync_stream(); }
 inline void d2d(void* dst, const void* src, size_t n) { LM_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, cur->s)); }   // stream-ordered
-inline void sync() { LM_HIP_CHECK(hipStreamSynchronize(cur->s)); }
+inline void sync() { sync_stream(); }
 inline void* halloc(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
 inline void hfree(void* p) { (void)hipHostFree(p); }
 inline uint64_t allocated_bytes() { return g_alloc.load(); }
@@ -90,7 +124,7 @@ inline void reset_times() { cur->names.clear(); cur->open = false; }
 template <class V>
 inline void flush_times(V& times) {
   if (cur->names.empty()) return;
-  LM_HIP_CHECK(hipStreamSynchronize(cur->s));
+  sync_stream();
   for (size_t k = 0; k < cur->names.size(); k++) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, cur->ev[2 * k], cur->ev[2 * k + 1]);

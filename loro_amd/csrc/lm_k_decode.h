@@ -111,15 +111,43 @@ static constexpr uint32_t TB_WIDE = 0xFF, TB_ANCHOR = 0xFE;   // Dev::tb markers
 
 // -------------------------------------------------------------------------------------------------
 static constexpr uint64_t BIG_BLOB = 32768;   // blobs from this size on are hashed by a whole wave
-// K0: one wave per large blob (listed by the host, which knows the blob lengths) — the envelope checksum
+// K0: the envelope checksum of the large blobs (listed by the host, which knows the blob lengths, longest first) — SIXTEEN blobs
+// per wave: lanes 4g..4g+3 are the four accumulators of blob g's stripe loop, each reading its own word of every 16-byte stripe
+// (xxh32's accumulator chain is serial by construction — add, rotate, multiply per stripe, ≈1.5 ms for a 2.4 MB blob whatever
+// runs beside it; rounds 2-4a gave every blob a wave of its own, 60 lanes of which only fetched: ≈320 wave instructions per KB of
+// ONE blob against ≈24 per 64 bytes of SIXTEEN here.  configs[2]: 17,408 blobs of 150 KB-2.4 MB per 2,048 documents were 6.9 ms
+// of issue slots; neighbours in the list have similar lengths, so the groups of a wave finish together.)
+static constexpr uint32_t HASH_G = 16;
 LM_KERNEL void k_hash_big_blobs(Dev d, const uint32_t* big, uint32_t n_big) {
-  uint32_t i = (uint32_t)lmw::bid();
-  if (i >= n_big) return;
-  uint32_t b = big[i];
-  const uint8_t* p = d.data + d.blob_off[b];
-  uint64_t len = d.blob_len[b];
-  uint32_t h = len >= 22 ? xxh32_wave(p + 20, len - 20, 0x4f524f4cu) : 0u;
-  if (lmw::lane() == 0) d.blob_hash[b] = h;
+  const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, P4 = 0x27D4EB2Fu, P5 = 0x165667B1u;
+  const uint32_t seed = 0x4f524f4cu;
+  uint32_t lane = (uint32_t)lmw::lane(), grp = lane >> 2, a = lane & 3;
+  uint32_t i = (uint32_t)lmw::bid() * HASH_G + grp;
+  bool have = i < n_big;
+  uint32_t b = have ? big[i] : 0u;
+  uint64_t blen = have ? d.blob_len[b] : 0ull;
+  uint64_t len = blen >= 22 ? blen - 20 : 0ull;          // (listed blobs are >= BIG_BLOB bytes; anything shorter hashes to 0 as before)
+  const uint8_t* p = d.data + (have ? d.blob_off[b] : 0ull) + 20;   // blob starts are 16-byte aligned: p is 4-byte aligned
+  const uint32_t* w = (const uint32_t*)p + a;
+  uint32_t v = a == 0 ? seed + P1 + P2 : a == 1 ? seed + P2 : a == 2 ? seed : seed - P1;
+  uint64_t n_str = len >> 4, s_ = 0;
+  for (; s_ + 8 <= n_str; s_ += 8) {                     // eight stripes per trip: the loads are issued before the chain needs them
+    const uint32_t* q = w + 4 * s_;
+    uint32_t x0 = q[0], x1 = q[4], x2 = q[8], x3 = q[12], x4 = q[16], x5 = q[20], x6 = q[24], x7 = q[28];
+    v = rotl32(v + x0 * P2, 13) * P1; v = rotl32(v + x1 * P2, 13) * P1; v = rotl32(v + x2 * P2, 13) * P1; v = rotl32(v + x3 * P2, 13) * P1;
+    v = rotl32(v + x4 * P2, 13) * P1; v = rotl32(v + x5 * P2, 13) * P1; v = rotl32(v + x6 * P2, 13) * P1; v = rotl32(v + x7 * P2, 13) * P1;
+  }
+  for (; s_ < n_str; s_++) v = rotl32(v + w[4 * s_] * P2, 13) * P1;
+  int g0 = (int)(lane & ~3u);
+  uint32_t v1 = lmw::shfl(v, g0), v2 = lmw::shfl(v, g0 + 1), v3 = lmw::shfl(v, g0 + 2), v4 = lmw::shfl(v, g0 + 3);
+  uint32_t h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+  h += (uint32_t)len;
+  const uint8_t* q = p + (n_str << 4);
+  const uint8_t* end = p + len;
+  while (q + 4 <= end) { h = rotl32(h + ld32le(q) * P3, 17) * P4; q += 4; }
+  while (q < end) { h = rotl32(h + (*q) * P5, 11) * P1; q++; }
+  h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+  if (have && a == 0) d.blob_hash[b] = len >= 16 ? h : 0u;
 }
 
 // K1: one lane per blob — envelope, xxh32, block count.

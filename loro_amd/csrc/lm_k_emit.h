@@ -359,7 +359,8 @@ LM_DEV void sink_i64(Sink& s, int64_t v) {
   char buf[24];
   int n = 0;
   uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
-  uint64_t q1 = u / 1000000000ull, q2 = q1 / 1000000000ull;
+  // (a value below 10^9 — list indices, small counters, the bytes of a binary value — needs neither of the two 64-bit divisions)
+  uint64_t q1 = u < 1000000000ull ? 0ull : u / 1000000000ull, q2 = q1 < 1000000000ull ? 0ull : q1 / 1000000000ull;
   uint32_t c0 = (uint32_t)(u - q1 * 1000000000ull), c1 = (uint32_t)(q1 - q2 * 1000000000ull), c2 = (uint32_t)q2;
   const int top = c2 ? 2 : (c1 ? 1 : 0);
   for (int ci = 0; ci <= top; ci++) {

@@ -577,7 +577,7 @@ struct Engine {
       if (!big.empty()) {
         b_big.ensure(big.size() * 4);
         lmbe::h2d(b_big.p, big.data(), big.size() * 4);
-        LM_LAUNCH(k_hash_big_blobs, (uint32_t)big.size(), 64, d, (const uint32_t*)b_big.as<uint32_t>(), (uint32_t)big.size());
+        LM_LAUNCH(k_hash_big_blobs, cdiv(big.size(), HASH_G), 64, d, (const uint32_t*)b_big.as<uint32_t>(), (uint32_t)big.size());
       }
     }
     if (n_blobs) LM_LAUNCH(k_frame_count, cdiv(n_blobs, 64), 64, d);

@@ -50,6 +50,14 @@ def test_random_doubles_match_the_oracle_and_round_trip():
         cases.append(_bits(rng.uniform(-1e6, 1e6)))
         cases.append(_bits(round(rng.uniform(-1e4, 1e4), rng.randint(0, 6))))  # short decimals
         cases.append(_bits(float(rng.randint(-10**17, 10**17))))
+    for _ in range(60000):                                                  # every binary exponent the two-register path takes (-121 <= e2 <= 60) and its edges
+        cases.append((rng.getrandbits(1) << 63) | (rng.randint(1075 - 124, 1075 + 63) << 52) | rng.getrandbits(52))
+        cases.append(_bits(rng.random() * 10.0 ** rng.randint(-22, 35)))
+    for e in range(1075 - 124, 1075 + 64):                                   # … its powers of two, their neighbours, all-ones fractions
+        cases += [e << 52, (e << 52) + 1, (e << 52) - 1, (e << 52) | ((1 << 52) - 1), (e << 52) | (1 << 51)]
+    for d in range(1, 18):                                                  # decimals of every length around the powers of ten of that range
+        for ex in range(-21, 34):
+            cases.append(_bits(float("%de%d" % (rng.randint(10 ** (d - 1), 10 ** d - 1), ex - d))))
     for e in range(-1074, 1024, 7):                                         # powers of two (uneven neighbours) and ±1 ulp
         b = _bits(2.0 ** e) if e > -1023 else 1 << (e + 1074)
         cases += [b, b + 1, max(b - 1, 1)]

@@ -37,6 +37,9 @@ sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, 'tests')
 from loro_amd._cabi import Binding, Context
 from loro_amd import workload
 docs = [workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True).stamp(0)]
+if os.environ.get('ISA_DOC') == 'cfg4':   # one configs[3] document (mixed List / Map / Text, 4 peers, pairwise syncs): ISA_DOC=cfg4 ... k_integrate_span
+    import _fuzz
+    docs = [_fuzz.blobs_of(_fuzz.random_session(1000, n_peers=4, n_steps=1000, kinds=('text', 'list', 'map'), sync_prob=0.02, styles=True))]
 with Context(Binding(os.path.join({work!r}, 'libloroemu_cov.so'), 'lmemu_')) as c:
     assert c.merge_batch(docs)[0][0] == 0
 """], cwd=work, stderr=subprocess.DEVNULL, env=dict(os.environ, **({"LM_PLAIN": "1"} if kernel.endswith("_plain") else ({"LM_PLAIN": "2"} if kernel.endswith("_plain_sweep") else {}))))
