@@ -111,43 +111,79 @@ static constexpr uint32_t TB_WIDE = 0xFF, TB_ANCHOR = 0xFE;   // Dev::tb markers
 
 // -------------------------------------------------------------------------------------------------
 static constexpr uint64_t BIG_BLOB = 32768;   // blobs from this size on are hashed by a whole wave
-// K0: the envelope checksum of the large blobs (listed by the host, which knows the blob lengths, longest first) — SIXTEEN blobs
-// per wave: lanes 4g..4g+3 are the four accumulators of blob g's stripe loop, each reading its own word of every 16-byte stripe
-// (xxh32's accumulator chain is serial by construction — add, rotate, multiply per stripe, ≈1.5 ms for a 2.4 MB blob whatever
-// runs beside it; rounds 2-4a gave every blob a wave of its own, 60 lanes of which only fetched: ≈320 wave instructions per KB of
-// ONE blob against ≈24 per 64 bytes of SIXTEEN here.  configs[2]: 17,408 blobs of 150 KB-2.4 MB per 2,048 documents were 6.9 ms
-// of issue slots; neighbours in the list have similar lengths, so the groups of a wave finish together.)
-static constexpr uint32_t HASH_G = 16;
-LM_KERNEL void k_hash_big_blobs(Dev d, const uint32_t* big, uint32_t n_big) {
+// K0: the envelope checksum of the large blobs (listed by the host, which knows the blob lengths, longest first) — FOUR blobs per
+// wave, one per 16-lane row.  xxh32's four accumulators are a serial chain by construction (add, rotate, multiply per 16-byte
+// stripe: ≈1.5 ms for a 2.4 MB blob whatever runs beside it), so what a kernel can do about it is (1) never wait for memory inside
+// the chain and (2) spend few instructions per byte:
+//  * a row's 16 lanes load one 64-byte chunk per instruction (lane 4j+a: word a of stripe j) and lanes 0..3 — the accumulators —
+//    take the other lanes' words through the DPP crossbar (row_shl 4 / 8 / 12, no LDS);
+//  * three register banks of 1 KB per blob rotate: while one bank is consumed, the loads of the next two are in flight (2 KB per
+//    blob ahead of the chain — the chain needs 0.64 µs per KB, a load ≈1.5 µs).
+// Rounds 2-4a: one wave per blob, the KB loaded and waited for in front of its 64 chain steps, every step fed by an LDS permute
+// (≈5 ms per 2.4 MB blob, 6.9 ms for a configs[2] batch of 2,048 documents); a first 16-blobs-per-wave version with a dword per
+// lane and stripe kept only 128 bytes per blob in flight and measured 21 ms.
+static constexpr uint32_t HASH_G = 4;
+LM_DEV uint32_t xx_round(uint32_t v, uint32_t m) { return rotl32(v + m, 13) * 0x9E3779B1u; }
+LM_KERNEL LM_WAVES_PER_SIMD(2) LM_ONE_WAVE_GROUPS void k_hash_big_blobs(Dev d, const uint32_t* big, uint32_t n_big) {
   const uint32_t P1 = 0x9E3779B1u, P2 = 0x85EBCA77u, P3 = 0xC2B2AE3Du, P4 = 0x27D4EB2Fu, P5 = 0x165667B1u;
   const uint32_t seed = 0x4f524f4cu;
-  uint32_t lane = (uint32_t)lmw::lane(), grp = lane >> 2, a = lane & 3;
-  uint32_t i = (uint32_t)lmw::bid() * HASH_G + grp;
+  uint32_t lane = (uint32_t)lmw::lane(), row = lane >> 4, rl = lane & 15, a = lane & 3;
+  uint32_t i = (uint32_t)lmw::bid() * HASH_G + row;
   bool have = i < n_big;
-  uint32_t b = have ? big[i] : 0u;
+  uint32_t b = big[have ? i : 0u];                       // (a row without a blob reads the first listed blob's first KB and keeps nothing)
   uint64_t blen = have ? d.blob_len[b] : 0ull;
-  uint64_t len = blen >= 22 ? blen - 20 : 0ull;          // (listed blobs are >= BIG_BLOB bytes; anything shorter hashes to 0 as before)
-  const uint8_t* p = d.data + (have ? d.blob_off[b] : 0ull) + 20;   // blob starts are 16-byte aligned: p is 4-byte aligned
-  const uint32_t* w = (const uint32_t*)p + a;
+  uint64_t len = blen >= 1024 + 20 ? blen - 20 : 0ull;   // (listed blobs are >= BIG_BLOB bytes; anything shorter hashes to 0)
+  const uint8_t* p = d.data + d.blob_off[b] + 20;        // blob starts are 16-byte aligned: p is 4-byte aligned
+  const uint32_t* w = (const uint32_t*)p + rl;           // this lane's word of every 64-byte chunk
   uint32_t v = a == 0 ? seed + P1 + P2 : a == 1 ? seed + P2 : a == 2 ? seed : seed - P1;
-  uint64_t n_str = len >> 4, s_ = 0;
-  for (; s_ + 8 <= n_str; s_ += 8) {                     // eight stripes per trip: the loads are issued before the chain needs them
-    const uint32_t* q = w + 4 * s_;
-    uint32_t x0 = q[0], x1 = q[4], x2 = q[8], x3 = q[12], x4 = q[16], x5 = q[20], x6 = q[24], x7 = q[28];
-    v = rotl32(v + x0 * P2, 13) * P1; v = rotl32(v + x1 * P2, 13) * P1; v = rotl32(v + x2 * P2, 13) * P1; v = rotl32(v + x3 * P2, 13) * P1;
-    v = rotl32(v + x4 * P2, 13) * P1; v = rotl32(v + x5 * P2, 13) * P1; v = rotl32(v + x6 * P2, 13) * P1; v = rotl32(v + x7 * P2, 13) * P1;
+  const uint32_t n_str = (uint32_t)(len >> 4), n_kb = n_str >> 6;   // stripes, whole KBs (a blob is shorter than 4 GiB)
+  const uint32_t T = lmw::reduce_max(n_kb);              // trips of the wave: its longest blob's
+  uint32_t xa[16], xb[16], xc[16];
+  // (every load is unconditional — a lane past its blob's last KB reads that KB again and the chain drops the result: a load under
+  // a lane predicate becomes a branch with a wait for memory behind it, sixteen of them per KB)
+  const uint32_t kb_last = n_kb ? n_kb - 1 : 0u;
+#define LM_HASH_LOAD(x, t) do { const uint32_t* q_ = w + (size_t)256 * ((t) < kb_last ? (t) : kb_last); _Pragma("unroll") for (int k_ = 0; k_ < 16; k_++) x[k_] = q_[16 * k_]; } while (0)
+#define LM_HASH_CHAIN(x, t) do { uint32_t nv_ = v; _Pragma("unroll") for (int k_ = 0; k_ < 16; k_++) { const uint32_t m_ = x[k_] * P2; \
+      nv_ = xx_round(nv_, m_); nv_ = xx_round(nv_, lmw::row_down<4>(m_)); nv_ = xx_round(nv_, lmw::row_down<8>(m_)); nv_ = xx_round(nv_, lmw::row_down<12>(m_)); LM_SCHED_FENCE(); } \
+    if ((t) < n_kb) v = nv_; } while (0)
+  LM_HASH_LOAD(xa, 0u); LM_HASH_LOAD(xb, 1u);
+#pragma unroll 1
+  for (uint32_t t = 0; t < T; t += 3) {
+    LM_HASH_LOAD(xc, t + 2); LM_HASH_CHAIN(xa, t);
+    LM_HASH_LOAD(xa, t + 3); LM_HASH_CHAIN(xb, t + 1);
+    LM_HASH_LOAD(xb, t + 4); LM_HASH_CHAIN(xc, t + 2);
   }
-  for (; s_ < n_str; s_++) v = rotl32(v + w[4 * s_] * P2, 13) * P1;
-  int g0 = (int)(lane & ~3u);
+#undef LM_HASH_LOAD
+#undef LM_HASH_CHAIN
+  // the last partial KB: chunks of four stripes, each stripe under its own test
+  {
+    const uint32_t s0 = n_kb << 6;
+#pragma unroll 1
+    for (uint32_t c = 0; c < 16; c++) {
+      const uint32_t s_ = s0 + 4 * c;
+      const uint32_t st_ = s_ + (rl >> 2), stc_ = st_ < n_str ? st_ : (n_str ? n_str - 1 : 0u);
+      const uint32_t x = ((const uint32_t*)p)[(size_t)4 * stc_ + a];
+      const uint32_t m_ = x * P2;
+      uint32_t nv = xx_round(v, m_);
+      if (s_ < n_str) v = nv;
+      nv = xx_round(v, lmw::row_down<4>(m_));
+      if (s_ + 1 < n_str) v = nv;
+      nv = xx_round(v, lmw::row_down<8>(m_));
+      if (s_ + 2 < n_str) v = nv;
+      nv = xx_round(v, lmw::row_down<12>(m_));
+      if (s_ + 3 < n_str) v = nv;
+    }
+  }
+  int g0 = (int)(lane & ~15u);
   uint32_t v1 = lmw::shfl(v, g0), v2 = lmw::shfl(v, g0 + 1), v3 = lmw::shfl(v, g0 + 2), v4 = lmw::shfl(v, g0 + 3);
   uint32_t h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
   h += (uint32_t)len;
-  const uint8_t* q = p + (n_str << 4);
+  const uint8_t* q = p + ((uint64_t)n_str << 4);
   const uint8_t* end = p + len;
   while (q + 4 <= end) { h = rotl32(h + ld32le(q) * P3, 17) * P4; q += 4; }
   while (q < end) { h = rotl32(h + (*q) * P5, 11) * P1; q++; }
   h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
-  if (have && a == 0) d.blob_hash[b] = len >= 16 ? h : 0u;
+  if (have && rl == 0) d.blob_hash[b] = len >= 16 ? h : 0u;
 }
 
 // K1: one lane per blob — envelope, xxh32, block count.

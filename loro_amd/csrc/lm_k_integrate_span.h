@@ -19,7 +19,6 @@ LM_DEV uint32_t sa_leaf(uint32_t a) { return a & DIR_LEAF_MASK; }
 LM_DEV uint32_t sa_n(uint32_t a) { return (a >> 18) & 0x7f; }
 LM_DEV bool sa_nf(uint32_t a) { return (a & DIR_NF) != 0; }
 
-static constexpr uint32_t LOC_OFF = 0x80000000u;   // Ts::n_alive
 struct SpanRegs { uint32_t n, id, len, ol, orr, st; };   // one leaf in registers: lane i holds item i
 struct SpanItem { uint32_t id, len, ol, orr, st; };
 
@@ -37,8 +36,6 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   bool ds_on;
   uint32_t n_dir, dir_cap, n_leaf, leaf_cap, tot_active;
   uint32_t n_alive;               // elements inserted and never deleted by a replayed op = visible at the rendered version
-                                  // | LOC_OFF (bit 31): loc[] is not kept yet (ts_build_loc) — a flag here costs no register of its own: a
-                                  // nullable `loc` pointer did (two more live scalars: 11 instructions of spill traffic per op row)
   uint32_t cache_leaf;            // leaf mirrored in `cr` (NONE = none); WRITE-BACK: `cr` is the truth, HBM is updated by sp_flush
   uint32_t cache_p;               // its directory position (kept in step with directory inserts)
   uint32_t cache_pre;             // active elements in front of the cached leaf, NONE when not known: an edit at a position
@@ -116,7 +113,7 @@ static constexpr uint32_t LOC_W = LM_LOC_W;   // a power of two <= 64
 // stays a head; the nearest kept entry at or below an element of an item, inside its LOC_W-aligned counter window, is therefore an
 // element of the same item (ts_loc_find).  A flush writes 1 + len/16 entries per pending item instead of len.
 LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
-  if (t.n_alive & LOC_OFF) return;   // loc[] is not kept yet (ts_build_loc): nothing can ask for an element by id while the replay is one chain
+  if (!t.loc) return;   // loc[] is not kept yet (ts_build_loc): nothing can ask for an element by id while the replay is one chain
   uint32_t len = pend ? R.len : 0u;
   uint32_t c0 = pid_ctr(R.id);
   uint32_t g = pend ? t.ebase[pid_peer(R.id)] + c0 : 0u;
@@ -135,7 +132,7 @@ LM_DEV void sp_set_loc_lanes(Ts& t, const SpanRegs& R, bool pend, uint32_t L) {
 }
 // leaf of element `pid` (wave-uniform), NONE when no kept entry lies at or below it in its window
 LM_DEV uint32_t ts_loc_find(const Ts& t, uint32_t pid) {
-  if (t.n_alive & LOC_OFF) return NONE;
+  if (!t.loc) return NONE;
   uint32_t ctr = pid_ctr(pid), lo = ctr & ~(LOC_W - 1), eb = t.ebase[pid_peer(pid)];
   uint32_t lane = (uint32_t)lmw::lane();
   uint32_t v = (lane < LOC_W && lo + lane <= ctr) ? t.loc[eb + lo + lane] : NONE;
@@ -1084,9 +1081,9 @@ LM_DEV void ts_reset_to_base(Ts& t, const uint32_t* s_base) {
 // sibling scan to resolve, no op to retreat — so the flushes of the cached leaf write no loc[] entry (configs[1]: the 50k-op
 // base, 60 % of its rows; a document imported sequentially never pays for loc[] at all).  The first move of the tracker
 // (ts_goto) brings it up to date; from then on it is maintained as always.
-LM_DEV void ts_build_loc(Ts& t) {
+LM_DEV void ts_build_loc(Ts& t, uint32_t* loc_real) {
   int lane = lmw::lane();
-  t.n_alive &= ~LOC_OFF;
+  t.loc = loc_real;
   lmw::wave_sync();
   for (uint32_t q = 0; q < t.n_dir; q++) {
     uint32_t a = lmw::first(t.da[q]);
@@ -1238,19 +1235,14 @@ LM_DEV bool ts_sweep_pays(const Ts& t, const DocMeta& m, uint32_t P, const uint3
 }
 template <bool ML, bool SWEEP>
 LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t P, const uint32_t* vv, uint32_t* s_cur, uint32_t* s_base,
-                    bool conv) {
+                    bool& base_on, bool conv, uint32_t* loc_real) {
   int lane = lmw::lane();
-  if (t.n_alive & LOC_OFF) {
+  if (!t.loc) {
     bool mv = false;
     for (uint32_t p = (uint32_t)lane; p < P; p += 64) mv |= s_cur[p] != vv[p];
-    if (conv || lmw::any(mv)) ts_build_loc(t);
+    if (conv || lmw::any(mv)) ts_build_loc(t, loc_real);
   }
   bool reset = false;
-  bool base_on = false;
-  if (m.flags & DF_CUT) {   // (only a document whose nodes were cut ever gets a base, k_dag_b)
-    lmw::block_sync();
-    base_on = lmw::first(s_base[P]) != 0;   // (the word behind the base's P entries: the tracker has a base)
-  }
   if (base_on) {
     bool same = true;
     uint32_t back = 0;
@@ -1274,7 +1266,7 @@ LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32
     }
   lmw::block_sync();
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_cur[p] = vv[p]; if (conv) s_base[p] = vv[p]; }
-  if (conv && !t.err) { ts_convert_base(t); if (lane == 0) s_base[P] = 1; }
+  if (conv && !t.err) { ts_convert_base(t); base_on = true; }
   lmw::block_sync();
 }
 
@@ -1295,7 +1287,7 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
         if (ln == 0) { fprintf(stderr, "CHECK %s row=%u: dir[%u] leaf %u item %u has length 0\n", what, row, q, L, i); ok = false; }
         if (st_active(st)) act += ln;
         nf |= !(st & ST_FUT);
-        for (uint32_t k = 0; k < ln && !(t.n_alive & LOC_OFF); k++) {
+        for (uint32_t k = 0; k < ln && t.loc; k++) {
 #ifdef LM_LOC16
           uint32_t expect = (k == 0 || ((id0 + k) & (LOC_W - 1)) == 0) ? L : NONE;   // kept entries only: heads and multiples of LOC_W
 #else
@@ -1495,7 +1487,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   t.loc = d.loc + elem0;
   t.ebase = s_ebase; t.cur = s_cur; t.end = s_end; t.da = s_da; t.db = s_db; t.ds = s_ds; t.ds_on = false;
   t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0;
-  t.n_alive = 0;   // (bit 31 = LOC_OFF is read by sp_set_loc_lanes — the stored leaves' loc[] entries are written before any container sets the count)
+  t.n_alive = 0;
 #ifdef LM_PROF
   for (int i = 0; i < PF_N; i++) t.prof[i] = 0;
   uint64_t pf_begin = lmw::clock();
@@ -1560,17 +1552,16 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     }
     lmw::block_sync();
     bool touched = false;
-    if (PLAIN && !RES && LM_LAZY_LOC) t.n_alive |= LOC_OFF;   // (ts_build_loc)
-    uint32_t* s_base = s_tgt;          // the tracker's base version, ts_goto (not RES: the slot of the resident kernels' rendered version); [P] != 0: it has one
-    if (!RES && lane == 0) s_base[P] = 0;
-    lmw::block_sync();
+    t.loc = (PLAIN && !RES && LM_LAZY_LOC) ? nullptr : d.loc + elem0;   // (ts_build_loc)
+    bool base_on = false;              // the tracker has a base version (s_base), ts_goto
+    uint32_t* s_base = s_tgt;          // (not RES: the slot of the resident kernels' rendered version)
     for (uint32_t oi = 0; oi < m.n_nodes && !t.err; oi++) {
       uint32_t n = d.node_order[m.chg0 + oi];
       uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
       const uint32_t* vv = vvh_ro + vvh0 + (uint64_t)n * P;
       uint32_t node_peer = chg_ro[sorted_ro[m.chg0 + first]].peer;
-      // (k_dag_b's flag — node_done bit 1: the replayed history in front of this node is a critical version and a concurrent section
-      // begins behind it — is read where the tracker moves, ts_goto's call sites: not a value that lives across the row loop)
+      // (k_dag_b: the replayed history in front of this node is a critical version and a concurrent section begins behind it)
+      const bool conv_node = !RES && LM_BASE_RESET && (lmw::first(g.node_done[m.chg0 + n]) & 2u) != 0;
       if (RES) {   // a node the stored tracker has applied to its end
         const ChangeRow lc = chg_ro[sorted_ro[m.chg0 + last]];
         if (lc.ctr + lc.len <= s_app[node_peer]) continue;
@@ -1612,7 +1603,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
           // carries no test for it (7 instructions per op row, 4 of them register moves in front of the branch)
           checked_out = true;
-          ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, !RES && LM_BASE_RESET && (m.flags & DF_CUT) && (lmw::first(g.node_done[m.chg0 + n]) & 2u) != 0);
+          ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0);
           PROF_ADD(t, PF_CHECKOUT);
           TS_CHECK("checkout", ch.op0);
         }
@@ -1640,7 +1631,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           uint32_t b = PLAIN ? r.len : (r.ctr + r.len <= pe ? r.len : pe - r.ctr);
           if (!(PLAIN && !RES) && !checked_out) {
             checked_out = true;
-            if (!RES) ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, !RES && LM_BASE_RESET && (m.flags & DF_CUT) && (lmw::first(g.node_done[m.chg0 + n]) & 2u) != 0);
+            if (!RES) ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0);
             else {
             lmw::block_sync();
             if (RES && !ML && d.dcnt && ts_sweep_pays(t, m, P, vv, node_peer, r.ctr + a, s_cur)) ts_sweep_version(t, d, m, cidx, P, vv, node_peer, r.ctr + a, s_cur, d.dcnt + elem0);
@@ -1759,7 +1750,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
       // (a MovableList exists once an element was ever inserted — k_mlist_post adds that case after this stage)
       // (RES: visible at the latest version — n_alive counts every applied op — or at the version the tracker was just moved to;
       // earlier runs' verdicts are OR-ed in by k_res_exists)
-      if (touched && ((t.n_alive & ~LOC_OFF) > 0 || (RES && !PLAIN && to_version && t.tot_active > 0))) d.cont[m.cid0 + cidx].touched = 1;
+      if (touched && (t.n_alive > 0 || (RES && !PLAIN && to_version && t.tot_active > 0))) d.cont[m.cid0 + cidx].touched = 1;
     }
     dir_used += t.n_dir;
     lmw::block_sync();

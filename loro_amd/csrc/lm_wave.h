@@ -15,6 +15,7 @@
 #define LM_DEV_NOINLINE __device__ __noinline__
 #define LM_KERNEL extern "C" __global__
 #define LM_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget: 512 / n VGPRs
+#define LM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
 #define LM_ONE_WAVE_GROUPS __launch_bounds__(64)   // launched with 64-thread workgroups only: lifts the 128-VGPR cap of a 1,024-thread group
 #define LM_SHARED(type, name, n) __shared__ type name[n]
 #define LM_DYN_SHARED(type, name) extern __shared__ type name[]
@@ -71,6 +72,7 @@ LM_DEV uint64_t clock() { return __builtin_readcyclecounter(); }
 #define LM_KERNEL inline
 #define LM_WAVES_PER_SIMD(n)
 #define LM_ONE_WAVE_GROUPS
+#define LM_SCHED_FENCE() do {} while (0)
 #define LM_SHARED(type, name, n) static type name[n]
 #define LM_DYN_SHARED(type, name) type* name = (type*)lmw::emu_dyn_shared()
 typedef const uint8_t* lm_lds_bytes;
@@ -298,6 +300,12 @@ LM_DEV uint32_t shift_up0(uint32_t v, int d) {
 #else
 LM_DEV uint32_t shift_up(uint32_t v, int d) { return shfl_up(v, d); }
 LM_DEV uint32_t shift_up0(uint32_t v, int d) { uint32_t t = shfl_up(v, d); return lane() < d ? 0u : t; }
+#endif
+// lane i receives lane i+N of its own 16-lane row (DPP row_shl:N, one VALU move; lanes whose source lies beyond the row receive 0)
+#ifndef LM_EMU
+template <int N> LM_DEV uint32_t row_down(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x100 | N, 0xf, 0xf, true); }
+#else
+template <int N> LM_DEV uint32_t row_down(uint32_t v) { int l = lane(); uint32_t t = shfl(v, (l & ~15) | ((l + N) & 15)); return (l & 15) + N > 15 ? 0u : t; }
 #endif
 // wave sum: the DPP prefix scan's last lane (six VALU ops + one readlane instead of six dependent LDS swizzles)
 LM_DEV uint32_t reduce_add(uint32_t v) { return bcast(scan_incl_add(v), 63); }
