@@ -97,6 +97,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* fuse;               // [2 x op row] k_fuse_rows: a run head's leftmost delete target counter | signed total length (nullptr: no run was chained)
   uint32_t* dec_stat;           // [0] blocks whose head (everything before the value payloads) exceeds dec_slot bytes, [1] the largest such head, [2] the largest span of such a block's op / delete-start columns
   uint32_t dec_slot;            // the decoder's default LDS slot (k_block_count compares against it)
+  uint32_t vs_row_cost;         // ts_sweep_pays_batch: what a row-by-row tracker move costs per op row, in the units of the pass's cost estimate
   uint32_t cut_min_rows;        // k_dag_a: documents of at least this many op rows get the node cut + descending-peer replay order (DF_CUT)
   // outputs
   uint8_t* out;          // JSON bytes

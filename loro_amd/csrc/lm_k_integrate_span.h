@@ -1233,9 +1233,29 @@ LM_DEV bool ts_sweep_pays(const Ts& t, const DocMeta& m, uint32_t P, const uint3
   return dist > 256 && (uint64_t)dist * 16 > (uint64_t)m.atoms / 32 + m.n_op + 40ull * t.n_dir + 2048;
 #endif
 }
-template <bool ML, bool SWEEP>
+// … and for a BATCH replay (the common kernel: documents with style anchors, small documents of several peers that sync every few
+// dozen ops — configs[3]): the pass costs ≈ 1.25 instructions per op row of the document + 60 per leaf + ≈600 per moved peer (the
+// two cuts) + ≈500; row by row a move costs ≈300 per ROW — rows ≈ moved ids x rows per id of the document.  configs[3] (≈1,000 op
+// rows, ≈3 ids per row): a move across 100 ids is ≈35 rows ≈ 10k instructions against ≈4k; the cost model had 74 % of that
+// config's integrate stage in ts_move_ops.
+LM_DEV bool ts_sweep_pays_batch(const Ts& t, const Dev& d, const DocMeta& m, uint32_t P, const uint32_t* vv, const uint32_t* s_cur) {
+  uint32_t dist = 0, np = 0;
+  for (uint32_t p = (uint32_t)lmw::lane(); p < P; p += 64) { uint32_t c = s_cur[p], g = vv[p]; dist += c > g ? c - g : g - c; np += c != g ? 1u : 0u; }
+  dist = lmw::reduce_add(dist);
+  np = lmw::reduce_add(np);
+#ifdef LM_SWEEP_EAGER   // tests: every move takes the pass
+  return dist > 0;
+#else
+  const uint64_t rows = (uint64_t)dist * m.n_op / (m.atoms ? m.atoms : 1u);
+  return dist > 16 && rows * d.vs_row_cost > 5ull * m.n_op / 4 + m.atoms / 40 + 60ull * t.n_dir + 600ull * np + 500;
+#endif
+}
+#ifndef LM_BATCH_VSWEEP
+#define LM_BATCH_VSWEEP 0   // 1: the common batch kernel moves its tracker by version passes when ts_sweep_pays_batch says so — measured on configs[3] (profiles/r04_batch_version_sweep.log): -9 % of the kernel at best, a slower step (52 B of scratch instead of 24); kept for the test build
+#endif
+template <bool ML, bool SWEEP, bool VS>
 LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t P, const uint32_t* vv, uint32_t* s_cur, uint32_t* s_base,
-                    bool& base_on, bool conv, uint32_t* loc_real) {
+                    bool& base_on, bool conv, uint32_t* loc_real, uint32_t* dcnt_real) {
   int lane = lmw::lane();
   if (!t.loc) {
     bool mv = false;
@@ -1258,6 +1278,9 @@ LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32
   if (getenv("LM_EMU_BASE") && lane == 0) fprintf(stderr, "BASE cont %u: %s%s (n_dir %u)\n", cidx, reset ? "reset" : "move", conv ? " +convert" : "", t.n_dir);
 #endif
   if (reset) ts_reset_to_base(t, s_base);
+  // (VS: the common batch kernel only — the plain instantiations move by leaf sweeps and base resets and stay as they are.  Not
+  // beside a base: the sticky ST_DEAD bits of the base and the counts of the pass would both hold the deletes below it)
+  else if (VS && !base_on && !conv && dcnt_real && (lmw::block_sync(), ts_sweep_pays_batch(t, d, m, P, vv, s_cur))) ts_sweep_version(t, d, m, cidx, P, vv, NONE, 0, s_cur, dcnt_real);
   else
     for (uint32_t p = 0; p < P && !t.err; p++) {
       uint32_t cur = s_cur[p], tgt = vv[p];
@@ -1603,7 +1626,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
           // carries no test for it (7 instructions per op row, 4 of them register moves in front of the branch)
           checked_out = true;
-          ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0);
+          ts_goto<ML, SWEEP, false>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0, nullptr);
           PROF_ADD(t, PF_CHECKOUT);
           TS_CHECK("checkout", ch.op0);
         }
@@ -1631,7 +1654,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           uint32_t b = PLAIN ? r.len : (r.ctr + r.len <= pe ? r.len : pe - r.ctr);
           if (!(PLAIN && !RES) && !checked_out) {
             checked_out = true;
-            if (!RES) ts_goto<ML, SWEEP>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0);
+            if (!RES) ts_goto<ML, SWEEP, (!ML && !PLAIN && !RES && LM_BATCH_VSWEEP)>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0, d.dcnt ? d.dcnt + elem0 : nullptr);
             else {
             lmw::block_sync();
             if (RES && !ML && d.dcnt && ts_sweep_pays(t, m, P, vv, node_peer, r.ctr + a, s_cur)) ts_sweep_version(t, d, m, cidx, P, vv, node_peer, r.ctr + a, s_cur, d.dcnt + elem0);

@@ -140,7 +140,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048; bool lww_lds = true, fuse_rows = true, version_sweep = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -156,6 +156,7 @@ struct Engine {
     if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
     if (const char* e = getenv("LM_HT_OPT")) k.ht_opt = (uint32_t)atoi(e);                       // slots of a document's optimistic LWW table (a power of two; 0: sized for its Map rows at once; tests: 64 forces the second pass)
     if (const char* e = getenv("LM_CUT_MIN_ROWS")) k.cut_min_rows = (uint32_t)atoll(e);           // op rows from which a document's nodes are cut at cross-peer dependency targets and replayed largest peer first (tests: 0)
+    if (const char* e = getenv("LM_VS_ROW_COST")) k.vs_row_cost = (uint32_t)atoi(e);             // ts_sweep_pays_batch (A/B)
     if (const char* e = getenv("LM_VERSION_SWEEP")) k.version_sweep = atoi(e) != 0;              // 0: resident trackers move row by row (rounds 3-4a: delete rows undone / redone one by one)
     if (const char* e = getenv("LM_FUSE_ROWS")) k.fuse_rows = atoi(e) != 0;                      // 0: one-change-per-keystroke documents are replayed row by row, as in rounds 1-3
     if (const char* e = getenv("LM_LWW_LDS")) k.lww_lds = atoi(e) != 0;                          // 0: every document's Map rows go through the HBM tables (k_map_lww), as in rounds 1-3
@@ -547,7 +548,7 @@ struct Engine {
     // profiles/r02_ab_prepared.log); LM_PLAIN=1 selects k_integrate_span_plain, LM_PLAIN=0 the common kernel for every document
     const int plain_mode = !span ? 0 : kn.plain;   // (resident documents: 0 = the general kernel for all, otherwise k_integrate_span_res_plain for the DF_PLAIN ones)
     const bool plain_on = plain_mode == 1 || plain_mode == 2;
-    bool any_plain = false, any_fused = false;
+    bool any_plain = false, any_fused = false, want_dcnt = false;
     if (reuse) {
       d = sv.d; g = sv.g;
       d.front = b_front.as<uint8_t>(); d.front_off = b_front_off.as<uint64_t>();
@@ -596,7 +597,7 @@ struct Engine {
     if (n_blobs) LM_LAUNCH(k_frame_fill, cdiv(n_blobs, 64), 64, d);
     if (NB) LM_LAUNCH(k_block_desc, cdiv(NB, 64), 64, d);
     b_tot.ensure(64 * 4);
-    d.dec_stat = b_tot.as<uint32_t>() + 48; d.dec_slot = kn.dec_slot; d.cut_min_rows = kn.cut_min_rows;
+    d.dec_stat = b_tot.as<uint32_t>() + 48; d.dec_slot = kn.dec_slot; d.cut_min_rows = kn.cut_min_rows; d.vs_row_cost = kn.vs_row_cost;
     lmbe::dmemset(d.dec_stat, 0, 12);
     if (NB) LM_LAUNCH(k_block_count, cdiv(NB, 64), 64, d);
     lmbe::toc("k_frame_fill+k_block_count", times, profiling);
@@ -699,6 +700,7 @@ struct Engine {
       if (resident || plain_mode != 2 || !kn.fuse_rows) m.flags &= ~DF_FUSED;
       any_plain |= (m.flags & DF_PLAIN) != 0;
       any_fused |= (m.flags & DF_FUSED) != 0;
+      want_dcnt |= ok && !(m.flags & (DF_PLAIN | DF_MOVABLE));   // replayed by the common kernel: its tracker may move by a version pass (ts_sweep_version)
       m.elem0_lo = (uint32_t)elem; m.elem0_hi = (uint32_t)(elem >> 32);
       if (resident) {
         // the document's slice of the element arena stays where it is while it is large enough (loc[] and the payload slots of
@@ -775,6 +777,7 @@ struct Engine {
       for (DBuf* b : {&b_dir_out, &b_dir_out2, &b_dir_b, &b_dir_b2}) b->ensure_keep(((size_t)leaf_top + 1) * 4, b->cap);
     } else {
       b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4); b_tb.ensure(elem + 16);
+      if (want_dcnt && span && kn.version_sweep) b_dcnt.ensure((elem + 1) * 4);
       b_it.ensure((leaves + 1) * (span ? (size_t)SP_REC : 256) * 4);
       b_dir_out.ensure((leaves + 1) * 4);
     }
@@ -789,7 +792,7 @@ struct Engine {
     b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4); b_ht_cnt.ensure((size_t)n_docs * 4 + 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
-    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>(); d.dcnt = (resident && kn.version_sweep) ? b_dcnt.as<uint32_t>() : nullptr; d.tb = b_tb.as<uint8_t>();
+    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>(); d.dcnt = ((resident || (want_dcnt && span)) && kn.version_sweep) ? b_dcnt.as<uint32_t>() : nullptr; d.tb = b_tb.as<uint8_t>();
     d.it = b_it.as<uint32_t>();
     d.dir_out = b_dir_out.as<uint32_t>();
     d.lf_chunk = b_lf_chunk.as<uint8_t>();

@@ -85,6 +85,27 @@ def test_leaf_sweep_on_every_range(monkeypatch):
         assert c.merge_batch(docs) == _oracle.merge_batch(docs)
 
 
+def test_batch_trackers_move_by_version_passes():
+    """The common batch kernel (documents with style anchors / sliced changes) moves its trackers with ts_sweep_version — delete
+    counts at the target version + one pass over the leaves — when the move is long enough; this build (-DLM_SWEEP_EAGER) sends
+    EVERY move through the pass, with the structural checker after every op, on configs[3]-shaped documents (4 peers, pairwise
+    syncs, marks), styled fuzz sessions, nested containers and checked-out versions."""
+    import _fuzz
+    from loro_amd._cabi import Context
+    b = _emu.variant(["LM_SWEEP_EAGER", "LM_EMU_CHECK", "LM_BATCH_VSWEEP=1"])   # (off in the product build: measured slower on configs[3], DESIGN 12)
+    docs = _cases.cfg4_docs(10, first=9100, n_steps=300)
+    docs += [_fuzz.blobs_of(_fuzz.random_session(9300 + d, n_peers=3 + d % 3, n_steps=150, kinds=("text", "list"), sync_prob=0.05, styles=True)) for d in range(12)]
+    docs += _nested_docs(4, n_peers=3, n_steps=120)
+    fronts = [None] * len(docs)
+    for d in range(3):
+        blobs, fr = workload.cfg5_doc(40 + d, n_ops=1500, turn=150, n_checkouts=6, commit_every=7)
+        docs += [blobs] * len(fr); fronts += fr
+    with Context(b) as c:
+        got = c.merge_batch(docs, fronts)
+    assert got == _oracle.merge_batch(docs, frontiers=fronts)
+    assert all(g[0] == 0 for g in got)
+
+
 def test_map_rendering_plain_groups_and_entry_by_entry():
     _check(_cases.map_render_docs())
 
