@@ -65,14 +65,16 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
     uint64_t iv = f >> (-e2);
     if (iv < 10000000000000000ull) {
       if (neg) out[n++] = '-';
-      char tmp[20];
+      // (digits least significant first, one per byte of two registers — an indexed private array is scratch memory on the device:
+      // a round trip per digit)
+      uint64_t t0 = 0, t1 = 0;
       int tn = 0;
       // (two chunks in 32-bit arithmetic: a 64-bit division per digit is a software routine on this target, see sink_i64)
-      uint64_t q1 = iv / 1000000000ull;
+      uint64_t q1 = iv < 1000000000ull ? 0ull : iv / 1000000000ull;
       uint32_t c0 = (uint32_t)(iv - q1 * 1000000000ull), c1 = (uint32_t)q1;
-      if (c1) { for (int i = 0; i < 9; i++) { tmp[tn++] = (char)('0' + c0 % 10u); c0 /= 10u; } c0 = c1; }
-      do { tmp[tn++] = (char)('0' + c0 % 10u); c0 /= 10u; } while (c0);
-      while (tn) out[n++] = tmp[--tn];
+      if (c1) { for (int i = 0; i < 9; i++) { uint64_t c = '0' + c0 % 10u; c0 /= 10u; if (tn < 8) t0 |= c << (8 * tn); else t1 |= c << (8 * (tn - 8)); tn++; } c0 = c1; }
+      do { uint64_t c = '0' + c0 % 10u; c0 /= 10u; if (tn < 8) t0 |= c << (8 * tn); else t1 |= c << (8 * (tn - 8)); tn++; } while (c0);
+      while (tn) { --tn; out[n++] = (char)(tn < 8 ? t0 >> (8 * tn) : t1 >> (8 * (tn - 8))); }
       out[n++] = '.'; out[n++] = '0';
       return n;
     }
@@ -84,8 +86,11 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
   int est = (int)t;
   if ((double)est < t - 1e-10) est++;           // ceil(t - 1e-10)
   if (t < 0 && (double)est > t + 1.0) est--;    // (int) truncates toward zero for negative t
-  char dig[20];
+  // the digits, most significant first, one per byte of three registers (no indexed private array: that is scratch memory)
+  uint64_t dw0 = 0, dw1 = 0, dw2 = 0;
   int nd = 0;
+  auto dput = [&](int dv) { uint64_t c = (uint64_t)('0' + dv); if (nd < 8) dw0 |= c << (8 * nd); else if (nd < 16) dw1 |= c << (8 * (nd - 8)); else dw2 |= c << (8 * (nd - 16)); nd++; };
+  auto dget = [&](int i) -> char { return (char)(i < 8 ? dw0 >> (8 * i) : (i < 16 ? dw1 >> (8 * (i - 8)) : dw2 >> (8 * (i - 16)))); };
   int k = est;
   if (e2 >= -121 && e2 <= 60) {
     // Everyday magnitudes (≈1.7e-21 … 1e34): the same algorithm, the same numbers — in two 64-bit registers each instead of limb
@@ -128,10 +133,10 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
       bool tc1 = even ? r <= mm : r < mm;
       u128 hi = r + mp;
       bool tc2 = even ? hi >= s : hi > s;
-      if (!tc1 && !tc2) { dig[nd++] = (char)('0' + d); r *= 10u; mp *= 10u; mm *= 10u; continue; }
+      if (!tc1 && !tc2) { dput(d); r *= 10u; mp *= 10u; mm *= 10u; continue; }
       if (tc1 && tc2) { u128 r2 = r << 1; if (r2 > s || (r2 == s && (d & 1))) d++; }   // nearer digit; an exact tie goes to the even digit
       else if (tc2) d++;
-      dig[nd++] = (char)('0' + d);
+      dput(d);
       break;
     }
   } else {
@@ -169,10 +174,10 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
     big_add(hi, mp, nl);
     int c2 = big_cmp(hi, s, nl);
     bool tc2 = even ? c2 >= 0 : c2 > 0;
-    if (!tc1 && !tc2) { dig[nd++] = (char)('0' + d); big_mul_small(r, 10, nl); big_mul_small(mp, 10, nl); big_mul_small(mm, 10, nl); continue; }
+    if (!tc1 && !tc2) { dput(d); big_mul_small(r, 10, nl); big_mul_small(mp, 10, nl); big_mul_small(mm, 10, nl); continue; }
     if (tc1 && tc2) { big_copy(r2, r, nl); big_shl(r2, 1, nl); int c3 = big_cmp(r2, s, nl); if (c3 > 0 || (c3 == 0 && (d & 1))) d++; }   // nearer digit; an exact tie goes to the even digit (as ryu / std::to_chars)
     else if (tc2) d++;
-    dig[nd++] = (char)('0' + d);
+    dput(d);
     break;
   }
   }
@@ -180,27 +185,26 @@ LM_DEV int f64_json(uint64_t bits, char* out, Big* ws) {
   if (neg) out[n++] = '-';
   int kk = k;                                   // position of the decimal point relative to the first digit
   if (nd <= kk && kk <= 16) {                   // integer value: digits, zeros, ".0"
-    for (int i = 0; i < nd; i++) out[n++] = dig[i];
+    for (int i = 0; i < nd; i++) out[n++] = dget(i);
     for (int i = nd; i < kk; i++) out[n++] = '0';
     out[n++] = '.'; out[n++] = '0';
   } else if (0 < kk && kk <= 16) {              // point inside the digits
-    for (int i = 0; i < kk; i++) out[n++] = dig[i];
+    for (int i = 0; i < kk; i++) out[n++] = dget(i);
     out[n++] = '.';
-    for (int i = kk; i < nd; i++) out[n++] = dig[i];
+    for (int i = kk; i < nd; i++) out[n++] = dget(i);
   } else if (-5 < kk && kk <= 0) {              // 0.000ddd
     out[n++] = '0'; out[n++] = '.';
     for (int i = 0; i < -kk; i++) out[n++] = '0';
-    for (int i = 0; i < nd; i++) out[n++] = dig[i];
+    for (int i = 0; i < nd; i++) out[n++] = dget(i);
   } else {                                      // d[.ddd]e[-]xx
-    out[n++] = dig[0];
-    if (nd > 1) { out[n++] = '.'; for (int i = 1; i < nd; i++) out[n++] = dig[i]; }
+    out[n++] = dget(0);
+    if (nd > 1) { out[n++] = '.'; for (int i = 1; i < nd; i++) out[n++] = dget(i); }
     out[n++] = 'e';
     int ex = kk - 1;
     if (ex < 0) { out[n++] = '-'; ex = -ex; }
-    char eb[4];
-    int en = 0;
-    do { eb[en++] = (char)('0' + ex % 10); ex /= 10; } while (ex);
-    while (en) out[n++] = eb[--en];
+    if (ex >= 100) { out[n++] = (char)('0' + ex / 100); ex %= 100; out[n++] = (char)('0' + ex / 10); out[n++] = (char)('0' + ex % 10); }
+    else if (ex >= 10) { out[n++] = (char)('0' + ex / 10); out[n++] = (char)('0' + ex % 10); }
+    else out[n++] = (char)('0' + ex);
   }
   return n;
 }

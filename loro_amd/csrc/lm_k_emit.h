@@ -306,8 +306,8 @@ LM_DEV void sink_byte(Sink& s, uint8_t b) {
   if (s.out && s.pos < s.cap && lmw::lane() == 0) s.out[s.pos] = b;
   s.pos++;
 }
-LM_DEV void sink_lit(Sink& s, const char* lit, uint32_t n) {
-  if (s.out && s.pos + n <= s.cap && lmw::lane() == 0) for (uint32_t i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)lit[i];
+LM_DEV void sink_lit(Sink& s, const char* lit, uint32_t n) {   // n <= 64: lane i writes byte i
+  if (s.out && s.pos + n <= s.cap && (uint32_t)lmw::lane() < n) s.out[s.pos + (uint32_t)lmw::lane()] = (uint8_t)lit[lmw::lane()];
   s.pos += n;
 }
 // each lane contributes `n` (<= 8) bytes packed little-endian in `bytes`; lanes are concatenated in lane order
@@ -356,21 +356,31 @@ LM_DEV void sink_string(Sink& s, const uint8_t* p, uint32_t len) {
 // division each on this target — ≈4,000 instructions for a 13-digit Map value, 90 % of the renderer's time on configs[2] and
 // most of the List renderer's on configs[3], tests/tools/gpu_prof_emit.py)
 LM_DEV void sink_i64(Sink& s, int64_t v) {
-  char buf[24];
-  int n = 0;
+  // (every lane works the digits out — wave-uniform arithmetic, least significant first, one digit per byte of three registers — and
+  // lane i writes byte i.  Rounds 2-4a kept them in an indexed private array, which is scratch memory on this target: a memory round
+  // trip per digit for lane 0, then one single-byte store after the other.)
   uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
   // (a value below 10^9 — list indices, small counters, the bytes of a binary value — needs neither of the two 64-bit divisions)
   uint64_t q1 = u < 1000000000ull ? 0ull : u / 1000000000ull, q2 = q1 < 1000000000ull ? 0ull : q1 / 1000000000ull;
   uint32_t c0 = (uint32_t)(u - q1 * 1000000000ull), c1 = (uint32_t)(q1 - q2 * 1000000000ull), c2 = (uint32_t)q2;
   const int top = c2 ? 2 : (c1 ? 1 : 0);
+  uint64_t d0 = 0, d1 = 0, d2 = 0;
+  uint32_t nd = 0;
   for (int ci = 0; ci <= top; ci++) {
     uint32_t c = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
-    if (ci < top) for (int i = 0; i < 9; i++) { buf[n++] = (char)('0' + c % 10u); c /= 10u; }
-    else do { buf[n++] = (char)('0' + c % 10u); c /= 10u; } while (c);
+    for (int i = 0; i < 9 && (ci < top || c || i == 0); i++) {
+      uint64_t dgt = '0' + c % 10u;
+      c /= 10u;
+      if (nd < 8) d0 |= dgt << (8 * nd); else if (nd < 16) d1 |= dgt << (8 * (nd - 8)); else d2 |= dgt << (8 * (nd - 16));
+      nd++;
+    }
   }
-  if (v < 0) buf[n++] = '-';
-  if (s.out && s.pos + (uint32_t)n <= s.cap && lmw::lane() == 0) for (int i = 0; i < n; i++) s.out[s.pos + i] = (uint8_t)buf[n - 1 - i];
-  s.pos += (uint32_t)n;
+  const uint32_t n = nd + (v < 0 ? 1u : 0u), lane = (uint32_t)lmw::lane();
+  if (s.out && s.pos + n <= s.cap && lane < n) {
+    const uint32_t j = n - 1 - lane;      // digit index from the least significant one; j == nd: the sign
+    s.out[s.pos + lane] = j == nd ? (uint8_t)'-' : (uint8_t)(j < 8 ? d0 >> (8 * j) : (j < 16 ? d1 >> (8 * (j - 8)) : d2 >> (8 * (j - 16))));
+  }
+  s.pos += n;
 }
 // one unicode scalar of a Text container → escaped UTF-8 (anchors contribute nothing)
 LM_DEV void cp_bytes(uint32_t cp, uint64_t& bytes, uint32_t& n) {
@@ -408,11 +418,27 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err, const Dev& d, uint32_t vb, 
     lmw::wave_sync();
   };
   uint32_t f_map = 0;   // bit i: frame i is a map
+  // Map frames of up to 64 entries are ORDERED ONCE when they open (f_sorted): the walk that finds the map's end also notes every
+  // entry's key row and value position, each lane then takes one entry — its key's first eight bytes as a big-endian word, the whole
+  // strings only on a tie — ranks it against the others (of equal keys the last occurrence wins) and the entries are laid out in
+  // key order in an LDS pool the frame reads one by one.  (Re-scanning the frame for the next larger key each time — the fallback
+  // for larger maps and an exhausted pool — is K passes of K entries with four dependent loads per comparison: a two-entry map
+  // nested in a list item cost as much as twenty scalar items.)
+  static constexpr uint32_t MPOOL = 256;
+  LM_SHARED(uint32_t, s_mrow, MPOOL);
+  LM_SHARED(uint32_t, s_mpos, MPOOL);
+  uint32_t f_sorted = 0, pool_top = 0;
+#ifdef LM_PROF_EMIT
+  uint32_t pf_tag = 0; uint64_t pf_t0 = 0;
+#endif
   int sp = 0;
   bool pending = true;  // a value waits at r.p
   for (uint32_t guard = 0; guard < (1u << 28); guard++) {
     if (r.bad) { err = ST_DATA_CORRUPTION; return; }
     if (!pending) {
+#ifdef LM_PROF_EMIT
+      if (sp == 0 && lane == 0) atomicAdd(&d.prof[pf_tag], (unsigned long long)(lmw::clock() - pf_t0));
+#endif
       if (sp == 0) return;
       int top = sp - 1;
       lmw::wave_sync();
@@ -421,6 +447,15 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err, const Dev& d, uint32_t vb, 
         if (cnt == 0) { sink_byte(s, ']'); sp--; continue; }
         if (done) sink_byte(s, ',');
         fset(top, cnt - 1, done + 1, start, endo, last);
+      } else if ((f_sorted >> top) & 1) {
+        // (cnt = entries that show, done = written so far, start = the frame's first pool slot)
+        if (done >= cnt) { sink_byte(s, '}'); r.p = base + endo; pool_top = start; sp--; continue; }
+        const uint32_t krow = s_mrow[start + done], vpos = s_mpos[start + done];
+        if (done) sink_byte(s, ',');
+        sink_string(s, d.data + d.key_off[krow], d.key_len[krow]);
+        sink_byte(s, ':');
+        fset(top, cnt, done + 1, start, endo, last);
+        r.p = base + vpos;
       } else {
         bool fin = done >= cnt;
         uint32_t best_row = NONE, best_pos = 0;
@@ -457,6 +492,9 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err, const Dev& d, uint32_t vb, 
     }
     pending = false;
     uint32_t tag = rd_u8(r);
+#ifdef LM_PROF_EMIT   // (experiment build: ticks per kind of top-level value, d.prof[0..7] — closed when the next top-level value starts)
+    if (sp == 0) { pf_tag = tag < 3 ? 0u : (tag - 2 < 7 ? tag - 2 : 7u); pf_t0 = lmw::clock(); }
+#endif
     switch (tag) {
       case 0: sink_lit(s, "null", 4); break;
       case 1: sink_lit(s, "true", 4); break;
@@ -472,7 +510,7 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err, const Dev& d, uint32_t vb, 
         if (lane == 0) s_f64[8] = (uint32_t)f64_json(bits, (char*)s_f64, s_big);
         lmw::block_sync();
         uint32_t n = s_f64[8];
-        if (s.out && s.pos + n <= s.cap && lane == 0) for (uint32_t i = 0; i < n; i++) s.out[s.pos + i] = ((const uint8_t*)s_f64)[i];
+        if (s.out && s.pos + n <= s.cap && (uint32_t)lane < n) s.out[s.pos + (uint32_t)lane] = ((const uint8_t*)s_f64)[lane];   // (n <= 32)
         s.pos += n;
         break;
       }
@@ -501,12 +539,52 @@ LM_DEV void sink_value(Sink& s, Rd& r, int32_t& err, const Dev& d, uint32_t vb, 
           have_keys = true;
         }
         if (tag == 8) {
+          const bool sorted = n <= 64 && pool_top + (uint32_t)n <= MPOOL;
           Rd q = r;   // the map frame jumps around inside its entries: find where the map ends first
-          for (uint64_t i = 0; i < n && !q.bad; i++) { (void)rd_uleb(q); bool u = false; skip_loro_value(q, u); }
+          lmw::wave_sync();
+          for (uint64_t i = 0; i < n && !q.bad; i++) {
+            uint64_t kidx = rd_uleb(q);
+            if (sorted) {
+              if (kidx >= n_keys) { err = ST_DATA_CORRUPTION; return; }
+              if (lane == 0) { s_mrow[pool_top + i] = key0 + (uint32_t)kidx; s_mpos[pool_top + i] = (uint32_t)(q.p - base); }
+            }
+            bool u = false;
+            skip_loro_value(q, u);
+          }
           if (q.bad) { err = ST_DATA_CORRUPTION; return; }
           endo = (uint32_t)(q.p - base);
           f_map |= 1u << sp;
+          f_sorted &= ~(1u << sp);
           sink_byte(s, '{');
+          if (sorted) {
+            lmw::wave_sync();
+            const uint32_t cnt = (uint32_t)n;
+            const bool in = (uint32_t)lane < cnt;
+            const uint32_t my_row = in ? s_mrow[pool_top + lane] : 0u, my_pos = in ? s_mpos[pool_top + lane] : 0u;
+            const uint8_t* kp = d.data + (in ? d.key_off[my_row] : 0ull);
+            const uint32_t kl = in ? d.key_len[my_row] : 0u;
+            uint32_t p_hi = 0, p_lo = 0;   // the key's first eight bytes, big endian, zero padded
+            for (uint32_t b8 = 0; b8 < 8; b8++) { uint32_t c = (in && b8 < kl) ? kp[b8] : 0u; if (b8 < 4) p_hi = (p_hi << 8) | c; else p_lo = (p_lo << 8) | c; }
+            uint64_t less_m = 0;           // bit j: key j sorts in front of this lane's key
+            bool shadowed = false;         // a later entry carries the same key
+            for (uint32_t j = 0; j < cnt; j++) {
+              const uint32_t jh = lmw::shfl(p_hi, (int)j), jl = lmw::shfl(p_lo, (int)j), jrow = lmw::shfl(my_row, (int)j), jlen = lmw::shfl(kl, (int)j);
+              int c = jh != p_hi ? (jh < p_hi ? -1 : 1) : (jl != p_lo ? (jl < p_lo ? -1 : 1) : 0);
+              if (in && c == 0 && (kl > 8 || jlen > 8 || kl != jlen)) c = bytes_cmp(d.data + d.key_off[jrow], jlen, kp, kl);   // (a tie of the padded words: the strings decide)
+              if (c < 0) less_m |= 1ull << j;
+              if (c == 0 && j > (uint32_t)lane) shadowed = true;
+            }
+            const uint64_t sh_m = lmw::ballot(in && shadowed);
+            const uint32_t rank = (uint32_t)lmw::popc64(less_m & ~sh_m);
+            lmw::wave_sync();
+            if (in && !shadowed) { s_mrow[pool_top + rank] = my_row; s_mpos[pool_top + rank] = my_pos; }
+            lmw::wave_sync();
+            f_sorted |= 1u << sp;
+            fset(sp, cnt - (uint32_t)lmw::popc64(sh_m), 0, pool_top, endo, NONE);
+            pool_top += cnt;
+            sp++;
+            break;
+          }
         } else {
           f_map &= ~(1u << sp);
           sink_byte(s, '[');

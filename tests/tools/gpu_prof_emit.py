@@ -26,5 +26,10 @@ with Context(b, 0) as e:
     b.lib.lm_prof_sum(e.h, out)
     tot = sum(out[8 + i] for i in range(8))
     print("%s, %d docs: renderer time by part (s_memtime ticks summed over waves)" % (which, n_docs))
+    vt = ["null / bool", "i64", "f64", "string", "binary", "list", "map", "other"]
+    tv = sum(out[i] for i in range(8))
+    print("  top-level values by kind (sink_value, ticks):")
+    for i, n in enumerate(vt):
+        print("    %-22s %14d  %5.1f%%" % (n, out[i], 100.0 * out[i] / max(tv, 1)))
     for i, n in enumerate(names):
         print("  %-24s %14d  %5.1f%%" % (n, out[8 + i], 100.0 * out[8 + i] / max(tot, 1)))
