@@ -337,8 +337,14 @@ def other_configs(device, cores):
             e.stage(docs, fronts)
             e.run()
             got = e.fetch()
-            if name.endswith(("heterogeneous", "traces")):   # every document is its own: the first `distinct` against the oracle, all must succeed
+            n_checked = distinct
+            if name.endswith(("heterogeneous", "traces")):   # every document is its own: all must succeed, and as many as the CPU port gets through in 25 s are compared
                 assert got[:distinct] == want and all(g[0] == 0 for g in got), f"{name}: device results differ from the CPU oracle"
+                t_chk = time.perf_counter()
+                while n_checked < len(docs) and time.perf_counter() - t_chk < 25.0:
+                    hi = min(len(docs), n_checked + 512)
+                    assert got[n_checked:hi] == _oracle.merge_batch(docs[n_checked:hi], threads=min(32, cores)), f"{name}: device results differ from the CPU oracle (documents {n_checked}..{hi})"
+                    n_checked = hi
             else:
                 assert all(got[i] == want[i % distinct] for i in range(len(docs))), f"{name}: device results differ from the CPU oracle"
             best = 1e9
@@ -382,7 +388,7 @@ def other_configs(device, cores):
                                       "sample": f"the {distinct} distinct documents of this entry through oracle/liblorooracle.so, one pass, {min(32, cores, distinct)} threads of one process "
                                                 "(the pass that produced the expected results; threads of one process share a heap and scale worse than the headline's one process per core)"},
                      "gpu_over_cpu": round(len(docs) / best / (distinct / t_cpu), 2),
-                     "parity": (f"first {distinct} results equal to the oracle's, all {len(docs)} succeeded" if name.endswith(("heterogeneous", "traces")) else f"all {len(docs)} results equal to the oracle's"),
+                     "parity": (f"the first {n_checked} of {len(docs)} results equal to the oracle's (every document differs; as many as the CPU port replays in 25 s), all {len(docs)} succeeded" if name.endswith(("heterogeneous", "traces")) else f"all {len(docs)} results equal to the oracle's"),
                      "workload": desc}
 
     run("configs[0]", cfg1, None, 100, "100 docs x 2 peers x 1,000 sequential inserts, 2 blobs/doc")

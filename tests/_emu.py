@@ -14,7 +14,9 @@ def binding():
         csrc = os.path.join(os.path.dirname(_HERE), "loro_amd", "csrc")
         newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith(".h")])
         if not os.path.exists(so) or os.path.getmtime(so) < newest:
-            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DLM_EMU_TRACE", "-o", so, src])
+            tmp = f"{so}.{os.getpid()}.tmp"   # (built beside the target and renamed: another pytest-xdist worker never loads a half-written file)
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DLM_EMU_TRACE", "-o", tmp, src])
+            os.replace(tmp, so)
         _B = Binding(so, "lmemu_")
     return _B
 
@@ -27,7 +29,9 @@ def variant(defines):
     csrc = os.path.join(os.path.dirname(_HERE), "loro_amd", "csrc")
     newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith(".h")])
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DLM_EMU_TRACE"] + ["-D" + d for d in defines] + ["-o", so, src])
+        tmp = f"{so}.{os.getpid()}.tmp"
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DLM_EMU_TRACE"] + ["-D" + d for d in defines] + ["-o", tmp, src])
+        os.replace(tmp, so)
     return Binding(so, "lmemu_")
 
 
