@@ -140,7 +140,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -156,6 +156,7 @@ struct Engine {
     if (const char* e = getenv("LM_SLAB_CAP")) k.slab_cap = atoll(e);                            // tests: force the re-emit pass
     if (const char* e = getenv("LM_HT_OPT")) k.ht_opt = (uint32_t)atoi(e);                       // slots of a document's optimistic LWW table (a power of two; 0: sized for its Map rows at once; tests: 64 forces the second pass)
     if (const char* e = getenv("LM_CUT_MIN_ROWS")) k.cut_min_rows = (uint32_t)atoll(e);           // op rows from which a document's nodes are cut at cross-peer dependency targets and replayed largest peer first (tests: 0)
+    if (const char* e = getenv("LM_SPAN_AUTO")) k.span_auto = atoi(e) != 0;                      // 0: the span-granular kernels for every batch (rounds 2-4b), whatever its documents' sizes
     if (const char* e = getenv("LM_VS_ROW_COST")) k.vs_row_cost = (uint32_t)atoi(e);             // ts_sweep_pays_batch (A/B)
     if (const char* e = getenv("LM_VERSION_SWEEP")) k.version_sweep = atoi(e) != 0;              // 0: resident trackers move row by row (rounds 3-4a: delete rows undone / redone one by one)
     if (const char* e = getenv("LM_FUSE_ROWS")) k.fuse_rows = atoi(e) != 0;                      // 0: one-change-per-keystroke documents are replayed row by row, as in rounds 1-3
@@ -538,16 +539,16 @@ struct Engine {
     uint32_t NB = 0, NC = 0, NO = 0, NCID = 0, NP = 0;
     DevDag g;
     memset(&g, 0, sizeof g);
-    const bool span = kn.span;
+    bool span = kn.span;   // (a batch of small documents for the common kernel switches to the element-granular one below, once the documents' records are known)
     if (resident && !span) throw std::runtime_error("resident documents need the span-granular integrate kernel (LM_SPAN=0 is set)");
     uint64_t ht = 0;
     uint32_t dir_cap = 64, dir_opt = 64, pmax = 2;
-    const uint32_t DIR_CAP_MAX = span ? 18000u : 36000u;
+    uint32_t DIR_CAP_MAX = span ? 18000u : 36000u;
     // DF_PLAIN (k_dag_a) survives only with the span kernel, for documents rendered at the latest version.  Such documents are
     // replayed by k_integrate_span_plain_sweep (default, = LM_PLAIN=2; measured -9 % against the common kernel on configs[1],
     // profiles/r02_ab_prepared.log); LM_PLAIN=1 selects k_integrate_span_plain, LM_PLAIN=0 the common kernel for every document
-    const int plain_mode = !span ? 0 : kn.plain;   // (resident documents: 0 = the general kernel for all, otherwise k_integrate_span_res_plain for the DF_PLAIN ones)
-    const bool plain_on = plain_mode == 1 || plain_mode == 2;
+    int plain_mode = !span ? 0 : kn.plain;   // (resident documents: 0 = the general kernel for all, otherwise k_integrate_span_res_plain for the DF_PLAIN ones)
+    bool plain_on = plain_mode == 1 || plain_mode == 2;
     bool any_plain = false, any_fused = false, want_dcnt = false;
     if (reuse) {
       d = sv.d; g = sv.g;
@@ -688,6 +689,28 @@ struct Engine {
     // kernel (lm_k_integrate.h), kept as the second implementation the parity suites also run
     // (directory entries that fit the 160 KiB LDS of a CU next to 3·MAX_PEERS words: one word per entry in the
     // element-granular kernel, two in the span-granular one: DIR_CAP_MAX)
+    if (span && !resident && kn.span_auto) {
+      // SMALL documents that the common span kernel would replay — style anchors, sliced changes, checkouts, MovableLists; a few
+      // thousand op rows from several peers that sync every few dozen ops — are replayed faster by the element-granular kernel
+      // (lm_k_integrate.h): its leaves are plain arrays of elements, a tracker move touches no run bookkeeping.  Measured on one
+      // box (profiles/r04_small_documents_element_kernel.log): configs[3] integrate 48.9 -> 39.9 ms per 12,500 documents, the
+      // MovableList batch 15.2 -> 13.4 ms per 4,096.  The mode is the batch's (leaf record, Text payload layout): taken when no
+      // document is large and the common kernel's documents hold at least half of the batch's op rows.
+      uint64_t rows_all = 0, rows_common = 0;
+      uint32_t rows_max = 0, elems_max = 0;
+      for (uint32_t i = 0; i < n_docs; i++) {
+        const DocMeta& m = h_doc[i];
+        if (m.status != ST_OK) continue;
+        const bool checked_out = h_front_off.size() > i + 1 && h_front_off[i + 1] > h_front_off[i];
+        rows_all += m.n_op;
+        if (!(m.flags & DF_PLAIN) || checked_out || !plain_on) rows_common += m.n_op;
+        rows_max = m.n_op > rows_max ? m.n_op : rows_max;
+        elems_max = m.n_elems > elems_max ? m.n_elems : elems_max;
+      }
+      if (rows_all && rows_max < 4096 && elems_max < 65536 && rows_common * 2 >= rows_all) {
+        span = false; DIR_CAP_MAX = 36000u; plain_mode = 0; plain_on = false;
+      }
+    }
     d.span = span ? 1u : 0u;
     d.res_vis = resident ? 1u : 0u;
     uint64_t elem = 0, leaves = 0, vvh = 0;

@@ -500,6 +500,31 @@ def test_retry_launch_of_every_span_instantiation(monkeypatch, plain):
     assert got == want
 
 
+def test_small_document_batches_pick_the_element_granular_kernel(monkeypatch):
+    """LM_SPAN_AUTO (the product default): a batch whose documents are small and mostly the common kernel's — configs[3]-shaped
+    documents, MovableLists, checkouts — is replayed by the element-granular kernel; plain documents, or one large document in the
+    batch, keep the span-granular kernels.  Same bytes either way."""
+    import _fuzz
+    from loro_amd._cabi import Context
+    monkeypatch.setenv("LM_SPAN_AUTO", "1")
+    small = _cases.cfg4_docs(6, first=8100, n_steps=200) + [_fuzz.blobs_of(_fuzz.movable_session(8200 + d, n_peers=3, n_steps=80, nested=True)) for d in range(3)]
+    plain = _cases.fuzz_docs(12, base=8300)
+    big = [workload.Cfg2Template(3000, 1500, seed=4, commit_every=1, fuse=False).stamp(0)]   # one op row per keystroke: >= 4,096 rows
+
+    def stage_names(docs):
+        with Context(_emu.binding()) as c:
+            c.stage(docs); c.set_profiling(1); c.run()
+            names = {n for n, _ in c.kernel_times()}
+            got = c.fetch()
+        assert got == _oracle.merge_batch(docs)
+        return names
+    assert "k_integrate" in stage_names(small)
+    assert "k_integrate" not in stage_names(plain)
+    assert "k_integrate" not in stage_names(small + big)
+    monkeypatch.setenv("LM_SPAN_AUTO", "0")
+    assert "k_integrate" not in stage_names(small)
+
+
 @pytest.mark.parametrize("span", ["1", "0"])
 def test_both_integrate_kernels(monkeypatch, span):
     """Both integrate kernels — span-granular (default, lm_k_integrate_span.h) and element-granular (LM_SPAN=0,

@@ -385,6 +385,30 @@ def test_two_contexts_in_flight(engine):
     assert rb[:40] == want_b and rb[40:80] == want_b
 
 
+def test_small_document_batches_pick_the_element_granular_kernel(engine, monkeypatch):
+    """LM_SPAN_AUTO=1 (the product default; the suites pin it off in conftest.py): configs[3]-shaped and MovableList batches are
+    replayed by the element-granular kernel, plain batches and batches with a large document by the span-granular ones — the stage
+    names say which — and the bytes are the oracle's either way."""
+    import _fuzz
+    monkeypatch.setenv("LM_SPAN_AUTO", "1")
+    small = _cases.cfg4_docs(24, first=8100) + [_fuzz.blobs_of(_fuzz.movable_session(8200 + d, n_peers=3, n_steps=200, nested=True)) for d in range(8)]
+    plain = [workload.Cfg2Template(2000, 1000, seed=s_, commit_every=10, fuse=True).stamp(s_) for s_ in range(8)]
+    big = [workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True).stamp(1)]
+
+    def stage_names(docs, reps=4):
+        engine.stage(docs * reps); engine.set_profiling(1); engine.run()
+        names = {n for n, _ in engine.kernel_times()}
+        engine.set_profiling(0)
+        got = engine.fetch()
+        assert got[: len(docs)] == _oracle.merge_batch(docs, threads=8) and got[len(docs): 2 * len(docs)] == got[: len(docs)]
+        return names
+    assert "k_integrate" in stage_names(small)
+    assert "k_integrate" not in stage_names(plain)
+    assert "k_integrate" not in stage_names(small + big)
+    monkeypatch.setenv("LM_SPAN_AUTO", "0")
+    assert "k_integrate" not in stage_names(small)
+
+
 @pytest.mark.parametrize("span,plain", [("1", None), ("1", "0"), ("1", "1"), ("0", None)],
                          ids=["span (default: plain documents by leaf sweep)", "span, common kernel for every document",
                               "span, plain kernel without the sweep", "element-granular"])
