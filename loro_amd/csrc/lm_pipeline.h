@@ -695,19 +695,21 @@ struct Engine {
       // (lm_k_integrate.h): its leaves are plain arrays of elements, a tracker move touches no run bookkeeping.  Measured on one
       // box (profiles/r04_small_documents_element_kernel.log): configs[3] integrate 48.9 -> 39.9 ms per 12,500 documents, the
       // MovableList batch 15.2 -> 13.4 ms per 4,096.  The mode is the batch's (leaf record, Text payload layout): taken when no
-      // document is large and the common kernel's documents hold at least half of the batch's op rows.
-      uint64_t rows_all = 0, rows_common = 0;
+      // document is large, the common kernel's documents hold at least half of the batch's op rows …
+      uint64_t rows_all = 0, rows_common = 0, atoms_common = 0;
       uint32_t rows_max = 0, elems_max = 0;
       for (uint32_t i = 0; i < n_docs; i++) {
         const DocMeta& m = h_doc[i];
         if (m.status != ST_OK) continue;
         const bool checked_out = h_front_off.size() > i + 1 && h_front_off[i + 1] > h_front_off[i];
         rows_all += m.n_op;
-        if (!(m.flags & DF_PLAIN) || checked_out || !plain_on) rows_common += m.n_op;
+        if (!(m.flags & DF_PLAIN) || checked_out || !plain_on) { rows_common += m.n_op; atoms_common += m.atoms; }
         rows_max = m.n_op > rows_max ? m.n_op : rows_max;
         elems_max = m.n_elems > elems_max ? m.n_elems : elems_max;
       }
-      if (rows_all && rows_max < 4096 && elems_max < 65536 && rows_common * 2 >= rows_all) {
+      // … and their op rows are SHORT — fewer than three op ids per row: single list items, one- or two-character edits.  (Rich text of
+      // the same size typed in runs — 5-6 ids per row, tests/tools/gpu_small_docs.py — stays 20 % faster in the span kernel.)
+      if (rows_all && rows_max < 4096 && elems_max < 65536 && rows_common * 2 >= rows_all && atoms_common < 3 * rows_common) {
         span = false; DIR_CAP_MAX = 36000u; plain_mode = 0; plain_on = false;
       }
     }
