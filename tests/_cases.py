@@ -391,3 +391,37 @@ def nested_key_docs():
         r.commit()
         good.append([r.export()])
     return good, [[patch(d[0])] for d in good]
+
+
+def nested_map_order_docs():
+    """List items and Map values that are MAPS: key order (bytewise, not insertion), keys that share their first eight bytes, keys
+    that are prefixes of one another, an empty key, DUPLICATE keys inside one encoded map (the last occurrence wins — what a map
+    built by successive inserts holds, value.rs read_value), a 70-entry map (beyond the 64 entries the renderer orders in one
+    pass), maps nested in maps in lists, and enough of them in one value to exhaust the renderer's pool."""
+    from loro_amd import wire
+
+    class PairMap(dict):   # a map value whose encoded entries are exactly these pairs, duplicates included
+        def __init__(self, pairs):
+            super().__init__()
+            self.pairs = list(pairs)
+
+        def items(self):
+            return self.pairs
+
+        def __len__(self):
+            return len(self.pairs)
+
+    r = wire.Replica(77)
+    long = ["prefix__%s" % x for x in ("b", "a", "", "aa", "ab", "zzzzzzzzzz", "a\u00e9")]
+    vals = [
+        PairMap([("k", 1), ("a", 2), ("k", 3), ("", 4), ("a", None)]),
+        PairMap([(k, i) for i, k in enumerate(long)] + [("prefix__", "short"), ("prefix_", 0.5), ("prefix__a", "again")]),
+        {"key%02d" % (i * 37 % 70): i for i in range(70)},
+        PairMap([("m", PairMap([("y", [1, {"q": 1, "p": 2}]), ("x", PairMap([("b", 1), ("b", 2), ("a", 3)])), ("y", "last")])), ("l", [PairMap([]), {}])]),
+        [{"n%d" % j: {"i%d" % i: i for i in range(60)} for j in range(6)}],     # 6 x 60 entries under one frame: the pool runs out
+        {},
+    ]
+    r.list_insert("list", 0, vals)
+    r.map_set("map", "m", PairMap([("z", 1), ("y", PairMap([("d", 1), ("c", 2), ("d", 3)])), ("z", 2)]))
+    r.commit()
+    return [[r.export()]]

@@ -106,6 +106,13 @@ def test_batch_trackers_move_by_version_passes():
     assert all(g[0] == 0 for g in got)
 
 
+def test_map_typed_values_are_rendered_in_key_order():
+    """nested map values: the one-pass ordering of up to 64 entries (lane-parallel rank, LDS pool), its fallback, duplicate keys"""
+    docs = _cases.nested_map_order_docs()
+    got, want = _check(docs)
+    assert got[0][0] == 0 and b'"k":3' in got[0][1] and b'"k":1' not in got[0][1]
+
+
 def test_map_rendering_plain_groups_and_entry_by_entry():
     _check(_cases.map_render_docs())
 

@@ -385,6 +385,15 @@ def test_two_contexts_in_flight(engine):
     assert rb[:40] == want_b and rb[40:80] == want_b
 
 
+def test_map_typed_values_are_rendered_in_key_order(engine):
+    """nested map values on the device: one-pass ordering of up to 64 entries (lane-parallel rank through the wave's permutes, LDS
+    pool), the re-scan fallback (70 entries, an exhausted pool), duplicate keys inside one encoded map (the last occurrence wins)"""
+    docs = _cases.nested_map_order_docs()
+    got = engine.merge_batch(docs * 64)
+    want = _oracle.merge_batch(docs)
+    assert got[0] == want[0] and all(g == got[0] for g in got) and got[0][0] == 0
+
+
 def test_small_document_batches_pick_the_element_granular_kernel(engine, monkeypatch):
     """LM_SPAN_AUTO=1 (the product default; the suites pin it off in conftest.py): configs[3]-shaped and MovableList batches are
     replayed by the element-granular kernel, plain batches and batches with a large document by the span-granular ones — the stage
