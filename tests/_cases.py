@@ -425,3 +425,23 @@ def nested_map_order_docs():
     r.map_set("map", "m", PairMap([("z", 1), ("y", PairMap([("d", 1), ("c", 2), ("d", 3)])), ("z", 2)]))
     r.commit()
     return [[r.export()]]
+
+
+def big_blob_checksum_docs(n=40, seed=3):
+    """Blobs large enough for the wave-per-four-blobs envelope checksum (k_hash_big_blobs: >= 32 KB), of many different lengths —
+    every tail length 0..15, stripe counts that are not multiples of 64, neighbours in a wave of very different lengths — some with
+    one bit of the stored checksum flipped (LM_CHECKSUM_MISMATCH for that document only)."""
+    import random, struct
+    from loro_amd import wire
+    rng = random.Random(seed)
+    docs = []
+    for k in range(n):
+        r = wire.Replica(1000 + k)
+        size = 33000 + rng.randrange(0, 70000) if k % 5 else 33000 + 1024 * rng.randrange(0, 40) + k % 16
+        r.text_insert("text", 0, "".join(rng.choice("abcdefgh") for _ in range(size)))
+        r.commit()
+        b = r.export()
+        if k % 7 == 3:
+            b = b[:16] + struct.pack("<I", struct.unpack("<I", b[16:20])[0] ^ (1 << (k % 32))) + b[20:]
+        docs.append([b])
+    return docs

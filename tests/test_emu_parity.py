@@ -106,6 +106,14 @@ def test_batch_trackers_move_by_version_passes():
     assert all(g[0] == 0 for g in got)
 
 
+def test_envelope_checksum_of_large_blobs():
+    """k_hash_big_blobs (four blobs per wave, words through the row's lane permutes, three rotating register banks) on blobs of many
+    lengths, good and damaged checksums, next to small blobs hashed by k_frame_count's lanes"""
+    docs = _cases.big_blob_checksum_docs() + _cases.fuzz_docs(6, base=77)
+    got, want = _check(docs)
+    assert sorted({g[0] for g in got}) == [0, 2]
+
+
 def test_map_typed_values_are_rendered_in_key_order():
     """nested map values: the one-pass ordering of up to 64 entries (lane-parallel rank, LDS pool), its fallback, duplicate keys"""
     docs = _cases.nested_map_order_docs()

@@ -385,6 +385,16 @@ def test_two_contexts_in_flight(engine):
     assert rb[:40] == want_b and rb[40:80] == want_b
 
 
+def test_envelope_checksum_of_large_blobs(engine):
+    """k_hash_big_blobs on the device (DPP row permutes, software-pipelined loads): blobs of many lengths, good and damaged
+    checksums, in groups of four per wave with very different lengths"""
+    docs = _cases.big_blob_checksum_docs(n=203, seed=9) + _cases.fuzz_docs(6, base=77)
+    got = engine.merge_batch(docs)
+    want = _oracle.merge_batch(docs, threads=8)
+    assert [g[0] for g in got] == [w[0] for w in want] and sorted({g[0] for g in got}) == [0, 2]
+    assert all(g == w for g, w in zip(got, want) if w[0] == 0)
+
+
 def test_map_typed_values_are_rendered_in_key_order(engine):
     """nested map values on the device: one-pass ordering of up to 64 entries (lane-parallel rank through the wave's permutes, LDS
     pool), the re-scan fallback (70 entries, an exhausted pool), duplicate keys inside one encoded map (the last occurrence wins)"""
