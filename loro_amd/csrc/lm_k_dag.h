@@ -216,9 +216,17 @@ LM_DEV uint32_t find_change(const Dev& d, const DocMeta& m, uint32_t peer, uint3
 }
 
 // K7a: one wave per doc — order blocks, select applied changes, build DAG nodes.
+#ifdef LM_PROF_DAG   // experiment build: ticks per pass of k_dag_a, summed over the batch's documents into d.prof[0..7] (tests/tools/gpu_prof_dag.py)
+#define DAG_PH(i) do { uint64_t n_ = lmw::clock(); dpacc[i] += n_ - dptp; dptp = n_; } while (0)
+#else
+#define DAG_PH(i) do {} while (0)
+#endif
 LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
+#ifdef LM_PROF_DAG
+  uint64_t dpacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dptp = lmw::clock();
+#endif
   LM_SHARED(uint32_t, s_valid, MAX_PEERS);   // valid (applied) exclusive end per peer
   LM_SHARED(uint32_t, s_ext, MAX_PEERS);     // contiguous covered end per peer
   DocMeta m = d.doc[doc];
@@ -239,6 +247,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   }
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_ext[p] = 0; s_valid[p] = 0; d.peer_chg0[m.praw0 + p] = 0; d.peer_chg1[m.praw0 + p] = 0; }
   lmw::block_sync();
+  DAG_PH(0);
   // ---- 2. coverage walk: drop known changes, slice straddling ones, park blocks behind a counter gap
   uint32_t n_sorted = 0;
   bool any_skip = false;   // a kept change whose prefix is already known (sliced): DF_PLAIN stays clear
@@ -282,6 +291,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   lmw::block_sync();
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_valid[p] = s_ext[p];
   lmw::block_sync();
+  DAG_PH(1);
   // ---- 3. dependency fixpoint: a change applies iff every dep is applied (pending otherwise)
   for (uint32_t iter = 0; iter < 4096; iter++) {
     bool changed = false;
@@ -300,6 +310,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     lmw::block_sync();
     if (!lmw::any(changed)) break;
   }
+  DAG_PH(2);
   // ---- 4. compact to applied changes, recompute per-peer ranges, count pending atoms
   uint32_t n_valid = 0;
   for (uint32_t i0 = 0; i0 < n_sorted; i0 += 64) {
@@ -321,6 +332,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     n_valid += (uint32_t)lmw::popc64(km);
     lmw::block_sync();
   }
+  DAG_PH(3);
   // per-peer ranges in the compacted order (changes of a peer stay contiguous and ordered)
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) { d.peer_chg0[m.praw0 + p] = NONE; d.peer_chg1[m.praw0 + p] = 0; }
   lmw::block_sync();
@@ -356,6 +368,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   // everything that depends on any part of it).
   lmw::mem_fence();
   lmw::block_sync();   // peer_chg0/1 (find_change) are complete
+  DAG_PH(4);
   // (every dependency is resolved to its change HERE, once — dep_ci — so that k_dag_b's passes, one per node, test readiness and
   // merge version vectors with two loads per dependency instead of a binary search each.  A dependency on the peer's own previous
   // op — nearly all of them — is the change right in front, no search.)
@@ -381,6 +394,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   // of the integrate stage); a small document of many peers that sync every few ops only gets more nodes out of it — more passes
   // here, more tracker moves in the replay (measured, tests/tools/gpu_other.py: MovableList batch integrate 15.1 -> 20.6 ms, k_dag_b
   // 2.9 -> 6.8 ms; configs[3] k_dag_b 5.1 -> 13.7 ms).  So: documents of at least LM_CUT_MIN_ROWS op rows (an environment knob, 2,048 by default; the parity suites also run with 0).
+  DAG_PH(5);
   const bool cut_doc = !LM_NO_NODE_CUT && m.n_op >= d.cut_min_rows;
   uint32_t n_nodes = 0;
   for (uint32_t i0 = 0; i0 < n_valid; i0 += 64) {
@@ -411,6 +425,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     d.node_last[m.chg0 + n] = (n + 1 < n_nodes ? d.node_first[m.chg0 + n + 1] : n_valid) - 1;
     g.node_done[m.chg0 + n] = 0;
   }
+  DAG_PH(6);
   // number of Map op rows (sizes the doc's LWW hash table)
   // (from the blocks' descriptors: the decoders count their rows by kind as they write them — lm_k_decode.h kc_add.  MovableList
   // move / set rows compete per element in the same LWW table, a move also places a new list item; rows of containers outside the
@@ -440,6 +455,10 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     // (DF_FUSED: few rows per change — one change per keystroke — k_fuse_rows chains the rows into runs, lm_k_fuse.h)
     else if (!any_skip_doc && n_style == 0) d.doc[doc].flags |= DF_PLAIN | ((LM_FUSE_ROWS && (uint64_t)n_valid * 8 > m.n_op) ? DF_FUSED : 0u);
   }
+#ifdef LM_PROF_DAG
+  DAG_PH(7);
+  if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&d.prof[i], (unsigned long long)dpacc[i]);
+#endif
 }
 
 // K7b: one wave per doc — Kahn passes over nodes: replay order, lamports, vv at node heads.

@@ -649,7 +649,7 @@ struct Engine {
     // one wave per group of DEC_G blocks, staged through LDS (lm_k_decode_wave.h); LM_DECODE=0 selects the one-lane-per-block
     // decoder (kept as the second, independently structured implementation the parity suites also run)
     if (NB) {
-#ifdef LM_PROF_DEC   // experiment build: cycle accounting of the decoder's phases (tests/tools/gpu_prof_dec.py)
+#if defined(LM_PROF_DEC) || defined(LM_PROF_DAG)   // experiment builds: cycle accounting of the decoder's phases / of k_dag_a's passes (tests/tools/gpu_prof_dec.py, gpu_prof_dag.py)
       b_prof.ensure((size_t)n_docs * 16 * 8); d.prof = b_prof.as<unsigned long long>(); lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
 #endif
       if (!kn.decode_wave) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
@@ -810,7 +810,7 @@ struct Engine {
     b_vvh.ensure((vvh + 1) * 4);
     b_prof.ensure((size_t)n_docs * 16 * 8);
     d.prof = b_prof.as<unsigned long long>();
-#ifndef LM_PROF_DEC
+#if !defined(LM_PROF_DEC) && !defined(LM_PROF_DAG)
     lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
 #endif
     b_ht_key.ensure((ht + 1) * 8); b_ht_best.ensure((ht + 1) * 8); b_ht_pfx.ensure((ht + 1) * 8); b_ht_list.ensure((ht + 1) * 8);   // per doc 2·cap entries: claimed slots [0, cap/2) + sort scratch
@@ -1144,7 +1144,7 @@ struct Engine {
     }
     payload_bytes = 0;
     for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) payload_bytes += (uint64_t)h_doc[i].out_len + h_doc[i].vv_len;
-#if defined(LM_PROF) || defined(LM_PROF_DEC) || defined(LM_PROF_EMIT)
+#if defined(LM_PROF) || defined(LM_PROF_DEC) || defined(LM_PROF_EMIT) || defined(LM_PROF_DAG)
     h_prof.resize((size_t)n_docs * 16);
     lmbe::d2h(h_prof.data(), d.prof, (size_t)n_docs * 16 * 8);
 #endif
