@@ -169,9 +169,28 @@ LM_DEV int64_t rle_next_any(RleCur& c, uint32_t mode) {   // the run value lives
 // values than the rows need, fails the block with DecodeError whatever the rows say.  The decoders read columns row by row; these
 // two give them the same verdict afterwards: is the column used up exactly, and how many values does the rest hold.
 LM_DEV bool rle_exhausted(const RleCur& c) { return c.rem == 0 && c.r.p >= c.r.end; }
-LM_DEV uint32_t rle_drain(RleCur& c, uint32_t mode) {   // values left in the column (c.r.bad: the rest does not decode)
+// A RUN is counted, not stepped through (a crafted column of a few bytes with a run count near 2^28 made one lane spin
+// 2^28 times per column): the rest of a run adds `rem` values at once — for a delta column the sum after the run must still fit
+// i64, and the sums inside a run are monotonic, so the end of the run decides — literals are decoded one by one (each consumes
+// at least a byte of the column), and once the count passes `cap` the verdict "more values than the rows need" stands.
+LM_DEV bool drain_run(int64_t& rem, int64_t& val, int64_t runv, uint32_t mode, uint32_t& n, uint32_t cap) {   // false: the sum overflows
+  bool ok = true;
+  if (mode == 2) { int64_t d; ok = !__builtin_mul_overflow(runv, rem, &d) && !__builtin_add_overflow(val, d, &val); }
+  uint64_t tot = (uint64_t)n + (uint64_t)rem;
+  n = tot > (uint64_t)cap + 1 ? cap + 1 : (uint32_t)tot;
+  rem = 0;
+  return ok;
+}
+LM_DEV uint32_t rle_drain(RleCur& c, uint32_t mode, uint32_t cap = (1u << 28)) {   // values left in the column, saturating at cap + 1 (c.r.bad: the rest does not decode)
   uint32_t n = 0;
-  while (!c.r.bad && !rle_exhausted(c) && n < (1u << 28)) { (void)rle_next_any(c, mode); if (!c.r.bad) n++; }
+  while (!c.r.bad && !rle_exhausted(c) && n <= cap) {
+    if (c.rem > 0 && c.run) {   // inside a run: its value was read with the run's first value (rle_next_any), the rest are copies
+      if (!drain_run(c.rem, c.val, c.runv, mode, n, cap)) c.r.bad = true;
+      continue;
+    }
+    (void)rle_next_any(c, mode);
+    if (!c.r.bad) n++;
+  }
   return n;
 }
 // The same cursor over a column of a block STAGED IN LDS (k_block_decode_wave): byte offsets into the slot instead of 64-bit
@@ -229,9 +248,16 @@ LM_DEV int64_t col_next_any(ColCur& c, uint32_t mode) {   // == rle_next_any
   return c.val;
 }
 LM_DEV bool col_exhausted(const ColCur& c) { return c.rem == 0 && c.p >= c.end; }
-LM_DEV uint32_t col_drain(ColCur& c, uint32_t mode) {
+LM_DEV uint32_t col_drain(ColCur& c, uint32_t mode, uint32_t cap = (1u << 28)) {   // == rle_drain
   uint32_t n = 0;
-  while (!c.bad && !col_exhausted(c) && n < (1u << 28)) { (void)col_next_any(c, mode); if (!c.bad) n++; }
+  while (!c.bad && !col_exhausted(c) && n <= cap) {
+    if (c.rem > 0 && c.run) {
+      if (!drain_run(c.rem, c.val, c.runv, mode, n, cap)) c.bad = true;
+      continue;
+    }
+    (void)col_next_any(c, mode);
+    if (!c.bad) n++;
+  }
   return n;
 }
 // number of values in a whole AnyRle payload whose literals are single bytes (Rle<u8>)

@@ -311,6 +311,10 @@ LM_KERNEL void k_block_count(Dev d) {
     Rd c2 = rd_bytes(o);
     if (o.bad) bad = true;
     if (!bad) { nops = rle_count_u8(c2); if (nops == ~0ull) bad = true; }
+    // every op row covers at least one op id of the block (block_encode.rs:651-704 advances the counter by the row's len; the
+    // writers never emit an empty op), so a value-type column that announces more rows than the block has ids — a run count of
+    // 2^28 in two bytes — cannot decode to a block: DecodeError here, before any table is sized by it
+    if (!bad && nops > (uint64_t)bd.counter_len) bad = true;
   }
   uint64_t nkeys = 0;
   {
@@ -590,10 +594,10 @@ LM_KERNEL void k_block_decode(Dev d) {
     {
       // every column decodes, the op columns to one value per row, the delete-start columns to equally many (lm_dev_util.h rle_drain)
       bool colbad = false;
-      { RleCur t = c_cont; uint32_t n = rle_drain(t, 2); colbad |= t.r.bad || n != n_ops; }
-      { RleCur t = c_prop; uint32_t n = rle_drain(t, 2); colbad |= t.r.bad || n != n_ops; }
-      { RleCur t = c_vt; uint32_t n = rle_drain(t, 0); colbad |= t.r.bad || n != n_ops; }
-      { RleCur t = c_len; uint32_t n = rle_drain(t, 1); colbad |= t.r.bad || n != n_ops; }
+      { RleCur t = c_cont; uint32_t n = rle_drain(t, 2, n_ops); colbad |= t.r.bad || n != n_ops; }
+      { RleCur t = c_prop; uint32_t n = rle_drain(t, 2, n_ops); colbad |= t.r.bad || n != n_ops; }
+      { RleCur t = c_vt; uint32_t n = rle_drain(t, 0, n_ops); colbad |= t.r.bad || n != n_ops; }
+      { RleCur t = c_len; uint32_t n = rle_drain(t, 1, n_ops); colbad |= t.r.bad || n != n_ops; }
       if (has_del) {
         RleCur t1 = d_peer, t2 = d_ctr, t3 = d_len;
         uint32_t n1 = rle_drain(t1, 2), n2 = rle_drain(t2, 2), n3 = rle_drain(t3, 2);

@@ -445,3 +445,43 @@ def big_blob_checksum_docs(n=40, seed=3):
             b = b[:16] + struct.pack("<I", struct.unpack("<I", b[16:20])[0] ^ (1 << (k % 32))) + b[20:]
         docs.append([b])
     return docs
+
+
+def huge_run_column_docs():
+    """columns of a few bytes whose AnyRle run count is near 2^28 (a decoder that steps through a run value by value
+    spins 2^28 times per column).  Each document is a small valid history whose one block has one column replaced: the value-type
+    column as ONE run of 2^28 - 3 values, the len column likewise, a delete-start column with a giant run appended, and a prop
+    column (DeltaRle) with a giant run of a delta that overflows i64.  All of them are DecodeError for the reference's reader
+    (serde_columnar decodes a column in full: more values than rows / unequal delete-start columns)."""
+    from loro_amd import wire
+    docs, names = [], []
+    giant = (1 << 28) - 3
+
+    def build(patch_name, nth, make):
+        orig = getattr(wire, patch_name)
+        calls = {"n": 0}
+
+        def patched(vals):
+            calls["n"] += 1
+            out = orig(vals)
+            return make(out) if calls["n"] == nth else out
+        setattr(wire, patch_name, patched)
+        try:
+            r = wire.Replica(7)
+            r.text_insert("text", 0, "hello world")
+            r.text_delete("text", 2, 3)
+            r.text_insert("text", 1, "xy")
+            r.text_delete("text", 0, 1)
+            r.commit()
+            return [r.export()]
+        finally:
+            setattr(wire, patch_name, orig)
+
+    docs.append(build("enc_rle_u8", 1, lambda b: wire.zigzag(giant) + b"\x05")); names.append("value-type column: one giant run")
+    # enc_any_rle_uvar calls per block: dep counts, dep peer idx, msg lens, then the len column (4th)
+    docs.append(build("enc_any_rle_uvar", 4, lambda b: wire.zigzag(giant) + wire.uleb(1))); names.append("len column: one giant run")
+    # enc_delta_rle calls per block: container idx, prop, then the three delete-start columns (3rd..5th)
+    docs.append(build("enc_delta_rle", 4, lambda b: b + wire.zigzag(giant) + wire.zigzag(0))); names.append("delete-start counter column: giant run appended")
+    docs.append(build("enc_delta_rle", 2, lambda b: b + wire.zigzag(giant) + wire.zigzag((1 << 62)))); names.append("prop column: giant run of an overflowing delta")
+    docs.append(build("enc_delta_rle", 5, lambda b: b + wire.zigzag(giant) + wire.zigzag(-(1 << 40)))); names.append("delete-start len column: giant run appended")
+    return names, docs

@@ -724,3 +724,18 @@ def test_two_level_directory_of_deep_histories():
         got = c.merge_batch(docs, fr)
         assert c.sizing()[0] > 64        # leaves used by the largest document: more than one block of sums
     assert got == want and all(w[0] == 0 for w in want)
+
+
+@pytest.mark.parametrize("decoder", ["1", "0"])
+def test_a_giant_run_in_a_column_costs_nothing(monkeypatch, decoder):
+    """a column of a few bytes whose AnyRle run count is near 2^28 is counted per run, not stepped through value by
+    value, and a value-type column that announces more rows than the block has op ids sizes no table — DecodeError at once
+    (both decoders)."""
+    import time
+    monkeypatch.setenv("LM_DECODE", decoder)
+    names, docs = _cases.huge_run_column_docs()
+    t = time.time()
+    got = _emu.merge_batch(docs)
+    assert time.time() - t < 20.0
+    assert [g[0] for g in got] == [1] * len(docs), list(zip(names, [g[0] for g in got]))
+    assert [w[0] for w in _oracle.merge_batch(docs)] == [1] * len(docs)

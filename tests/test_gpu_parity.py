@@ -179,6 +179,21 @@ def test_nested_map_key_index_beyond_the_key_table_is_rejected(engine, monkeypat
     assert [g[0] for g in got[-len(bad):]] == [3] * len(bad) and all(g[0] == 0 for g in got[10:10 + len(good)])
 
 
+@pytest.mark.parametrize("decoder", ["1", "0"])
+def test_a_giant_run_in_a_column_costs_nothing(engine, monkeypatch, decoder):
+    """columns of a few bytes with run counts near 2^28 among ordinary documents: DecodeError at once, no lane spins
+    through the run, no table is sized by it, the neighbours' results do not move."""
+    import time
+    monkeypatch.setenv("LM_DECODE", decoder)
+    names, bad = _cases.huge_run_column_docs()
+    fill = _cases.fuzz_docs(20, base=15700)
+    t = time.time()
+    got = _same(engine, fill[:10] + bad + fill[10:])
+    assert time.time() - t < 60.0
+    assert [g[0] for g in got[10:10 + len(bad)]] == [1] * len(bad)
+    assert all(g[0] == 0 for g in got[:10] + got[10 + len(bad):])
+
+
 def test_ascii_pastes_with_every_length_prefix_width(engine):
     """length prefixes of 1, 2, 3 and 4 bytes through the decoder's arithmetic walk and the flat payload copy"""
     docs = _cases.ascii_paste_docs()
