@@ -22,6 +22,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t span;              // 1: leaves hold runs (lm_k_integrate_span.h, SP_REC dwords per leaf), 0: one element per slot
   const uint32_t* res_old_blobs;   // resident documents: per document the number of blobs earlier runs already held (nullptr otherwise)
   uint32_t loc_cleared;       // 1: loc[] was set to NONE by a memset in front of the integrate stage (the waves skip their own clear)
+  uint32_t no_linear;         // 1 (LM_LINEAR=0): no linear prefix — every node of a plain document goes through the tracker (lm_k_integrate_linear.h; A/B runs)
   uint32_t res_vis;           // 1: resident documents — the trackers stand at the rendered version, an item shows iff it is active
   const uint8_t* front;       // optional checkout frontiers (postcard Vec<ID>), front_off[n_docs+1]; empty range = latest
   const uint64_t* front_off;

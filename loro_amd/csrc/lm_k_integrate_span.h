@@ -1344,6 +1344,10 @@ inline bool ts_check(Ts& t, const char* what, uint32_t row) {
 #define TS_CHECK(what, row) do {} while (0)
 #endif
 
+}  // namespace lm
+#include "lm_k_integrate_linear.h"
+namespace lm {
+
 // ---- resident documents (DiffCalculatorRetainMode::Persist, diff_calc.rs:62-68,1371-1376; Tracker::checkout /
 // forward, tracker.rs:350-546).  A context in resident mode keeps every document's trackers in HBM between runs: the leaf pool,
 // each sequence container's leaf directory (both words), the tracker's version per (container, peer) and what it has applied
@@ -1578,7 +1582,74 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     t.loc = (PLAIN && !RES && LM_LAZY_LOC) ? nullptr : d.loc + elem0;   // (ts_build_loc)
     bool base_on = false;              // the tracker has a base version (s_base), ts_goto
     uint32_t* s_base = s_tgt;          // (not RES: the slot of the resident kernels' rendered version)
-    for (uint32_t oi = 0; oi < m.n_nodes && !t.err; oi++) {
+    // ---- the linear prefix (lm_k_integrate_linear.h): the nodes in front of the first "a concurrent section begins here" flag —
+    // every version up to there is critical — are replayed as a positional rope, not through the tracker.  (DF_CUT: k_dag_b
+    // computed the flags; a document that is one chain has none and is replayed here to its end.)
+    uint32_t oi0 = 0;
+    if (PLAIN && !RES && LM_LINEAR && LM_LAZY_LOC && (m.flags & DF_CUT) && !d.no_linear) {
+      Tl c;
+      tl_none(c);
+      bool emptied = false;
+      const uint32_t* op_w = (const uint32_t*)op_ro;
+      for (; oi0 < m.n_nodes && !t.err; oi0++) {
+        uint32_t n = d.node_order[m.chg0 + oi0];
+        if (lmw::first(g.node_done[m.chg0 + n]) & 2u) break;
+        uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
+        uint32_t node_peer = chg_ro[sorted_ro[m.chg0 + first]].peer;
+        const ChangeRow lc = chg_ro[sorted_ro[m.chg0 + last]];
+        RowWin w;
+        w.base = NONE - 64; w.lim = m.op0 + m.n_op; w.cur = 0; w.nxt = 0;
+        bool node_contig = false, node_mine = true;
+        if (FUSE && last > first) {   // (see the tracker's loop below)
+          bool bad = false, mine = false;
+          for (uint32_t i = first + (uint32_t)lane; i <= last; i += 64) {
+            uint32_t cr0 = sorted_ro[m.chg0 + i];
+            if (i < last) { const ChangeRow c0 = chg_ro[cr0], c1 = chg_ro[sorted_ro[m.chg0 + i + 1]]; bad |= c0.op0 + c0.n_op != c1.op0; }
+            mine |= ((d.chg_mask[2 * (uint64_t)cr0 + ((cidx >> 5) & 1)] >> (cidx & 31)) & 1) != 0;
+          }
+          node_contig = !lmw::any(bad);
+          if (node_contig) node_mine = lmw::any(mine);
+        }
+        for (uint32_t ci = first; ci <= last && node_mine && !t.err; ci++) {
+          uint32_t crow = sorted_ro[m.chg0 + ci];
+          const ChangeRow ch = chg_ro[crow];
+          uint32_t n_rows = ((lmw::first(d.chg_mask[2 * (uint64_t)crow + ((cidx >> 5) & 1)]) >> (cidx & 31)) & 1) ? ch.n_op : 0u;
+          if (FUSE && node_contig) { n_rows = lc.op0 + lc.n_op - ch.op0; ci = last; }
+          for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
+            OpRow r = rw_get(w, op_w, row);
+            if ((r.cidx_kind & 0xffff) != cidx) continue;
+            if (FUSE) {
+              if (r.cidx_kind & OPF_CONT) continue;
+              if (r.cidx_kind & OPF_HEAD) {
+                lmw::wave_sync();
+                uint32_t fa1 = lmw::first(d.fuse[2 * (uint64_t)row]);
+                int32_t fa2 = (int32_t)lmw::first(d.fuse[2 * (uint64_t)row + 1]);
+                r.len = (uint32_t)(fa2 < 0 ? -fa2 : fa2);
+                if (((r.cidx_kind >> 16) & 0xff) == OK_DEL) { r.a1 = fa1; r.a2 = fa2; }
+              }
+            }
+            uint32_t kind = (r.cidx_kind >> 16) & 0xff;
+            touched = true;
+            if (kind == OK_TEXT_INS || kind == OK_LIST_INS) tl_insert(t, c, (uint32_t)r.prop, pid_make(node_peer, r.ctr), r.len);
+            else if (kind == OK_DEL) {
+              // (the row's checks are the tracker's, below: a span as long as its op, a position inside the sequence)
+              uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
+              const uint32_t bad_bits = (Ln ^ r.len) | ((uint32_t)r.prop >> 31) | (((uint32_t)r.a2 >> 31) & (((uint32_t)r.prop + 1u - Ln) >> 31));
+              if (bad_bits) LM_SETERR(t.err, ST_DATA_CORRUPTION);
+              else tl_delete(t, c, r.a2 > 0 ? (uint32_t)r.prop : (uint32_t)r.prop + 1u - Ln, Ln, pid_make(r.a0, r.a1), emptied);
+            }
+          }
+        }
+        if (lane == 0) s_cur[node_peer] = lc.ctr + lc.len;
+      }
+      tl_finish(t, c, emptied);
+      lmw::block_sync();
+#ifdef LM_EMU_TRACE
+      if (getenv("LM_EMU_BASE") && lane == 0) fprintf(stderr, "LINEAR cont %u: %u of %u nodes, %u elements in %u leaves%s\n", cidx, oi0, m.n_nodes, t.tot_active, t.n_dir, emptied ? " (compacted)" : "");
+#endif
+      TS_CHECK("linear prefix", oi0);
+    }
+    for (uint32_t oi = oi0; oi < m.n_nodes && !t.err; oi++) {
       uint32_t n = d.node_order[m.chg0 + oi];
       uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
       const uint32_t* vv = vvh_ro + vvh0 + (uint64_t)n * P;

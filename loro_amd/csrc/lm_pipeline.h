@@ -140,7 +140,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -160,6 +160,7 @@ struct Engine {
     if (const char* e = getenv("LM_VS_ROW_COST")) k.vs_row_cost = (uint32_t)atoi(e);             // ts_sweep_pays_batch (A/B)
     if (const char* e = getenv("LM_VERSION_SWEEP")) k.version_sweep = atoi(e) != 0;              // 0: resident trackers move row by row (rounds 3-4a: delete rows undone / redone one by one)
     if (const char* e = getenv("LM_FUSE_ROWS")) k.fuse_rows = atoi(e) != 0;                      // 0: one-change-per-keystroke documents are replayed row by row, as in rounds 1-3
+    if (const char* e = getenv("LM_LINEAR")) k.linear = atoi(e) != 0;                            // 0: no linear prefix in the plain batch kernels (rounds 1-4: every node through the tracker)
     if (const char* e = getenv("LM_LWW_LDS")) k.lww_lds = atoi(e) != 0;                          // 0: every document's Map rows go through the HBM tables (k_map_lww), as in rounds 1-3
     kn = k;
   }
@@ -831,6 +832,7 @@ struct Engine {
     // slice, as resident documents always do — they keep loc[] between runs).  cp[] needs no fill: every element that can be
     // placed was written by k_elem_fill
     d.loc_cleared = (!resident && span && kn.loc_memset) ? 1u : 0u;
+    d.no_linear = kn.linear ? 0u : 1u;
     if (d.loc_cleared && elem) lmbe::dmemset(b_loc.p, 0xff, (size_t)elem * 4);
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
       if (resident) {

@@ -217,6 +217,21 @@ def fuzz_docs(n, base=0, steps=40, peers=None, **kw):
     return docs
 
 
+def linear_prefix_docs(n, base=90000):
+    """Histories that begin as ONE chain (a replica working alone: inserts at random places, typing that continues an item,
+    deletes of a few elements up to whole leaves), which every other replica imports before the concurrent part begins: the
+    hand-over is a critical version and everything before it the batch replay's linear prefix (lm_k_integrate_linear.h) —
+    leaf splits, items cut by inserts and deletes, emptied leaves, prefixes of every length incl. whole documents (1 peer)."""
+    docs = []
+    for seed in range(n):
+        kinds = [("text",), ("text", "list"), ("text", "list", "map")][seed % 3]
+        n_peers = 1 + seed % 4
+        reps = _fuzz.random_session(base + seed, n_peers=n_peers, n_steps=20 + seed % 40, kinds=kinds, solo_steps=40 + (seed * 37) % 400,
+                                    max_del=[4, 40, 200][seed % 3], max_ins=[6, 30, 3][(seed // 3) % 3], solo_peer=(seed // 2) % n_peers)
+        docs.append(_fuzz.blobs_of(reps, random.Random(seed)))
+    return docs
+
+
 def trace_docs(n_base, variants=((10, True), (10, False), (0, True)), n_docs=2, seed=2):
     docs = []
     for ce, fuse in variants:

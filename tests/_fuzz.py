@@ -7,7 +7,7 @@ ALPHA = "abcdefghijklmnopqrstuvwxyz ABCDEFGH\n\"\\\t" + "äßλ中😀"
 
 
 def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15, max_ins=6, commit_prob=0.4,
-                   peer_base=None, styles=False, snapshots=None):
+                   peer_base=None, styles=False, snapshots=None, solo_steps=0, max_del=4, solo_peer=0):
     """Returns (list of blobs in a random delivery order, replicas).  Replicas edit concurrently and sync
     pairwise; after a sync the receiver's visible sequences are refreshed from the oracle."""
     rng = random.Random(seed)
@@ -26,14 +26,22 @@ def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15,
             if (cid.kind == wire.KIND_TEXT and "text" in kinds) or (cid.kind == wire.KIND_LIST and "list" in kinds):
                 r.set_visible(cid.name, cid.kind, _oracle.visible_ids([blob], cid.name, cid.kind))
 
-    for _ in range(n_steps):
-        r = rng.choice(reps)
+    # solo_steps: the session begins with that many steps of ONE replica (reps[solo_peer]) — a history that is a single chain — which
+    # every other replica then imports: the version at the hand-over is a critical version (the linear prefix of the batch replay,
+    # lm_k_integrate_linear.h); max_del: longest delete of a step (whole items, leaves emptied)
+    for step in range(solo_steps + n_steps):
+        if step == solo_steps and solo_steps and n_peers > 1:
+            reps[solo_peer].commit()
+            for o in reps:
+                if o is not reps[solo_peer] and o.merge_from(reps[solo_peer]):
+                    refresh(o)
+        r = reps[solo_peer] if step < solo_steps else rng.choice(reps)
         kind = rng.choice(kinds)
         if kind == "text":
             ids = r.seq.setdefault(wire.root_cid("text", wire.KIND_TEXT), [])
             if ids and rng.random() < 0.35:
                 pos = rng.randrange(len(ids))
-                n = min(len(ids) - pos, rng.randint(1, 4))
+                n = min(len(ids) - pos, rng.randint(1, max_del))
                 r.text_delete("text", pos, n)
             elif styles and len(ids) >= 2 and rng.random() < 0.1:
                 s = rng.randrange(len(ids) - 1)
@@ -47,7 +55,7 @@ def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15,
             ids = r.seq.setdefault(wire.root_cid("list", wire.KIND_LIST), [])
             if ids and rng.random() < 0.3:
                 pos = rng.randrange(len(ids))
-                r.list_delete("list", pos, min(len(ids) - pos, rng.randint(1, 3)))
+                r.list_delete("list", pos, min(len(ids) - pos, rng.randint(1, max(3, max_del // 2))))
             else:
                 vals = [rng.choice([None, True, False, rng.randint(-10**12, 10**12), "s%d" % rng.randint(0, 99), b"\x00\x01\xff",
                                     [1, "x", [None]], rng.uniform(-1e3, 1e3), rng.choice([0.5, 1e-9, 3.0e22, -0.0]),
@@ -65,7 +73,7 @@ def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15,
             if snapshots is not None and r.frontiers and rng.random() < 0.5:
                 # (version, updates holding exactly that version's causal history)
                 snapshots.append((list(r.frontiers), r.export()))
-        if rng.random() < sync_prob and n_peers > 1:
+        if rng.random() < sync_prob and n_peers > 1 and step >= solo_steps:
             a, b = rng.sample(reps, 2)
             a.commit(); b.commit()
             if a.merge_from(b):

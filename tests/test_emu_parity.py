@@ -157,6 +157,24 @@ def test_node_cut_replay_order_and_tracker_base_on_small_documents(monkeypatch):
     assert got == want
 
 
+def test_linear_prefix_of_a_batch_replay(monkeypatch):
+    """The nodes in front of the first critical version that opens a concurrent section are replayed as a positional rope
+    (lm_k_integrate_linear.h: no origins, no tombstones, no loc[]) and handed to the tracker — under the structural checker, for
+    documents of every size (LM_CUT_MIN_ROWS=0: k_dag_b's flags), against the oracle's full replay; LM_LINEAR=0 (the tracker from
+    the first node on) gives the same bytes."""
+    from loro_amd._cabi import Context
+    monkeypatch.setenv("LM_CUT_MIN_ROWS", "0")
+    b = _emu.variant(["LM_SWEEP_EAGER", "LM_EMU_CHECK"])
+    docs = _cases.linear_prefix_docs(60) + _cases.trace_docs(2000, n_docs=1)
+    want = _oracle.merge_batch(docs)
+    with Context(b) as c:
+        got = c.merge_batch(docs)
+    assert got == want
+    monkeypatch.setenv("LM_LINEAR", "0")
+    with Context(b) as c:
+        assert c.merge_batch(docs[:24]) == want[:24]
+
+
 def test_concurrent_sibling_scans():
     # many peers typing long runs at the same spots: stresses the run-head sibling scan
     _check(_cases.fuzz_docs(12, base=1000, steps=120, peers=4, max_ins=30, sync_prob=0.08))

@@ -162,6 +162,19 @@ def test_node_cut_replay_order_and_tracker_base_on_small_documents(engine, monke
     _same(engine, docs)
 
 
+@pytest.mark.parametrize("cut_min", ["0", None])
+def test_linear_prefix_of_a_batch_replay(engine, monkeypatch, cut_min):
+    """histories that begin as one chain: the nodes in front of the first critical version are replayed as a positional rope
+    (lm_k_integrate_linear.h) and handed to the tracker — prefixes of every length, leaf splits, emptied leaves; with k_dag_b's
+    flags for documents of every size (LM_CUT_MIN_ROWS=0) and at the default; LM_LINEAR=0 gives the same bytes"""
+    if cut_min is not None:
+        monkeypatch.setenv("LM_CUT_MIN_ROWS", cut_min)
+    docs = _cases.linear_prefix_docs(240) + _cases.trace_docs(3000, n_docs=2)
+    got = _same(engine, docs)
+    monkeypatch.setenv("LM_LINEAR", "0")
+    assert engine.merge_batch(docs) == got
+
+
 def test_map_rendering_plain_groups_and_entry_by_entry(engine):
     _same(engine, _cases.map_render_docs() * 40)
 
