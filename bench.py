@@ -407,13 +407,15 @@ def other_configs(device, cores):
     run("configs[1]-128-traces", [ttr[(d * 7919) % len(ttr)].stamp(d) for d in range(10000)], None, 64,
         "configs[1] at its stated size (10,000 docs x 100k ops, 2 concurrent peers, 3 blobs) from 128 DIFFERENT synthetic traces interleaved "
         "pseudo-randomly, letters stamped per document: neighbouring waves replay different histories (the headline batch stamps one trace)")
-    docs5, fr5 = [], []
-    for blobs, fr in g5:
-        docs5 += [blobs] * len(fr); fr5 += fr
-    n5 = len(docs5)
-    run("configs[4]", [docs5[i % n5] for i in range(1024)], [fr5[i % n5] for i in range(1024)], n5,
-        "1M-op rich-text documents (2 peers alternating every 1k trace actions, ~1% marks), 16 checkouts each: 1,024 renderings = "
-        "64 documents x 16 versions (of the config's 1,000 documents); every rendering replays its version from the empty one", reps=2)
+    # configs[4]: 256 document INSTANCES (own copies of the blobs of 4 distinct histories) x 16 versions.  The 16 entries of an instance
+    # name the same blobs: lm_stage folds them into one document, lm_run imports it once and renders the 16 versions by moving its
+    # trackers (include/loro_merge.h "Shared replay"); LM_SHARE_REPLAY=0 replays the history once per entry (rounds 1-4: 1,148 renderings/s)
+    n5 = 64
+    inst = [[bytes(bytearray(b)) for b in g5[d % 4][0]] for d in range(256)]
+    run("configs[4]", [inst[i // 16] for i in range(4096)], [g5[(i // 16) % 4][1][i % 16] for i in range(4096)], n5,
+        "1M-op rich-text documents (2 peers alternating every 1k trace actions, ~1% marks), 16 checkouts each: 4,096 renderings = "
+        "256 documents x 16 versions (of the config's 1,000 documents; 4 distinct histories); the 16 entries of a document share their "
+        "blobs: imported once per lm_run, every version rendered by a move of the document's trackers", reps=2)
     # not a BASELINE config: the MovableList row of SURVEY §8f (N4), timed like the others so the row has a number on hardware;
     # guarded — a failure here is reported in its own entry and leaves the BASELINE entries and the headline value alone
     try:

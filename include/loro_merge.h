@@ -102,6 +102,17 @@ int lm_fetch(lm_ctx* ctx, lm_doc_out* outs);
 int lm_run_async(lm_ctx* ctx);
 int lm_wait(lm_ctx* ctx);
 
+/* Shared replay (a live LoroDoc serves every checkout from ONE imported history and its persistent DiffCalculator,
+ * crates/loro-internal/src/loro.rs:1625-1760, diff_calc.rs:62-68): entries of a staged batch that name the same blobs — the same
+ * pointers and lengths, in the same order — and differ only in checkout_frontiers are ONE document rendered at several versions.
+ * lm_stage uploads such a document once; every lm_run imports it once (decode, causal graph, replay from the empty version) and
+ * renders each entry by moving the document's trackers to the entry's version, instead of replaying the history once per entry.
+ * Results are per entry and are those of import_batch + checkout on a document of its own.  Not available on such a batch:
+ * lm_import (stage the documents once and import their checkouts instead), lm_summary_layout.  LM_SHARE_REPLAY=0 in the
+ * environment switches the folding off.  lm_shared_documents: the number of documents the batch staged last was folded into
+ * (0 = every entry is its own document). */
+int lm_shared_documents(lm_ctx* ctx);
+
 /* Resident documents: import MORE blobs into the documents the context already holds, and / or render them
  * at other versions — what a Rust host does with
  *     doc.import(bytes)           crates/loro/src/lib.rs:710 → loro-internal/src/loro.rs:568-649,720-851 (a document with history)

@@ -25,6 +25,26 @@ struct lm_ctx_impl {
   std::string async_err;
   bool in_flight = false;
 
+  // ---- shared replay (loro.rs:1625-1760 — a live LoroDoc serves every checkout from ONE imported history and its
+  // persistent DiffCalculator).  Entries of a staged batch that name the same blobs (same pointers, same lengths) and differ only in
+  // checkout_frontiers are one DOCUMENT rendered at several versions: the document is staged once, imported once per lm_run (the
+  // resident machinery of lm_import: decode, DAG, replay from the empty version), and every rendering is a move of its trackers
+  // (ts_sweep_version) + the emit stage — instead of one replay of the whole history per entry.  Results are per entry, as if every
+  // entry had been import_batch + checkout on its own (k_res_exists modes 1 / 2 keep the state store's view per rendering).
+  struct Shared {
+    bool on = false;
+    uint32_t n_entries = 0, G = 0;                     // API-level documents; rendering runs behind the import run
+    std::vector<uint32_t> uniq_of, slot_of;            // entry -> staged document, entry -> the run that renders it (0 = the import run: latest version)
+    std::vector<std::vector<uint32_t>> by_slot;        // by_slot[s][u] = the entry document u renders in run s (NONE = none)
+    std::vector<std::vector<uint8_t>> fronts;          // entry -> its checkout frontiers (copied: inputs are borrowed for lm_stage only)
+    std::vector<lm::DocResult> res;                    // per entry; json_off / vv_off index the arenas of the entry's part
+    std::vector<uint32_t> part_of;                     // entry -> part
+    std::vector<lm::DBuf> d_out, d_vv;                 // per part: device arenas of the rendered bytes of all its runs
+    std::vector<uint64_t> out_top, vv_top;
+    std::vector<std::vector<uint8_t>> h_out, h_vv;     // per part, after lm_fetch
+  } sh;
+  uint32_t api_docs() const { return sh.on ? sh.n_entries : n_docs; }
+
   int device = 0;                  // HIP device of this context: every engine (stream, buffers) is created on it
   // lm_summary_layout: the summary rows of this context's documents, written on the device by every run (k_summary_rows)
   lm::DBuf sum_buf, sum_all;       // rows_padded x 6 int64 (this rank's), world x rows_padded x 6 (gathered)
@@ -46,7 +66,67 @@ struct lm_ctx_impl {
   ~lm_ctx_impl() { if (runner.joinable()) runner.join(); }
   uint32_t n_parts() const { return (uint32_t)first.size() - 1; }
 
-  void stage(const lm::Engine::DocIn* docs, size_t n) {
+  void stage(const lm::Engine::DocIn* docs_api, size_t n_api) {
+    // entries that share their blobs: staged once (see Shared above).  LM_SHARE_REPLAY=0: every entry is its own document (rounds 1-4)
+    std::vector<lm::Engine::DocIn> udocs;
+    const lm::Engine::DocIn* docs = docs_api;
+    size_t n = n_api;
+    sh.on = false;
+    {
+      const char* e = getenv("LM_SHARE_REPLAY");
+      const char* sp = getenv("LM_SPAN");
+      bool want = !(e && atoi(e) == 0) && !(sp && atoi(sp) == 0);   // (the resident machinery is the span-granular kernels')
+      // (folded: groups of two or more entries of which at least one asks for a checkout — entries that all render the latest
+      // version stay documents of their own: a caller may stage a batch of equal documents and lm_import different updates into each)
+      std::map<std::vector<uint64_t>, std::vector<uint32_t>> groups;
+      std::vector<uint32_t> uniq_of(n_api);
+      std::vector<uint64_t> key;
+      for (size_t i = 0; want && i < n_api; i++) {
+        key.clear();
+        key.push_back(docs_api[i].n);
+        for (size_t b = 0; b < docs_api[i].n; b++) { key.push_back((uint64_t)(uintptr_t)docs_api[i].blobs[b]); key.push_back((uint64_t)docs_api[i].lens[b]); }
+        groups[key].push_back((uint32_t)i);
+      }
+      if (want) {
+        std::vector<uint8_t> fold(n_api, 0);
+        for (auto& kv : groups) {
+          bool any_front = false;
+          for (uint32_t i : kv.second) any_front |= docs_api[i].front != nullptr;
+          if (kv.second.size() >= 2 && any_front && docs_api[kv.second[0]].n) for (uint32_t i : kv.second) fold[i] = 1;
+        }
+        std::map<std::vector<uint64_t>, uint32_t> seen;
+        for (size_t i = 0; i < n_api; i++) {   // staged documents in the order of their first entries
+          uint32_t u = (uint32_t)udocs.size();
+          if (fold[i]) {
+            key.clear();
+            key.push_back(docs_api[i].n);
+            for (size_t b = 0; b < docs_api[i].n; b++) { key.push_back((uint64_t)(uintptr_t)docs_api[i].blobs[b]); key.push_back((uint64_t)docs_api[i].lens[b]); }
+            auto it = seen.find(key);
+            if (it != seen.end()) { uniq_of[i] = it->second; continue; }
+            seen.emplace(key, u);
+          }
+          udocs.push_back(lm::Engine::DocIn{docs_api[i].blobs, docs_api[i].lens, docs_api[i].n, nullptr, 0});
+          uniq_of[i] = u;
+        }
+      }
+      if (want && udocs.size() < n_api) {
+        for (size_t i = 0; i < n_api; i++)
+          if (docs_api[i].front && docs_api[i].front_len == 0) throw std::runtime_error("checkout_frontiers with zero length (the empty version is the byte 00)");
+        sh = Shared();
+        sh.on = true; sh.n_entries = (uint32_t)n_api; sh.uniq_of = uniq_of;
+        sh.slot_of.assign(n_api, 0); sh.fronts.assign(n_api, {});
+        std::vector<uint32_t> used(udocs.size(), 0);
+        for (size_t i = 0; i < n_api; i++) {
+          if (!docs_api[i].front) continue;                      // the latest version: what the import run itself renders
+          sh.fronts[i].assign(docs_api[i].front, docs_api[i].front + docs_api[i].front_len);
+          sh.slot_of[i] = ++used[uniq_of[i]];
+          if (sh.slot_of[i] > sh.G) sh.G = sh.slot_of[i];
+        }
+        sh.by_slot.assign(sh.G + 1, std::vector<uint32_t>(udocs.size(), lm::NONE));
+        for (size_t i = 0; i < n_api; i++) sh.by_slot[sh.slot_of[i]][uniq_of[i]] = (uint32_t)i;   // (several entries at the latest version: the last one is rendered, the others copy it)
+        docs = udocs.data(); n = udocs.size();
+      }
+    }
     n_docs = (uint32_t)n;
     ran = false;
     sum_rows_padded = 0;             // (a new batch: lm_summary_layout is called again for it)
@@ -73,9 +153,22 @@ struct lm_ctx_impl {
     body(0);
     for (auto& t : th) t.join();
     for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+    if (sh.on) {
+      // the staged documents become resident at once (lm_import straight after lm_stage: one import_batch, lm_pipeline.h)
+      std::vector<lm::Engine::DocIn> none(n_docs, lm::Engine::DocIn{nullptr, nullptr, 0, nullptr, 0});
+      import_parts(none.data(), n_docs);
+      sh.part_of.assign(sh.n_entries, 0);
+      for (uint32_t i = 0; i < sh.n_entries; i++) { uint32_t p = 0; while (p + 1 < n_parts() && sh.uniq_of[i] >= first[p + 1]) p++; sh.part_of[i] = p; }
+      sh.d_out.resize(n_parts()); sh.d_vv.resize(n_parts()); sh.out_top.assign(n_parts(), 0); sh.vv_top.assign(n_parts(), 0);
+      sh.h_out.assign(n_parts(), {}); sh.h_vv.assign(n_parts(), {});
+    }
   }
   // lm_import: more blobs / other checkouts for the documents of the resident batch — each part takes its own documents
   void import_more(const lm::Engine::DocIn* docs, size_t n) {
+    if (sh.on) throw std::runtime_error("lm_import: the staged batch renders shared documents at several versions (entries with the same blobs); stage the documents once and use lm_import for their checkouts instead");
+    import_parts(docs, n);
+  }
+  void import_parts(const lm::Engine::DocIn* docs, size_t n) {
     if (n != n_docs) throw std::runtime_error("lm_import: the document count differs from the resident batch");
     ran = false;
     uint32_t np2 = n_parts();
@@ -92,6 +185,72 @@ struct lm_ctx_impl {
     for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
   }
   void run() {
+    if (!sh.on) { run_parts(); return; }
+    // every lm_run is the whole job: the import (decode, DAG, replay from the empty version) and one rendering run per checkout slot
+    if (sum_rows_padded) throw std::runtime_error("lm_summary_layout is not available for a batch that renders shared documents at several versions");
+    uint32_t np = n_parts();
+    std::vector<lm::KernelTime> all_times;
+    sh.res.assign(sh.n_entries, lm::DocResult{0, 0, 0, 0, 0, 0, 0});
+    std::vector<int32_t> import_status(n_docs, 0);
+    {   // the import run renders the latest version (and the blob tables are those of the documents as staged)
+      std::vector<lm::Engine::DocIn> none(n_docs, lm::Engine::DocIn{nullptr, nullptr, 0, nullptr, 0});
+      import_parts(none.data(), n_docs);
+    }
+    for (uint32_t p = 0; p < np; p++) {
+      lm::Engine& e = *parts[p];
+      e.tables_valid = false; e.have_prev = false;
+      std::fill(e.tk_reset.begin(), e.tk_reset.end(), (uint8_t)1);
+      for (uint32_t i = 0; i < e.n_docs; i++) e.r_step[i] = (uint32_t)e.r_blobs[i].size();   // (a document whose import fails is empty afterwards, loro.rs:780-838)
+      sh.out_top[p] = sh.vv_top[p] = 0;
+    }
+    std::vector<std::vector<std::vector<lm::Engine::BlobRef>>> blobs0(np);
+    for (uint32_t p = 0; p < np; p++) blobs0[p] = parts[p]->r_blobs;
+    for (uint32_t s = 0; s <= sh.G; s++) {
+      if (s) {
+        // the trackers move to this slot's versions (a document without an entry in the slot stays where it is)
+        std::vector<lm::Engine::DocIn> in(n_docs, lm::Engine::DocIn{nullptr, nullptr, 0, nullptr, 0});
+        for (uint32_t u = 0; u < n_docs; u++) {
+          uint32_t en = sh.by_slot[s][u];
+          for (uint32_t s2 = s; en == lm::NONE && s2-- > 1;) en = sh.by_slot[s2][u];
+          if (en != lm::NONE && sh.slot_of[en]) { in[u].front = sh.fronts[en].data(); in[u].front_len = sh.fronts[en].size(); }
+        }
+        import_parts(in.data(), n_docs);
+      }
+      for (uint32_t p = 0; p < np; p++) parts[p]->shared_mode = s ? 2u : 1u;
+      run_parts();
+      for (auto& t : times) all_times.push_back(t);
+      for (uint32_t p = 0; p < np; p++) {
+        lm::Engine& e = *parts[p];
+        lmbe::bind(e.sc);
+        // this run's rendered bytes go behind the earlier runs' in the part's arenas (one copy each, on the part's stream)
+        if (s == 0) { sh.d_out[p].ensure((e.out_bytes + 64) * (sh.G + 1) + (e.out_bytes >> 2) + 256); sh.d_vv[p].ensure((e.vv_bytes + 64) * (sh.G + 1) + 256); }
+        sh.d_out[p].ensure_keep(sh.out_top[p] + e.out_bytes + 64, sh.out_top[p]);
+        sh.d_vv[p].ensure_keep(sh.vv_top[p] + e.vv_bytes + 64, sh.vv_top[p]);
+        if (e.out_bytes) lmbe::d2d((uint8_t*)sh.d_out[p].p + sh.out_top[p], e.b_out.p, e.out_bytes);
+        if (e.vv_bytes) lmbe::d2d((uint8_t*)sh.d_vv[p].p + sh.vv_top[p], e.b_vv_out.p, e.vv_bytes);
+        lmbe::sync();
+        for (uint32_t i = 0; i < e.n_docs; i++) {
+          uint32_t u = first[p] + i;
+          if (s == 0) import_status[u] = e.results[i].status;
+          uint32_t en = sh.by_slot[s][u];
+          if (en == lm::NONE) continue;
+          lm::DocResult r = e.results[i];
+          // a document whose import failed fails for every entry (its later runs would render the empty document it is left as)
+          if (s && import_status[u] != lm::ST_OK && import_status[u] != lm::ST_UNSUPPORTED) { r = lm::DocResult{import_status[u], 0, 0, 0, 0, 0, 0}; }
+          r.json_off += sh.out_top[p]; r.vv_off += sh.vv_top[p];
+          sh.res[en] = r;
+        }
+        sh.out_top[p] += e.out_bytes; sh.vv_top[p] += e.vv_bytes;
+      }
+    }
+    // entries at the latest version beyond the one that was rendered: the same bytes
+    for (uint32_t i = 0; i < sh.n_entries; i++) if (sh.slot_of[i] == 0) { uint32_t en = sh.by_slot[0][sh.uniq_of[i]]; if (en != i) sh.res[i] = sh.res[en]; }
+    // the documents are as they were staged (a failed import dropped its blobs from the resident lists)
+    for (uint32_t p = 0; p < np; p++) { parts[p]->r_blobs = blobs0[p]; parts[p]->shared_mode = 0; }
+    times = all_times;
+    ran = true;
+  }
+  void run_parts() {
     uint32_t np = n_parts();
     for (uint32_t p = 0; p < np; p++) parts[p]->profiling = profiling != 0;
     std::vector<std::string> errs(np);
@@ -116,6 +275,7 @@ struct lm_ctx_impl {
     ran = true;
   }
   template <class F> void for_docs(F f) {
+    if (sh.on) { for (uint32_t i = 0; i < sh.n_entries; i++) f(i, *parts[sh.part_of[i]], sh.res[i]); return; }
     for (uint32_t p = 0; p < n_parts(); p++)
       for (uint32_t i = 0; i < parts[p]->n_docs; i++) f(first[p] + i, *parts[p], parts[p]->results[i]);
   }
@@ -158,7 +318,8 @@ int LM_API(import)(void* c, const lm_doc_in_c* docs, size_t n) {
 // computed: no resident run yet, a failed document, more than 16 common-ancestor ids), computed on the device by k_import_lca
 int LM_API(import_modes)(void* c, int32_t* modes) {
   auto* x = (lm_ctx_impl*)c;
-  for (size_t i = 0; i < x->n_docs; i++) modes[i] = -1;
+  for (size_t i = 0; i < x->api_docs(); i++) modes[i] = -1;
+  if (x->sh.on) return 0;
   for (uint32_t p = 0; p < x->n_parts(); p++) {
     lm::Engine& e = *x->parts[p];
     for (uint32_t i = 0; i < e.n_docs; i++)
@@ -170,6 +331,7 @@ int LM_API(import_modes)(void* c, int32_t* modes) {
 // returns the length, or -1 when unknown / `cap` too small
 long LM_API(import_lca)(void* c, size_t doc, uint8_t* buf, size_t cap) {
   auto* x = (lm_ctx_impl*)c;
+  if (x->sh.on) return -1;
   for (uint32_t p = 0; p < x->n_parts(); p++) {
     if (doc < x->first[p] || doc >= x->first[p + 1]) continue;
     lm::Engine& e = *x->parts[p];
@@ -197,6 +359,8 @@ int LM_API(resident_fresh)(void* c) {
   for (uint32_t p = 0; p < x->n_parts(); p++) n += (int)x->parts[p]->last_fresh;
   return n;
 }
+// diagnostics of the shared replay: the number of documents the batch staged last was folded into (0: every entry is its own document)
+int LM_API(shared_documents)(void* c) { auto* x = (lm_ctx_impl*)c; return x->sh.on ? (int)x->n_docs : 0; }
 int LM_API(run)(void* c) {
   auto* x = (lm_ctx_impl*)c;
   try { x->run(); return 0; } catch (const std::exception& e) { x->err = e.what(); return -1; }
@@ -230,6 +394,24 @@ int LM_API(fetch)(void* c, lm_doc_out_c* outs) {
   auto* x = (lm_ctx_impl*)c;
   try {
     if (!x->ran) throw std::runtime_error("lm_fetch before lm_run");
+    if (x->sh.on) {
+      for (uint32_t p = 0; p < x->n_parts(); p++) {
+        lmbe::bind(x->parts[p]->sc);
+        x->sh.h_out[p].resize(x->sh.out_top[p] + 1); x->sh.h_vv[p].resize(x->sh.vv_top[p] + 1);
+        if (x->sh.out_top[p]) lmbe::d2h(x->sh.h_out[p].data(), x->sh.d_out[p].p, x->sh.out_top[p]);
+        if (x->sh.vv_top[p]) lmbe::d2h(x->sh.h_vv[p].data(), x->sh.d_vv[p].p, x->sh.vv_top[p]);
+        lmbe::sync();
+      }
+      for (uint32_t i = 0; i < x->sh.n_entries; i++) {
+        const lm::DocResult& r = x->sh.res[i];
+        uint32_t p = x->sh.part_of[i];
+        outs[i].status = r.status;
+        outs[i].json = x->sh.h_out[p].data() + r.json_off; outs[i].json_len = (size_t)r.json_len;
+        outs[i].vv = x->sh.h_vv[p].data() + r.vv_off; outs[i].vv_len = (size_t)r.vv_len;
+        outs[i].pending_ops = r.pending;
+      }
+      return 0;
+    }
     for (uint32_t p = 0; p < x->n_parts(); p++) x->parts[p]->fetch();
     x->for_docs([&](uint32_t i, lm::Engine& e, const lm::DocResult& r) {
       outs[i].status = r.status;
@@ -297,6 +479,7 @@ int LM_API(export)(void* c, size_t doc, const uint8_t* from_vv, size_t from_len,
   auto* x = (lm_ctx_impl*)c;
   try {
     if (!x->ran) throw std::runtime_error("lm_export before lm_run");
+    if (x->sh.on) { if (doc >= x->sh.n_entries) throw std::runtime_error("lm_export: no such document"); doc = x->sh.uniq_of[doc]; }
     for (uint32_t p = 0; p < x->n_parts(); p++) {
       if (doc < x->first[p] || doc >= x->first[p + 1]) continue;
       lmenc::Bytes b = x->parts[p]->export_doc((uint32_t)(doc - x->first[p]), from_vv, from_len);
@@ -312,7 +495,16 @@ int LM_API(export)(void* c, size_t doc, const uint8_t* from_vv, size_t from_len,
 void LM_API(free_bytes)(uint8_t* p) { free(p); }
 int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   auto* x = (lm_ctx_impl*)c;
-  s->n_docs = x->n_docs; s->n_blobs = 0; s->in_bytes = 0; s->out_bytes = 0;
+  s->n_docs = x->api_docs(); s->n_blobs = 0; s->in_bytes = 0; s->out_bytes = 0;
+  if (x->sh.on) {   // per ENTRY, as for a batch whose entries are documents of their own: its blobs in, its rendering out
+    for (uint32_t i = 0; i < x->sh.n_entries; i++) {
+      lm::Engine& e = *x->parts[x->sh.part_of[i]];
+      uint32_t u = x->sh.uniq_of[i] - x->first[x->sh.part_of[i]];
+      s->n_blobs += e.h_doc_blob[u + 1] - e.h_doc_blob[u];
+      for (uint32_t b = e.h_doc_blob[u]; b < e.h_doc_blob[u + 1]; b++) s->in_bytes += e.h_blob_len[b];
+      if (i < x->sh.res.size()) s->out_bytes += x->sh.res[i].json_len + x->sh.res[i].vv_len;
+    }
+  } else
   for (uint32_t p = 0; p < x->n_parts(); p++) {
     s->n_blobs += x->parts[p]->n_blobs; s->in_bytes += x->parts[p]->in_bytes; s->out_bytes += x->parts[p]->payload_bytes;
   }
@@ -434,6 +626,7 @@ int LM_API(comm_init)(void* c, int rank, int world, const uint8_t* id128) {
 int LM_API(summary_layout)(void* c, int64_t first_id, int64_t stride, size_t rows_padded) {
   auto* x = (lm_ctx_impl*)c;
   try {
+    if (x->sh.on) throw std::runtime_error("lm_summary_layout is not available for a batch that renders shared documents at several versions");
     if (rows_padded < x->n_docs) throw std::runtime_error("lm_summary_layout: fewer rows than staged documents");
     if (x->in_flight) throw std::runtime_error("lm_summary_layout while a run is in flight");
     lm::Engine& e = *x->parts[0];
@@ -482,7 +675,7 @@ long LM_API(summary_allgather)(void* c, const int64_t* doc_ids, int64_t* table, 
     if (!x->ran) throw std::runtime_error("lm_summary_allgather before lm_run");
     lm_comm_state st;
     { std::lock_guard<std::mutex> lk(lm_comms_mu()); auto it = lm_comms().find(c); if (it != lm_comms().end()) st = it->second; }
-    size_t n = x->n_docs;
+    size_t n = x->api_docs();
     std::vector<int64_t> local(n * 6);
     x->for_docs([&](uint32_t i, lm::Engine&, const lm::DocResult& r) {
       int64_t* w = local.data() + (size_t)i * 6;

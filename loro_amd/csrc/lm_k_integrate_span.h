@@ -2014,7 +2014,18 @@ LM_KERNEL void k_res_layout(Dev d, DevRes rs) {
 // After every stage that decides which containers the state store holds (integrate, k_map_lww, k_mlist_post, k_state_roots):
 // a container state, once created, stays (state.rs:621-849 never drops one) — `touched` of a resident document is the OR over
 // all its runs.  One wave per document.
-LM_KERNEL void k_res_exists(Dev d, DevRes rs) {
+// a rendering run of a shared replay reuses the tables of the import run: what the previous rendering's checkout showed must not
+// leak into this one's view of the state store (the containers' `touched` words live in those tables)
+LM_KERNEL void k_cont_untouch(Dev d, uint32_t n_cid) {
+  uint32_t t = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (t < n_cid) d.cont[t].touched = 0;
+}
+LM_KERNEL void k_res_exists(Dev d, DevRes rs, uint32_t mode) {
+  // mode 0: a resident document — OR over all its runs.  Documents staged once for several renderings (lm_capi_impl.h, "shared
+  // replay": entries of one batch that name the same blobs and differ in their checkout): every rendering is import_batch + ONE
+  // checkout of its own, so what the state store holds is what the import created (mode 1: this run IS that import — the verdict is
+  // kept in the record's word 4) plus what this rendering's checkout shows (mode 2: word 4 | this run), never what another
+  // rendering's checkout showed.
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   const DocMeta m = d.doc[doc];
@@ -2024,8 +2035,10 @@ LM_KERNEL void k_res_exists(Dev d, DevRes rs) {
   uint32_t* tk = rs.tk + rd.tk_off;
   for (uint32_t c = (uint32_t)lane; c < m.n_cont; c += 64) {
     uint32_t* rec = tk_cont(tk, rd.pcap, c);
-    uint32_t e = (rec[3] == 1u ? 1u : 0u) | (d.cont[m.cid0 + c].touched ? 1u : 0u);
+    uint32_t t = d.cont[m.cid0 + c].touched ? 1u : 0u;
+    uint32_t e = mode == 1 ? t : ((mode == 2 ? rec[4] == 1u : rec[3] == 1u) ? 1u : 0u) | t;
     rec[3] = e;
+    if (mode == 1) rec[4] = e;
     d.cont[m.cid0 + c].touched = e;
   }
 }

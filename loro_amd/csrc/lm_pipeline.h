@@ -107,6 +107,7 @@ struct Engine {
   // versions reuses the tables as well.
   struct BlobRef { uint64_t off; uint32_t len; };
   bool resident = false;
+  uint32_t shared_mode = 0;                       // lm_capi_impl.h "shared replay": 1 = the run that imports, 2 = a run that renders one checkout of it (k_res_exists)
   std::vector<std::vector<BlobRef>> r_blobs;      // per document: its blobs in import order (arena offsets)
   std::vector<uint32_t> r_step;                   // per document: blobs appended since the last run (dropped again if that run fails for it)
   std::vector<std::vector<uint8_t>> r_front;      // per document: checkout frontiers of the next run (empty = latest)
@@ -560,6 +561,7 @@ struct Engine {
       lmbe::d2d(b_doc.p, b_doc_saved.p, (size_t)n_docs * sizeof(DocMeta));   // the documents' records as they were in front of the checkout
       if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
       lmbe::dmemset(b_ht_cnt.p, 0, (size_t)n_docs * 4 + 4);
+      if (shared_mode == 2 && NCID) LM_LAUNCH(k_cont_untouch, cdiv(NCID, 256), 256, d, NCID);
     } else {
     // 1. envelope / checksum / block count
     b_blob_status.ensure((size_t)n_blobs * 4 + 4);
@@ -1026,7 +1028,7 @@ struct Engine {
     if (h_froot_off.size() > n_docs && h_froot_off[n_docs] > 0) LM_LAUNCH(k_state_roots, n_docs, 64, d);        // documents initialised from a snapshot only
     // documents holding a MovableList only: element → item maxima and the items' elements (loc[] is free from here on)
     if (any_ml) LM_LAUNCH(k_mlist_post, n_docs, 64, d);
-    if (resident) LM_LAUNCH(k_res_exists, n_docs, 64, d, rs);   // the state store keeps what it once held: OR over the document's runs
+    if (resident) LM_LAUNCH(k_res_exists, n_docs, 64, d, rs, shared_mode);   // the state store keeps what it once held: OR over the document's runs
 #ifdef LM_EMU_TRACE
     if (getenv("LM_EMU_DUMP")) {  // kernel-logic harness only: leaves of document 0 in document order
       lmbe::d2h(h_doc.data(), b_doc.p, (size_t)n_docs * sizeof(DocMeta));

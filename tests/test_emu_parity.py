@@ -283,6 +283,64 @@ def test_checkout_versions():
     assert n_ok > 60
 
 
+def _shared_replay_cases():
+    """(docs, frontiers) whose entries share blob objects: every recorded version of random sessions (all container kinds, styles,
+    MovableLists) against ONE list of blobs per session, the latest version among them, versions that differ in which root
+    containers are visible (the state store's view is per rendering), and a document whose import fails."""
+    import _fuzz
+    docs, fronts = _checkout_cases()
+    for s in range(5):
+        snaps = []
+        reps = _fuzz.random_session(4400 + s, n_peers=3, n_steps=90, kinds=("text", "list", "map"), styles=bool(s % 2), snapshots=snaps)
+        full = _fuzz.blobs_of(reps)
+        for fr, _ in snaps[:: max(1, len(snaps) // 12)]:
+            docs.append(full); fronts.append(wire.encode_frontiers(fr))
+        docs.append(full); fronts.append(None)
+        docs.append(full); fronts.append(None)
+    # text visible at an early version only / at a late version only: absent from the renderings where nothing shows
+    r = wire.Replica(7)
+    r.text_insert("early", 0, "abc"); r.commit(); v1 = list(r.frontiers)
+    r.text_delete("early", 0, 3); r.commit(); v2 = list(r.frontiers)
+    r.text_insert("late", 0, "xyz"); r.map_set("m", "k", 1); r.commit(); v3 = list(r.frontiers)
+    r.text_delete("late", 0, 3); r.commit(); v4 = list(r.frontiers)
+    tb = [r.export()]
+    for v in (v1, v3, v2, v4, v1, v2, []):
+        docs.append(tb); fronts.append(wire.encode_frontiers(v))
+    docs.append(tb); fronts.append(None)
+    bad = [tb[0][:-3] + b"\x00\x01\x02"]   # checksum mismatch: every entry of the document fails
+    for v in (v1, v3):
+        docs.append(bad); fronts.append(wire.encode_frontiers(v))
+    return docs, fronts
+
+
+def test_entries_that_share_their_blobs_are_replayed_once(monkeypatch):
+    """lm_stage folds entries with the same blobs into one document (lm_shared_documents), lm_run imports it once and renders every
+    entry by a move of the resident trackers: per entry the result of import_batch + checkout on a document of its own — the
+    oracle's — and what LM_SHARE_REPLAY=0 (one replay per entry) gives."""
+    from loro_amd._cabi import Context
+    docs, fronts = _shared_replay_cases()
+    want = _oracle.merge_batch(docs, frontiers=fronts)
+    with Context(_emu.binding()) as c:
+        c.stage(docs, fronts)
+        n_shared = c.b.shared_documents(c.h)
+        assert 0 < n_shared < len(docs) // 3
+        c.run()
+        got = c.fetch()
+        c.run()                       # every lm_run is the whole job again
+        assert c.fetch() == got
+    monkeypatch.setenv("LM_SHARE_REPLAY", "0")
+    with Context(_emu.binding()) as c:
+        c.stage(docs, fronts)
+        assert c.b.shared_documents(c.h) == 0
+        c.run()
+        plain = c.fetch()
+    for i, (g, p, w) in enumerate(zip(got, plain, want)):
+        if w[0] == 0:
+            assert g == w and p == w, (i, g[:2], p[:2], w[:2])
+        else:
+            assert g[0] == w[0] and p[0] == w[0], (i, g[0], p[0], w[0])
+
+
 def test_snapshot_blobs_are_ingested_through_their_change_store():
     docs, check = _cases.snapshot_cases()
     check(_emu.merge_batch(docs))

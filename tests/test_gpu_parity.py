@@ -538,11 +538,41 @@ def test_config3_full_size_16_peers_10k_writes(engine):
     assert len({g[1] for g in got}) == 8
 
 
-def test_config5_full_size_1m_op_documents_with_16_checkouts(engine):
+def test_entries_that_share_their_blobs_are_replayed_once(engine, monkeypatch):
+    """lm_stage folds entries with the same blobs into one document, lm_run imports it once and renders every entry by a move of the
+    resident trackers (include/loro_merge.h "Shared replay"): per entry the oracle's import_batch + checkout, and the bytes of
+    LM_SHARE_REPLAY=0 (one replay per entry)"""
+    import test_emu_parity
+    docs, fronts = test_emu_parity._shared_replay_cases()
+    docs, fronts = docs * 6, fronts * 6           # (the same list objects again: still one document each)
+    want = _oracle.merge_batch(docs, threads=8, frontiers=fronts)
+    engine.stage(docs, fronts)
+    n_shared = engine.b.shared_documents(engine.h)
+    assert 0 < n_shared < len(docs) // 12
+    engine.run()
+    got = engine.fetch()
+    engine.run()
+    assert engine.fetch() == got
+    monkeypatch.setenv("LM_SHARE_REPLAY", "0")
+    engine.stage(docs, fronts)
+    assert engine.b.shared_documents(engine.h) == 0
+    engine.run()
+    plain = engine.fetch()
+    for i, (g, p, w) in enumerate(zip(got, plain, want)):
+        if w[0] == 0:
+            assert g == w and p == w, (i, g[:2], p[:2], w[:2])
+        else:
+            assert g[0] == w[0] and p[0] == w[0], (i, g[0], p[0], w[0])
+
+
+@pytest.mark.parametrize("share", ["1", "0"])
+def test_config5_full_size_1m_op_documents_with_16_checkouts(engine, monkeypatch, share):
     """BASELINE.json configs[4] at its stated size: 1M-op deep-history rich-text documents (two peers alternating every
     1k trace actions, ~1 % bold marks), each rendered at 16 random versions plus the latest one; 8 distinct documents
-    (136 renderings) bit-exact against the oracle."""
+    (136 renderings) bit-exact against the oracle — as ONE replay per document and 17 renderings of its resident trackers (the
+    entries share their blobs: the default) and with one replay per rendering (LM_SHARE_REPLAY=0)."""
     import multiprocessing
+    monkeypatch.setenv("LM_SHARE_REPLAY", share)
     with multiprocessing.get_context("fork").Pool(8) as pool:
         gens = pool.map(_gen_cfg5, [(d, 1000000) for d in range(8)])
     docs, fronts = [], []
