@@ -107,10 +107,10 @@ int lm_wait(lm_ctx* ctx);
  * pointers and lengths, in the same order — and differ only in checkout_frontiers are ONE document rendered at several versions.
  * lm_stage uploads such a document once; every lm_run imports it once (decode, causal graph, replay from the empty version) and
  * renders each entry by moving the document's trackers to the entry's version, instead of replaying the history once per entry.
- * Results are per entry and are those of import_batch + checkout on a document of its own.  Not available on such a batch:
- * lm_import (stage the documents once and import their checkouts instead), lm_summary_layout.  LM_SHARE_REPLAY=0 in the
- * environment switches the folding off.  lm_shared_documents: the number of documents the batch staged last was folded into
- * (0 = every entry is its own document). */
+ * Results are per entry and are those of import_batch + checkout on a document of its own.  lm_import on such a batch unfolds it
+ * first — every entry becomes a resident document of its own over the bytes already in HBM — and then behaves as always; not
+ * available on it: lm_summary_layout.  LM_SHARE_REPLAY=0 in the environment switches the folding off.  lm_shared_documents: the
+ * number of documents the batch staged last was folded into (0 = every entry is its own document, also after an lm_import). */
 int lm_shared_documents(lm_ctx* ctx);
 
 /* Resident documents: import MORE blobs into the documents the context already holds, and / or render them

@@ -44,6 +44,36 @@ struct lm_ctx_impl {
     std::vector<std::vector<uint8_t>> h_out, h_vv;     // per part, after lm_fetch
   } sh;
   uint32_t api_docs() const { return sh.on ? sh.n_entries : n_docs; }
+  // lm_import on a batch that was staged folded: the documents are unfolded in HBM (Engine::expand — every entry becomes a resident
+  // document of the part that holds its blobs) and the API's document order is no longer a part's contiguous range
+  bool mapped = false;
+  std::vector<std::pair<uint32_t, uint32_t>> emap;   // API document -> (part, document of the part)
+  std::vector<std::vector<uint32_t>> inv;            // part -> its documents' API indices
+  void unfold() {
+    uint32_t np = n_parts();
+    std::vector<std::vector<uint32_t>> src(np);
+    std::vector<std::vector<std::vector<uint8_t>>> fr(np);
+    emap.assign(sh.n_entries, {0u, 0u});
+    inv.assign(np, {});
+    for (uint32_t i = 0; i < sh.n_entries; i++) {
+      uint32_t p = sh.part_of[i];
+      emap[i] = {p, (uint32_t)src[p].size()};
+      inv[p].push_back(i);
+      src[p].push_back(sh.uniq_of[i] - first[p]);
+      fr[p].push_back(sh.fronts[i]);
+    }
+    const bool was_run = ran;
+    for (uint32_t p = 0; p < np; p++) parts[p]->expand(src[p], fr[p]);
+    for (uint32_t p = 0; p < np; p++) first[p + 1] = first[p] + (uint32_t)src[p].size();
+    n_docs = sh.n_entries;
+    sh = Shared();
+    mapped = true;
+    if (was_run) {   // lm_stage; lm_run; lm_import: the staged blobs are the resident documents' first step, an import of its own (lm_pipeline.h import_more)
+      for (uint32_t p = 0; p < np; p++) for (uint32_t i = 0; i < parts[p]->n_docs; i++) parts[p]->r_step[i] = (uint32_t)parts[p]->r_blobs[i].size();
+      run_parts();
+    }
+    ran = false;
+  }
 
   int device = 0;                  // HIP device of this context: every engine (stream, buffers) is created on it
   // lm_summary_layout: the summary rows of this context's documents, written on the device by every run (k_summary_rows)
@@ -129,6 +159,7 @@ struct lm_ctx_impl {
     }
     n_docs = (uint32_t)n;
     ran = false;
+    mapped = false;
     sum_rows_padded = 0;             // (a new batch: lm_summary_layout is called again for it)
     for (auto& pt : parts) pt->sum_rows = nullptr;
     // split into contiguous ranges of about equal blob bytes; small batches stay in one part
@@ -165,7 +196,10 @@ struct lm_ctx_impl {
   }
   // lm_import: more blobs / other checkouts for the documents of the resident batch — each part takes its own documents
   void import_more(const lm::Engine::DocIn* docs, size_t n) {
-    if (sh.on) throw std::runtime_error("lm_import: the staged batch renders shared documents at several versions (entries with the same blobs); stage the documents once and use lm_import for their checkouts instead");
+    if (n != api_docs()) throw std::runtime_error("lm_import: the document count differs from the resident batch");
+    for (size_t i = 0; i < n; i++)
+      if (docs[i].front && docs[i].front_len == 0) throw std::runtime_error("checkout_frontiers with zero length (the empty version is the byte 00)");
+    if (sh.on) unfold();
     import_parts(docs, n);
   }
   void import_parts(const lm::Engine::DocIn* docs, size_t n) {
@@ -173,7 +207,13 @@ struct lm_ctx_impl {
     ran = false;
     uint32_t np2 = n_parts();
     std::vector<std::string> errs(np2);
-    auto body = [&](uint32_t p) { try { parts[p]->import_more(docs + first[p], first[p + 1] - first[p]); } catch (const std::exception& e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "error"; } };
+    std::vector<std::vector<lm::Engine::DocIn>> per;
+    if (mapped) {
+      per.resize(np2);
+      for (uint32_t p = 0; p < np2; p++) per[p].resize(inv[p].size());
+      for (size_t i = 0; i < n; i++) per[emap[i].first][emap[i].second] = docs[i];
+    }
+    auto body = [&](uint32_t p) { try { if (mapped) parts[p]->import_more(per[p].data(), per[p].size()); else parts[p]->import_more(docs + first[p], first[p + 1] - first[p]); } catch (const std::exception& e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "error"; } };
     std::vector<std::thread> th;
 #ifdef LM_PARALLEL_PARTS
     for (uint32_t p = 1; p < np2; p++) th.emplace_back(body, p);
@@ -276,6 +316,7 @@ struct lm_ctx_impl {
   }
   template <class F> void for_docs(F f) {
     if (sh.on) { for (uint32_t i = 0; i < sh.n_entries; i++) f(i, *parts[sh.part_of[i]], sh.res[i]); return; }
+    if (mapped) { for (uint32_t i = 0; i < n_docs; i++) f(i, *parts[emap[i].first], parts[emap[i].first]->results[emap[i].second]); return; }
     for (uint32_t p = 0; p < n_parts(); p++)
       for (uint32_t i = 0; i < parts[p]->n_docs; i++) f(first[p] + i, *parts[p], parts[p]->results[i]);
   }
@@ -323,7 +364,7 @@ int LM_API(import_modes)(void* c, int32_t* modes) {
   for (uint32_t p = 0; p < x->n_parts(); p++) {
     lm::Engine& e = *x->parts[p];
     for (uint32_t i = 0; i < e.n_docs; i++)
-      if ((size_t)(i + 1) * lm::LCA_OUT <= e.h_lca.size()) { uint32_t m = e.h_lca[(size_t)i * lm::LCA_OUT]; modes[x->first[p] + i] = m == lm::DM_UNKNOWN ? -1 : (int32_t)m; }
+      if ((size_t)(i + 1) * lm::LCA_OUT <= e.h_lca.size()) { uint32_t m = e.h_lca[(size_t)i * lm::LCA_OUT]; modes[x->mapped ? x->inv[p][i] : x->first[p] + i] = m == lm::DM_UNKNOWN ? -1 : (int32_t)m; }
   }
   return 0;
 }
@@ -331,11 +372,11 @@ int LM_API(import_modes)(void* c, int32_t* modes) {
 // returns the length, or -1 when unknown / `cap` too small
 long LM_API(import_lca)(void* c, size_t doc, uint8_t* buf, size_t cap) {
   auto* x = (lm_ctx_impl*)c;
-  if (x->sh.on) return -1;
+  if (x->sh.on || doc >= x->n_docs) return -1;
   for (uint32_t p = 0; p < x->n_parts(); p++) {
-    if (doc < x->first[p] || doc >= x->first[p + 1]) continue;
+    if (x->mapped ? x->emap[doc].first != p : (doc < x->first[p] || doc >= x->first[p + 1])) continue;
     lm::Engine& e = *x->parts[p];
-    size_t i = doc - x->first[p];
+    size_t i = x->mapped ? x->emap[doc].second : doc - x->first[p];
     if ((i + 1) * lm::LCA_OUT > e.h_lca.size()) return -1;
     const uint32_t* o = e.h_lca.data() + i * lm::LCA_OUT;
     if (o[0] == lm::DM_UNKNOWN) return -1;
@@ -480,9 +521,10 @@ int LM_API(export)(void* c, size_t doc, const uint8_t* from_vv, size_t from_len,
   try {
     if (!x->ran) throw std::runtime_error("lm_export before lm_run");
     if (x->sh.on) { if (doc >= x->sh.n_entries) throw std::runtime_error("lm_export: no such document"); doc = x->sh.uniq_of[doc]; }
+    if (x->mapped && doc >= x->n_docs) throw std::runtime_error("lm_export: no such document");
     for (uint32_t p = 0; p < x->n_parts(); p++) {
-      if (doc < x->first[p] || doc >= x->first[p + 1]) continue;
-      lmenc::Bytes b = x->parts[p]->export_doc((uint32_t)(doc - x->first[p]), from_vv, from_len);
+      if (x->mapped ? x->emap[doc].first != p : (doc < x->first[p] || doc >= x->first[p + 1])) continue;
+      lmenc::Bytes b = x->parts[p]->export_doc(x->mapped ? x->emap[doc].second : (uint32_t)(doc - x->first[p]), from_vv, from_len);
       *out = (uint8_t*)malloc(b.size() ? b.size() : 1);
       if (!*out) throw std::runtime_error("out of memory");
       memcpy(*out, b.data(), b.size());
@@ -626,7 +668,7 @@ int LM_API(comm_init)(void* c, int rank, int world, const uint8_t* id128) {
 int LM_API(summary_layout)(void* c, int64_t first_id, int64_t stride, size_t rows_padded) {
   auto* x = (lm_ctx_impl*)c;
   try {
-    if (x->sh.on) throw std::runtime_error("lm_summary_layout is not available for a batch that renders shared documents at several versions");
+    if (x->sh.on || x->mapped) throw std::runtime_error("lm_summary_layout is not available for a batch that renders shared documents at several versions");
     if (rows_padded < x->n_docs) throw std::runtime_error("lm_summary_layout: fewer rows than staged documents");
     if (x->in_flight) throw std::runtime_error("lm_summary_layout while a run is in flight");
     lm::Engine& e = *x->parts[0];

@@ -22,6 +22,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t span;              // 1: leaves hold runs (lm_k_integrate_span.h, SP_REC dwords per leaf), 0: one element per slot
   const uint32_t* res_old_blobs;   // resident documents: per document the number of blobs earlier runs already held (nullptr otherwise)
   uint32_t loc_cleared;       // 1: loc[] was set to NONE by a memset in front of the integrate stage (the waves skip their own clear)
+  uint32_t* posdel;           // per document 3 * PD_CAP words: the delete rows the span-granular batch kernels applied by position (lm_k_integrate_span.h ts_del_positional); nullptr = a mismatch is LM_DATA_CORRUPTION
   uint32_t no_linear;         // 1 (LM_LINEAR=0): no linear prefix — every node of a plain document goes through the tracker (lm_k_integrate_linear.h; A/B runs)
   uint32_t res_vis;           // 1: resident documents — the trackers stand at the rendered version, an item shows iff it is active
   const uint8_t* front;       // optional checkout frontiers (postcard Vec<ID>), front_off[n_docs+1]; empty range = latest
@@ -428,6 +429,12 @@ LM_DEV void skip_loro_value(Rd& r, bool& unsupported, int cdepth = -1) {   // (c
   if (vf & VF_UNSUPPORTED) unsupported = true;
 }
 
+// (the lane decoder's verdicts: the first finding stays; the kernel-logic harness names the line, LM_EMU_TRACE)
+#if defined(LM_EMU) && defined(LM_EMU_TRACE)
+#define DEC_ST(code) do { if (!st) { if (getenv("LM_EMU_DEC")) fprintf(stderr, "lm emu: block verdict " #code " at %s:%d\n", __FILE__, __LINE__); st = (code); } } while (0)
+#else
+#define DEC_ST(code) do { st = st ? st : (code); } while (0)
+#endif
 // K4: one lane per block — full decode into the row tables (block-local indices; K6 remaps them).
 // Per-block row statistics both decoders leave in the block's descriptor for k_dag_a (which used to read every op row of the
 // document again just to count them — 10 GB per configs[2] batch): BlockDesc.flags = rows that compete in the LWW table (Map
@@ -540,7 +547,7 @@ LM_KERNEL void k_block_decode(Dev d) {
     RleCur mc = rle_make(m);
     uint64_t tot = 0;
     for (uint32_t i = 0; i < N; i++) tot += rle_next_uvar(mc);
-    if (mc.r.bad || tot > rd_left(mc.r)) st = st ? st : ST_DATA_CORRUPTION;
+    if (mc.r.bad || tot > rd_left(mc.r)) DEC_ST(ST_DATA_CORRUPTION);
   }
   // ---- keys
   {
@@ -564,8 +571,8 @@ LM_KERNEL void k_block_decode(Dev d) {
       int64_t koc = rd_zigzag(k);
       if (fields != 4) st = st ? st : ST_DECODE_ERROR;
       uint32_t* w = d.cid_raw + (uint64_t)(cid0 + i) * 4;
-      if (is_root) { if (koc < 0 || (uint64_t)koc >= n_keys) { st = st ? st : ST_DATA_CORRUPTION; koc = 0; } }
-      else { if (pidx >= n_peers) { st = st ? st : ST_DATA_CORRUPTION; pidx = 0; } if (koc < 0 || koc >= (int64_t)MAX_COUNTER) { st = st ? st : ST_UNSUPPORTED; koc = 0; } }
+      if (is_root) { if (koc < 0 || (uint64_t)koc >= n_keys) { DEC_ST(ST_DATA_CORRUPTION); koc = 0; } }
+      else { if (pidx >= n_peers) { DEC_ST(ST_DATA_CORRUPTION); pidx = 0; } if (koc < 0 || koc >= (int64_t)MAX_COUNTER) { st = st ? st : ST_UNSUPPORTED; koc = 0; } }
       w[0] = kind | (is_root ? 0x100u : 0u);
       w[1] = (uint32_t)pidx;
       w[2] = (uint32_t)koc;
@@ -616,7 +623,7 @@ LM_KERNEL void k_block_decode(Dev d) {
       int64_t prop = rle_next_delta(c_prop);
       uint32_t vt = rle_next_u8(c_vt) & 0x7f;
       uint64_t len = rle_next_uvar(c_len);
-      if (ci < 0 || (uint64_t)ci >= n_cids) { st = st ? st : ST_DATA_CORRUPTION; ci = 0; }
+      if (ci < 0 || (uint64_t)ci >= n_cids) { DEC_ST(ST_DATA_CORRUPTION); ci = 0; }
       if (prop < INT32_MIN || prop > INT32_MAX) { st = st ? st : ST_DECODE_ERROR; prop = 0; }
       uint32_t ckind = n_cids ? (d.cid_raw[(uint64_t)(cid0 + (uint32_t)ci) * 4] & 0xff) : 0xff;
       OpRow r;
@@ -658,7 +665,7 @@ LM_KERNEL void k_block_decode(Dev d) {
           (void)rd_u8(v);
           mark_len = (uint32_t)rd_uleb(v);
           uint64_t key_idx = rd_uleb(v);
-          if (key_idx >= n_keys) st = st ? st : ST_DATA_CORRUPTION;
+          if (key_idx >= n_keys) DEC_ST(ST_DATA_CORRUPTION);
           uint32_t u = 0;
           skip_loro_value(v, u, -1);
           vfl |= u & VF_CORRUPT;
@@ -684,7 +691,7 @@ LM_KERNEL void k_block_decode(Dev d) {
         default: { uint64_t l = rd_uleb(v); rd_skip(v, l); break; }
       }
       if (vfl & VF_UNSUPPORTED) unsupported = true;
-      if (vfl & VF_CORRUPT) st = st ? st : ST_DATA_CORRUPTION;
+      if (vfl & VF_CORRUPT) DEC_ST(ST_DATA_CORRUPTION);
       // decode_op mapping (outdated_encode_reordered.rs:215-476)
       bool take_del = false;
       if (ckind == CK_TEXT) {
@@ -692,34 +699,34 @@ LM_KERNEL void k_block_decode(Dev d) {
         else if (vt == 9) { kind = OK_DEL; take_del = true; }
         else if (vt == 12) { kind = OK_STYLE_START; r.a0 = mark_len; }
         else if (vt == 0) kind = OK_STYLE_END;
-        else st = st ? st : ST_DATA_CORRUPTION;
+        else DEC_ST(ST_DATA_CORRUPTION);
       } else if (ckind == CK_MAP) {
-        if (prop < 0 || (uint64_t)prop >= n_keys) st = st ? st : ST_DATA_CORRUPTION;
+        if (prop < 0 || (uint64_t)prop >= n_keys) DEC_ST(ST_DATA_CORRUPTION);
         if (vt == 8) kind = OK_MAP_DEL;
         else if (vt == 11) kind = OK_MAP_SET;
-        else st = st ? st : ST_DATA_CORRUPTION;
+        else DEC_ST(ST_DATA_CORRUPTION);
       } else if (ckind == CK_LIST) {
-        if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else st = st ? st : ST_DATA_CORRUPTION; }
+        if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else DEC_ST(ST_DATA_CORRUPTION); }
         else if (vt == 9) { kind = OK_DEL; take_del = true; }
-        else st = st ? st : ST_DATA_CORRUPTION;
+        else DEC_ST(ST_DATA_CORRUPTION);
       } else if (ckind == CK_MOVABLE) {   // outdated_encode_reordered.rs:388-459
-        if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else st = st ? st : ST_DATA_CORRUPTION; }
+        if (vt == 11) { if (is_list_value) kind = OK_LIST_INS; else DEC_ST(ST_DATA_CORRUPTION); }
         else if (vt == 9) { kind = OK_DEL; take_del = true; }
         else if (vt == 14 || vt == 15) {
           kind = vt == 14 ? OK_LIST_MOVE : OK_LIST_SET;
-          if (mv_peer >= n_peers || mv_lam > 0xFFFFFFFFull || mv_from > 0x7FFFFFFFull || prop < 0 || len != 1) { st = st ? st : ST_DATA_CORRUPTION; mv_peer = 0; }
+          if (mv_peer >= n_peers || mv_lam > 0xFFFFFFFFull || mv_from > 0x7FFFFFFFull || prop < 0 || len != 1) { DEC_ST(ST_DATA_CORRUPTION); mv_peer = 0; }
           r.a0 = (uint32_t)mv_peer; r.a1 = (uint32_t)mv_lam; r.a2 = (int32_t)(uint32_t)mv_from;
-        } else st = st ? st : ST_DATA_CORRUPTION;
+        } else DEC_ST(ST_DATA_CORRUPTION);
       }
       if (take_del) {
-        if (!has_del) st = st ? st : ST_DATA_CORRUPTION;
+        if (!has_del) DEC_ST(ST_DATA_CORRUPTION);
         else {
           int64_t dp = rle_next_delta(d_peer), dctr = rle_next_delta(d_ctr), dl = rle_next_delta(d_len);
-          if (dp < 0 || (uint64_t)dp >= n_peers) { st = st ? st : ST_DATA_CORRUPTION; dp = 0; }
-          if (dl == 0 || dl > (int64_t)MAX_COUNTER || dl < -(int64_t)MAX_COUNTER) { st = st ? st : ST_DATA_CORRUPTION; dl = 1; }
-          if (dctr < 0 || dctr >= (int64_t)MAX_COUNTER) { st = st ? st : ST_DATA_CORRUPTION; dctr = 0; }
+          if (dp < 0 || (uint64_t)dp >= n_peers) { DEC_ST(ST_DATA_CORRUPTION); dp = 0; }
+          if (dl == 0 || dl > (int64_t)MAX_COUNTER || dl < -(int64_t)MAX_COUNTER) { DEC_ST(ST_DATA_CORRUPTION); dl = 1; }
+          if (dctr < 0 || dctr >= (int64_t)MAX_COUNTER) { DEC_ST(ST_DATA_CORRUPTION); dctr = 0; }
           r.a0 = (uint32_t)dp; r.a1 = (uint32_t)dctr; r.a2 = (int32_t)dl;
-          if (d_peer.r.bad || d_ctr.r.bad || d_len.r.bad) st = st ? st : ST_DATA_CORRUPTION;
+          if (d_peer.r.bad || d_ctr.r.bad || d_len.r.bad) DEC_ST(ST_DATA_CORRUPTION);
         }
       }
       r.cidx_kind |= (kind << 16) | ((nested && (vt != 12 || kind == OK_STYLE_START)) ? OPF_NESTED : 0u);
@@ -729,9 +736,9 @@ LM_KERNEL void k_block_decode(Dev d) {
       d.op_blk[op0 + row] = bi;
       counter += len;
       if (counter > MAX_COUNTER) { st = st ? st : ST_UNSUPPORTED; counter = MAX_COUNTER; }
-      if (change_index >= N) { st = st ? st : ST_DATA_CORRUPTION; change_index = N - 1; }
+      if (change_index >= N) { DEC_ST(ST_DATA_CORRUPTION); change_index = N - 1; }
       d.chg[chg0 + change_index].n_op++;
-      if (counter > next_boundary && change_index + 1 < N) st = st ? st : ST_DATA_CORRUPTION;   // an op crosses a change boundary (docs/encoding.md §10.6)
+      if (counter > next_boundary && change_index + 1 < N) DEC_ST(ST_DATA_CORRUPTION);   // an op crosses a change boundary (docs/encoding.md §10.6)
       if (counter >= next_boundary && change_index + 1 < N) {
         change_index++;
         d.chg[chg0 + change_index].op0 = op0 + row + 1;
@@ -741,7 +748,7 @@ LM_KERNEL void k_block_decode(Dev d) {
     // changes that received no rows still need a valid op0
     for (uint32_t i = 1; i < N; i++) if (d.chg[chg0 + i].n_op == 0) d.chg[chg0 + i].op0 = op0 + n_ops;
     if (c_cont.r.bad || c_prop.r.bad || c_vt.r.bad || c_len.r.bad || v.bad) st = st ? st : ST_DECODE_ERROR;
-    if (counter != (uint64_t)bd.counter_start + bd.counter_len) st = st ? st : ST_DATA_CORRUPTION;
+    if (counter != (uint64_t)bd.counter_start + bd.counter_len) DEC_ST(ST_DATA_CORRUPTION);
   }
   if (st == ST_OK && unsupported) st = ST_UNSUPPORTED;
   d.blk[bi].status = st;

@@ -172,8 +172,9 @@ LM_DEV void tl_insert(Ts& t, Tl& c, uint32_t pos, uint32_t pid0, uint32_t len) {
   }
 }
 // delete of the Ln elements from position pos0 (0-based) on; the row names them as ids [x0, x0 + Ln), ascending with the position
-// (list_op.rs:288-379; the decoders normalise a backward span to its leftmost target).  The reference deletes by position
-// (crdt_rope.rs:256-335); a row whose ids are not the ones at its position is LM_DATA_CORRUPTION, as in ts_del_pos_ok.
+// (list_op.rs:288-379; the decoders normalise a backward span to its leftmost target).  The reference deletes by position and never
+// looks at the ids while it does (crdt_rope.rs:256-335) — so does the prefix: nothing here is ever retreated, what a damaged row
+// names instead of the elements at its position is of no consequence (the tracker behind the prefix: ts_del_positional).
 LM_DEV void tl_delete(Ts& t, Tl& c, uint32_t pos0, uint32_t Ln, uint32_t x0, bool& emptied) {
   uint32_t lane = (uint32_t)lmw::lane();
   if (pos0 > t.tot_active || Ln > t.tot_active - pos0) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
@@ -190,7 +191,6 @@ LM_DEV void tl_delete(Ts& t, Tl& c, uint32_t pos0, uint32_t Ln, uint32_t x0, boo
     uint32_t inc = lmw::scan_incl_add(c.len), start = inc - c.len;
     uint32_t lo = start > s ? start : s, hi = inc < e ? inc : e;
     bool has = hi > lo;
-    bool bad = has & (c.id + (lo - start) != x0 + (lo - s));
     uint64_t mid = lmw::ballot(has & (lo > start) & (hi < inc));
     uint32_t cut = has ? hi - lo : 0u;
     if (mid) {
@@ -217,9 +217,8 @@ LM_DEV void tl_delete(Ts& t, Tl& c, uint32_t pos0, uint32_t Ln, uint32_t x0, boo
         emptied |= c.n == 0;
       }
     }
-    if (lmw::any(bad)) LM_SETERR(t.err, ST_DATA_CORRUPTION);
     c.tot -= take; c.dirty = true;
-    x0 += take; Ln -= take;
+    (void)x0; Ln -= take;
   } while (Ln > 0 && !t.err);
 }
 // the prefix is done: everything goes back to HBM / LDS in the tracker's form; leaves that lost every item leave the directory

@@ -49,6 +49,21 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   mutable uint64_t prof[PF_N];
 #endif
 };
+// internal verdict of a delete row whose target ids are not the elements at its position: the row loop applies the rest of the row
+// BY POSITION, as the reference applies every delete (crdt_rope.rs:256-335), and remembers what it deleted for later retreats
+static constexpr int32_t ST_POSDEL = 101;
+static constexpr uint32_t PD_CAP = 63;   // pieces per document (3 words each; one lane per piece when the list is searched)
+// The bookkeeping of positional deletes lives in eight LDS words in front of the peer tables (t.ebase - PD_LDS .. t.ebase) and in the
+// document's list in HBM — NOT in the wave-uniform context: the kernel sits at its SGPR limit, seven more live scalars cost the
+// replay of every healthy document 3 % (profiles/r05_posdel_ab.log).  [0] position where the row stopped matching  [1] ids left
+// [2] first id of the row  [3] ids that matched  [4] pieces in the list  [5,6] the list (pointer; 0 = positional deletes are off)
+static constexpr uint32_t PD_LDS = 8;
+LM_DEV uint32_t* pd_w(const Ts& t) { return const_cast<uint32_t*>(t.ebase) - PD_LDS; }
+template <bool POS>
+LM_DEV void pd_stop(Ts& t, uint32_t k, uint32_t left, uint32_t first, uint32_t matched) {   // (cold: a delete row that does not match its position)
+  t.err = ST_POSDEL;   // (every kernel but k_integrate_span_pos: the document leaves with this verdict and is replayed by that kernel)
+  if (POS && lmw::lane() == 0) { uint32_t* w = pd_w(t); w[0] = k; w[1] = left; w[2] = first; w[3] = matched; }
+}
 
 LM_DEV uint32_t ts_g(const Ts& t, uint32_t pid) { return t.ebase[pid_peer(pid)] + pid_ctr(pid); }
 LM_DEV bool sp_has(uint32_t id0, uint32_t len, uint32_t x) { return x >= id0 && x - id0 < len; }   // element x inside the run (same peer implied)
@@ -503,11 +518,20 @@ LM_DEV bool ts_insert_fast(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   return true;
 }
 
+// An insert whose position lies beyond the active length (a damaged row: no writer emits one).  The reference's position query
+// comes back with the END of the rope (crdt_rope.rs:83 `query::<ActiveLenQueryPreferLeft>`, "missing": behind the last element
+// whatever its status) — behind whatever concurrent branches its iteration happened to replay before, which depends on a hash map
+// (dag/iter.rs:268-274): such a row has no value that is independent of the replay order.  LM_DATA_CORRUPTION, not a guess.  (The
+// linear prefix — nothing concurrent exists there — keeps the clamp: the end of the rope is the end of the text.)
 // ---- insert (Fugue integrate, crdt_rope.rs:63-247) of run [pid0, pid0+len) at active position pos
+template <bool POS = false>
 LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   int lane = lmw::lane();
   PROF_T0();
   PROF_CNT(t, PF_NINS, 1);
+  // (POS: the kernel that replays damaged documents rejects the row — see above; the others clamp it as they always did: the check
+  // was measured at 2 % of the replay of healthy documents, an exit edge in front of the in-leaf path)
+  if (POS && pos > t.tot_active) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
   if (pos > t.tot_active) pos = t.tot_active;
   t.n_alive += len;
   if (ts_insert_fast(t, pos, pid0, len)) { PROF_ADD(t, PF_PLACE); PROF_CNT(t, PF_LEAF, 1u << 20); return; }
@@ -730,6 +754,7 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
 
 // ---- the common status update, instruction-lean: the run holding element (peer, c) sits in the cached leaf, which has room
 // for a cut; the run (or its part inside [c, c1)) gets the new status, c advances.  false = general path.
+template <bool POS = false>
 LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int mode, uint32_t hint_k = 0) {
   if (t.cr.n > 62) return false;   // (no cached leaf: n = 255)
   int lane = lmw::lane();
@@ -750,9 +775,9 @@ LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int m
 #if defined(LM_NO_DEL_CHECK)
   (void)hint_k;
 #elif defined(LM_DEL_CHECK_LIGHT)
-  if (hint_k && t.cache_pre != NONE && !ts_del_pos_ok(t, t.cr, slot, s_off, st0, hint_k)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); c = c1; return true; }
+  if (hint_k && t.cache_pre != NONE && !ts_del_pos_ok(t, t.cr, slot, s_off, st0, hint_k)) { pd_stop<POS>(t, hint_k, c1 - c, NONE, c); c = c1; return true; }
 #else
-  if (hint_k && !ts_del_pos_ok(t, t.cr, slot, s_off, st0, hint_k)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); c = c1; return true; }
+  if (hint_k && !ts_del_pos_ok(t, t.cr, slot, s_off, st0, hint_k)) { pd_stop<POS>(t, hint_k, c1 - c, NONE, c); c = c1; return true; }
 #endif
   if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= mid;
   if ((s_off | tail) == 0) {
@@ -789,6 +814,7 @@ LM_DEV bool ts_update_fast(Ts& t, uint32_t peer, uint32_t& c, uint32_t c1, int m
 // ---- status update of the elements with ids [c0,c1) of `peer` (crdt_rope.rs:345-381 by id): walk run by run
 // hint_k != 0: the first target is the hint_k-th active element (1-based) of the tracker's current version — a delete row
 // carries its position — so the leaf is found through the LDS directory and only verified by id; loc[] is the fallback
+template <bool POS = false>
 LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int mode, uint32_t hint_k = 0) {
   int lane = lmw::lane();
   uint32_t c = c0;
@@ -797,17 +823,21 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   // the whole cached leaf through its phi nodes — 70 instructions per row, most of them register moves)
   if (c >= c1) return;
   bool tried = true;   // the in-leaf path has just declined this very element
-  if (ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); if (c >= c1) return; tried = false; }
+  if (ts_update_fast<POS>(t, peer, c, c1, mode, hint_k)) {
+    PROF_CNT(t, PF_LEAF, 1);
+    if (c >= c1) { if (POS && t.err == ST_POSDEL && lmw::lane() == 0) { uint32_t* w = pd_w(t); w[2] = pid_make(peer, c0); w[3] -= c0; } return; }   // (the in-leaf path leaves the counter it stopped at in word 3)
+    tried = false;
+  }
   uint32_t eb = t.ebase[peer];
   if (c1 > t.end[peer]) {   // a damaged target range cannot make the walk longer than the peer's history
     // a delete row whose targets lie beyond what its peer has inserted (a damaged peer table, ...): the reference deletes whatever sits
     // at the row's position (crdt_rope.rs:256-335) — not a value this engine reproduces (see ts_del_pos_ok)
-    if (hint_k) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+    if (hint_k) { pd_stop<POS>(t, hint_k, c1 - c, pid_make(peer, c0), c - c0); return; }
     c1 = t.end[peer];
   }
   for (uint32_t guard = 0; c < c1 && !t.err && guard < (1u << 26); guard++) {
     lmw::wave_sync();
-    if (!tried && ts_update_fast(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); continue; }
+    if (!tried && ts_update_fast<POS>(t, peer, c, c1, mode, hint_k)) { PROF_CNT(t, PF_LEAF, 1); if (POS && t.err == ST_POSDEL && lmw::lane() == 0) { uint32_t* w = pd_w(t); w[2] = pid_make(peer, c0); w[3] -= c0; } continue; }
     tried = false;
     uint32_t x = pid_make(peer, c);
     uint32_t p;
@@ -829,7 +859,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
       }
     }
     if (!hm) {
-      if (hint_k) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }   // the element at the row's position is not the row's target (see ts_del_pos_ok)
+      if (hint_k) { pd_stop<POS>(t, hint_k, c1 - c, pid_make(peer, c0), c - c0); return; }   // the element at the row's position is not the row's target (see ts_del_pos_ok)
 #ifdef LM_LOC16
       uint32_t lf = ts_loc_find(t, x);
 #else
@@ -863,7 +893,7 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     uint32_t endc = pid_ctr(id0) + ln < c1 ? pid_ctr(id0) + ln : c1;
     uint32_t tail = pid_ctr(id0) + ln - endc;                   // elements of the run beyond the range
 #ifndef LM_NO_DEL_CHECK
-    if (hint_k && !ts_del_pos_ok(t, R, slot, s_off, st0, hint_k)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+    if (hint_k && !ts_del_pos_ok(t, R, slot, s_off, st0, hint_k)) { pd_stop<POS>(t, hint_k, c1 - c, pid_make(peer, c0), c - c0); return; }
 #endif
     if (mode == UPD_DEL_INC && !(st0 & ST_EVER)) t.n_alive -= endc - c;
     lmw::wave_sync();
@@ -893,6 +923,80 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
     }
     c = endc;
   }
+}
+
+// ---- a delete row applied BY POSITION (crdt_rope.rs:256-335: the reference never looks at a delete's target ids while it applies
+// it — it removes the `len` active elements from the row's position on and remembers their ids for later retreats / forwards,
+// tracker.rs:193-252).  Every writer's rows name exactly those elements, and the replay applies rows by id and only compares; a
+// DAMAGED row (a flipped byte in a peer table, a target span that is off) still has a value in the reference, which this gives: the
+// part of the row that matched (n_match ids from `first` on, pieces verified at the position) stays as it is, the pd_n elements
+// that follow at position pd_k are deleted whatever their ids, and all pieces go into the document's list (row, id, length), which
+// ts_move_ops consults instead of the row's own target span.  Cold: the row loop comes here only on ST_POSDEL.
+LM_DEV void ts_del_positional(Ts& t, uint32_t row) {
+  int lane = lmw::lane();
+  t.err = 0;
+  lmw::wave_sync();
+  uint32_t* w = pd_w(t);
+  const uint32_t k0 = lmw::first(w[0]), first = lmw::first(w[2]), n_match = lmw::first(w[3]);
+  uint32_t n = lmw::first(w[1]), n_pos = lmw::first(w[4]);
+  uint32_t* pos_list = (uint32_t*)(uintptr_t)(((uint64_t)lmw::first(w[6]) << 32) | lmw::first(w[5]));
+  if (!pos_list) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+  if (n_match) {
+    if (n_pos >= PD_CAP) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+    if (lane == 0) { pos_list[3 * n_pos] = row; pos_list[3 * n_pos + 1] = first; pos_list[3 * n_pos + 2] = n_match; }
+    n_pos++;
+  }
+  for (uint32_t guard = 0; n > 0 && !t.err && guard < (1u << 24); guard++) {
+    if (k0 > t.tot_active) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }   // delete beyond the end: the reference's query fails
+    uint32_t k = k0;
+    uint32_t p = sd_find_kth(t, k);
+    if (p == NONE) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    lmw::wave_sync();
+    uint32_t a = lmw::first(t.da[p]);
+    SpanRegs R = sp_load(t, sa_leaf(a), sa_n(a));
+    uint32_t al = sp_alen(R);
+    uint32_t inc = lmw::scan_incl_add(al);
+    uint64_t hit = lmw::ballot((al != 0) & (inc >= k));
+    if (!hit) { LM_SETERR(t.err, ST_INTERNAL); return; }
+    int slot = lmw::ffs64(hit);
+    uint32_t off = k - (lmw::bcast(inc, slot) - lmw::bcast(al, slot)) - 1;   // 0-based offset of the k-th active element inside its item
+    uint32_t id0 = lmw::bcast(R.id, slot), ln = lmw::bcast(R.len, slot);
+    uint32_t piece = ln - off < n ? ln - off : n;
+    uint32_t x = id0 + off;
+    if (n_pos >= PD_CAP) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+    if (lane == 0) { pos_list[3 * n_pos] = row; pos_list[3 * n_pos + 1] = x; pos_list[3 * n_pos + 2] = piece; w[4] = n_pos + 1; }
+    n_pos++;
+#ifdef LM_EMU_TRACE
+    if (getenv("LM_EMU_BASE") && lane == 0) fprintf(stderr, "POSDEL row %u: position %u, %u left, matched %u from %u:%u; piece %u:%u+%u\n", row, k0, n, n_match, first >> 24, first & 0xffffff, x >> 24, x & 0xffffff, piece);
+#endif
+    // the leaf becomes the cached leaf: the by-id update below then finds the item without loc[] (a plain replay may not keep it yet)
+    sp_take(t, sa_leaf(a)); t.cache_p = p; t.cache_pre = k0 - k; t.cr = R;
+    ts_update_range(t, pid_peer(x), pid_ctr(x), pid_ctr(x) + piece, UPD_DEL_INC);
+    n -= piece;
+  }
+  if (lane == 0) w[4] = n_pos;
+  lmw::mem_fence();
+  lmw::wave_sync();
+}
+// the pieces of a row that was applied by position (ts_move_ops: retreat / forward of a delete row); false = not such a row
+LM_DEV bool ts_move_positional(Ts& t, uint32_t row, bool whole, int mode) {
+  lmw::wave_sync();
+  const uint32_t* w = pd_w(t);
+  const uint32_t n_pos = lmw::first(w[4]);
+  if (!n_pos) return false;
+  const uint32_t* pos_list = (const uint32_t*)(uintptr_t)(((uint64_t)lmw::first(w[6]) << 32) | lmw::first(w[5]));
+  uint32_t lane = (uint32_t)lmw::lane();
+  uint64_t pm = lmw::ballot(lane < n_pos && pos_list[3 * lane] == row);
+  if (!pm) return false;
+  // (a version that ends inside such a row would need the op-offset → piece mapping of tracker.rs:193-252; not reproduced)
+  if (!whole) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return true; }
+  while (pm && !t.err) {
+    int j = lmw::ffs64(pm);
+    pm &= pm - 1;
+    uint32_t x = lmw::first(pos_list[3 * j + 1]), ln = lmw::first(pos_list[3 * j + 2]);
+    ts_update_range(t, pid_peer(x), pid_ctr(x), pid_ctr(x) + ln, mode);
+  }
+  return true;
 }
 
 // ---- op rows are read eight at a time: one 256-byte wave load per window (lane = dword of the window), and the next
@@ -943,7 +1047,7 @@ LM_DEV uint32_t ts_active_id_at(Ts& t, uint32_t pos) {
 // SWEEP (k_integrate_span_plain_sweep, the default kernel of DF_PLAIN documents; LM_PLAIN=1 / 0 switch it off): a long range toggles the future flag of its INSERT rows'
 // items in one pass over the leaves — every item of `peer` with ids inside [c0,c1) belongs to an insert row of this container —
 // instead of one by-id update per row; the runs straddling c0 / c1 are cut first by two single-element updates.
-template <bool ML, bool SWEEP>
+template <bool ML, bool SWEEP, bool POS = false>
 LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t peer, uint32_t c0, uint32_t c1, int dir) {
   uint32_t ci = find_change(d, m, peer, c0);
   if (ci == NONE) return;
@@ -1014,7 +1118,8 @@ LM_DEV void ts_move_ops(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, ui
           uint32_t t0, t1;
           if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
           else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }
-          ts_update_range(t, r.a0, t0, t1, dir < 0 ? UPD_DEL_DEC : UPD_DEL_INC);
+          if (!POS || !ts_move_positional(t, row, a == 0 && b == r.len, dir < 0 ? UPD_DEL_DEC : UPD_DEL_INC))
+            ts_update_range(t, r.a0, t0, t1, dir < 0 ? UPD_DEL_DEC : UPD_DEL_INC);
         }
         if (!ML || mv_tgt == NONE || pid_peer(mv_tgt) >= m.n_peers) break;
         r.a0 = pid_peer(mv_tgt); r.a1 = pid_ctr(mv_tgt); r.a2 = 1; kind = OK_DEL; mv_tgt = NONE;   // (a, b) = (0, 1)
@@ -1253,7 +1358,7 @@ LM_DEV bool ts_sweep_pays_batch(const Ts& t, const Dev& d, const DocMeta& m, uin
 #ifndef LM_BATCH_VSWEEP
 #define LM_BATCH_VSWEEP 0   // 1: the common batch kernel moves its tracker by version passes when ts_sweep_pays_batch says so — measured on configs[3] (profiles/r04_batch_version_sweep.log): -9 % of the kernel at best, a slower step (52 B of scratch instead of 24); kept for the test build
 #endif
-template <bool ML, bool SWEEP, bool VS>
+template <bool ML, bool SWEEP, bool VS, bool POS = false>
 LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t P, const uint32_t* vv, uint32_t* s_cur, uint32_t* s_base,
                     bool& base_on, bool conv, uint32_t* loc_real, uint32_t* dcnt_real) {
   int lane = lmw::lane();
@@ -1284,8 +1389,8 @@ LM_DEV void ts_goto(Ts& t, const Dev& d, const DocMeta& m, uint32_t cidx, uint32
   else
     for (uint32_t p = 0; p < P && !t.err; p++) {
       uint32_t cur = s_cur[p], tgt = vv[p];
-      if (cur > tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, tgt, cur, -1);
-      else if (cur < tgt) ts_move_ops<ML, SWEEP>(t, d, m, cidx, p, cur, tgt, +1);
+      if (cur > tgt) ts_move_ops<ML, SWEEP, POS>(t, d, m, cidx, p, tgt, cur, -1);
+      else if (cur < tgt) ts_move_ops<ML, SWEEP, POS>(t, d, m, cidx, p, cur, tgt, +1);
     }
   lmw::block_sync();
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_cur[p] = vv[p]; if (conv) s_base[p] = vv[p]; }
@@ -1402,7 +1507,11 @@ LM_DEV uint32_t* tk_cont(uint32_t* tk, uint32_t pcap, uint32_t c) { return tk + 
 // PLAIN = true (k_integrate_span_plain_sweep by default, k_integrate_span_plain under LM_PLAIN=1; LM_PLAIN=0 = common kernel): the
 // documents flagged DF_PLAIN — no checkout, no sliced change, no style anchor — whose row loop needs neither the slicing of a row
 // against the known prefix / the rendered version nor the style branches.
-template <bool ML, bool PLAIN, bool SWEEP = false, bool RES = false, bool FUSE = false>
+// POS (k_integrate_span_pos): the replay of the documents an earlier launch left with ST_POSDEL — a delete row that does not match
+// its position — with ts_del_positional / ts_move_positional compiled in.  A kernel of its own: inlined into the other
+// instantiations, the two routines' copies of ts_update_range grew every kernel by a sixth and cost the replay of HEALTHY documents
+// 15 % through the instruction cache (profiles/r05_posdel_ab.log: 7.8 -> 9.0 ms per 5,000 configs[1] documents).
+template <bool ML, bool PLAIN, bool SWEEP = false, bool RES = false, bool FUSE = false, bool POS = false>
 LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
                                 const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
@@ -1413,7 +1522,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   uint32_t* s_da = s_mem;
   uint32_t* s_db = s_mem + dir_cap;
   uint32_t* s_ds = s_db + dir_cap;                 // block sums
-  uint32_t* s_ebase = s_ds + ((dir_cap >> SD_BSH) + 2);
+  uint32_t* s_ebase = s_ds + ((dir_cap >> SD_BSH) + 2) + PD_LDS;   // (PD_LDS words of positional-delete bookkeeping in front of the peer tables)
   uint32_t* s_cur = s_ebase + pmax;
   uint32_t* s_end = s_cur + pmax;
   uint32_t* s_tgt = s_end + pmax;    // RES only: the version being rendered (s_end is the latest applied version there)
@@ -1430,11 +1539,11 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   {
     uint32_t fl = m.flags;
     if (RES && (fl & DF_PLAIN) && d.front_off[doc + 1] > d.front_off[doc]) fl &= ~DF_PLAIN;   // resident, rendered at a checked-out version: the general instantiation's
-    if ((fl & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
+    if (POS ? (fl & DF_MOVABLE) != 0 : (fl & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
     if (PLAIN && !RES && ((fl & DF_FUSED) != 0 && d.fuse != nullptr) != FUSE) return;                      // (k_integrate_span_plain_fuse's / the plain kernel's)
   }
   (void)SWEEP;
-  if (retry_pass && m.status != ST_RETRY) return;
+  if (retry_pass && m.status != (POS ? ST_POSDEL : ST_RETRY)) return;
   if (status_fatal(m.status) && !retry_pass) return;
   // RES: the element layout is the stored tracker's (k_res_layout) — loc[] is kept, only the slots new to this run are cleared
   const bool keep_loc = RES && !ML && !retry_pass && (m.flags & DF_LAYOUT_SAME) != 0;
@@ -1515,6 +1624,11 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   t.ebase = s_ebase; t.cur = s_cur; t.end = s_end; t.da = s_da; t.db = s_db; t.ds = s_ds; t.ds_on = false;
   t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0;
   t.n_alive = 0;
+  if (lane == 0) {   // (resident trackers keep the by-id verdict — LM_DATA_CORRUPTION: their lists would have to outlive the run)
+    uint64_t pl = (!POS || !d.posdel) ? 0ull : (uint64_t)(uintptr_t)(d.posdel + (uint64_t)doc * (3 * PD_CAP));
+    uint32_t* w = s_ebase - PD_LDS;
+    w[0] = w[1] = w[2] = w[3] = w[4] = 0; w[5] = (uint32_t)pl; w[6] = (uint32_t)(pl >> 32);
+  }
 #ifdef LM_PROF
   for (int i = 0; i < PF_N; i++) t.prof[i] = 0;
   uint64_t pf_begin = lmw::clock();
@@ -1697,12 +1811,15 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
           // carries no test for it (7 instructions per op row, 4 of them register moves in front of the branch)
           checked_out = true;
-          ts_goto<ML, SWEEP, false>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0, nullptr);
+          ts_goto<ML, SWEEP, false, POS>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0, nullptr);
           PROF_ADD(t, PF_CHECKOUT);
           TS_CHECK("checkout", ch.op0);
         }
-        for (uint32_t row = ch.op0; row < ch.op0 + n_rows && !t.err; row++) {
+        uint32_t row0 = ch.op0, last_row = 0;   // (POS only: where the row loop is entered again behind a row that was finished by position)
+      rows_again:
+        for (uint32_t row = row0; row < ch.op0 + n_rows && !t.err; row++) {
           PROF_T0();
+          if (POS) last_row = row;
           OpRow r = rw_get(w, op_w, row);
           if ((r.cidx_kind & 0xffff) != cidx) continue;
           if (FUSE) {
@@ -1725,7 +1842,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           uint32_t b = PLAIN ? r.len : (r.ctr + r.len <= pe ? r.len : pe - r.ctr);
           if (!(PLAIN && !RES) && !checked_out) {
             checked_out = true;
-            if (!RES) ts_goto<ML, SWEEP, (!ML && !PLAIN && !RES && LM_BATCH_VSWEEP)>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0, d.dcnt ? d.dcnt + elem0 : nullptr);
+            if (!RES) ts_goto<ML, SWEEP, (!ML && !PLAIN && !RES && !POS && LM_BATCH_VSWEEP), POS>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0, d.dcnt ? d.dcnt + elem0 : nullptr);
             else {
             lmw::block_sync();
             if (RES && !ML && d.dcnt && ts_sweep_pays(t, m, P, vv, node_peer, r.ctr + a, s_cur)) ts_sweep_version(t, d, m, cidx, P, vv, node_peer, r.ctr + a, s_cur, d.dcnt + elem0);
@@ -1760,7 +1877,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           }
           for (;;) {
             if (kind == OK_TEXT_INS || kind == OK_LIST_INS) {
-              ts_insert(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
+              ts_insert<POS>(t, (uint32_t)r.prop + a, pid_make(node_peer, r.ctr + a), b - a);
               TS_CHECK("insert", row);
             } else if (PLAIN || kind == OK_DEL) {
               // (PLAIN: a two-way dispatch — a row that is neither an insert nor a delete becomes an empty range below; a third
@@ -1782,12 +1899,12 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
               uint32_t hint = 0;
               if (a == 0 && b == r.len) hint = r.a2 > 0 ? (uint32_t)r.prop + 1 : (uint32_t)r.prop + 2 - Ln;
               if (not_del | bad_bits) { if (!not_del) LM_SETERR(t.err, ST_DATA_CORRUPTION); t1 = t0; hint = 0; }
-              ts_update_range(t, r.a0, t0, t1, UPD_DEL_INC, hint);
+              ts_update_range<POS>(t, r.a0, t0, t1, UPD_DEL_INC, hint);
               PROF_ADD(t, PF_DELETE);
               PROF_CNT(t, PF_NDEL, 1);
               TS_CHECK("delete", row);
             } else if (!PLAIN && kind == OK_STYLE_START) {
-              ts_insert(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
+              ts_insert<POS>(t, (uint32_t)r.prop, pid_make(node_peer, r.ctr), 1);
             } else if (!PLAIN && kind == OK_STYLE_END) {
               uint32_t end_pos = NONE;
               if (row > ch.op0) {
@@ -1797,11 +1914,16 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
               }
               if (end_pos == NONE) { LM_SETERR(t.err, ST_UNSUPPORTED); break; }
               uint32_t pos = end_pos + 1 < t.tot_active ? end_pos + 1 : t.tot_active;
-              ts_insert(t, pos, pid_make(node_peer, r.ctr), 1);
+              ts_insert<POS>(t, pos, pid_make(node_peer, r.ctr), 1);
             }
             if (!ML || mv_to == NONE || t.err) break;
             r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
           }
+        }
+        if (POS && t.err == ST_POSDEL) {   // a delete row that does not match its position: finished by position, then on with the next row
+          ts_del_positional(t, last_row);
+          row0 = last_row + 1;
+          goto rows_again;
         }
         if (checked_out && lane == 0) s_cur[node_peer] = (FUSE && node_contig) ? pe : (ch.ctr + ch.len < pe ? ch.ctr + ch.len : pe);
       }
@@ -1849,9 +1971,13 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
     dir_used += t.n_dir;
     lmw::block_sync();
   }
+  // a delete row that does not match its position: the document is replayed by k_integrate_span_pos (lm_pipeline.h) — unless this IS
+  // that kernel, the document is resident (its list would have to outlive the run) or holds a MovableList: LM_DATA_CORRUPTION
+  if (t.err == ST_POSDEL && (POS || RES || ML || !d.posdel)) t.err = ST_DATA_CORRUPTION;
   if (t.err && lane == 0) {
     d.doc[doc].status = t.err;
     if (t.err == ST_RETRY) lmw::atomic_add(retry_count, 1u);
+    if (t.err == ST_POSDEL) lmw::atomic_add(retry_count + 3, 1u);
   }
   if (RES && !t.err) {
     // the record of this run: peers (the numbering the leaves are packed with), what has been applied, the element layout
@@ -1907,6 +2033,13 @@ LM_KERNEL LM_WAVES_PER_SIMD(LM_INTEGRATE_WAVES) void k_integrate_span_ml(Dev d, 
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {
   integrate_span_body<true, false>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
+}
+// the documents an earlier launch left with ST_POSDEL (a damaged delete row), whatever their DF_PLAIN flag: the common body + POS
+LM_KERNEL LM_WAVES_PER_SIMD(4) LM_ONE_WAVE_GROUPS void k_integrate_span_pos(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count) {
+  integrate_span_body<false, false, false, false, false, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
 }
 // Resident documents (DevRes above): the common body with PLAIN = false (sliced rows: the applied prefix), SWEEP, RES.
 // (128 VGPRs: the prologue / epilogue state of a resident document does not fit the 96 of five waves per SIMD without scratch)

@@ -65,6 +65,7 @@ struct Engine {
   uint64_t data_bytes = 0, in_bytes = 0;
   std::vector<uint64_t> h_blob_off, h_front_off, h_froot_off;
   std::vector<uint8_t> h_front_bytes;             // the staged checkout frontiers, back to back (h_front_off)
+  std::vector<uint8_t> h_froot;                   // per document: the root containers its first snapshot's state section holds (h_froot_off)
   std::vector<uint32_t> h_blob_len, h_doc_blob, h_blob_doc;
   DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc, b_front, b_front_off, b_froot, b_froot_off, b_blob_hash, b_big;
   // work buffers
@@ -74,7 +75,7 @@ struct Engine {
   DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
   DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
-  DBuf b_cp, b_loc, b_tb, b_fuse, b_dcnt;
+  DBuf b_cp, b_loc, b_tb, b_fuse, b_dcnt, b_posdel;
   DBuf b_it, b_dir_out, b_lf_chunk;
   DBuf b_cont_root0, b_cont_nroot;
   DBuf b_ht_key, b_ht_pfx, b_ht_best, b_ht0, b_ht_cap, b_ht_list, b_ht_cnt;
@@ -93,7 +94,7 @@ struct Engine {
   bool profiling = false;
   std::string last_error;
   uint64_t device_bytes = 0;
-  uint32_t last_retries = 0, last_reemits = 0;
+  uint32_t last_retries = 0, last_reemits = 0, last_posdel = 0;
   lmbe::StreamCtx* sc = nullptr;   // this engine's HIP stream + timing events
   long long* sum_rows = nullptr;   // lm_summary_layout: where this engine's documents' summary rows go (device), first id, stride
   long long sum_id0 = 0, sum_stride = 1;
@@ -141,7 +142,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -161,6 +162,7 @@ struct Engine {
     if (const char* e = getenv("LM_VS_ROW_COST")) k.vs_row_cost = (uint32_t)atoi(e);             // ts_sweep_pays_batch (A/B)
     if (const char* e = getenv("LM_VERSION_SWEEP")) k.version_sweep = atoi(e) != 0;              // 0: resident trackers move row by row (rounds 3-4a: delete rows undone / redone one by one)
     if (const char* e = getenv("LM_FUSE_ROWS")) k.fuse_rows = atoi(e) != 0;                      // 0: one-change-per-keystroke documents are replayed row by row, as in rounds 1-3
+    if (const char* e = getenv("LM_POSDEL")) k.posdel = atoi(e) != 0;                            // 0: a delete row whose target ids are not the elements at its position is LM_DATA_CORRUPTION (rounds 3-4) instead of being applied by position
     if (const char* e = getenv("LM_LINEAR")) k.linear = atoi(e) != 0;                            // 0: no linear prefix in the plain batch kernels (rounds 1-4: every node through the tracker)
     if (const char* e = getenv("LM_LWW_LDS")) k.lww_lds = atoi(e) != 0;                          // 0: every document's Map rows go through the HBM tables (k_map_lww), as in rounds 1-3
     kn = k;
@@ -178,7 +180,7 @@ struct Engine {
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
-                   &b_dir_out, &b_lf_chunk, &b_fuse, &b_dcnt,
+                   &b_dir_out, &b_lf_chunk, &b_fuse, &b_dcnt, &b_posdel,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_elem_cap, &b_old_blobs, &b_prev_doc, &b_prev_uniq, &b_prev_end, &b_lca_out, &b_lca_scratch, &b_lca_off};
     for (DBuf* b : all) b->release();
@@ -207,7 +209,8 @@ struct Engine {
     std::vector<const uint8_t*> bsrc(nb);
     std::vector<size_t> blen(nb);
     std::vector<std::vector<uint8_t>> conv;
-    std::vector<uint8_t> froot;                 // per document: root containers of the state section of the snapshot that initialises it
+    std::vector<uint8_t>& froot = h_froot;      // per document: root containers of the state section of the snapshot that initialises it
+    froot.clear();
     size_t best_changes = 0;
     bool have_snapshot = false;
     h_froot_off.assign(nd + 1, 0);
@@ -354,6 +357,41 @@ struct Engine {
     tk_elem0.assign(n_docs, 0); tk_elem_cap.assign(n_docs, 0); elem_top = 0;
     tk_top = 0; leaf_top = 0; dir_parity = 0;
     resident = true; tables_valid = false; have_prev = false;
+  }
+  // The resident batch becomes a batch of src.size() documents, document i holding the blobs of the present document src[i] — the
+  // SAME bytes of the arena — and rendered at fronts[i] by the next run: what lm_import needs from a batch that was staged folded
+  // (lm_capi_impl.h "shared replay": entries with the same blobs were uploaded once).  Trackers start from the empty version.
+  void expand(const std::vector<uint32_t>& src, const std::vector<std::vector<uint8_t>>& fronts) {
+    lmbe::bind(sc);
+    if (!resident) adopt_resident();
+    std::vector<std::vector<BlobRef>> old = r_blobs;
+    std::vector<uint64_t> old_froot_off = h_froot_off;
+    std::vector<uint8_t> old_froot = h_froot;
+    n_docs = (uint32_t)src.size();
+    r_blobs.assign(n_docs, {});
+    r_front.assign(n_docs, {});
+    h_froot.clear();
+    h_froot_off.assign((size_t)n_docs + 1, 0);
+    for (uint32_t i = 0; i < n_docs; i++) {
+      r_blobs[i] = old[src[i]];
+      r_front[i] = fronts[i];
+      h_froot_off[i] = h_froot.size();
+      if (src[i] + 1 < old_froot_off.size()) h_froot.insert(h_froot.end(), old_froot.begin() + old_froot_off[src[i]], old_froot.begin() + old_froot_off[src[i] + 1]);
+    }
+    h_froot_off[n_docs] = h_froot.size();
+    b_froot.ensure(h_froot.size() + 16); if (!h_froot.empty()) lmbe::h2d(b_froot.p, h_froot.data(), h_froot.size());
+    b_froot_off.ensure(((size_t)n_docs + 1) * 8); lmbe::h2d(b_froot_off.p, h_froot_off.data(), ((size_t)n_docs + 1) * 8);
+    r_step.assign(n_docs, 0);
+    tk_leaf0.assign(n_docs, 0); tk_leaf_cap.assign(n_docs, 0); tk_pcap.assign(n_docs, 0); tk_ccap.assign(n_docs, 0);
+    tk_off.assign(n_docs, 0); tk_reset.assign(n_docs, 1);
+    tk_elem0.assign(n_docs, 0); tk_elem_cap.assign(n_docs, 0); elem_top = 0;
+    tk_top = 0; leaf_top = 0; dir_parity = 0;
+    tk_new.clear();
+    tables_valid = false; have_prev = false; h_lca.clear();
+    shared_mode = 0;
+    rebuild_blob_tables();
+    lmbe::sync();
+    ran = fetched = false;
   }
   void rebuild_blob_tables() {
     size_t nd = n_docs, nb = 0;
@@ -835,6 +873,7 @@ struct Engine {
     // placed was written by k_elem_fill
     d.loc_cleared = (!resident && span && kn.loc_memset) ? 1u : 0u;
     d.no_linear = kn.linear ? 0u : 1u;
+    if (span && !resident && kn.posdel) { b_posdel.ensure((size_t)n_docs * 3 * PD_CAP * 4 + 16); d.posdel = b_posdel.as<uint32_t>(); }
     if (d.loc_cleared && elem) lmbe::dmemset(b_loc.p, 0xff, (size_t)elem * 4);
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
       if (resident) {
@@ -898,7 +937,7 @@ struct Engine {
     lmbe::tic(profiling);
     b_tot.ensure(64 * 4);
     uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
-    lmbe::dmemset(retry_cnt, 0, 12);   // [0] documents to re-run with the worst-case directory, [1] resident documents replayed from the empty version, [2] documents whose optimistic LWW table filled up
+    lmbe::dmemset(retry_cnt, 0, 16);   // [0] documents to re-run with the worst-case directory, [1] resident documents replayed from the empty version, [2] documents whose optimistic LWW table filled up, [3] documents with a delete row that does not match its position (k_integrate_span_pos)
     if (NO && ht) {   // (ht == 0: no document holds a Map / MovableList-LWW / out-of-scope row, k_dag_a)
       // documents whose (optimistic) table fits LDS are resolved by a workgroup each (lm_k_lww_doc.h); the others — resident
       // documents, MovableLists, tables sized for every row — one row per lane in their HBM tables
@@ -933,7 +972,7 @@ struct Engine {
       DBuf& wa = dir_parity ? b_dir_out2 : b_dir_out; DBuf& ra = dir_parity ? b_dir_out : b_dir_out2;
       DBuf& wb = dir_parity ? b_dir_b2 : b_dir_b;     DBuf& rb = dir_parity ? b_dir_b : b_dir_b2;
       d.dir_out = wa.as<uint32_t>(); rs.dir_a_prev = ra.as<uint32_t>(); rs.dir_b = wb.as<uint32_t>(); rs.dir_b_prev = rb.as<uint32_t>();
-      const size_t lds = (size_t)(2 * dir_opt + (dir_opt >> SD_BSH) + 2 + 6 * pmax) * 4 + lds_pad;
+      const size_t lds = (size_t)(2 * dir_opt + (dir_opt >> SD_BSH) + 2 + PD_LDS + 6 * pmax) * 4 + lds_pad;
       if (any_plain)
         LM_LAUNCH_DYN(k_integrate_span_res_plain, n_docs, 64, lds, d, g, dir_opt, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                       (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
@@ -945,31 +984,31 @@ struct Engine {
                       (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt, rs);
     } else if (span) {
       if (any_plain && plain_mode == 2) {
-        LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
         if (d.fuse)
-          LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       }
       else if (any_plain)
-        LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       if (any_common || !(any_ml || any_plain))
-        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
       if (any_ml)
-        LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_opt + (span ? (dir_opt >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
     } else {
       LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_opt + 3 * pmax) * 4 + lds_pad, d, g, dir_opt, pmax, (const OpRow*)d.op,
                     (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 0u, retry_cnt);
     }
-    uint32_t n_retry = 0, n_lww = 0;
+    uint32_t n_retry = 0, n_lww = 0, n_posdel = 0;
     {
-      uint32_t three[3] = {0, 0, 0};
-      lmbe::d2h(three, retry_cnt, 12);
-      n_retry = three[0]; n_lww = three[2];
-      if (resident) last_fresh = three[1];
+      uint32_t four[4] = {0, 0, 0, 0};
+      lmbe::d2h(four, retry_cnt, 16);
+      n_retry = four[0]; n_lww = four[2]; n_posdel = four[3];
+      if (resident) last_fresh = four[1];
     }
     if (n_lww) {
       // documents with more keys than their optimistic LWW table holds: full-size tables behind the others', their Map rows again
@@ -992,7 +1031,7 @@ struct Engine {
     }
     if (n_retry) {  // rare: re-run the overflowed documents with the worst-case directory
       if (resident) {
-        const size_t lds = (size_t)(2 * dir_cap + (dir_cap >> SD_BSH) + 2 + 6 * pmax) * 4;
+        const size_t lds = (size_t)(2 * dir_cap + (dir_cap >> SD_BSH) + 2 + PD_LDS + 6 * pmax) * 4;
         if (any_plain)
           LM_LAUNCH_DYN(k_integrate_span_res_plain, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                         (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
@@ -1003,20 +1042,20 @@ struct Engine {
           LM_LAUNCH_DYN(k_integrate_span_res_ml, n_docs, 64, lds, d, g, dir_cap, pmax, (const OpRow*)d.op, (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted,
                         (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt, rs);
       } else if (span) {
-        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+        LM_LAUNCH_DYN(k_integrate_span, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                       (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         if (any_ml)
-          LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_ml, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         if (any_plain && plain_mode == 2) {
-          LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_plain_sweep, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
           if (d.fuse)
-            LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+            LM_LAUNCH_DYN(k_integrate_span_plain_fuse, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                           (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
         }
         else if (any_plain)
-          LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+          LM_LAUNCH_DYN(k_integrate_span_plain, n_docs, 64, (size_t)(dir_words * dir_cap + (span ? (dir_cap >> SD_BSH) + 2 + PD_LDS : 0) + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                         (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 1u, retry_cnt);
       } else {
         LM_LAUNCH_DYN(k_integrate, n_docs, 64, (size_t)(dir_cap + 3 * pmax) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
@@ -1024,6 +1063,15 @@ struct Engine {
       }
     }
     last_retries = n_retry;
+    if (n_retry && span && !resident && d.posdel) lmbe::d2h(&n_posdel, retry_cnt + 3, 4);   // (the retry launch may have met such a row too)
+    if (n_posdel && span && !resident) {
+      // Documents with a delete row whose target ids are not the elements at its position — damaged input; the reference applies
+      // every delete by position (crdt_rope.rs:256-335) — left the launches above with ST_POSDEL: replayed once more by the kernel
+      // that finishes such rows by position and remembers what they deleted (ts_del_positional), with the worst-case directory
+      LM_LAUNCH_DYN(k_integrate_span_pos, n_docs, 64, (size_t)(2 * dir_cap + (dir_cap >> SD_BSH) + 2 + PD_LDS + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                    (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 2u, retry_cnt);
+    }
+    last_posdel = n_posdel;
     if (!resident && h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only (a resident tracker knows both versions)
     if (h_froot_off.size() > n_docs && h_froot_off[n_docs] > 0) LM_LAUNCH(k_state_roots, n_docs, 64, d);        // documents initialised from a snapshot only
     // documents holding a MovableList only: element → item maxima and the items' elements (loc[] is free from here on)

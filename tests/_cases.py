@@ -232,6 +232,39 @@ def linear_prefix_docs(n, base=90000):
     return docs
 
 
+def misnamed_delete_docs(n, base=97000):
+    """Concurrent sessions (some with a solo prefix) in which delete ops NAME other elements than the ones at their positions: the
+    target id of a few delete ops (up to five per document) is moved to another counter or another peer after the session was recorded.  The
+    reference applies a delete by position and only remembers what it met (crdt_rope.rs:256-335, tracker.rs:193-252): the value
+    of such a document is the value of the unharmed session.  Returns (damaged documents, unharmed documents)."""
+    import copy
+    bad, good = [], []
+    for seed in range(n):
+        kinds = [("text",), ("text", "list")][seed % 2]
+        reps = _fuzz.random_session(base + seed, n_peers=2 + seed % 3, n_steps=60 + seed % 60, kinds=kinds, sync_prob=0.12, max_del=[4, 12][seed % 2],
+                                    solo_steps=[0, 60][(seed // 2) % 2], max_ins=8)
+        good.append(_fuzz.blobs_of(reps, random.Random(seed)))
+        rng = random.Random(seed * 7 + 1)
+        peers = [r.peer for r in reps]
+        reps2 = copy.deepcopy(reps)
+        hit = 0
+        for r in reps2:
+            for ch in r.changes.get(r.peer, []):
+                for op in ch.ops:
+                    if op.kind == "delete" and hit < 5 and rng.random() < 0.3:
+                        p, c = op.del_id
+                        if rng.random() < 0.5:
+                            op.del_id = (rng.choice(peers), max(0, c + rng.randint(-5, 40)))
+                        else:
+                            op.del_id = (p, max(0, c + rng.choice([-3, -1, 1, 2, 7, 1000])))
+                        hit += 1
+        if hit == 0:
+            good.pop()
+            continue
+        bad.append(_fuzz.blobs_of(reps2, random.Random(seed)))
+    return bad, good
+
+
 def trace_docs(n_base, variants=((10, True), (10, False), (0, True)), n_docs=2, seed=2):
     docs = []
     for ce, fuse in variants:

@@ -516,15 +516,35 @@ def test_damaged_blobs_never_take_the_batch_down():
     assert n_dev_only == 0   # the device never renders a document the oracle rejects (surplus column values, nested key indices, ops across change boundaries)
 
 
-def test_delete_rows_that_name_elements_nobody_inserted():
-    """tests/golden/damaged_peer_table.json: a flipped PeerID byte in one blob's peer table leaves the other blobs' delete rows
-    pointing at elements of a peer without any — the reference deletes by position and accepts the document (the oracle too);
-    the kernel deletes by id, so the document is LM_DATA_CORRUPTION, never a different rendering."""
+def test_delete_rows_that_name_elements_nobody_inserted(monkeypatch):
+    """The reference applies a delete BY POSITION and only remembers the ids it met (crdt_rope.rs:256-335, tracker.rs:193-252); the
+    span-granular batch kernels apply rows by id, compare with the position, and on a mismatch apply the rest of the row by
+    position too (ts_del_positional) — retreats / forwards of such a row use what was deleted, not what the row names.
+    tests/golden/damaged_peer_table.json: a flipped PeerID byte in one blob's peer table leaves the other blobs' delete rows
+    pointing at elements of a peer without any; sessions whose delete ops were re-pointed at other counters / peers after the fact
+    render like the unharmed sessions (oracle == device == the unharmed value), under the structural checker, with the linear
+    prefix and the tracker's base on documents of every size, through the common kernel; LM_POSDEL=0: LM_DATA_CORRUPTION."""
     import json, os
+    from loro_amd._cabi import Context
     fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "damaged_peer_table.json")))
     doc = [bytes.fromhex(h) for h in fx["blobs_hex"]]
-    assert _oracle.merge_batch([doc])[0][0] == 0
-    assert _emu.merge_batch([doc])[0][0] == 3
+    want = _oracle.merge_batch([doc])[0]
+    assert want[0] == 0 and _emu.merge_batch([doc])[0] == want
+    bad, good = _cases.misnamed_delete_docs(48)
+    want = _oracle.merge_batch(bad, threads=8)
+    assert want == _oracle.merge_batch(good, threads=8) and all(w[0] == 0 for w in want)
+    b = _emu.variant(["LM_SWEEP_EAGER", "LM_EMU_CHECK"])
+    for env in ({}, {"LM_CUT_MIN_ROWS": "0"}, {"LM_PLAIN": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with Context(b) as c:
+            assert c.merge_batch(bad) == want, env
+        for k in env:
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("LM_POSDEL", "0")
+    got = _emu.merge_batch(bad)
+    assert all(g[0] in (0, 3) for g in got) and sum(g[0] == 3 for g in got) > len(bad) // 2
+    assert all(g == w for g, w in zip(got, want) if g[0] == 0)
 
 
 def test_optimistic_lww_table_overflow_takes_the_second_pass(monkeypatch):

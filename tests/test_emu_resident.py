@@ -79,6 +79,41 @@ def test_several_streams_keep_their_documents():
         del os.environ["LM_PART_MIN_DOCS"]
 
 
+def test_lm_import_unfolds_a_batch_that_was_staged_folded():
+    """entries of the staged batch that name the same blobs and ask for checkouts are uploaded ONCE (shared replay, lm_capi_impl.h);
+    lm_import on such a batch makes every entry a resident document of its own over those bytes (Engine::expand) — with one stream
+    and with the entries of a document spread over two — and the sessions go on like any others; also after an lm_run in between"""
+    from loro_amd._cabi import Context
+    base = _sessions("flat", range(700, 712))
+    v = wire.encode_frontiers([])
+    sessions = []
+    for s in base:   # every history three times, the first step rendered at a checkout by two of them
+        sessions += [[(s[0][0], v)] + s[1:], [(s[0][0], None)] + s[1:], [(s[0][0], s[-1][1] or v)] + s[1:]]
+    want = _resident.oracle_sessions(sessions)
+    for env, run_first in (({}, False), ({"LM_PART_MIN_DOCS": "4"}, False), ({"LM_PART_MIN_DOCS": "4"}, True)):
+        os.environ.update(env)
+        try:
+            with Context(_emu.binding()) as c:
+                docs = [s[0][0] for s in sessions]; fr = [s[0][1] for s in sessions]
+                c.stage(docs, fr)
+                assert 0 < c.b.shared_documents(c.h) < len(docs)
+                if run_first:
+                    c.run()
+                    first = c.fetch()
+                    assert [f[:3] for f in first] == [w[:3] for w in _oracle.merge_batch(docs, frontiers=fr)]
+                got = []
+                for k in range(len(sessions[0])):
+                    c.import_more([[] if k == 0 else s[k][0] for s in sessions], [s[k][1] for s in sessions])
+                    assert c.b.shared_documents(c.h) == 0
+                    c.run()
+                    got.append(c.fetch())
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert [x[:3] for x in g] == [x[:3] for x in w], (env, run_first, k)
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
 @pytest.mark.parametrize("defines,mode", [(["LM_SWEEP_EAGER", "LM_EMU_CHECK"], "text"), (["LM_SWEEP_EAGER", "LM_EMU_CHECK"], "movable"),
                                            (["LM_LOC_FULL", "LM_EMU_CHECK"], "flat")])
 def test_structural_checker_builds(defines, mode):

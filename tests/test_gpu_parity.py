@@ -388,11 +388,29 @@ def test_damaged_blobs_never_take_the_batch_down(engine):
     # kernel by id) or whose span length differs from its op length is LM_DATA_CORRUPTION since round 3 (ts_del_pos_ok,
     # lm_k_integrate_span.h): what both sides accept, they render alike
     assert n_both_ok > 0 and n_same == n_both_ok
-    # delete rows that name elements nobody inserted (a flipped PeerID byte in another blob's peer table): accepted by the
-    # reference, which deletes by position — LM_DATA_CORRUPTION here (tests/golden/damaged_peer_table.json)
+
+
+def test_delete_rows_that_name_elements_nobody_inserted(engine, monkeypatch):
+    """a delete row whose target ids are not the elements at its position is applied by position, as the reference applies every
+    delete (ts_del_positional, lm_k_integrate_span.h): tests/golden/damaged_peer_table.json (a flipped PeerID byte in another blob's
+    peer table) and sessions whose delete ops were re-pointed afterwards render like the oracle — which renders them like the
+    unharmed sessions; LM_POSDEL=0 keeps the round-3 verdict (LM_DATA_CORRUPTION)"""
     fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "damaged_peer_table.json")))
     doc = [bytes.fromhex(h) for h in fx["blobs_hex"]]
-    assert _oracle.merge_batch([doc])[0][0] == 0 and engine.merge_batch([doc])[0][0] == 3
+    want = _oracle.merge_batch([doc])[0]
+    assert want[0] == 0 and engine.merge_batch([doc])[0] == want
+    bad, good = _cases.misnamed_delete_docs(400)
+    want = _oracle.merge_batch(bad, threads=8)
+    assert want == _oracle.merge_batch(good, threads=8) and all(w[0] == 0 for w in want)
+    for env in ({}, {"LM_CUT_MIN_ROWS": "0"}, {"LM_PLAIN": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert engine.merge_batch(bad) == want, env
+        for k in env:
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("LM_POSDEL", "0")
+    got = engine.merge_batch(bad)
+    assert all(g[0] in (0, 3) for g in got) and sum(g[0] == 3 for g in got) > len(bad) // 2
 
 
 def test_two_contexts_in_flight(engine):
