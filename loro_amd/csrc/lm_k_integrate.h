@@ -771,7 +771,15 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
               uint32_t t0, t1;
               if (r.a2 > 0) { t0 = r.a1 + a; t1 = r.a1 + b; }
               else { t0 = r.a1 + (Ln - b); t1 = r.a1 + (Ln - a); }  // op offset j deletes target + (L-1-j)
+              // every target of a delete that is applied for the first time is an ACTIVE element of this container — the writer saw it
+              // when it deleted it (handler.rs:2245-2288).  This kernel deletes by id and does not compare with the row's position (the
+              // span-granular kernels do, and finish a damaged row by position: ts_del_positional); the cheap half of that comparison is
+              // kept: the active length must drop by exactly the row's length — a row that names elements nobody inserted, elements of
+              // another container, deleted or future ones is LM_DATA_CORRUPTION, never a value the reference would not have computed
+              // from it.  (A row re-pointed at OTHER active elements passes: DESIGN §7.)
+              const uint32_t act0 = t.tot_active;
               tr_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
+              if ((act0 - t.tot_active) != (t1 - t0) || Ln != r.len) LM_SETERR(t.err, ST_DATA_CORRUPTION);
               PROF_ADD(t, PF_DELETE);
               PROF_CNT(t, PF_NDEL, 1);
               TR_CHECK("delete", row);

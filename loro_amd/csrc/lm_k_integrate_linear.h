@@ -34,12 +34,13 @@ struct Tl {               // the cached leaf of the linear replay: lane i = item
   bool dirty;
 };
 LM_DEV void tl_none(Tl& c) { c.n = 255; c.tot = 0; c.id = NONE; c.len = 0; c.ol = NONE; c.leaf = NONE; c.p = NONE; c.pre = 0; c.dirty = false; }
-// write-back: leaf record (status 0, origin_right NONE) and both directory words
+// write-back: the leaf record's id / length / origin_left words and both directory words (status 0 and origin_right NONE are the same
+// for every item of the prefix: tl_finish writes them once per leaf — 40 % of the prefix's stores otherwise)
 LM_DEV void tl_store(Ts& t, Tl& c) {
   if (c.n == 255 || !c.dirty) return;
   int lane = lmw::lane();
   uint32_t* rec = t.it + (uint64_t)c.leaf * SP_REC;
-  if ((uint32_t)lane < c.n) { rec[lane] = c.id; rec[64 + lane] = c.len; rec[128 + lane] = c.ol; rec[192 + lane] = NONE; rec[256 + lane] = 0u; }
+  if ((uint32_t)lane < c.n) { rec[lane] = c.id; rec[64 + lane] = c.len; rec[128 + lane] = c.ol; }
   lmw::wave_sync();
   if (lane == 0) { t.da[c.p] = sa_make(c.leaf, c.n, c.n != 0); t.db[c.p] = c.tot; }
   lmw::wave_sync();
@@ -103,7 +104,7 @@ LM_DEV void tl_split(Ts& t, Tl& c, uint32_t pos) {
   bool keep_upper = pos > c.pre + tot_lo;
   if (keep_upper) {
     uint32_t* rec = t.it + (uint64_t)c.leaf * SP_REC;
-    if (lane < 32) { rec[lane] = c.id; rec[64 + lane] = c.len; rec[128 + lane] = c.ol; rec[192 + lane] = NONE; rec[256 + lane] = 0u; }
+    if (lane < 32) { rec[lane] = c.id; rec[64 + lane] = c.len; rec[128 + lane] = c.ol; }
     lmw::wave_sync();
     if (lane == 0) { t.da[c.p] = sa_make(c.leaf, 32, true); t.db[c.p] = tot_lo; }
     tl_dir_insert_after(t, c.p, sa_make(NL, nu, true), c.tot - tot_lo);
@@ -111,7 +112,7 @@ LM_DEV void tl_split(Ts& t, Tl& c, uint32_t pos) {
     c.id = uid; c.len = uln; c.ol = uol;
   } else {
     uint32_t* rec = t.it + (uint64_t)NL * SP_REC;
-    if ((uint32_t)lane < nu) { rec[lane] = uid; rec[64 + lane] = uln; rec[128 + lane] = uol; rec[192 + lane] = NONE; rec[256 + lane] = 0u; }
+    if ((uint32_t)lane < nu) { rec[lane] = uid; rec[64 + lane] = uln; rec[128 + lane] = uol; }
     tl_dir_insert_after(t, c.p, sa_make(NL, nu, true), c.tot - tot_lo);
     c.n = 32; c.tot = tot_lo;
     if (lane >= 32) { c.id = NONE; c.len = 0; c.ol = NONE; }
@@ -242,6 +243,11 @@ LM_DEV void tl_finish(Ts& t, Tl& c, bool emptied) {
     t.n_dir = w ? w : 1u;   // (nothing left: entry 0 still is the container's first leaf, empty — the state a replay starts from)
     if (!w && lane == 0) { t.da[0] = sa_make(sa_leaf(t.da[0]), 0, false); t.db[0] = 0; }
     lmw::wave_sync();
+  }
+  // origin_right / status of every item the prefix leaves behind (all 64 slots of a leaf: what lies beyond its items is never read)
+  for (uint32_t q = 0; q < t.n_dir; q++) {
+    uint32_t* rec = t.it + (uint64_t)sa_leaf(lmw::first(t.da[q])) * SP_REC;
+    rec[192 + lane] = NONE; rec[256 + lane] = 0u;
   }
   t.n_alive = t.tot_active;
   t.cache_leaf = NONE; t.cr.n = 255; t.cache_pre = NONE; t.dirty = false; t.loc_pend = 0;

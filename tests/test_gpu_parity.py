@@ -474,6 +474,35 @@ def test_small_document_batches_pick_the_element_granular_kernel(engine, monkeyp
     assert "k_integrate" not in stage_names(small)
 
 
+def test_the_suites_corpora_under_the_product_default_kernel_choice(engine, monkeypatch):
+    """the suites pin LM_SPAN_AUTO=0 (conftest.py) so that small test documents reach the span-granular
+    kernels; the PRODUCT default lets a batch of small common-kernel documents take the element-granular kernel.  The corpora the
+    other tests use — random sessions of every container kind, configs[3] shapes, nested containers, MovableLists, histories with a
+    linear prefix, checkouts (shared replay) and documents with re-pointed delete ops — once more under that default, batch by batch
+    as the rule decides per batch, against the oracle."""
+    import _fuzz, test_emu_parity
+    monkeypatch.setenv("LM_SPAN_AUTO", "1")
+    batches = [_cases.fuzz_docs(200, base=31000), _cases.cfg4_docs(48, first=8400, n_steps=300),
+               [_fuzz.blobs_of(_fuzz.nested_session(8600 + i, n_steps=120)) for i in range(32)],
+               [_fuzz.blobs_of(_fuzz.movable_session(8700 + d, n_peers=3, n_steps=150, nested=True)) for d in range(32)],
+               _cases.linear_prefix_docs(120, base=91000),
+               _cases.fuzz_docs(64, base=31500) + [workload.Cfg2Template(4000, 2000, seed=5, commit_every=10, fuse=True).stamp(d) for d in range(4)]]
+    for docs in batches:
+        _same(engine, docs)
+    docs, fronts = test_emu_parity._checkout_cases()
+    want = _oracle.merge_batch(docs, threads=8, frontiers=fronts)
+    got = engine.merge_batch(docs, fronts)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert (g == w) if w[0] == 0 else (g[0] == w[0]), (i, g[:2], w[:2])
+    bad, good = _cases.misnamed_delete_docs(64)
+    want = _oracle.merge_batch(bad, threads=8)
+    got = engine.merge_batch(bad)
+    # (the element-granular kernel deletes by id; it keeps the cheap half of the position comparison — the active length must drop by the
+    # row's length — so a re-pointed row is LM_DATA_CORRUPTION there unless it happens to name other ACTIVE elements: never a crash, and
+    # what it accepts of THIS corpus equals the oracle; the healthy twins are exact)
+    assert all(g[0] == 3 or g == w for g, w in zip(got, want)) and engine.merge_batch(good) == _oracle.merge_batch(good, threads=8)
+
+
 @pytest.mark.parametrize("span,plain", [("1", None), ("1", "0"), ("1", "1"), ("0", None)],
                          ids=["span (default: plain documents by leaf sweep)", "span, common kernel for every document",
                               "span, plain kernel without the sweep", "element-granular"])
