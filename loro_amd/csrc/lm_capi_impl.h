@@ -596,20 +596,33 @@ int LM_API(kernel_time)(void* c, uint32_t i, const char** name, double* ms) {
 // summary of its own documents — 6 words each: document id, status, pending ops, JSON length, VV length, xxh64 of the JSON
 // (computed on the device, k_hash_json) — and receives the table of all documents, by ONE RCCL all-gather over xGMI (after a
 // one-word all-gather of the shard sizes).  RCCL is loaded at lm_comm_init (dlopen): the library itself does not depend on it.
-#ifndef LM_EMU
+// (The kernel-logic harness compiles the same exchange code: its "device" memory is host memory and there is no stream, so a
+// collective library that works on host pointers — tests/emu/rccl_stub.c, named through LM_RCCL_LIB — exercises lm_comm_init,
+// lm_summary_allgather and lm_summary_allgather_device end to end between two processes without a GPU.  LM_RCCL_LIB also lets a
+// deployment name its librccl.so explicitly.)
 #include <dlfcn.h>
 namespace lmcomm {
+#ifndef LM_EMU
+typedef hipStream_t Stream;
+inline Stream cur_stream() { return lmbe::cur->s; }
+#else
+typedef void* Stream;
+inline Stream cur_stream() { return nullptr; }
+#endif
 typedef struct { char internal[128]; } UniqueId;
 typedef int (*GetUniqueIdFn)(UniqueId*);
 typedef int (*CommInitRankFn)(void**, int, UniqueId, int);
-typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, Stream);
 typedef int (*CommDestroyFn)(void*);
 struct Api { void* h = nullptr; GetUniqueIdFn get_id = nullptr; CommInitRankFn init = nullptr; AllGatherFn all_gather = nullptr; CommDestroyFn destroy = nullptr; };
 inline Api& api() {
   static Api a;
   if (!a.h) {
-    a.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (const char* e = getenv("LM_RCCL_LIB")) a.h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+#ifndef LM_EMU
+    if (!a.h) a.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!a.h) a.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+#endif
     if (a.h) {
       a.get_id = (GetUniqueIdFn)dlsym(a.h, "ncclGetUniqueId"); a.init = (CommInitRankFn)dlsym(a.h, "ncclCommInitRank");
       a.all_gather = (AllGatherFn)dlsym(a.h, "ncclAllGather"); a.destroy = (CommDestroyFn)dlsym(a.h, "ncclCommDestroy");
@@ -618,24 +631,18 @@ inline Api& api() {
   return a;
 }
 }  // namespace lmcomm
-#endif
 struct lm_comm_state { int rank = 0, world = 1; void* comm = nullptr; };
 static std::map<void*, lm_comm_state>& lm_comms() { static std::map<void*, lm_comm_state> m; return m; }
 static std::mutex& lm_comms_mu() { static std::mutex m; return m; }   // contexts may be created / destroyed from several threads
 
 // rank 0 creates the id and hands it to the other ranks out of band (128 bytes)
 int LM_API(comm_unique_id)(uint8_t* out128) {
-#ifndef LM_EMU
   auto& a = lmcomm::api();
   if (!a.get_id) return -1;
   lmcomm::UniqueId id;
   if (a.get_id(&id) != 0) return -1;
   memcpy(out128, id.internal, 128);
   return 0;
-#else
-  memset(out128, 0, 128);
-  return 0;
-#endif
 }
 // world == 1 needs no communicator (and no RCCL); otherwise every rank calls this with the same id, on its own context
 int LM_API(comm_init)(void* c, int rank, int world, const uint8_t* id128) {
@@ -644,16 +651,14 @@ int LM_API(comm_init)(void* c, int rank, int world, const uint8_t* id128) {
   lm_comm_state st;
   st.rank = rank; st.world = world;
   if (world > 1) {
-#ifndef LM_EMU
     auto& a = lmcomm::api();
     if (!a.init || !a.all_gather) { x->err = "lm_comm_init: librccl.so could not be loaded"; return -1; }
+#ifndef LM_EMU
     (void)hipSetDevice(x->device);
+#endif
     lmcomm::UniqueId id;
     memcpy(id.internal, id128, 128);
     if (a.init(&st.comm, world, id, rank) != 0) { x->err = "ncclCommInitRank failed"; return -1; }
-#else
-    x->err = "the kernel-logic harness has no collective"; return -1;
-#endif
   }
   { std::lock_guard<std::mutex> lk(lm_comms_mu()); lm_comms()[c] = st; }
   return 0;
@@ -693,18 +698,14 @@ long LM_API(summary_allgather_device)(void* c, const int64_t** table_dev) {
     lm_comm_state st;
     { std::lock_guard<std::mutex> lk(lm_comms_mu()); auto it = lm_comms().find(c); if (it != lm_comms().end()) st = it->second; }
     if (st.world == 1) { *table_dev = (const int64_t*)x->sum_buf.p; return (long)x->sum_rows_padded; }
-#ifndef LM_EMU
     auto& a = lmcomm::api();
     lm::Engine& e = *x->parts[0];
     lmbe::bind(e.sc);
     x->sum_all.ensure((size_t)st.world * x->sum_rows_padded * 48);
-    if (a.all_gather(x->sum_buf.p, x->sum_all.p, x->sum_rows_padded * 6, /*ncclInt64*/ 4, st.comm, lmbe::cur->s) != 0) throw std::runtime_error("ncclAllGather (summaries) failed");
+    if (a.all_gather(x->sum_buf.p, x->sum_all.p, x->sum_rows_padded * 6, /*ncclInt64*/ 4, st.comm, lmcomm::cur_stream()) != 0) throw std::runtime_error("ncclAllGather (summaries) failed");
     lmbe::sync();
     *table_dev = (const int64_t*)x->sum_all.p;
     return (long)((size_t)st.world * x->sum_rows_padded);
-#else
-    throw std::runtime_error("the kernel-logic harness has no collective");
-#endif
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
 // doc_ids[n_docs] = the global ids of this context's documents; table receives rows of 6 int64 (layout above = loro_amd/dist.py
@@ -725,7 +726,6 @@ long LM_API(summary_allgather)(void* c, const int64_t* doc_ids, int64_t* table, 
     });
     std::vector<int64_t> all;
     if (st.world == 1) all = local;
-#ifndef LM_EMU
     else {
       auto& a = lmcomm::api();
       lm::Engine& e = *x->parts[0];
@@ -735,7 +735,7 @@ long LM_API(summary_allgather)(void* c, const int64_t* doc_ids, int64_t* table, 
       sz_in.ensure(8); sz_out.ensure((size_t)st.world * 8);
       int64_t nn = (int64_t)n;
       lmbe::h2d(sz_in.p, &nn, 8);
-      if (a.all_gather(sz_in.p, sz_out.p, 1, /*ncclInt64*/ 4, st.comm, lmbe::cur->s) != 0) throw std::runtime_error("ncclAllGather (sizes) failed");
+      if (a.all_gather(sz_in.p, sz_out.p, 1, /*ncclInt64*/ 4, st.comm, lmcomm::cur_stream()) != 0) throw std::runtime_error("ncclAllGather (sizes) failed");
       std::vector<int64_t> sizes(st.world);
       lmbe::d2h(sizes.data(), sz_out.p, (size_t)st.world * 8);
       int64_t n_max = 0;
@@ -744,13 +744,12 @@ long LM_API(summary_allgather)(void* c, const int64_t* doc_ids, int64_t* table, 
       memcpy(padded.data(), local.data(), local.size() * 8);
       tb_in.ensure((size_t)n_max * 48 + 8); tb_out.ensure((size_t)st.world * n_max * 48 + 8);
       lmbe::h2d(tb_in.p, padded.data(), padded.size() * 8);
-      if (a.all_gather(tb_in.p, tb_out.p, (size_t)n_max * 6, 4, st.comm, lmbe::cur->s) != 0) throw std::runtime_error("ncclAllGather (summaries) failed");
+      if (a.all_gather(tb_in.p, tb_out.p, (size_t)n_max * 6, 4, st.comm, lmcomm::cur_stream()) != 0) throw std::runtime_error("ncclAllGather (summaries) failed");
       std::vector<int64_t> raw((size_t)st.world * n_max * 6);
       lmbe::d2h(raw.data(), tb_out.p, raw.size() * 8);
       for (int r = 0; r < st.world; r++) all.insert(all.end(), raw.begin() + (size_t)r * n_max * 6, raw.begin() + ((size_t)r * n_max + sizes[r]) * 6);
       sz_in.release(); sz_out.release(); tb_in.release(); tb_out.release();
     }
-#endif
     size_t rows = all.size() / 6;
     if (rows > cap_rows) throw std::runtime_error("lm_summary_allgather: the table does not fit");
     std::vector<size_t> order(rows);
@@ -768,9 +767,7 @@ void LM_API(destroy)(void* c) {
     auto it = lm_comms().find(c);
     if (it != lm_comms().end()) { st = it->second; lm_comms().erase(it); }
   }
-#ifndef LM_EMU
   if (st.comm && lmcomm::api().destroy) (void)lmcomm::api().destroy(st.comm);
-#endif
   delete (lm_ctx_impl*)c;
 }
 // number of engine parts (HIP streams) the last staged batch was split into

@@ -134,3 +134,77 @@ def test_summary_rows_written_on_the_device_match_the_host_summary():
         assert c.b.summary_allgather_device(c.h, ctypes.byref(out)) == rows and out.value == ptr
         c.run()   # the rows are rewritten by every run
         assert (lmdist.rows_tensor(ptr, rows).numpy()[:len(docs)] == want).all()
+
+
+def _stub_rccl():
+    """tests/emu/rccl_stub.c → a shared library with the four RCCL entry points the product resolves by dlsym, on host pointers"""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, so = os.path.join(here, "emu", "rccl_stub.c"), os.path.join(here, "emu", "librccl_stub.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        tmp = f"{so}.{os.getpid()}.tmp"
+        subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-o", tmp, src])
+        os.replace(tmp, so)
+    return so
+
+
+def _cabi_worker(rank, world, id_hex, per_rank, stub, out_dir):
+    """the C ABI's own exchange (lm_comm_init + lm_summary_layout + lm_summary_allgather_device, and the host-table form
+    lm_summary_allgather) between two processes: the kernel-logic harness for the GPU, the stub for librccl.so (LM_RCCL_LIB)"""
+    import ctypes, sys
+    os.environ["LM_RCCL_LIB"] = stub
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import _emu
+    from loro_amd._cabi import Context
+    total = per_rank * world + 1                      # uneven shards: rank 0 holds one document more
+    docs = _cases.fuzz_docs(total)
+    mine = lmdist.owned_docs(total, rank, world)      # documents dealt doc % world
+    rows_padded = (total + world - 1) // world
+    with Context(_emu.binding()) as c:
+        c.comm_init(rank, world, bytes.fromhex(id_hex))
+        c.stage([docs[d] for d in mine])
+        c.summary_layout(rank, world, rows_padded)
+        c.run()
+        tp = ctypes.c_void_p()
+        n = c.b.summary_allgather_device(c.h, ctypes.byref(tp))
+        assert n == world * rows_padded, c.b.last_error(c.h)
+        dev = np.ctypeslib.as_array(ctypes.cast(tp.value, ctypes.POINTER(ctypes.c_int64)), shape=(n, 6)).copy()
+        host = c.summary_allgather(mine, total)
+    np.save(os.path.join(out_dir, f"dev{rank}.npy"), dev)
+    np.save(os.path.join(out_dir, f"host{rank}.npy"), host)
+
+
+def test_c_abi_exchange_between_two_processes_through_a_stub_rccl(tmp_path):
+    """lm_comm_unique_id / lm_comm_init (dlopen of the collective library) / lm_summary_layout /
+    lm_summary_allgather_device — the ONE collective on device memory — and lm_summary_allgather, world 2, end to end before the
+    first run on an 8-GPU node.  Unmeasured on hardware: what is under test is the ABI's plumbing (ranks, padding of uneven shards,
+    the gathered table's layout and content: document id, status, pending, lengths, xxh64 of the JSON computed by k_hash_json)."""
+    import xxhash
+    stub = _stub_rccl()
+    os.environ["LM_RCCL_LIB"] = stub
+    os.environ["LM_RCCL_STUB_DIR"] = str(tmp_path)
+    try:
+        import _emu
+        from loro_amd._cabi import Context
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        assert _emu.binding().comm_unique_id(buf) == 0
+        world, per_rank = 2, 5
+        mp.spawn(_cabi_worker, args=(world, buf.raw.hex(), per_rank, stub, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        del os.environ["LM_RCCL_LIB"]; del os.environ["LM_RCCL_STUB_DIR"]
+    total = per_rank * world + 1
+    docs = _cases.fuzz_docs(total)
+    want = _oracle.merge_batch(docs)
+    ref = np.array([[d, w[0], w[3], len(w[1]), len(w[2]), np.uint64(xxhash.xxh64(w[1]).intdigest() if w[0] in (0, 4) and w[1] else 0).astype(np.int64)]
+                    for d, w in enumerate(want)], dtype=np.int64)
+    rows_padded = (total + world - 1) // world
+    for r in range(world):
+        host = np.load(os.path.join(str(tmp_path), f"host{r}.npy"))
+        assert host.shape == ref.shape and (host == ref).all(), f"rank {r}: lm_summary_allgather"
+        dev = np.load(os.path.join(str(tmp_path), f"dev{r}.npy"))
+        assert dev.shape == (world * rows_padded, 6)
+        got = dev[dev[:, 0] >= 0]
+        got = got[np.argsort(got[:, 0])]
+        assert (got == ref).all(), f"rank {r}: lm_summary_allgather_device"
+        assert (dev[rows_padded + (total // world):, 0] == -1).all()   # rank 1's padding row
