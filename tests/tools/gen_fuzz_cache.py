@@ -21,7 +21,8 @@ for i in range(n):
         reps = _fuzz.random_session(seed0 + i, n_peers=rng.choice([2, 3, 4, 6, 9]), n_steps=rng.choice([100, 300, 800, 1500]),
                                     kinds=rng.choice([("text",), ("text", "list"), ("text", "list", "map"), ("map",), ("list",)]),
                                     sync_prob=rng.choice([0.005, 0.02, 0.08, 0.2]), max_ins=rng.choice([2, 6, 30, 90]), styles=rng.random() < 0.5,
-                                    commit_prob=rng.choice([0.1, 0.4, 0.9]), snapshots=snaps)
+                                    commit_prob=rng.choice([0.1, 0.4, 0.9]), snapshots=snaps,
+                                    solo_steps=rng.choice([0, 0, 50, 400, 1200]), max_del=rng.choice([4, 4, 40, 300]))   # (round 5: histories with a linear prefix, long deletes)
     blobs = _fuzz.blobs_of(reps, rng=rng if rng.random() < 0.5 else None)
     docs.append(blobs); fronts.append(None)
     for fr, _ in snaps[:: max(1, len(snaps) // 3)][:3]:      # a few checkouts of the same history
