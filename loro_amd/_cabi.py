@@ -148,6 +148,7 @@ class Context:
         Frontiers (loro_amd.wire.encode_frontiers) = render the state at that version (LoroDoc::checkout)."""
         arr, keep = self._pack(docs, frontiers)
         self.n = len(docs)
+        self._sum_rows = 0   # (lm_stage drops the summary layout: lm_summary_layout is called again for the new batch)
         if self.b.stage(self.h, arr, self.n) != 0:
             raise RuntimeError(self.b.last_error(self.h).decode())
         del keep  # the engine copied the blobs into its staging buffer
@@ -204,7 +205,10 @@ class Context:
 
     def summary_rows_ptr(self):
         """(device address, rows) of the summary rows the last run wrote (lm_summary_rows_device)"""
-        return self.b.summary_rows_device(self.h), getattr(self, "_sum_rows", 0)
+        ptr = self.b.summary_rows_device(self.h)
+        if not ptr:
+            raise RuntimeError("no summary rows: lm_summary_layout has not been called for the batch staged last")
+        return ptr, getattr(self, "_sum_rows", 0)
 
     def import_info(self):
         """[(DiffMode name or None, encoded LCA Frontiers or None)] of the last run's import, per resident document"""

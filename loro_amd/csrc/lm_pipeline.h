@@ -843,7 +843,7 @@ struct Engine {
       for (DBuf* b : {&b_dir_out, &b_dir_out2, &b_dir_b, &b_dir_b2}) b->ensure_keep(((size_t)leaf_top + 1) * 4, b->cap);
     } else {
       b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4); b_tb.ensure(elem + 16);
-      if (want_dcnt && span && kn.version_sweep) b_dcnt.ensure((elem + 1) * 4);
+      if (LM_BATCH_VSWEEP && want_dcnt && span && kn.version_sweep) b_dcnt.ensure((elem + 1) * 4);   // (the batch kernels' only reader is ts_goto's version pass, compiled out by default: ADVICE r4)
       b_it.ensure((leaves + 1) * (span ? (size_t)SP_REC : 256) * 4);
       b_dir_out.ensure((leaves + 1) * 4);
     }
@@ -858,7 +858,7 @@ struct Engine {
     b_ht0.ensure((size_t)n_docs * 8); b_ht_cap.ensure((size_t)n_docs * 4); b_ht_cnt.ensure((size_t)n_docs * 4 + 4);
     lmbe::h2d(b_ht0.p, h_ht0.data(), (size_t)n_docs * 8);
     lmbe::h2d(b_ht_cap.p, h_ht_cap.data(), (size_t)n_docs * 4);
-    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>(); d.dcnt = ((resident || (want_dcnt && span)) && kn.version_sweep) ? b_dcnt.as<uint32_t>() : nullptr; d.tb = b_tb.as<uint8_t>();
+    d.cp = b_cp.as<uint32_t>(); d.loc = b_loc.as<uint32_t>(); d.dcnt = ((resident || (LM_BATCH_VSWEEP && want_dcnt && span)) && kn.version_sweep) ? b_dcnt.as<uint32_t>() : nullptr; d.tb = b_tb.as<uint8_t>();
     d.it = b_it.as<uint32_t>();
     d.dir_out = b_dir_out.as<uint32_t>();
     d.lf_chunk = b_lf_chunk.as<uint8_t>();

@@ -609,6 +609,16 @@ def test_retry_launch_of_every_span_instantiation(monkeypatch, plain):
         got = c.merge_batch(docs)
         assert c.sizing()[3] >= 1
     assert got == want
+    # … also when the overflow happens inside the linear prefix (tl_dir_insert_after; flags for documents of every size), and for
+    # documents that are then replayed a THIRD time by k_integrate_span_pos (a delete row that does not match its position)
+    monkeypatch.setenv("LM_CUT_MIN_ROWS", "0")
+    bad, good = _cases.misnamed_delete_docs(12)
+    docs = _cases.linear_prefix_docs(18) + bad
+    want = _oracle.merge_batch(docs)
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        assert c.sizing()[3] >= 1
+    assert got == want
 
 
 def test_small_document_batches_pick_the_element_granular_kernel(monkeypatch):
