@@ -1811,6 +1811,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           // whose mask names the container holds a row for it, so the move is decided here, once per change, and the row loop
           // carries no test for it (7 instructions per op row, 4 of them register moves in front of the branch)
           checked_out = true;
+          PROF_T0();
           ts_goto<ML, SWEEP, false, POS>(t, d, m, cidx, P, vv, s_cur, s_base, base_on, conv_node, d.loc + elem0, nullptr);
           PROF_ADD(t, PF_CHECKOUT);
           TS_CHECK("checkout", ch.op0);

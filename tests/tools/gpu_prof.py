@@ -13,6 +13,8 @@ for kv in sys.argv[2:]:
     os.environ[k] = v
 tpl = workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True)
 docs = [tpl.stamp(d) for d in range(n_docs)]
+if os.environ.get("GPU_PROF_BLOBS"):   # e.g. 02 = base + B's branch only (round 5: what the THIRD node — A against B's future items — costs = the difference)
+    docs = [[b_[int(c)] for c in os.environ["GPU_PROF_BLOBS"]] for b_ in docs]
 names = ["row", "find", "leaf", "oright", "between", "place", "delete", "checkout", "n_ins", "n_del", "n_leaf_loads", "n_between_items", "total", "n_ins_inside_run", "n_ins_merged", "n_upd_via_loc"]
 with Context(b, 0) as e:
     print("selftest mismatches:", b.selftest(e.h))
