@@ -1833,15 +1833,44 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
         }
         uint32_t row0 = ch.op0, last_row = 0;   // (POS only: where the row loop is entered again behind a row that was finished by position)
       rows_again:
-        for (uint32_t row = row0; row < ch.op0 + n_rows && !t.err; row++) {
+        // R64 (the plain batch kernels): op rows 64 at a time, lane = row — two 16-byte loads per lane, one ballot picks the rows of this
+        // container (FUSE: that head a run), a row's words come out of the registers with one lane index; the other instantiations keep
+        // the 8-row window (rw_get: lane = word of the window) — their register budgets have no room for eight more vector registers
+#ifndef LM_ROWS64
+#define LM_ROWS64 1
+#endif
+        constexpr bool R64 = PLAIN && !RES && !POS && LM_ROWS64;
+        struct alignas(16) U4 { uint32_t x, y, z, w; };
+        const uint32_t row_end = ch.op0 + n_rows;
+        for (uint32_t base = row0; base < row_end && !t.err; base += (R64 ? 64u : 1u)) {
+          U4 a4 = {0u, 0u, 0u, 0u}, b4 = {0u, 0u, 0u, 0u};
+          uint64_t mine = 1;
+          if (R64) {
+            const bool in = base + (uint32_t)lane < row_end;
+            if (in) { const U4* p = (const U4*)(op_ro + base + (uint32_t)lane); a4 = p[0]; b4 = p[1]; }
+            mine = lmw::ballot(in & ((a4.x & 0xffff) == cidx) & (!FUSE | !(a4.x & OPF_CONT)));
+          }
+          while (mine && !t.err) {
           PROF_T0();
+          uint32_t row;
+          OpRow r;
+          if (R64) {
+            const int j = lmw::ffs64(mine);
+            mine &= mine - 1;
+            row = base + (uint32_t)j;
+            r.cidx_kind = lmw::bcast(a4.x, j); r.prop = (int32_t)lmw::bcast(a4.y, j); r.len = lmw::bcast(a4.z, j); r.ctr = lmw::bcast(a4.w, j);
+            r.a0 = lmw::bcast(b4.x, j); r.a1 = lmw::bcast(b4.y, j); r.a2 = (int32_t)lmw::bcast(b4.z, j); r.chg = 0;
+          } else {
+            mine = 0;
+            row = base;
+            r = rw_get(w, op_w, row);
+            if ((r.cidx_kind & 0xffff) != cidx) continue;
+            if (FUSE && (r.cidx_kind & OPF_CONT)) continue;
+          }
           if (POS) last_row = row;
-          OpRow r = rw_get(w, op_w, row);
-          if ((r.cidx_kind & 0xffff) != cidx) continue;
           if (FUSE) {
-            // k_fuse_rows (lm_k_fuse.h): a row that continues the run of the row in front of it was replayed with its head; a head
-            // carries its run's extent (inserts: the total length; deletes: the leftmost target and the signed total)
-            if (r.cidx_kind & OPF_CONT) continue;
+            // k_fuse_rows (lm_k_fuse.h): a row that continues the run of the row in front of it was replayed with its head (skipped
+            // above); a head carries its run's extent (inserts: the total length; deletes: the leftmost target and the signed total)
             if (r.cidx_kind & OPF_HEAD) {
               lmw::wave_sync();
               uint32_t fa1 = lmw::first(d.fuse[2 * (uint64_t)row]);
@@ -1935,6 +1964,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
             if (!ML || mv_to == NONE || t.err) break;
             r.prop = (int32_t)mv_to; kind = OK_LIST_INS; mv_to = NONE;   // second half of a move: the new item
           }
+          }   // (rows of this step)
         }
         if (POS && t.err == ST_POSDEL) {   // a delete row that does not match its position: finished by position, then on with the next row
           ts_del_positional(t, last_row);
