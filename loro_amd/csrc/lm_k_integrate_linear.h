@@ -172,55 +172,55 @@ LM_DEV void tl_insert(Ts& t, Tl& c, uint32_t pos, uint32_t pid0, uint32_t len) {
     c.len = lane == slot ? sln + len : c.len;
   }
 }
-// delete of the Ln elements from position pos0 (0-based) on; the row names them as ids [x0, x0 + Ln), ascending with the position
-// (list_op.rs:288-379; the decoders normalise a backward span to its leftmost target).  The reference deletes by position and never
-// looks at the ids while it does (crdt_rope.rs:256-335) — so does the prefix: nothing here is ever retreated, what a damaged row
-// names instead of the elements at its position is of no consequence (the tracker behind the prefix: ts_del_positional).
-LM_DEV void tl_delete(Ts& t, Tl& c, uint32_t pos0, uint32_t Ln, uint32_t x0, bool& emptied) {
+// delete of the Ln elements from position pos0 (0-based) on — the part of it that lies in ONE leaf; returns the number of elements left
+// (the range runs on into the next leaf: the row loop queues the rest as a row of its own — a loop in here put 49 register moves in
+// front of every delete row).  The row names its targets as ids, ascending with the position (list_op.rs:288-379); the reference
+// deletes by position and never looks at the ids while it does (crdt_rope.rs:256-335) — so does the prefix: nothing here is ever
+// retreated, what a damaged row names instead of the elements at its position is of no consequence (the tracker behind the prefix:
+// ts_del_positional).
+LM_DEV uint32_t tl_delete(Ts& t, Tl& c, uint32_t pos0, uint32_t Ln, bool& emptied) {
   uint32_t lane = (uint32_t)lmw::lane();
-  if (pos0 > t.tot_active || Ln > t.tot_active - pos0) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
-  t.tot_active -= Ln;
+  if (pos0 > t.tot_active || Ln > t.tot_active - pos0) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return 0; }
   const uint32_t pos = pos0 + 1;
-  do {   // (one trip unless the range runs on into the next leaf)
-    {
-      uint32_t k0 = pos - c.pre - 1;
-      if ((k0 >= c.tot ? 1u : 0u) | (c.n > 63 ? 1u : 0u)) tl_prepare(t, c, pos, 1);
-      if (t.err) { tl_none(c); return; }
+  {
+    uint32_t k0 = pos - c.pre - 1;
+    if ((k0 >= c.tot ? 1u : 0u) | (c.n > 63 ? 1u : 0u)) tl_prepare(t, c, pos, 1);
+    if (t.err) { tl_none(c); return 0; }
+  }
+  uint32_t s = pos - c.pre - 1, e = s + Ln < c.tot ? s + Ln : c.tot;     // elements [s, e) of the leaf
+  uint32_t take = e - s;
+  uint32_t inc = lmw::scan_incl_add(c.len), start = inc - c.len;
+  uint32_t lo = start > s ? start : s, hi = inc < e ? inc : e;
+  bool has = hi > lo;
+  uint64_t mid = lmw::ballot(has & (lo > start) & (hi < inc));
+  uint32_t cut = has ? hi - lo : 0u;
+  if (mid) {
+    // strictly inside one item: left part | (deleted) | right part — one more item
+    uint32_t slot = (uint32_t)lmw::ffs64(mid);
+    uint32_t sid = lmw::bcast(c.id, (int)slot), sln = lmw::bcast(c.len, (int)slot), a = s - lmw::bcast(start, (int)slot);
+    c.len = lane == slot ? a : c.len;
+    tl_shift_in(c, slot + 1, sid + a + take, sln - a - take, sid + a + take - 1);
+  } else {
+    bool keep_tail = has & (lo == start) & (hi < inc);         // the item loses its head (an item that loses its tail only shrinks)
+    c.len -= cut;
+    c.id = keep_tail ? c.id + cut : c.id;
+    c.ol = keep_tail ? c.id - 1 : c.ol;
+    uint64_t mf = lmw::ballot(has & (c.len == 0));
+    if (mf) {   // whole items go: the items behind them move down (they are one contiguous range of lanes)
+      uint32_t r0 = (uint32_t)lmw::ffs64(mf), dn = (uint32_t)lmw::popc64(mf);
+      uint32_t src = (lane + dn) & 63;
+      uint32_t gid = lmw::shfl(c.id, (int)src), gln = lmw::shfl(c.len, (int)src), gol = lmw::shfl(c.ol, (int)src);
+      bool mv = lane >= r0, gone = lane + dn >= c.n;
+      c.id = mv ? (gone ? NONE : gid) : c.id;
+      c.len = mv ? (gone ? 0u : gln) : c.len;
+      c.ol = mv ? (gone ? NONE : gol) : c.ol;
+      c.n -= dn;
+      emptied |= c.n == 0;
     }
-    uint32_t s = pos - c.pre - 1, e = s + Ln < c.tot ? s + Ln : c.tot;     // elements [s, e) of the leaf
-    uint32_t take = e - s;
-    uint32_t inc = lmw::scan_incl_add(c.len), start = inc - c.len;
-    uint32_t lo = start > s ? start : s, hi = inc < e ? inc : e;
-    bool has = hi > lo;
-    uint64_t mid = lmw::ballot(has & (lo > start) & (hi < inc));
-    uint32_t cut = has ? hi - lo : 0u;
-    if (mid) {
-      // strictly inside one item: left part | (deleted) | right part — one more item
-      uint32_t slot = (uint32_t)lmw::ffs64(mid);
-      uint32_t sid = lmw::bcast(c.id, (int)slot), sln = lmw::bcast(c.len, (int)slot), a = s - lmw::bcast(start, (int)slot);
-      c.len = lane == slot ? a : c.len;
-      tl_shift_in(c, slot + 1, sid + a + take, sln - a - take, sid + a + take - 1);
-    } else {
-      bool keep_tail = has & (lo == start) & (hi < inc);         // the item loses its head (an item that loses its tail only shrinks)
-      c.len -= cut;
-      c.id = keep_tail ? c.id + cut : c.id;
-      c.ol = keep_tail ? c.id - 1 : c.ol;
-      uint64_t mf = lmw::ballot(has & (c.len == 0));
-      if (mf) {   // whole items go: the items behind them move down (they are one contiguous range of lanes)
-        uint32_t r0 = (uint32_t)lmw::ffs64(mf), dn = (uint32_t)lmw::popc64(mf);
-        uint32_t src = (lane + dn) & 63;
-        uint32_t gid = lmw::shfl(c.id, (int)src), gln = lmw::shfl(c.len, (int)src), gol = lmw::shfl(c.ol, (int)src);
-        bool mv = lane >= r0, gone = lane + dn >= c.n;
-        c.id = mv ? (gone ? NONE : gid) : c.id;
-        c.len = mv ? (gone ? 0u : gln) : c.len;
-        c.ol = mv ? (gone ? NONE : gol) : c.ol;
-        c.n -= dn;
-        emptied |= c.n == 0;
-      }
-    }
-    c.tot -= take; c.dirty = true;
-    (void)x0; Ln -= take;
-  } while (Ln > 0 && !t.err);
+  }
+  c.tot -= take; c.dirty = true;
+  t.tot_active -= take;
+  return Ln - take;
 }
 // the prefix is done: everything goes back to HBM / LDS in the tracker's form; leaves that lost every item leave the directory
 LM_DEV void tl_finish(Ts& t, Tl& c, bool emptied) {

@@ -1739,7 +1739,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           U4 na = z4, nb = z4;
           if (ch.op0 + (uint32_t)lane < row_end) { const U4* p = (const U4*)(op_ro + ch.op0 + (uint32_t)lane); na = p[0]; nb = p[1]; }
           for (uint32_t base = ch.op0; base < row_end && !t.err; base += 64) {
-            const U4 a4 = na, b4 = nb;
+            U4 a4 = na, b4 = nb;
             if (base + 64 + (uint32_t)lane < row_end) { const U4* p = (const U4*)(op_ro + base + 64 + (uint32_t)lane); na = p[0]; nb = p[1]; }
             uint64_t mine = lmw::ballot((base + (uint32_t)lane < row_end) & ((a4.x & 0xffff) == cidx) & (!FUSE | !(a4.x & OPF_CONT)));
             while (mine && !t.err) {
@@ -1764,7 +1764,15 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
                 uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
                 const uint32_t bad_bits = (Ln ^ r.len) | ((uint32_t)r.prop >> 31) | (((uint32_t)r.a2 >> 31) & (((uint32_t)r.prop + 1u - Ln) >> 31));
                 if (bad_bits) LM_SETERR(t.err, ST_DATA_CORRUPTION);
-                else tl_delete(t, c, r.a2 > 0 ? (uint32_t)r.prop : (uint32_t)r.prop + 1u - Ln, Ln, pid_make(r.a0, r.a1), emptied);
+                else {
+                  const uint32_t pos0 = r.a2 > 0 ? (uint32_t)r.prop : (uint32_t)r.prop + 1u - Ln;
+                  const uint32_t left = tl_delete(t, c, pos0, Ln, emptied);
+                  if (left) {   // the range runs on into the next leaf: the rest is queued as a (forward) delete row of its own, in this row's lane
+                    const bool me = lane == j;
+                    a4.x = me ? (a4.x & ~OPF_HEAD) : a4.x; a4.y = me ? pos0 : a4.y; a4.z = me ? left : a4.z; b4.z = me ? left : b4.z;
+                    mine |= 1ull << j;
+                  }
+                }
               }
             }
           }
@@ -1839,7 +1847,10 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
 #ifndef LM_ROWS64
 #define LM_ROWS64 1
 #endif
-        constexpr bool R64 = PLAIN && !RES && !POS && LM_ROWS64;
+#ifndef LM_ROWS64_ALL
+#define LM_ROWS64_ALL 0
+#endif
+        constexpr bool R64 = LM_ROWS64 && ((PLAIN && !RES && !POS) || (LM_ROWS64_ALL && !ML));
         struct alignas(16) U4 { uint32_t x, y, z, w; };
         const uint32_t row_end = ch.op0 + n_rows;
         for (uint32_t base = row0; base < row_end && !t.err; base += (R64 ? 64u : 1u)) {
