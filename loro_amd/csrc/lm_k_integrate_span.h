@@ -1741,39 +1741,38 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           for (uint32_t base = ch.op0; base < row_end && !t.err; base += 64) {
             U4 a4 = na, b4 = nb;
             if (base + 64 + (uint32_t)lane < row_end) { const U4* p = (const U4*)(op_ro + base + 64 + (uint32_t)lane); na = p[0]; nb = p[1]; }
-            uint64_t mine = lmw::ballot((base + (uint32_t)lane < row_end) & ((a4.x & 0xffff) == cidx) & (!FUSE | !(a4.x & OPF_CONT)));
+            const bool in = base + (uint32_t)lane < row_end;
+            // what a row needs beyond its words — kind, the delete's leftmost position and length, its checks, the insert's first id — is
+            // worked out for all 64 rows at once on the vector unit (the kernel is bound by SCALAR issue: ≈25 scalar instructions per row
+            // as wave-uniform arithmetic, ≈25 vector instructions per 64 rows here); the row loop reads four words per row
+            if (FUSE && in && (a4.x & OPF_HEAD)) {   // a head row carries its run's extent (k_fuse_rows): total length; deletes: leftmost target, signed total
+              const uint32_t row = base + (uint32_t)lane;
+              uint32_t fa1 = d.fuse[2 * (uint64_t)row];
+              int32_t fa2 = (int32_t)d.fuse[2 * (uint64_t)row + 1];
+              a4.z = (uint32_t)(fa2 < 0 ? -fa2 : fa2);
+              if (((a4.x >> 16) & 0xff) == OK_DEL) { b4.y = fa1; b4.z = (uint32_t)fa2; }
+            }
+            const uint32_t kindv = (a4.x >> 16) & 0xff;
+            const bool insv = (kindv == OK_TEXT_INS) | (kindv == OK_LIST_INS), delv = kindv == OK_DEL;
+            const int32_t a2v = (int32_t)b4.z;
+            const uint32_t Lnv = (uint32_t)(a2v < 0 ? -a2v : a2v);
+            // (the row's checks are the tracker's, below: a span as long as its op, a position inside the sequence)
+            const uint32_t badv = (Lnv ^ a4.z) | (a4.y >> 31) | ((b4.z >> 31) & ((a4.y + 1u - Lnv) >> 31));
+            uint32_t codev = insv ? 1u : (delv ? (badv ? 3u : 2u) : 0u);               // 1 insert, 2 delete, 3 a delete row that fails its checks
+            uint32_t posv = delv ? (a2v > 0 ? a4.y : a4.y + 1u - Lnv) : a4.y;            // active position (a delete: of its leftmost target)
+            uint32_t lenv = delv ? Lnv : a4.z;
+            const uint32_t pidv = pid_make(node_peer, a4.w);
+            uint64_t mine = lmw::ballot(in & ((a4.x & 0xffff) == cidx) & (!FUSE | !(a4.x & OPF_CONT)) & (codev != 0));
             while (mine && !t.err) {
               const int j = lmw::ffs64(mine);
               mine &= mine - 1;
-              OpRow r;
-              r.cidx_kind = lmw::bcast(a4.x, j); r.prop = (int32_t)lmw::bcast(a4.y, j); r.len = lmw::bcast(a4.z, j); r.ctr = lmw::bcast(a4.w, j);
-              r.a0 = lmw::bcast(b4.x, j); r.a1 = lmw::bcast(b4.y, j); r.a2 = (int32_t)lmw::bcast(b4.z, j);
-              if (FUSE && (r.cidx_kind & OPF_HEAD)) {
-                const uint32_t row = base + (uint32_t)j;
-                lmw::wave_sync();
-                uint32_t fa1 = lmw::first(d.fuse[2 * (uint64_t)row]);
-                int32_t fa2 = (int32_t)lmw::first(d.fuse[2 * (uint64_t)row + 1]);
-                r.len = (uint32_t)(fa2 < 0 ? -fa2 : fa2);
-                if (((r.cidx_kind >> 16) & 0xff) == OK_DEL) { r.a1 = fa1; r.a2 = fa2; }
-              }
-              uint32_t kind = (r.cidx_kind >> 16) & 0xff;
+              const uint32_t code = lmw::bcast(codev, j), pos = lmw::bcast(posv, j), n = lmw::bcast(lenv, j);
               touched = true;
-              if (kind == OK_TEXT_INS || kind == OK_LIST_INS) tl_insert(t, c, (uint32_t)r.prop, pid_make(node_peer, r.ctr), r.len);
-              else if (kind == OK_DEL) {
-                // (the row's checks are the tracker's, below: a span as long as its op, a position inside the sequence)
-                uint32_t Ln = (uint32_t)(r.a2 < 0 ? -r.a2 : r.a2);
-                const uint32_t bad_bits = (Ln ^ r.len) | ((uint32_t)r.prop >> 31) | (((uint32_t)r.a2 >> 31) & (((uint32_t)r.prop + 1u - Ln) >> 31));
-                if (bad_bits) LM_SETERR(t.err, ST_DATA_CORRUPTION);
-                else {
-                  const uint32_t pos0 = r.a2 > 0 ? (uint32_t)r.prop : (uint32_t)r.prop + 1u - Ln;
-                  const uint32_t left = tl_delete(t, c, pos0, Ln, emptied);
-                  if (left) {   // the range runs on into the next leaf: the rest is queued as a (forward) delete row of its own, in this row's lane
-                    const bool me = lane == j;
-                    a4.x = me ? (a4.x & ~OPF_HEAD) : a4.x; a4.y = me ? pos0 : a4.y; a4.z = me ? left : a4.z; b4.z = me ? left : b4.z;
-                    mine |= 1ull << j;
-                  }
-                }
-              }
+              if (code == 1) tl_insert(t, c, pos, lmw::bcast(pidv, j), n);
+              else if (code == 2) {
+                const uint32_t left = tl_delete(t, c, pos, n, emptied);
+                if (left) { lenv = lane == j ? left : lenv; mine |= 1ull << j; }   // the range runs on into the next leaf: the rest is this lane's row again
+              } else LM_SETERR(t.err, ST_DATA_CORRUPTION);
             }
           }
         }
