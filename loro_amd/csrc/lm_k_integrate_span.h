@@ -1838,6 +1838,63 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           PROF_ADD(t, PF_CHECKOUT);
           TS_CHECK("checkout", ch.op0);
         }
+#ifndef LM_ROWS64
+#define LM_ROWS64 1
+#endif
+#ifndef LM_ROWS64_VEC
+#define LM_ROWS64_VEC 1
+#endif
+        // V64 (the plain batch kernels — no sliced change, no style anchor, no move, no checkout: a row is an insert or a delete): op rows
+        // 64 at a time, lane = row, and what the replay needs of a row is worked out for all 64 at once on the vector unit — the kind,
+        // the delete's target range [t0, t1), its position hint and its checks, the insert's first id.  The kernel is bound by SCALAR
+        // issue: as wave-uniform arithmetic that was ≈30 scalar instructions per row, here ≈30 vector instructions per 64
+        // rows; the row loop reads five words per row with one lane index.
+        constexpr bool V64 = PLAIN && !RES && !POS && LM_ROWS64 && LM_ROWS64_VEC;
+        if (V64) {
+          struct alignas(16) V4 { uint32_t x, y, z, w; };
+          const uint32_t v_end = ch.op0 + n_rows;
+          for (uint32_t base = ch.op0; base < v_end && !t.err; base += 64) {
+            V4 a4 = {0u, 0u, 0u, 0u}, b4 = {0u, 0u, 0u, 0u};
+            const bool in = base + (uint32_t)lane < v_end;
+            if (in) { const V4* p = (const V4*)(op_ro + base + (uint32_t)lane); a4 = p[0]; b4 = p[1]; }
+            if (FUSE && in && (a4.x & OPF_HEAD)) {   // a head row carries its run's extent (k_fuse_rows): total length; deletes: leftmost target, signed total
+              const uint32_t row = base + (uint32_t)lane;
+              uint32_t fa1 = d.fuse[2 * (uint64_t)row];
+              int32_t fa2 = (int32_t)d.fuse[2 * (uint64_t)row + 1];
+              a4.z = (uint32_t)(fa2 < 0 ? -fa2 : fa2);
+              if (((a4.x >> 16) & 0xff) == OK_DEL) { b4.y = fa1; b4.z = (uint32_t)fa2; }
+            }
+            const uint32_t kindv = (a4.x >> 16) & 0xff;
+            const bool insv = (kindv == OK_TEXT_INS) | (kindv == OK_LIST_INS), delv = kindv == OK_DEL;
+            const int32_t a2v = (int32_t)b4.z;
+            const uint32_t Lnv = (uint32_t)(a2v < 0 ? -a2v : a2v);
+            // a delete span as long as its op and with a position inside the sequence (see the general loop below for the why)
+            const uint32_t badv = (Lnv ^ a4.z) | (a4.y >> 31) | ((b4.z >> 31) & ((a4.y + 1u - Lnv) >> 31));
+            const uint32_t codev = insv ? 1u : (delv ? (badv ? 3u : 2u) : 0u);   // (a row that is neither is no row of a plain document's replay)
+            // insert: position, first id, length | delete: position hint (1-based, leftmost target), [t0, t1) of peer a0
+            const uint32_t w0v = insv ? a4.y : (a2v > 0 ? a4.y + 1u : a4.y + 2u - Lnv);
+            const uint32_t w1v = insv ? pid_make(node_peer, a4.w) : (a2v > 0 ? b4.y : b4.y + (Lnv - a4.z));
+            const uint32_t w2v = insv ? a4.z : (a2v > 0 ? b4.y + a4.z : b4.y + Lnv);
+            uint64_t mine = lmw::ballot(in & ((a4.x & 0xffff) == cidx) & (!FUSE | !(a4.x & OPF_CONT)) & (codev != 0));
+            while (mine && !t.err) {
+              PROF_T0();
+              const int j = lmw::ffs64(mine);
+              mine &= mine - 1;
+              const uint32_t code = lmw::bcast(codev, j), w0 = lmw::bcast(w0v, j), w1 = lmw::bcast(w1v, j), w2 = lmw::bcast(w2v, j);
+              touched = true;
+              PROF_ADD(t, PF_ROW);
+              if (code == 1) {
+                ts_insert(t, w0, w1, w2);
+                TS_CHECK("insert", base + (uint32_t)j);
+              } else if (code == 2) {
+                ts_update_range(t, lmw::bcast(b4.x, j), w1, w2, UPD_DEL_INC, w0);
+                PROF_ADD(t, PF_DELETE);
+                PROF_CNT(t, PF_NDEL, 1);
+                TS_CHECK("delete", base + (uint32_t)j);
+              } else LM_SETERR(t.err, ST_DATA_CORRUPTION);
+            }
+          }
+        } else {
         uint32_t row0 = ch.op0, last_row = 0;   // (POS only: where the row loop is entered again behind a row that was finished by position)
       rows_again:
         // R64 (the plain batch kernels): op rows 64 at a time, lane = row — two 16-byte loads per lane, one ballot picks the rows of this
@@ -1849,7 +1906,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
 #ifndef LM_ROWS64_ALL
 #define LM_ROWS64_ALL 0
 #endif
-        constexpr bool R64 = LM_ROWS64 && ((PLAIN && !RES && !POS) || (LM_ROWS64_ALL && !ML));
+        constexpr bool R64 = LM_ROWS64 && ((PLAIN && !RES && !POS) || (LM_ROWS64_ALL && !ML));   // (PLAIN && !RES && !POS: only in -DLM_ROWS64_VEC=0 builds — V64 above otherwise)
         struct alignas(16) U4 { uint32_t x, y, z, w; };
         const uint32_t row_end = ch.op0 + n_rows;
         for (uint32_t base = row0; base < row_end && !t.err; base += (R64 ? 64u : 1u)) {
@@ -1981,6 +2038,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
           row0 = last_row + 1;
           goto rows_again;
         }
+        }   // (!V64)
         if (checked_out && lane == 0) s_cur[node_peer] = (FUSE && node_contig) ? pe : (ch.ctr + ch.len < pe ? ch.ctr + ch.len : pe);
       }
       lmw::block_sync();
