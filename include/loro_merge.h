@@ -198,6 +198,22 @@ int lm_encode_updates(const uint8_t* const* blocks, const size_t* block_lens, si
 int lm_export(lm_ctx* ctx, size_t doc, const uint8_t* from_vv, size_t from_vv_len, uint8_t** out, size_t* out_len);
 void lm_free_bytes(uint8_t* p);
 
+/* ---- Richtext values: what TextHandler::get_richtext_value (crates/loro/src/lib.rs:2774 →
+ * crates/loro-internal/src/handler.rs:1502 → container/richtext/richtext_state.rs:2546-2584) returns for every Text container of
+ * the documents of the last lm_run, at the version that run rendered: a list of spans {"insert": text, "attributes": {key: value}}
+ * — a scalar carries, per style key, the value of the mark (StyleOp, container/richtext.rs:31-57) with the greatest (lamport, peer)
+ * among those whose StyleStart anchor stands in front of it and whose StyleEnd anchor stands behind it (style_range_map.rs;
+ * state/richtext_state.rs:730-812), keys whose value is null are dropped (unmark), neighbouring spans with equal attributes are one.
+ * lm_richtext renders them ON THE DEVICE (k_richtext: one wave per document over the trackers the integrate stage left) and copies
+ * them back; lm_richtext_result returns document `doc`'s bytes: one JSON object {"<container id>": [span, ...], ...} over the Text
+ * containers in which something (a scalar, an anchor) is visible at that version (ContainerID Display: cid:root-<name>:Text / cid:<counter>@<peer>:Text; members in the order of
+ * the document's container table), every span the canonical JSON of the LoroValue map it is ({"attributes":{...},"insert":"..."},
+ * keys bytewise sorted, no "attributes" member when there are none).  *status: LM_OK, the document's import error, or
+ * LM_UNSUPPORTED (more than 64 marks open at one scalar).  The bytes stay valid until the next lm_richtext / lm_stage / lm_destroy.
+ * Not available on a batch folded by shared replay.  get_deep_value (lm_fetch) never shows styles: this is a call of its own. */
+int lm_richtext(lm_ctx* ctx);
+int lm_richtext_result(lm_ctx* ctx, size_t doc, int32_t* status, const uint8_t** json, size_t* json_len);
+
 /* Wave-primitive self test on the device (DPP scan, ballot ranks); returns the number of mismatches. */
 int lm_selftest(lm_ctx* ctx);
 

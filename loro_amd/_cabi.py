@@ -21,7 +21,7 @@ class RunStats(ctypes.Structure):
 
 SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
            "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca", "export", "comm_unique_id", "comm_init", "summary_allgather",
-           "summary_layout", "summary_rows_device", "summary_allgather_device", "shared_documents"]
+           "summary_layout", "summary_rows_device", "summary_allgather_device", "shared_documents", "richtext", "richtext_result"]
 
 
 class Binding:
@@ -55,6 +55,9 @@ class Binding:
         self.import_lca.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
         self.export = g("export"); self.export.restype = ctypes.c_int
         self.export.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        self.richtext = g("richtext"); self.richtext.restype = ctypes.c_int; self.richtext.argtypes = [ctypes.c_void_p]
+        self.richtext_result = g("richtext_result"); self.richtext_result.restype = ctypes.c_int
+        self.richtext_result.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
         self.comm_unique_id = g("comm_unique_id"); self.comm_unique_id.restype = ctypes.c_int; self.comm_unique_id.argtypes = [ctypes.c_char_p]
         self.comm_init = g("comm_init"); self.comm_init.restype = ctypes.c_int; self.comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
         self.summary_allgather = g("summary_allgather"); self.summary_allgather.restype = ctypes.c_long
@@ -181,6 +184,19 @@ class Context:
         b = ctypes.string_at(out.value, n.value)
         self.b.free_bytes(out)
         return b
+
+    def richtext(self):
+        """lm_richtext + lm_richtext_result for every document of the last run: [(status, bytes)] — the richtext values
+        (get_richtext_value) of the document's Text containers as one JSON object {"<container id>": [spans]}"""
+        if self.b.richtext(self.h) != 0:
+            raise RuntimeError(self.b.last_error(self.h).decode())
+        out = []
+        st, p, n = ctypes.c_int32(), ctypes.c_void_p(), ctypes.c_size_t()
+        for i in range(self.n):
+            if self.b.richtext_result(self.h, i, ctypes.byref(st), ctypes.byref(p), ctypes.byref(n)) != 0:
+                raise RuntimeError(self.b.last_error(self.h).decode())
+            out.append((st.value, ctypes.string_at(p.value, n.value) if n.value else b""))
+        return out
 
     def comm_init(self, rank=0, world=1, unique_id=None):
         if self.b.comm_init(self.h, rank, world, unique_id or bytes(128)) != 0:

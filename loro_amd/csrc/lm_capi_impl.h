@@ -535,6 +535,35 @@ int LM_API(export)(void* c, size_t doc, const uint8_t* from_vv, size_t from_len,
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
 void LM_API(free_bytes)(uint8_t* p) { free(p); }
+// Richtext values of the documents of the last lm_run (lm_k_richtext.h): lm_richtext renders them on the device and copies them
+// back, lm_richtext_result hands out one document's bytes (valid until the next lm_richtext / lm_stage / lm_destroy).
+int LM_API(richtext)(void* c) {
+  auto* x = (lm_ctx_impl*)c;
+  try {
+    if (!x->ran) throw std::runtime_error("lm_richtext before lm_run");
+    if (x->sh.on) throw std::runtime_error("lm_richtext: not available on a batch folded by shared replay (stage with LM_SHARE_REPLAY=0)");
+    for (uint32_t p = 0; p < x->n_parts(); p++) x->parts[p]->richtext();
+    return 0;
+  } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
+int LM_API(richtext_result)(void* c, size_t doc, int32_t* status, const uint8_t** json, size_t* json_len) {
+  auto* x = (lm_ctx_impl*)c;
+  try {
+    if (x->sh.on || doc >= x->n_docs) throw std::runtime_error("lm_richtext_result: no such document");
+    for (uint32_t p = 0; p < x->n_parts(); p++) {
+      if (x->mapped ? x->emap[doc].first != p : (doc < x->first[p] || doc >= x->first[p + 1])) continue;
+      lm::Engine& e = *x->parts[p];
+      if (!e.rt_ran) throw std::runtime_error("lm_richtext_result before lm_richtext");
+      const uint32_t i = x->mapped ? x->emap[doc].second : (uint32_t)(doc - x->first[p]);
+      const bool ok = e.h_rt_status[i] == lm::ST_OK;
+      if (status) *status = e.h_rt_status[i];
+      if (json) *json = e.h_rt.data() + e.h_rt_off[i];
+      if (json_len) *json_len = ok ? (size_t)e.h_rt_len[i] : 0;
+      return 0;
+    }
+    throw std::runtime_error("lm_richtext_result: no such document");
+  } catch (const std::exception& e) { x->err = e.what(); return -1; }
+}
 int LM_API(get_stats)(void* c, lm_run_stats_c* s) {
   auto* x = (lm_ctx_impl*)c;
   s->n_docs = x->api_docs(); s->n_blobs = 0; s->in_bytes = 0; s->out_bytes = 0;

@@ -766,7 +766,9 @@ LM_KERNEL void k_elem_fill(Dev d) {
     if (want && !d.chg_flag[r.chg]) want = false;
     if (want && r.ctr + r.len > ext) want = false;
     uint64_t e0 = ebase + r.ctr;
-    if (want && (kind == OK_STYLE_START || kind == OK_STYLE_END)) { if (span) d.tb[e0] = (uint8_t)TB_ANCHOR; else d.cp[e0] = 0xFFFFFFFFu; want = false; }
+    // a style anchor: cp[] names its op row (CP_ANCHOR | row inside the document) — what k_richtext resolves the StyleOp from; the
+    // renderers only look at the marker (tb[] == TB_ANCHOR, cp[] >= CP_ANCHOR)
+    if (want && (kind == OK_STYLE_START || kind == OK_STYLE_END)) { if (span) d.tb[e0] = (uint8_t)TB_ANCHOR; d.cp[e0] = CP_ANCHOR | (row - m.op0); want = false; }
     const uint8_t* p = want ? d.data + d.op_val[row] : lim;
     Rd v = rd_make(p, (uint64_t)(lim - p));
     uint64_t nbytes = 0;

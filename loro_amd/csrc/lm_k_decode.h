@@ -77,7 +77,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint32_t* node_order;  // replay order (doc-relative node ids)
   uint32_t* vvh;         // [vvh0 + node*P + p]
   // elements
-  uint32_t* cp;          // text: unicode scalar (0xFFFFFFFF = style anchor) | list: value offset rel. to the doc's first byte
+  uint32_t* cp;          // text: unicode scalar (CP_ANCHOR | op row = style anchor) | list: value offset rel. to the doc's first byte
   uint32_t* loc;         // element → leaf
   uint32_t* dcnt;        // resident documents: element → delete ops of the version a tracker is being moved to (ts_sweep_version); nullptr otherwise
   uint8_t* tb;           // span-granular leaves: one byte per Text element — the scalar when it is ASCII, TB_WIDE: cp[] holds it, TB_ANCHOR: a style anchor
@@ -111,6 +111,7 @@ static constexpr int BCN = 8;  // counters per block: chg, dep, op, key, cid, pe
 enum { BC_CHG = 0, BC_DEP, BC_OP, BC_KEY, BC_CID, BC_PEER, BC_MAPOP, BC_ATOMS };
 static constexpr uint32_t VIS_CAP = 1024;
 static constexpr uint32_t TB_WIDE = 0xFF, TB_ANCHOR = 0xFE;   // Dev::tb markers (neither is a byte of an ASCII scalar)
+static constexpr uint32_t CP_ANCHOR = 0x80000000u, CP_ALIVE = 0x40000000u;   // Dev::cp of a style anchor: CP_ANCHOR | op row inside the document (no unicode scalar has bit 31); CP_ALIVE: k_richtext's mark while it runs
 
 // -------------------------------------------------------------------------------------------------
 static constexpr uint64_t BIG_BLOB = 32768;   // blobs from this size on are hashed by a whole wave

@@ -384,7 +384,7 @@ LM_DEV void sink_i64(Sink& s, int64_t v) {
 }
 // one unicode scalar of a Text container → escaped UTF-8 (anchors contribute nothing)
 LM_DEV void cp_bytes(uint32_t cp, uint64_t& bytes, uint32_t& n) {
-  if (cp == 0xFFFFFFFFu) { n = 0; bytes = 0; return; }
+  if (cp >= CP_ANCHOR) { n = 0; bytes = 0; return; }
   if (cp < 0x80) { esc_byte(cp, bytes, n); return; }
   if (cp < 0x800) { bytes = (0xC0 | (cp >> 6)) | ((uint64_t)(0x80 | (cp & 0x3F)) << 8); n = 2; }
   else if (cp < 0x10000) {

@@ -20,6 +20,7 @@
 #include "lm_k_lww_doc.h"
 #include "lm_k_fuse.h"
 #include "lm_k_lca.h"
+#include "lm_k_richtext.h"
 #include "lm_snapshot.h"
 #include "lm_export.h"
 
@@ -90,6 +91,14 @@ struct Engine {
   std::vector<uint64_t> h_out_off, h_vv_off;
   uint64_t out_bytes = 0, vv_bytes = 0;
   bool ran = false, fetched = false;
+  // lm_richtext (lm_k_richtext.h): the tables of the last run, the rendered richtext values
+  Dev last_d;
+  DBuf b_rt_out, b_rt_off, b_rt_len;
+  std::vector<uint8_t> h_rt;
+  std::vector<uint64_t> h_rt_off;
+  std::vector<uint32_t> h_rt_len;
+  std::vector<int32_t> h_rt_status;
+  bool rt_ran = false;
   std::vector<KernelTime> times;
   bool profiling = false;
   std::string last_error;
@@ -1238,6 +1247,41 @@ struct Engine {
     }
     ran = true;
     fetched = false;
+    last_d = d;
+    rt_ran = false;
+  }
+
+  // ---- lm_richtext: get_richtext_value of every Text container of every document, from the trackers the last run left (two
+  // launches of k_richtext: sizes, then the bytes)
+  void richtext() {
+    lmbe::bind(sc);
+    if (!ran) throw std::runtime_error("lm_richtext before lm_run");
+    if (shared_mode != 0) throw std::runtime_error("lm_richtext: not available on a batch folded by shared replay (stage with LM_SHARE_REPLAY=0)");
+    h_rt_off.assign(n_docs + 1, 0);
+    h_rt_len.assign(n_docs, 0);
+    h_rt_status.assign(n_docs, 0);
+    h_rt.assign(1, 0);
+    rt_ran = true;
+    if (n_docs == 0) return;
+    Dev d = last_d;
+    b_rt_len.ensure((size_t)n_docs * 8 + 8);
+    uint32_t* len = b_rt_len.as<uint32_t>();
+    int32_t* st = (int32_t*)(b_rt_len.as<uint32_t>() + n_docs);
+    LM_LAUNCH(k_richtext, n_docs, 64, d, (uint8_t*)nullptr, (const uint64_t*)nullptr, len, st, 0);
+    lmbe::d2h(h_rt_len.data(), len, (size_t)n_docs * 4);
+    lmbe::sync();
+    for (uint32_t i = 0; i < n_docs; i++) h_rt_off[i + 1] = h_rt_off[i] + (((uint64_t)h_rt_len[i] + 15) & ~15ull);
+    b_rt_out.ensure(h_rt_off[n_docs] + 64);
+    b_rt_off.ensure((size_t)(n_docs + 1) * 8);
+    lmbe::h2d(b_rt_off.p, h_rt_off.data(), (size_t)(n_docs + 1) * 8);
+    LM_LAUNCH(k_richtext, n_docs, 64, d, b_rt_out.as<uint8_t>(), (const uint64_t*)b_rt_off.as<uint64_t>(), len, st, 1);
+    std::vector<uint32_t> len2(n_docs);
+    lmbe::d2h(len2.data(), len, (size_t)n_docs * 4);
+    lmbe::d2h(h_rt_status.data(), st, (size_t)n_docs * 4);
+    h_rt.resize(h_rt_off[n_docs] + 1);
+    if (h_rt_off[n_docs]) lmbe::d2h(h_rt.data(), b_rt_out.p, h_rt_off[n_docs]);
+    lmbe::sync();
+    for (uint32_t i = 0; i < n_docs; i++) if (h_rt_status[i] == ST_OK && len2[i] != h_rt_len[i]) h_rt_status[i] = ST_INTERNAL;
   }
 
   // ---- lm_export: the updates document `i` holds beyond `from_vv` (lm_export.h).  The blobs come back from the arena, the

@@ -11,9 +11,10 @@ using namespace lo;
 
 struct DocResult {
   int32_t status = 0;
-  std::string json, vv, err;
+  std::string json, vv, err, richtext;
   uint64_t pending = 0;
 };
+static std::atomic<int> g_richtext(0);   // lo_option_richtext: also render every Text container's richtext value
 struct Batch {
   std::vector<DocResult> res;
 };
@@ -48,6 +49,8 @@ static void run_one(const uint8_t* data, const uint64_t* blob_off, uint32_t b0, 
     if (front) d.set_checkout(front, front_len);
     r.json = d.to_json();
     r.vv = d.vv_bytes();
+    r.richtext.clear();
+    if (g_richtext.load()) r.richtext = d.to_richtext();
     r.pending = d.pending_atoms();
     r.status = d.unsupported ? ST_UNSUPPORTED : ST_OK;
   } catch (const DecodeErr& e) {
@@ -55,6 +58,7 @@ static void run_one(const uint8_t* data, const uint64_t* blob_off, uint32_t b0, 
     r.err = e.what;
     r.json.clear();
     r.vv.clear();
+    r.richtext.clear();
   } catch (const std::exception& e) {
     r.status = ST_INTERNAL;
     r.err = e.what();
@@ -101,6 +105,8 @@ int32_t lo_batch_status(void* h, uint32_t i) { return ((Batch*)h)->res[i].status
 uint64_t lo_batch_pending(void* h, uint32_t i) { return ((Batch*)h)->res[i].pending; }
 const char* lo_batch_json(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*)h)->res[i]; *len = r.json.size(); return r.json.data(); }
 const char* lo_batch_vv(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*)h)->res[i]; *len = r.vv.size(); return r.vv.data(); }
+void lo_option_richtext(int on) { g_richtext.store(on); }
+const char* lo_batch_richtext(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*)h)->res[i]; *len = r.richtext.size(); return r.richtext.data(); }
 const char* lo_batch_err(void* h, uint32_t i) { return ((Batch*)h)->res[i].err.c_str(); }
 void lo_batch_free(void* h) { delete (Batch*)h; }
 
@@ -166,6 +172,7 @@ int32_t lo_session_step(void* h, const uint8_t* data, const uint64_t* blob_off, 
       r.vv = d.vv_bytes();
       s->sticky = d.seq_exists;
     }
+    if (g_richtext.load()) r.richtext = d.to_richtext();
   } catch (const DecodeErr& e) {
     r.status = e.st; r.err = e.what; r.json.clear(); r.vv.clear(); r.pending = 0;
   } catch (const std::exception& e) {
@@ -180,6 +187,7 @@ const char* lo_session_lca(void* h, uint64_t* len) { auto& l = ((Session*)h)->lc
 uint64_t lo_session_pending(void* h) { return ((Session*)h)->last.pending; }
 const char* lo_session_json(void* h, uint64_t* len) { auto& r = ((Session*)h)->last; *len = r.json.size(); return r.json.data(); }
 const char* lo_session_vv(void* h, uint64_t* len) { auto& r = ((Session*)h)->last; *len = r.vv.size(); return r.vv.data(); }
+const char* lo_session_richtext(void* h, uint64_t* len) { auto& r = ((Session*)h)->last; *len = r.richtext.size(); return r.richtext.data(); }
 const char* lo_session_err(void* h) { return ((Session*)h)->last.err.c_str(); }
 
 uint32_t lo_xxh32(const uint8_t* p, uint64_t n, uint32_t seed) { return xxh32(p, (size_t)n, seed); }

@@ -685,6 +685,8 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
     Value lv;
     bool have_lv = false;
     uint32_t mark_len = 0;
+    std::string mark_key;   // MarkStart: the style's key and value (container/richtext.rs:31-57 StyleOp)
+    Value mark_val;
     uint64_t mv_from = 0, mv_peer = 0, mv_lamport = 0;
     std::string str_payload;
     switch (vt) {
@@ -701,7 +703,8 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
         uint64_t ml = values_b.uleb();
         uint64_t key_idx = values_b.uleb();
         if (key_idx >= ctx.keys.size()) fail(ST_DATA_CORRUPTION, "mark key idx");
-        (void)read_loro_value(values_b, arena, op_id, 0, true);
+        mark_val = read_loro_value(values_b, arena, op_id, 0, true);
+        if (key_idx < ctx.keys.size()) mark_key = ctx.keys[(size_t)key_idx];
         mark_len = (uint32_t)ml;
         break;
       }
@@ -739,7 +742,7 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
           op.kind = OP_TEXT_INSERT;
           utf8_to_cps((const uint8_t*)str_payload.data(), str_payload.size(), op.cps);
         } else if (vt == 9) take_del();
-        else if (vt == 12) { op.kind = OP_STYLE_START; op.style_end = (uint32_t)prop + mark_len; }
+        else if (vt == 12) { op.kind = OP_STYLE_START; op.style_end = (uint32_t)prop + mark_len; op.key = mark_key; op.value = std::move(mark_val); }
         else if (vt == 0) op.kind = OP_STYLE_END;
         else fail(ST_DATA_CORRUPTION, "bad text op value");
         break;

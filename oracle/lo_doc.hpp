@@ -25,6 +25,7 @@
 #pragma once
 #include <map>
 #include <set>
+#include <tuple>
 #include <string>
 #include <vector>
 #include <cmath>
@@ -93,6 +94,9 @@ inline void json_value(const Doc& d, const Value& v, std::string& out, int depth
 
 // ---------------------------------------------------------------- document
 struct StyleRec { PeerID peer; Counter cnt; uint32_t end; };
+// a style anchor as the richtext state keeps it (RichtextStateChunk::Style { style: Arc<StyleOp>, anchor_type },
+// container/richtext.rs:31-57, richtext_state.rs:60-75): the StyleOp is identified by its StyleStart op
+struct AnchorRec { bool is_end; PeerID peer; Counter start_cnt; Lamport lamport; std::string key; Value value; };
 
 struct IdLpKey {   // IdLp (loro-common/src/lib.rs:524-528): ordered by lamport, then peer
   Lamport lamport; PeerID peer;
@@ -104,6 +108,7 @@ struct SeqState {
   std::vector<uint32_t> cps;      // text: unicode scalars; 0xFFFFFFFF = style anchor
   std::vector<Value> values;      // list
   std::vector<StyleRec> styles;
+  std::map<uint32_t, AnchorRec> anchors;   // content index (cps) of an anchor → its StyleOp
   // MovableList: per list item (index = content index, parallel to `values`): its own IdLp and the element it positions
   struct ItemRec { IdLpKey item, elem; };
   std::vector<ItemRec> items;
@@ -511,6 +516,7 @@ struct Doc {
               uint32_t start = (uint32_t)st.cps.size();
               st.cps.push_back(0xFFFFFFFFu);
               st.styles.push_back(StyleRec{ch.id.peer, op.counter, op.style_end});
+              st.anchors[start] = AnchorRec{false, ch.id.peer, op.counter, ch.lamport + (Lamport)(op.counter - ch.id.counter), op.key, op.value};
               st.tr.insert(op_id, op.prop, 1, start);
               break;
             }
@@ -528,6 +534,7 @@ struct Doc {
               }
               uint32_t start = (uint32_t)st.cps.size();
               st.cps.push_back(0xFFFFFFFFu);
+              st.anchors[start] = AnchorRec{true, ch.id.peer, op.counter - 1, 0, std::string(), Value()};
               int64_t pos = std::min<int64_t>(end_pos + 1, st.tr.active_len());
               st.tr.insert(op_id, pos, 1, start);
               break;
@@ -646,6 +653,114 @@ struct Doc {
       json_escape(kv.first, out);
       out.push_back(':');
       container_json(kv.second, out, 0);
+    }
+    out.push_back('}');
+    return out;
+  }
+  // ---- richtext values (TextHandler::get_richtext_value, handler.rs:1502; richtext_state.rs:2500-2584)
+  // A scalar carries the StyleOps whose Start anchor stands in front of it and whose End anchor stands behind it
+  // (state/richtext_state.rs:730-812: the End anchor's insertion annotates start..=end; style_range_map.rs insert():
+  // an element inserted inside a range inherits it, at a boundary the intersection of both sides; an anchor that is
+  // deleted takes its range along, richtext_state.rs:2275-2300) — for every key the op with the greatest (lamport, peer)
+  // decides (StyleValue::get = BTreeSet::last under StyleOp::cmp, container/richtext.rs:120-126), a null value removes the
+  // key (StyleMeta::to_value, delta/text.rs:125-140); neighbouring spans with equal attributes are one span
+  // (richtext_state.rs:2546-2584).  A span is rendered as the canonical JSON of the LoroValue map it is:
+  // {"attributes":{…},"insert":"…"} (keys bytewise sorted; no attributes entry when the map is empty).
+  // Anchors without their partner at the rendered version annotate nothing (more than 64 StyleOps open at one scalar:
+  // the device path's limit, LM_UNSUPPORTED there).
+  void richtext_json(uint32_t idx, std::string& out) const {
+    out.push_back('[');
+    auto it = seqs.find(idx);
+    if (it == seqs.end()) { out.push_back(']'); return; }
+    const SeqState& st = *it->second;
+    std::map<std::tuple<PeerID, Counter, bool>, uint64_t> alive;   // visible anchors → position in the sequence
+    uint64_t seq_pos = 0;
+    for (Span* sp = st.tr.head; sp; sp = sp->next)
+      if (sp->active())
+        for (int32_t k = 0; k < sp->len; k++, seq_pos++) {
+          auto a = st.anchors.find(sp->content + (uint32_t)k);
+          if (a != st.anchors.end()) alive[std::make_tuple(a->second.peer, a->second.start_cnt, a->second.is_end)] = seq_pos;
+        }
+    seq_pos = 0;
+    std::vector<const AnchorRec*> active;
+    std::string open_attr, cur_text;
+    bool span_open = false, first = true;
+    auto attrs_now = [&]() {
+      std::map<std::string, const AnchorRec*> win;
+      for (const AnchorRec* a : active) {
+        auto w = win.find(a->key);
+        if (w == win.end() || w->second->lamport < a->lamport || (w->second->lamport == a->lamport && w->second->peer < a->peer)) win[a->key] = a;
+      }
+      std::string o;
+      for (auto& kv : win) {
+        if (kv.second->value.kind == V_NULL) continue;
+        o.push_back(o.empty() ? '{' : ',');
+        json_escape(kv.first, o);
+        o.push_back(':');
+        json_value(*this, kv.second->value, o, 1);
+      }
+      if (!o.empty()) o.push_back('}');
+      return o;
+    };
+    auto close_span = [&]() {
+      if (!span_open) return;
+      if (!first) out.push_back(',');
+      first = false;
+      out.push_back('{');
+      if (!open_attr.empty()) { out += "\"attributes\":"; out += open_attr; out.push_back(','); }
+      out += "\"insert\":";
+      json_escape(cur_text, out);
+      out.push_back('}');
+      span_open = false;
+      cur_text.clear();
+    };
+    for (Span* sp = st.tr.head; sp; sp = sp->next)
+      if (sp->active())
+        for (int32_t k = 0; k < sp->len; k++, seq_pos++) {
+          uint32_t ci = sp->content + (uint32_t)k;
+          if ((uint64_t)ci >= st.cps.size()) fail(ST_DATA_CORRUPTION, "visible span without content");
+          uint32_t cp = st.cps[ci];
+          if (cp != 0xFFFFFFFFu) {
+            std::string a = attrs_now();
+            if (span_open && a != open_attr) close_span();
+            if (!span_open) { span_open = true; open_attr = a; }
+            cp_to_utf8(cp, cur_text);
+            continue;
+          }
+          auto a = st.anchors.find(ci);
+          if (a == st.anchors.end()) continue;
+          const AnchorRec& r = a->second;
+          if (!r.is_end) {   // (an End in FRONT of its Start — damaged input only — annotates nothing)
+            auto e = alive.find(std::make_tuple(r.peer, r.start_cnt, true));
+            if (e != alive.end() && e->second > seq_pos) active.push_back(&r);
+          }
+          else
+            for (size_t j = 0; j < active.size(); j++)
+              if (active[j]->peer == r.peer && active[j]->start_cnt == r.start_cnt) { active.erase(active.begin() + j); break; }
+        }
+    close_span();
+    out.push_back(']');
+  }
+  static std::string cid_string(const ContainerID& c) {   // ContainerID's Display (loro-common/src/lib.rs: "cid:root-{name}:{Type}" / "cid:{counter}@{peer}:{Type}")
+    return c.root ? "cid:root-" + c.name + ":Text" : "cid:" + std::to_string(c.counter) + "@" + std::to_string(c.peer) + ":Text";
+  }
+  // every Text container in which something (a scalar, an anchor) is visible at the rendered version:
+  // {"<container id>": <richtext value>, …}, ids bytewise sorted
+  std::string to_richtext() {
+    materialize();
+    std::map<std::string, uint32_t> texts;
+    for (uint32_t i = 0; i < containers.size(); i++) {
+      auto it = seqs.find(i);
+      if (containers[i].kind == CK_TEXT && it != seqs.end() && it->second->tr.active_len() > 0) texts[cid_string(containers[i])] = i;
+    }
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : texts) {
+      if (!first) out.push_back(',');
+      first = false;
+      json_escape(kv.first, out);
+      out.push_back(':');
+      richtext_json(kv.second, out);
     }
     out.push_back('}');
     return out;

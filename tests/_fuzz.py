@@ -46,7 +46,11 @@ def random_session(seed, n_peers=3, n_steps=60, kinds=("text",), sync_prob=0.15,
             elif styles and len(ids) >= 2 and rng.random() < 0.1:
                 s = rng.randrange(len(ids) - 1)
                 e = rng.randrange(s + 1, len(ids))
-                r.text_mark("text", s, e, "bold", True)
+                if styles == "rich":   # several keys, values of several types, unmarks (null) — what lm_richtext resolves (lm_k_richtext.h)
+                    r.text_mark("text", s, e, rng.choice(["bold", "link", "color", "a\"b"]),
+                                rng.choice([True, True, None, None, "https://x.y/?q=\"1\"", 7, -2.5, "red", [1, "z"], {"k": 1}]))
+                else:
+                    r.text_mark("text", s, e, "bold", True)
             else:
                 pos = rng.randint(0, len(ids))
                 s = "".join(rng.choice(ALPHA) for _ in range(rng.randint(1, max_ins)))

@@ -27,6 +27,9 @@ def lib():
         L.lo_batch_err.restype = ctypes.c_char_p
         L.lo_batch_err.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         L.lo_batch_free.argtypes = [ctypes.c_void_p]
+        L.lo_option_richtext.argtypes = [ctypes.c_int]
+        L.lo_batch_richtext.restype = ctypes.c_void_p
+        L.lo_batch_richtext.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
         L.lo_xxh32.restype = ctypes.c_uint32
         L.lo_xxh32.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32]
         L.lo_visible_ids.restype = ctypes.c_int64
@@ -81,6 +84,35 @@ def merge_batch(docs, threads=1, packed=None, frontiers=None):
     return out
 
 
+def richtext_batch(docs, frontiers=None):
+    """Per document (status, richtext bytes): the richtext value (TextHandler::get_richtext_value) of every Text container in
+    which something is visible at the rendered version, as one canonical JSON object {"<container id>": [spans…], …} — the checker of lm_richtext."""
+    L = lib()
+    data, off, doc_blob = pack(docs)
+    n = len(doc_blob) - 1
+    L.lo_option_richtext(1)
+    try:
+        if frontiers is not None:
+            fb = [f or b"" for f in frontiers]
+            foff = np.zeros(n + 1, dtype=np.uint64)
+            foff[1:] = np.cumsum([len(f) for f in fb], dtype=np.uint64)
+            fdata = np.frombuffer(b"".join(fb) or b"\0", dtype=np.uint8).copy()
+            h = L.lo_batch_run_at(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, fdata.ctypes.data, foff.ctypes.data, 1)
+        else:
+            h = L.lo_batch_run(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, 1)
+    finally:
+        L.lo_option_richtext(0)
+    out = []
+    try:
+        ln = ctypes.c_uint64()
+        for i in range(n):
+            p = L.lo_batch_richtext(h, i, ctypes.byref(ln))
+            out.append((L.lo_batch_status(h, i), ctypes.string_at(p, ln.value) if ln.value else b""))
+    finally:
+        L.lo_batch_free(h)
+    return out
+
+
 class Session:
     """One resident document rendered step by step: step(new_blobs, frontiers=None) imports more blobs into the same
     document and renders it — the checker of lm_import + lm_run.  Returns (status, json, vv, pending) like merge()."""
@@ -98,12 +130,25 @@ class Session:
         for f in (L.lo_session_json, L.lo_session_vv, L.lo_session_lca):
             f.restype = ctypes.c_void_p
             f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.lo_session_richtext.restype = ctypes.c_void_p
+        L.lo_session_richtext.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         self.L, self.h = L, L.lo_session_new()
+        self.want_richtext = False   # True: every step also renders the richtext values (richtext())
+
+    def richtext(self):
+        """the richtext values of the document as the last step left it (needs want_richtext = True before that step)"""
+        ln = ctypes.c_uint64()
+        p = self.L.lo_session_richtext(self.h, ctypes.byref(ln))
+        return ctypes.string_at(p, ln.value) if ln.value else b""
 
     def step(self, new_blobs, frontiers=None):
         L = self.L
         data, off, _ = pack([list(new_blobs)])
-        st = L.lo_session_step(self.h, data.ctypes.data, off.ctypes.data, len(new_blobs), frontiers, len(frontiers) if frontiers else 0)
+        L.lo_option_richtext(1 if self.want_richtext else 0)
+        try:
+            st = L.lo_session_step(self.h, data.ctypes.data, off.ctypes.data, len(new_blobs), frontiers, len(frontiers) if frontiers else 0)
+        finally:
+            L.lo_option_richtext(0)
         ln = ctypes.c_uint64()
         p = L.lo_session_json(self.h, ctypes.byref(ln))
         js = ctypes.string_at(p, ln.value) if ln.value else b""

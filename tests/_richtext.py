@@ -1,0 +1,149 @@
+"""Richtext values (lm_richtext): cases shared by the kernel-logic (CPU) and the GPU tests.  The checker is the
+oracle's Doc::to_richtext (oracle/lo_doc.hpp), itself pinned on the reference's known answers below."""
+import json
+import random
+
+import _fuzz, _oracle, _resident
+from loro_amd import wire
+
+
+def known_answers():
+    """[(name, blobs, expected richtext value of root Text "text" as Python data)] — reference tests restated through the blob
+    writer (wire.Replica places the anchors where TextHandler::mark places them for a plain range: StyleStart in front of the
+    first scalar, StyleEnd behind the last, handler.rs mark_with_transaction):
+      crates/loro/tests/loro_rust_test.rs:448-474 richtext_test (mark, then unmark 3..5 = a mark with value null)
+      crates/loro/tests/loro_rust_test.rs:476-498 sync (the mark arrives as an update of another peer)
+      crates/loro/src/lib.rs:2750-2772 get_richtext_value doc example"""
+    out = []
+    d = wire.Replica(1)
+    d.text_insert("text", 0, "Hello world!"); d.text_mark("text", 0, 5, "bold", True); d.commit()
+    out.append(("richtext_test: mark", [d.export()], [{"insert": "Hello", "attributes": {"bold": True}}, {"insert": " world!"}]))
+    # unmark(3..5): scalars 3..5 sit behind the first Start anchor → entities 4..6
+    d.text_mark("text", 4, 6, "bold", None); d.commit()
+    out.append(("richtext_test: unmark", [d.export()], [{"insert": "Hel", "attributes": {"bold": True}}, {"insert": "lo world!"}]))
+    a, b = wire.Replica(1), wire.Replica(2)
+    a.text_insert("text", 0, "Hello world!"); a.commit()
+    b.merge_from(a)
+    b.set_visible("text", wire.KIND_TEXT, _oracle.visible_ids([a.export()], "text", wire.KIND_TEXT))
+    b.text_mark("text", 0, 5, "bold", True); b.commit()
+    own = wire.Replica(2); own.changes = {2: b.changes[2]}
+    out.append(("sync", [a.export(), own.export()], [{"insert": "Hello", "attributes": {"bold": True}}, {"insert": " world!"}]))
+    e = wire.Replica(3)
+    e.text_insert("text", 0, "Hello world!"); e.text_mark("text", 0, 5, "bold", True); e.commit()
+    out.append(("doc example", [e.export()], [{"insert": "Hello", "attributes": {"bold": True}}, {"insert": " world!"}]))
+    return out
+
+
+def hand_cases():
+    """[(name, blobs)] — shapes the rule has to get right: two peers mark the same range concurrently (greater (lamport, peer)
+    decides), overlapping marks of different keys, a mark whose End anchor was deleted / whose Start anchor was deleted,
+    text typed inside and at both edges of a range, an unmark over part of a range, equal values from different ops (one span),
+    several Text containers (a child Text in a Map, a Text without any visible scalar, a Text that holds only anchors)."""
+    out = []
+    a, b = wire.Replica(10), wire.Replica(20)
+    a.text_insert("text", 0, "0123456789"); a.commit()
+    b.merge_from(a); b.set_visible("text", wire.KIND_TEXT, _oracle.visible_ids([a.export()], "text", wire.KIND_TEXT))
+    a.text_mark("text", 2, 6, "color", "red"); a.commit()
+    b.text_mark("text", 4, 8, "color", "blue"); b.text_mark("text", 0, 3, "bold", True); b.commit()
+    out.append(("concurrent marks of one key", _fuzz.blobs_of([a, b])))
+    c = wire.Replica(5)
+    c.text_insert("text", 0, "abcdefgh"); c.text_mark("text", 1, 5, "bold", True); c.commit()
+    c.text_delete("text", 6, 1); c.commit()      # the End anchor (entity 6: a b c d e | End) … entity positions: 0 a,1 S,2 b..5 e,6 E
+    out.append(("end anchor deleted", [c.export()]))
+    c2 = wire.Replica(6)
+    c2.text_insert("text", 0, "abcdefgh"); c2.text_mark("text", 1, 5, "bold", True); c2.commit()
+    c2.text_delete("text", 1, 1); c2.commit()    # the Start anchor
+    out.append(("start anchor deleted", [c2.export()]))
+    t = wire.Replica(7)
+    t.text_insert("text", 0, "abcd"); t.text_mark("text", 1, 3, "bold", True); t.commit()   # a S b c E d
+    t.text_insert("text", 3, "X"); t.text_insert("text", 1, "L"); t.text_insert("text", 7, "R"); t.commit()
+    out.append(("typing inside and at the edges", [t.export()]))
+    u = wire.Replica(8)
+    u.text_insert("text", 0, "abcdef"); u.text_mark("text", 0, 6, "link", "u1"); u.text_mark("text", 3, 5, "link", "u1"); u.text_mark("text", 1, 2, "em", 1); u.commit()
+    out.append(("equal values from different ops", [u.export()]))
+    n = wire.Replica(9)
+    n.map_set("m", "k", 1); n.text_insert("empty", 0, "zz"); n.text_delete("empty", 0, 2); n.text_insert("t2", 0, "plain \"text\"\n"); n.commit()
+    n.text_insert("only_anchors", 0, "q"); n.text_mark("only_anchors", 0, 1, "b", True); n.text_delete("only_anchors", 1, 1); n.commit()
+    out.append(("several text containers", [n.export()]))
+    return out
+
+
+def fuzz_docs(n, base=5000, n_steps=90, **kw):
+    return [_fuzz.blobs_of(_fuzz.random_session(base + s, n_peers=2 + s % 3, n_steps=n_steps, kinds=("text",) if s % 3 else ("text", "list", "map"),
+                                                styles="rich", sync_prob=0.1, **kw)) for s in range(n)]
+
+
+def nested_docs(n, base=5200):
+    return [_fuzz.blobs_of(_fuzz.nested_session(base + s, n_peers=3, n_steps=120)) for s in range(n)]
+
+
+def checkout_cases(n=6, base=5400):
+    """(docs, frontiers): every few recorded versions of rich sessions, incl. versions that cut a StyleStart from its StyleEnd"""
+    docs, fronts = [], []
+    for s in range(n):
+        snaps = []
+        reps = _fuzz.random_session(base + s, n_peers=3, n_steps=70, kinds=("text",), styles="rich", snapshots=snaps)
+        full = _fuzz.blobs_of(reps)
+        for fr, _ in snaps[:: max(1, len(snaps) // 8)]:
+            docs.append(list(full)); fronts.append(wire.encode_frontiers(fr))
+    r = wire.Replica(77)
+    r.text_insert("text", 0, "abcdef"); r.text_mark("text", 1, 4, "bold", True); r.text_insert("text", 0, "Z"); r.commit()
+    blob = [r.export()]
+    for c in range(0, 9):   # frontiers at every op of the change: between the two anchors as well
+        docs.append(list(blob)); fronts.append(wire.encode_frontiers([(77, c)]))
+    return docs, fronts
+
+
+def resident_sessions(seeds, n_steps=5):
+    out = []
+    for seed in seeds:
+        rng = random.Random(seed * 11 + 3)
+        snaps = []
+        reps = _fuzz.random_session(seed, n_peers=rng.randint(2, 4), n_steps=rng.randint(60, 140), kinds=("text",), snapshots=snaps, styles="rich")
+        out.append(_resident.plan_steps(_resident.chunked_blobs(reps, rng), rng, n_steps, versions=[v for v, _ in snaps]))
+    return out
+
+
+def run_resident(ctx, sessions):
+    """per step: [(status, richtext bytes)] from lm_richtext behind every lm_run"""
+    got = []
+    for k in range(len(sessions[0])):
+        docs = [s[k][0] for s in sessions]
+        fr = [s[k][1] for s in sessions]
+        if k == 0:
+            ctx.stage(docs, fr)
+            ctx.import_more([[] for _ in docs], fr)
+        else:
+            ctx.import_more(docs, fr)
+        ctx.run()
+        res = ctx.fetch()
+        rt = ctx.richtext()
+        got.append([(r[0], t[0], t[1]) for r, t in zip(res, rt)])
+    return got
+
+
+def oracle_resident(sessions):
+    out = [[] for _ in sessions[0]]
+    for s in sessions:
+        o = _oracle.Session()
+        o.want_richtext = True
+        for k, (blobs, f) in enumerate(s):
+            st = o.step(blobs, f)
+            out[k].append((st[0], o.richtext()))
+        o.close()
+    return out
+
+
+def same(got, want, what=""):
+    """got / want: [(status, bytes)].  Equal statuses; equal values — as JSON data (the members of the per-document object are in the
+    order of the device's container table, the spans themselves byte for byte)"""
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g[0] == w[0], (what, i, g[0], w[0])
+        if w[0] != 0:
+            continue
+        if g[1] == w[1]:
+            continue
+        gj, wj = json.loads(g[1]), json.loads(w[1])
+        assert gj == wj, (what, i, g[1][:400], w[1][:400])
+        assert sorted(g[1]) == sorted(w[1]), (what, i)   # same bytes, members in another order

@@ -1,0 +1,86 @@
+"""Richtext values (lm_richtext; SURVEY §8f N4, second half — container/richtext/style_range_map.rs, richtext_state.rs:2500-2584,
+state/richtext_state.rs:730-812): the oracle against the reference's known answers, and k_richtext's logic through the host harness
+(tests/emu) against the oracle — batch documents under both integrate kernels, checkouts, resident documents step by step."""
+import json
+
+import pytest
+
+import _emu, _oracle, _richtext
+from loro_amd._cabi import Context
+
+
+def test_oracle_gives_the_references_known_answers():
+    for name, blobs, want in _richtext.known_answers():
+        st, js = _oracle.richtext_batch([blobs])[0]
+        assert st == 0, name
+        assert json.loads(js) == {"cid:root-text:Text": want}, (name, js)
+
+
+def test_oracle_hand_cases_read_as_expected():
+    got = {name: json.loads(_oracle.richtext_batch([blobs])[0][1]) for name, blobs in _richtext.hand_cases()}
+    t = got["concurrent marks of one key"]["cid:root-text:Text"]
+    # b's color mark (peer 20, same lamport region) wins where both apply; text is rendered once
+    assert "".join(s["insert"] for s in t) == "0123456789"
+    assert [s.get("attributes", {}).get("color") for s in t if "4" in s["insert"] or "5" in s["insert"]] == ["blue"]
+    assert got["end anchor deleted"]["cid:root-text:Text"] == [{"insert": "abcdefgh"}]
+    assert got["start anchor deleted"]["cid:root-text:Text"] == [{"insert": "abcdefgh"}]
+    assert got["typing inside and at the edges"]["cid:root-text:Text"] == [{"insert": "aL"}, {"attributes": {"bold": True}, "insert": "bXc"}, {"insert": "Rd"}]
+    # (entity positions: S1 S3 a E3 b S2 c d E2 e f E1 — "cd" carries two link ops with the same value: one span with "b" and "ef")
+    assert got["equal values from different ops"]["cid:root-text:Text"] == [
+        {"attributes": {"em": 1, "link": "u1"}, "insert": "a"}, {"attributes": {"link": "u1"}, "insert": "bcdef"}]
+    # (a Text in which nothing is visible is not listed; one that holds only anchors is: its value is the empty list)
+    assert got["several text containers"] == {"cid:root-only_anchors:Text": [], "cid:root-t2:Text": [{"insert": "plain \"text\"\n"}]}
+
+
+def _harness(docs, fronts=None):
+    with Context(_emu.binding()) as c:
+        res = c.merge_batch(docs, fronts)
+        return res, c.richtext()
+
+
+@pytest.mark.parametrize("span", ["1", "0"])
+def test_batch_documents_under_both_integrate_kernels(monkeypatch, span):
+    monkeypatch.setenv("LM_SPAN", span)
+    docs = [b for _, b, _ in _richtext.known_answers()] + [b for _, b in _richtext.hand_cases()] + _richtext.fuzz_docs(30) + _richtext.nested_docs(6)
+    bad = [docs[0][0][:-2] + b"\x00\x01"]   # a document whose import fails: its richtext result carries that status
+    docs.append(bad)
+    res, got = _harness(docs)
+    assert res == _oracle.merge_batch(docs)
+    want = _oracle.richtext_batch(docs)
+    assert want[-1][0] != 0
+    _richtext.same(got, want, "span=" + span)
+    assert sum(1 for s, b in got if b.count(b'"attributes"') >= 2) >= 15
+
+
+def test_checkouts_cut_marks_at_every_op():
+    docs, fronts = _richtext.checkout_cases()
+    with Context(_emu.binding()) as c:
+        import os
+        os.environ["LM_SHARE_REPLAY"] = "0"     # (entries here have blob lists of their own anyway)
+        try:
+            res = c.merge_batch(docs, fronts)
+            got = c.richtext()
+        finally:
+            del os.environ["LM_SHARE_REPLAY"]
+    assert res == _oracle.merge_batch(docs, frontiers=fronts)
+    _richtext.same(got, _oracle.richtext_batch(docs, frontiers=fronts), "checkout")
+
+
+def test_resident_documents_step_by_step():
+    sessions = _richtext.resident_sessions(range(6100, 6110))
+    want = _richtext.oracle_resident(sessions)
+    with Context(_emu.binding()) as c:
+        got = _richtext.run_resident(c, sessions)
+    for k, (g, w) in enumerate(zip(got, want)):
+        ok = [(x[1], x[2]) if x[0] == 0 else (x[0], b"") for x in g]      # (a step whose checkout was refused: the fetch status says so)
+        _richtext.same([o for o, x in zip(ok, g) if x[0] == 0], [y for y, x in zip(w, g) if x[0] == 0], "step %d" % k)
+
+
+def test_a_folded_batch_refuses():
+    docs, fronts = _richtext.checkout_cases(n=1)
+    shared = [docs[0]] * 3
+    with Context(_emu.binding()) as c:
+        c.merge_batch(shared, fronts[:3])
+        assert c.b.shared_documents(c.h) == 1
+        with pytest.raises(RuntimeError):
+            c.richtext()
