@@ -1,0 +1,80 @@
+"""GPU parity for richtext values (lm_richtext; SURVEY.md §8f N4, second half): k_richtext on the device through the C ABI against
+the oracle (Doc::to_richtext) and the reference's known answers.  Same cases as the kernel-logic harness (test_emu_richtext.py) at
+larger sizes, plus configs[4]-shaped documents (1 % of the ops are bold marks) at the latest version and at checkouts."""
+import json, os
+import pytest
+
+import _oracle, _richtext
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import loro_amd
+    e = loro_amd.MergeEngine(0)
+    yield e
+    e.close()
+
+
+def _run(engine, docs, fronts=None):
+    res = engine.merge_batch(docs, fronts)
+    return res, engine.richtext()
+
+
+def test_known_answers(engine):
+    ka = _richtext.known_answers()
+    res, got = _run(engine, [b for _, b, _ in ka])
+    for (name, _, want), (st, js) in zip(ka, got):
+        assert st == 0 and json.loads(js) == {"cid:root-text:Text": want}, (name, js)
+
+
+@pytest.mark.parametrize("span", ["1", "0"])
+def test_batch_documents_under_both_integrate_kernels(engine, monkeypatch, span):
+    monkeypatch.setenv("LM_SPAN", span)
+    docs = [b for _, b in _richtext.hand_cases()] + _richtext.fuzz_docs(120, n_steps=140) + _richtext.nested_docs(16)
+    docs.append([docs[0][0][:-2] + b"\x00\x01"])
+    res, got = _run(engine, docs)
+    assert res == _oracle.merge_batch(docs, threads=8)
+    _richtext.same(got, _oracle.richtext_batch(docs), "span=" + span)
+
+
+def test_product_default_kernel_choice(engine, monkeypatch):
+    monkeypatch.setenv("LM_SPAN_AUTO", "1")
+    docs = _richtext.fuzz_docs(64, base=5600)
+    res, got = _run(engine, docs)
+    _richtext.same(got, _oracle.richtext_batch(docs), "auto")
+
+
+def test_checkouts(engine, monkeypatch):
+    monkeypatch.setenv("LM_SHARE_REPLAY", "0")
+    docs, fronts = _richtext.checkout_cases(n=16)
+    res, got = _run(engine, docs, fronts)
+    assert res == _oracle.merge_batch(docs, frontiers=fronts)
+    _richtext.same(got, _oracle.richtext_batch(docs, frontiers=fronts), "checkout")
+
+
+def test_resident_documents_step_by_step(engine):
+    sessions = _richtext.resident_sessions(range(6200, 6232), n_steps=6)
+    want = _richtext.oracle_resident(sessions)
+    got = _richtext.run_resident(engine, sessions)
+    for k, (g, w) in enumerate(zip(got, want)):
+        keep = [x[0] == 0 for x in g]
+        _richtext.same([(x[1], x[2]) for x, kp in zip(g, keep) if kp], [y for y, kp in zip(w, keep) if kp], "step %d" % k)
+
+
+def test_config5_shaped_documents_with_bold_marks(engine, monkeypatch):
+    """two peers alternating every 1,000 trace actions, 1 % of the actions are bold marks (workload.cfg5_doc): several hundred
+    StyleOps per document, many leaves — at the latest version and at recorded checkouts"""
+    from loro_amd import workload
+    monkeypatch.setenv("LM_SHARE_REPLAY", "0")
+    docs, fronts = [], []
+    for d in range(6):
+        blobs, fr = workload.cfg5_doc(d, n_ops=20000, n_checkouts=3)
+        docs.append(blobs); fronts.append(None)
+        for f in fr:
+            docs.append(list(blobs)); fronts.append(f)
+    res, got = _run(engine, docs, fronts)
+    want = _oracle.richtext_batch(docs, frontiers=fronts)
+    _richtext.same(got, want, "cfg5")
+    assert all(st == 0 for st, _ in got) and max(js.count(b'"attributes"') for _, js in got) > 50
