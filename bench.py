@@ -427,6 +427,35 @@ def other_configs(device, cores):
             "with pairwise syncs, nested child containers; 4,096 docs = 16 distinct histories")
     except Exception as ex:
         out["movable-lists (SURVEY 8f N4)"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    # the richtext row of SURVEY §8f N4 (lm_richtext, lm_k_richtext.h): the configs[4] histories (1M ops, ~1 % marks: ≈10k StyleOps per
+    # document) at the latest version, 256 document instances; timed = lm_richtext (two launches of k_richtext + the copy back), every
+    # result compared with the oracle's Doc::to_richtext of its history.  Guarded like the entry above.
+    name = "richtext (SURVEY 8f N4)"
+    try:
+        import json as _json
+        rt_docs = [[bytes(bytearray(b)) for b in g5[d % 4][0]] for d in range(256)]
+        t_cpu = time.perf_counter()
+        want = _oracle.richtext_batch([g5[d][0] for d in range(4)])
+        t_cpu = time.perf_counter() - t_cpu
+        with loro_amd.MergeEngine(device) as e:
+            e.stage(rt_docs, None); e.run()
+            got = e.richtext()
+            assert all(g[0] == 0 for g in got) and all(w[0] == 0 for w in want)
+            assert all(_json.loads(got[i][1]) == _json.loads(want[i % 4][1]) and len(got[i][1]) == len(want[i % 4][1]) for i in range(len(rt_docs))), "richtext values differ from the CPU oracle's"
+            best = 1e9
+            for _ in range(3):
+                t = time.perf_counter(); e.richtext(); best = min(best, time.perf_counter() - t)
+        rt_bytes = sum(len(g[1]) for g in got)
+        out[name] = {"docs": len(rt_docs), "distinct_docs": 4, "docs_per_s": round(len(rt_docs) / best, 1), "ms_per_batch": round(best * 1e3, 2),
+                     "richtext_bytes": rt_bytes, "spans_with_attributes_per_doc": got[0][1].count(b'"attributes"'),
+                     "timed": "lm_richtext after lm_run: k_richtext twice (sizes, bytes) + the copy back; the import itself is the configs[4] entry's",
+                     "cpu_baseline": {"value": round(4 / t_cpu, 2), "unit": "docs/s", "cores": 1, "kind": "port", "sample": "import + Doc::to_richtext of the 4 distinct histories, one thread (the replay dominates)"},
+                     "parity": f"all {len(rt_docs)} results equal to the oracle's",
+                     "workload": "1M-op rich-text documents (2 peers alternating every 1k trace actions, ~1% of the actions are bold marks), richtext value of the root Text at the latest version; 256 instances of 4 distinct histories"}
+        note(f"other configs: {name} done")
+    except Exception as ex:
+        out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        note(f"other configs: {name} FAILED: {type(ex).__name__}: {ex}"[:200])
     return out
 
 

@@ -21,7 +21,7 @@
 //      of the set, the winners per key are worked out and compared BY VALUE (key bytes, encoded value bytes) with the open span's.
 // Output per document: {"<container id>":[span,…],…} for the Text containers in which something — a scalar or an anchor — is visible
 // at the rendered version, in the order of the document's container table (ContainerID Display: cid:root-<name>:Text / cid:<counter>@<peer>:Text).
-// Limits: at most RT_MAX StyleOps open at one scalar (LM_UNSUPPORTED beyond); two values are "equal" when their encodings are
+// Limits: at most RT_MAX StyleOps open at one scalar and RT_MAX distinct style keys per Text (LM_UNSUPPORTED beyond); two values are "equal" when their encodings are
 // (map-typed style values with the same entries in another order split a span the reference would merge).
 #pragma once
 #include "lm_k_emit.h"
@@ -81,12 +81,26 @@ LM_DEV void rt_walk(const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t vis_
   const int lane = lmw::lane();
   const uint32_t r0 = d.cont_root0[m.cid0 + cidx], nr = d.cont_nroot[m.cid0 + cidx];
   const uint32_t* dirp = d.dir_out + m.leaf0 + r0;
+  const bool span = d.span != 0;
+  const uint32_t rec_words = span ? SP_REC : 256u, st_at = span ? 256u : 192u;
+  // (one wave walks the document: the record of the next leaf and the directory entry behind it are requested before this leaf's
+  // elements are handled — f() loads and stores global memory, the compiler cannot move these loads across it)
+  uint32_t de1 = nr > 0 ? dirp[0] : 0u, de2 = nr > 1 ? dirp[1] : 0u;
+  uint32_t p_id = NONE, p_ln = 1, p_st = ST_EVER;
+  if (nr > 0 && (uint32_t)lane < de_n(de1)) {
+    const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + de_leaf(de1)) * rec_words;
+    p_id = rec[lane]; p_st = rec[st_at + lane]; if (span) p_ln = rec[64 + lane];
+  }
   for (uint32_t ri = 0; ri < nr; ri++) {
-    const uint32_t de = dirp[ri];
-    const uint32_t L = de_leaf(de), n = de_n(de);
-    if (d.span) {
-      uint32_t id0 = NONE, ln = 0, st = ST_EVER;
-      if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * SP_REC; id0 = rec[lane]; ln = rec[64 + lane]; st = rec[256 + lane]; }
+    const uint32_t id0 = p_id, ln = p_ln, st = p_st;
+    de1 = de2;
+    de2 = ri + 2 < nr ? dirp[ri + 2] : 0u;
+    p_id = NONE; p_ln = 1; p_st = ST_EVER;
+    if (ri + 1 < nr && (uint32_t)lane < de_n(de1)) {
+      const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + de_leaf(de1)) * rec_words;
+      p_id = rec[lane]; p_st = rec[st_at + lane]; if (span) p_ln = rec[64 + lane];
+    }
+    if (span) {
       const uint32_t vl = (id0 != NONE && !(st & vis_mask)) ? ln : 0u;
       const uint32_t inc = lmw::scan_incl_add(vl);
       const uint32_t total = lmw::bcast(inc, 63);
@@ -105,15 +119,14 @@ LM_DEV void rt_walk(const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t vis_
         f(e < total, g);
       }
     } else {
-      uint32_t id = NONE, st = ST_EVER;
-      if ((uint32_t)lane < n) { const uint32_t* rec = d.it + (uint64_t)(m.leaf0 + L) * 256; id = rec[lane]; st = rec[192 + lane]; }
-      const bool vis = id != NONE && !(st & vis_mask);
-      if (lmw::any(vis)) f(vis, vis ? s_eb[pid_peer(id)] + pid_ctr(id) : 0u);
+      const bool vis = id0 != NONE && !(st & vis_mask);
+      if (lmw::any(vis)) f(vis, vis ? s_eb[pid_peer(id0)] + pid_ctr(id0) : 0u);
     }
   }
 }
 
-// mode 0: sizes only (rt_len) | 1: write into out + out_off[doc] (capacity out_off[doc + 1] - out_off[doc])
+// mode 0: sizes only | 1: write into out + out_off[doc] (capacity out_off[doc + 1] - out_off[doc]; nothing is written beyond it).
+// rt_len[doc] = the exact size either way
 LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t* rt_len, int32_t* rt_status, int mode) {
   const uint32_t doc = (uint32_t)lmw::bid();
   const int lane = lmw::lane();
@@ -126,6 +139,12 @@ LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t
   LM_SHARED(uint32_t, s_inc, 64);
   LM_SHARED(uint32_t, s_g0, 64);
   LM_SHARED(uint32_t, s_act, RT_MAX);    // StyleStart rows (inside the document) of the open StyleOps
+  LM_SHARED(uint32_t, s_alam, RT_MAX);   // … their lamports, peer | null value << 31, and key numbers (keys are numbered per container as they
+  LM_SHARED(uint32_t, s_apk, RT_MAX);    //   turn up — s_kp / s_kl — so that the winners per key are worked out in LDS alone: resolving a StyleOp
+  LM_SHARED(uint32_t, s_akid, RT_MAX);   //   from its row is five dependent loads, measured ≈10 µs per anchor when it was redone for every comparison)
+  LM_SHARED(uint32_t, s_wsl, RT_MAX);    // winners(): the deciding SLOT of s_act per key
+  LM_SHARED(unsigned long long, s_kp, RT_MAX);
+  LM_SHARED(uint32_t, s_kl, RT_MAX);
   LM_SHARED(uint32_t, s_win, RT_MAX);    // … the deciding op of every key with a value, now
   LM_SHARED(uint32_t, s_open, RT_MAX);   // … and when the span being written was opened
   for (uint32_t p = (uint32_t)lane; p < m.n_peers && p < MAX_PEERS; p += 64) s_eb[p] = d.elem_base[m.praw0 + p];
@@ -166,22 +185,22 @@ LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t
     uint32_t n_act = 0, n_win = 0, n_open = 0;
     bool dirty = false, span_open = false, first_span = true;
     auto lds_set = [&](uint32_t* a, uint32_t i, uint32_t v) { lmw::block_sync(); if (lane == 0) a[i] = v; lmw::block_sync(); };
+    uint32_t n_keys = 0;
     auto winners = [&]() {   // the op that decides each key, keys without a value dropped
       n_win = 0;
-      for (uint32_t i = 0; i < n_act && !err; i++) {
-        const uint32_t a = s_act[i];
-        const RtStyle A = rt_style(d, m, a, err);
+      for (uint32_t i = 0; i < n_act; i++) {
+        const uint32_t kid = s_akid[i], lam = s_alam[i], pk = s_apk[i] & 0x7fffffffu;
         uint32_t found = NONE;
         for (uint32_t j = 0; j < n_win && found == NONE; j++) {
-          const RtStyle W = rt_style(d, m, s_win[j], err);
-          if (W.kl == A.kl && bytes_eq(W.kp, A.kp, A.kl)) { found = j; if (A.lam > W.lam || (A.lam == W.lam && A.peer > W.peer)) lds_set(s_win, j, a); }
+          const uint32_t w = s_wsl[j];
+          if (s_akid[w] == kid) { found = j; const uint32_t wl = s_alam[w], wp = s_apk[w] & 0x7fffffffu; if (lam > wl || (lam == wl && pk > wp)) lds_set(s_wsl, j, i); }
         }
-        if (found == NONE) { lds_set(s_win, n_win, a); n_win++; }
+        if (found == NONE) { lds_set(s_wsl, n_win, i); n_win++; }
       }
       uint32_t k = 0;
-      for (uint32_t j = 0; j < n_win && !err; j++) {
-        const uint32_t w = s_win[j];
-        if (!rt_style(d, m, w, err).null) { lds_set(s_win, k, w); k++; }
+      for (uint32_t j = 0; j < n_win; j++) {
+        const uint32_t w = s_wsl[j];
+        if (!(s_apk[w] >> 31)) { lds_set(s_win, k, s_act[w]); k++; }
       }
       n_win = k;
     };
@@ -277,12 +296,34 @@ LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t
           const uint32_t peer = d.chg[r.chg].peer;
           const bool pair = r.ctr + 2 <= d.peer_ext[m.praw0 + peer] && d.cp[elem0 + ag + 1] == (CP_ANCHOR | CP_ALIVE | (rrel + 1));
           if (pair) {
-            if (n_act >= RT_MAX) err = ST_UNSUPPORTED;
-            else { lds_set(s_act, n_act, rrel); n_act++; dirty = true; }
+            const RtStyle A = rt_style(d, m, rrel, err);
+            uint32_t kid = NONE;
+            for (uint32_t q = 0; q < n_keys && kid == NONE; q++)
+              if (s_kl[q] == A.kl && (s_kp[q] == (unsigned long long)(uintptr_t)A.kp || bytes_eq((const uint8_t*)(uintptr_t)s_kp[q], A.kp, A.kl))) kid = q;
+            if (kid == NONE && n_keys < RT_MAX) {
+              lmw::block_sync();
+              if (lane == 0) { s_kp[n_keys] = (unsigned long long)(uintptr_t)A.kp; s_kl[n_keys] = A.kl; }
+              lmw::block_sync();
+              kid = n_keys++;
+            }
+            if (n_act >= RT_MAX || kid == NONE) err = err ? err : ST_UNSUPPORTED;
+            else {
+              lmw::block_sync();
+              if (lane == 0) { s_act[n_act] = rrel; s_alam[n_act] = A.lam; s_apk[n_act] = A.peer | (A.null ? 0x80000000u : 0u); s_akid[n_act] = kid; }
+              lmw::block_sync();
+              n_act++; dirty = true;
+            }
           }
         } else if (kind == OK_STYLE_END && rrel > 0) {
           for (uint32_t i = 0; i < n_act; i++)
-            if (s_act[i] == rrel - 1) { const uint32_t lastv = s_act[n_act - 1]; lds_set(s_act, i, lastv); n_act--; dirty = true; break; }
+            if (s_act[i] == rrel - 1) {
+              const uint32_t l = n_act - 1, v0 = s_act[l], v1 = s_alam[l], v2 = s_apk[l], v3 = s_akid[l];
+              lmw::block_sync();
+              if (lane == 0) { s_act[i] = v0; s_alam[i] = v1; s_apk[i] = v2; s_akid[i] = v3; }
+              lmw::block_sync();
+              n_act--; dirty = true;
+              break;
+            }
         }
         am &= am - 1;
         lo = a + 1;
@@ -299,7 +340,7 @@ LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t
   sink_byte(s, '}');
   if (lane == 0) {
     rt_len[doc] = err ? 0u : (uint32_t)s.pos;
-    rt_status[doc] = err ? err : ((mode && s.pos > s.cap) ? (int32_t)ST_INTERNAL : (int32_t)ST_OK);
+    rt_status[doc] = err ? err : (int32_t)ST_OK;   // (s.pos > s.cap: the host sees the size and launches again with room for it)
   }
 }
 

@@ -99,6 +99,7 @@ struct Engine {
   std::vector<uint32_t> h_rt_len;
   std::vector<int32_t> h_rt_status;
   bool rt_ran = false;
+  int rt_launches = 0;                            // k_richtext launches of the last lm_richtext (2: a slab was too small)
   std::vector<KernelTime> times;
   bool profiling = false;
   std::string last_error;
@@ -1251,8 +1252,11 @@ struct Engine {
     rt_ran = false;
   }
 
-  // ---- lm_richtext: get_richtext_value of every Text container of every document, from the trackers the last run left (two
-  // launches of k_richtext: sizes, then the bytes)
+  // ---- lm_richtext: get_richtext_value of every Text container of every document, from the trackers the last run left.  One launch
+  // of k_richtext into optimistic slabs (twice the document's JSON + a few KB: a span costs ~40 bytes on top of its text); the kernel
+  // never writes beyond a slab and always reports the exact size, so a document that needs more sends the batch through a second
+  // launch at exact sizes (as the JSON renderer's DF_REEMIT does).  LM_RT_SLAB=<bytes> overrides the slab size (tests: 0 forces the
+  // second launch).
   void richtext() {
     lmbe::bind(sc);
     if (!ran) throw std::runtime_error("lm_richtext before lm_run");
@@ -1262,26 +1266,35 @@ struct Engine {
     h_rt_status.assign(n_docs, 0);
     h_rt.assign(1, 0);
     rt_ran = true;
+    rt_launches = 0;
     if (n_docs == 0) return;
     Dev d = last_d;
     b_rt_len.ensure((size_t)n_docs * 8 + 8);
     uint32_t* len = b_rt_len.as<uint32_t>();
     int32_t* st = (int32_t*)(b_rt_len.as<uint32_t>() + n_docs);
-    LM_LAUNCH(k_richtext, n_docs, 64, d, (uint8_t*)nullptr, (const uint64_t*)nullptr, len, st, 0);
-    lmbe::d2h(h_rt_len.data(), len, (size_t)n_docs * 4);
-    lmbe::sync();
-    for (uint32_t i = 0; i < n_docs; i++) h_rt_off[i + 1] = h_rt_off[i] + (((uint64_t)h_rt_len[i] + 15) & ~15ull);
-    b_rt_out.ensure(h_rt_off[n_docs] + 64);
-    b_rt_off.ensure((size_t)(n_docs + 1) * 8);
-    lmbe::h2d(b_rt_off.p, h_rt_off.data(), (size_t)(n_docs + 1) * 8);
-    LM_LAUNCH(k_richtext, n_docs, 64, d, b_rt_out.as<uint8_t>(), (const uint64_t*)b_rt_off.as<uint64_t>(), len, st, 1);
-    std::vector<uint32_t> len2(n_docs);
-    lmbe::d2h(len2.data(), len, (size_t)n_docs * 4);
-    lmbe::d2h(h_rt_status.data(), st, (size_t)n_docs * 4);
+    const char* slab_env = getenv("LM_RT_SLAB");
+    for (uint32_t i = 0; i < n_docs; i++) {
+      uint64_t cap = h_doc[i].status == ST_OK ? (slab_env ? (uint64_t)atoll(slab_env) : 2ull * h_doc[i].out_len + 64ull * h_doc[i].n_cont + 4096) : 0;
+      h_rt_off[i + 1] = h_rt_off[i] + ((cap + 15) & ~15ull);
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+      b_rt_out.ensure(h_rt_off[n_docs] + 64);
+      b_rt_off.ensure((size_t)(n_docs + 1) * 8);
+      lmbe::h2d(b_rt_off.p, h_rt_off.data(), (size_t)(n_docs + 1) * 8);
+      LM_LAUNCH(k_richtext, n_docs, 64, d, b_rt_out.as<uint8_t>(), (const uint64_t*)b_rt_off.as<uint64_t>(), len, st, 1);
+      rt_launches++;
+      lmbe::d2h(h_rt_len.data(), len, (size_t)n_docs * 4);
+      lmbe::d2h(h_rt_status.data(), st, (size_t)n_docs * 4);
+      lmbe::sync();
+      bool over = false;
+      for (uint32_t i = 0; i < n_docs; i++) over |= h_rt_status[i] == ST_OK && h_rt_len[i] > h_rt_off[i + 1] - h_rt_off[i];
+      if (!over) break;
+      if (attempt == 1) { for (uint32_t i = 0; i < n_docs; i++) if (h_rt_status[i] == ST_OK && h_rt_len[i] > h_rt_off[i + 1] - h_rt_off[i]) h_rt_status[i] = ST_INTERNAL; break; }
+      for (uint32_t i = 0; i < n_docs; i++) h_rt_off[i + 1] = h_rt_off[i] + (h_rt_status[i] == ST_OK ? ((uint64_t)h_rt_len[i] + 15) & ~15ull : 0);
+    }
     h_rt.resize(h_rt_off[n_docs] + 1);
     if (h_rt_off[n_docs]) lmbe::d2h(h_rt.data(), b_rt_out.p, h_rt_off[n_docs]);
     lmbe::sync();
-    for (uint32_t i = 0; i < n_docs; i++) if (h_rt_status[i] == ST_OK && len2[i] != h_rt_len[i]) h_rt_status[i] = ST_INTERNAL;
   }
 
   // ---- lm_export: the updates document `i` holds beyond `from_vv` (lm_export.h).  The blobs come back from the arena, the

@@ -84,3 +84,14 @@ def test_a_folded_batch_refuses():
         assert c.b.shared_documents(c.h) == 1
         with pytest.raises(RuntimeError):
             c.richtext()
+
+
+def test_a_slab_that_is_too_small_sends_the_batch_through_a_second_launch(monkeypatch):
+    docs = _richtext.fuzz_docs(8, base=5700)
+    want = _oracle.richtext_batch(docs)
+    monkeypatch.setenv("LM_RT_SLAB", "16")     # nothing fits: exact sizes come back, the second launch has room
+    _, got = _harness(docs)
+    _richtext.same(got, want, "slab 16")
+    monkeypatch.delenv("LM_RT_SLAB")
+    _, got = _harness(docs)
+    _richtext.same(got, want, "default slab")
