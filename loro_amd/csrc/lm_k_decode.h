@@ -448,11 +448,22 @@ LM_DEV void kc_add(uint32_t& n_map, uint32_t& n_el, uint32_t& n_style, uint32_t 
 }
 LM_DEV uint32_t kc_pack(uint32_t n_map, uint32_t n_style) { return (n_map & 0x7fffffffu) | (n_style ? 0x80000000u : 0u); }
 
-LM_KERNEL void k_block_decode(Dev d) {
+// EXACT (k_block_reclassify): the same sequential decode run once more over the blocks a decoder REJECTED with DecodeError, with the
+// value walk that names corruption where it stands (an undefined value tag, a nested map key index beyond the block's key table, an
+// oversized collection are DecodeDataCorruptionError in the reference, value.rs:342-459 — the hot decoders only latch their reader
+// there and report the block as DecodeError at its end; a write to a flag inside their walker costs them ~20 %, see above).  Only the
+// verdict is taken from this pass, and only DataCorruption: the rows it writes belong to a block whose document has failed.
+static constexpr uint32_t DEC_RECLASS = 0xDEC0DE01u;   // BlockDesc.pad of a block a decoder left with ST_DECODE_ERROR
+template <bool EXACT> LM_DEV void lane_skip_value(Rd& r, uint32_t& vf, int cdepth, uint32_t n_keys) {
+  uint32_t f_cnt[16];
+  if (EXACT) skip_loro_value_fs<true>(r, vf, cdepth, f_cnt, n_keys);
+  else skip_loro_value_fs(r, vf, cdepth, f_cnt);
+}
+template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
   uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
   if (bi >= d.n_blocks) return;
   BlockDesc bd = d.blk[bi];
-  if (bd.status != ST_OK) return;
+  if (EXACT ? (bd.status != ST_DECODE_ERROR || bd.pad != DEC_RECLASS) : (bd.status != ST_OK)) return;
   const uint32_t* off = d.boff + (uint64_t)bi * BCN;
   const uint32_t* cnt = d.bcnt + (uint64_t)bi * BCN;
   uint32_t N = bd.n_changes;
@@ -659,7 +670,7 @@ LM_KERNEL void k_block_decode(Dev d) {
             r.a0 = (uint32_t)rd_uleb(t);
           }
           // (values of containers outside the device scope are never rendered: any shape is accepted)
-          skip_loro_value(v, vfl, ckind == CK_MAP ? 0 : (is_list_value && (ckind == CK_LIST || ckind == CK_MOVABLE) ? 1 : (ckind > CK_TEXT && ckind != CK_MOVABLE ? 16 : -1)));
+          lane_skip_value<EXACT>(v, vfl, ckind == CK_MAP ? 0 : (is_list_value && (ckind == CK_LIST || ckind == CK_MOVABLE) ? 1 : (ckind > CK_TEXT && ckind != CK_MOVABLE ? 16 : -1)), n_keys);
           break;
         }
         case 12: {
@@ -668,7 +679,7 @@ LM_KERNEL void k_block_decode(Dev d) {
           uint64_t key_idx = rd_uleb(v);
           if (key_idx >= n_keys) DEC_ST(ST_DATA_CORRUPTION);
           uint32_t u = 0;
-          skip_loro_value(v, u, -1);
+          lane_skip_value<EXACT>(v, u, -1, n_keys);
           vfl |= u & VF_CORRUPT;
           nested = true;
           break;
@@ -678,8 +689,8 @@ LM_KERNEL void k_block_decode(Dev d) {
         case 15: {   // ListSet: element peer idx, element lamport, then the nested value (op_val points at it)
           mv_peer = rd_uleb(v); mv_lam = rd_uleb(v);
           val_at = (uint64_t)(v.p - d.data);
-          if (ckind == CK_MOVABLE) skip_loro_value(v, vfl, 0);
-          else { uint32_t u = 0; skip_loro_value(v, u, -1); vfl |= u & VF_CORRUPT; }
+          if (ckind == CK_MOVABLE) lane_skip_value<EXACT>(v, vfl, 0, n_keys);
+          else { uint32_t u = 0; lane_skip_value<EXACT>(v, u, -1, n_keys); vfl |= u & VF_CORRUPT; }
           nested = true;
           break;
         }
@@ -751,10 +762,13 @@ LM_KERNEL void k_block_decode(Dev d) {
     if (c_cont.r.bad || c_prop.r.bad || c_vt.r.bad || c_len.r.bad || v.bad) st = st ? st : ST_DECODE_ERROR;
     if (counter != (uint64_t)bd.counter_start + bd.counter_len) DEC_ST(ST_DATA_CORRUPTION);
   }
+  if (EXACT) { if (st == ST_DATA_CORRUPTION) d.blk[bi].status = st; return; }
   if (st == ST_OK && unsupported) st = ST_UNSUPPORTED;
   d.blk[bi].status = st;
-  d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = kc_el;
+  d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = st == ST_DECODE_ERROR ? DEC_RECLASS : kc_el;
 }
+LM_KERNEL void k_block_decode(Dev d) { block_decode_lane<false>(d); }
+LM_KERNEL void k_block_reclassify(Dev d) { block_decode_lane<true>(d); }
 
 }  // namespace lm
 

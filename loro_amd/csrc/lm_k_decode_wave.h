@@ -771,7 +771,7 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
     if (st == ST_OK && (tail & 2)) st = ST_DATA_CORRUPTION;
     if (st == ST_OK && (tail & 4)) st = ST_UNSUPPORTED;
     d.blk[bi].status = st;
-    d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = kc_el;
+    d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = st == ST_DECODE_ERROR ? DEC_RECLASS : kc_el;   // (k_block_reclassify looks at such a block once more)
   }
 #ifdef LM_PROF_DEC
   DEC_PH(7);

@@ -152,12 +152,13 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
     if (const char* e = getenv("LM_PLAIN")) k.plain = atoi(e);
     if (const char* e = getenv("LM_DECODE")) k.decode_wave = atoi(e) != 0;
+    if (const char* e = getenv("LM_RECLASS")) k.reclass = atoi(e) != 0;
     if (const char* e = getenv("LM_DEC_SLOT")) k.dec_slot = ((uint32_t)atoi(e) + 15u) & ~15u;   // LDS bytes per block for everything before its value payloads (per 5k configs[1] documents: 512 5.4 ms, 1024 4.5, 1280 4.2, 1536 4.9, 2048 5.7 — occupancy against the share of heads that fit; larger heads are read from HBM)
     if (const char* e = getenv("LM_DEC_SLOT_BIG")) k.dec_slot_big = ((uint32_t)atoi(e) + 15u) & ~15u;   // slot of the second decoder launch (groups with a head beyond LM_DEC_SLOT); 0: one launch, as in rounds 2-3
     if (const char* e = getenv("LM_DEC_BIG_MODE")) k.dec_big_mode = (uint32_t)atoi(e);
@@ -722,6 +723,10 @@ struct Engine {
           LM_LAUNCH_DYN(k_block_decode_wave, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_cap + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_cap, 0u, slot_big ? slot_cap : 0xffffffffu);
         if (slot_big) LM_LAUNCH_DYN(k_block_decode_wave_map, cdiv(NB, DEC_G), 64, (size_t)DEC_G * slot_big + DEC_LDS_FIXED + DEC_G * DEC_KINDS, d, slot_big, slot_cap, 0xffffffffu);
       }
+      // blocks a decoder rejected with DecodeError are read once more, sequentially, by the decode that names corruption where it stands
+      // (lm_k_decode.h EXACT): the reference's error for an undefined value tag / a nested key index beyond the key table is
+      // DecodeDataCorruptionError.  One lane per block; every healthy block leaves at once.  LM_RECLASS=0 switches it off.
+      if (kn.reclass) LM_LAUNCH(k_block_reclassify, cdiv(NB, 64), 64, d);
     }
     lmbe::toc("k_block_decode", times, profiling);
     lmbe::tic(profiling);

@@ -845,3 +845,33 @@ def test_a_giant_run_in_a_column_costs_nothing(monkeypatch, decoder):
     assert time.time() - t < 20.0
     assert [g[0] for g in got] == [1] * len(docs), list(zip(names, [g[0] for g in got]))
     assert [w[0] for w in _oracle.merge_batch(docs)] == [1] * len(docs)
+
+
+def test_value_level_corruption_in_a_rejected_block_is_named_like_the_reference(monkeypatch):
+    """k_block_reclassify: a block a row decoder rejected with DecodeError is read once more, sequentially, with the value reader
+    that reports an undefined value tag / a nested key index beyond the key table / an oversized collection as the reference does
+    (DecodeDataCorruptionError, value.rs:342-459).  On a 450-document damaged corpus the documents BOTH sides reject agree on the
+    code more often with the pass than without it, the pass never changes what is accepted, and a hand-damaged value tag is
+    LM_DATA_CORRUPTION on both sides."""
+    docs = _cases.corrupted_docs(150, seed=7) + _cases.corrupted_docs(150, seed=8) + _cases.corrupted_docs(150, seed=21)
+    want = _oracle.merge_batch(docs, threads=8)
+
+    def differing(env):
+        monkeypatch.setenv("LM_RECLASS", env)
+        got = _emu.merge_batch(docs)
+        assert [g[0] == 0 for g in got] == [g[0] == 0 for g in got0] if env == "0" else True
+        return got, sum(1 for g, w in zip(got, want) if g[0] != 0 and w[0] != 0 and g[0] != w[0])
+    got0, with_pass = differing("1")
+    _, without = differing("0")
+    assert with_pass < without and with_pass * 10 <= sum(1 for w in want if w[0] != 0), (with_pass, without)
+    # a Map value whose tag byte is undefined: tag 0x3f where the string's tag 5 stood
+    r = wire.Replica(3)
+    r.map_set("m", "k", "abcdefgh"); r.commit()
+    blob = bytearray(r.export())
+    at = blob.index(b"\x05\x08abcdefgh")
+    blob[at] = 0x3f
+    import struct
+    body = bytes(blob[20:])
+    bad = bytes(blob[:16]) + struct.pack("<I", _oracle.xxh32(body)) + body
+    monkeypatch.setenv("LM_RECLASS", "1")
+    assert _oracle.merge_batch([[bad]])[0][0] == 3 == _emu.merge_batch([[bad]])[0][0]
