@@ -206,8 +206,8 @@ void lm_free_bytes(uint8_t* p);
  * state/richtext_state.rs:730-812), keys whose value is null are dropped (unmark), neighbouring spans with equal attributes are one.
  * lm_richtext renders them ON THE DEVICE (k_richtext: one wave per document over the trackers the integrate stage left) and copies
  * them back; lm_richtext_result returns document `doc`'s bytes: one JSON object {"<container id>": [span, ...], ...} over the Text
- * containers in which something (a scalar, an anchor) is visible at that version (ContainerID Display: cid:root-<name>:Text / cid:<counter>@<peer>:Text; members in the order of
- * the document's container table), every span the canonical JSON of the LoroValue map it is ({"attributes":{...},"insert":"..."},
+ * containers in which something (a scalar, an anchor) is visible at that version (ContainerID Display: cid:root-<name>:Text / cid:<counter>@<peer>:Text; members in the
+ * bytewise order of their JSON-encoded keys), every span the canonical JSON of the LoroValue map it is ({"attributes":{...},"insert":"..."},
  * keys bytewise sorted, no "attributes" member when there are none).  *status: LM_OK, the document's import error, or
  * LM_UNSUPPORTED (more than 64 marks open at one scalar).  The bytes stay valid until the next lm_richtext / lm_stage / lm_destroy.
  * Not available on a batch folded by shared replay.  get_deep_value (lm_fetch) never shows styles: this is a call of its own. */

@@ -20,7 +20,8 @@
 //      opens / closes its StyleOp in the active set (LDS) and takes its mark off again; before scalars are written after a change
 //      of the set, the winners per key are worked out and compared BY VALUE (key bytes, encoded value bytes) with the open span's.
 // Output per document: {"<container id>":[span,…],…} for the Text containers in which something — a scalar or an anchor — is visible
-// at the rendered version, in the order of the document's container table (ContainerID Display: cid:root-<name>:Text / cid:<counter>@<peer>:Text).
+// at the rendered version; the kernel writes the members in the order of the document's container table, the host (Engine::richtext)
+// puts the members of a document that lists several into the bytewise order of their JSON-encoded keys (ContainerID Display: cid:root-<name>:Text / cid:<counter>@<peer>:Text).
 // Limits: at most RT_MAX StyleOps open at one scalar and RT_MAX distinct style keys per Text (LM_UNSUPPORTED beyond); two values are "equal" when their encodings are
 // (map-typed style values with the same entries in another order split a span the reference would merge).
 #pragma once
@@ -127,11 +128,11 @@ LM_DEV void rt_walk(const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t vis_
 
 // mode 0: sizes only | 1: write into out + out_off[doc] (capacity out_off[doc + 1] - out_off[doc]; nothing is written beyond it).
 // rt_len[doc] = the exact size either way
-LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t* rt_len, int32_t* rt_status, int mode) {
+LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t* rt_len, int32_t* rt_status, uint32_t* rt_cnt, int mode) {
   const uint32_t doc = (uint32_t)lmw::bid();
   const int lane = lmw::lane();
   const DocMeta m = d.doc[doc];
-  if (status_fatal(m.status)) { if (lane == 0) { rt_len[doc] = 0; rt_status[doc] = m.status; } return; }
+  if (status_fatal(m.status)) { if (lane == 0) { rt_len[doc] = 0; rt_status[doc] = m.status; rt_cnt[doc] = 0; } return; }
   const uint32_t C = m.n_cont;
   const uint64_t elem0 = ((uint64_t)m.elem0_hi << 32) | m.elem0_lo;
   const uint32_t vis_mask = (d.res_vis && d.front_off[doc + 1] > d.front_off[doc] && !(m.flags & DF_FRONT_ERR)) ? (ST_FUT | ST_DELMASK) : ST_EVER;
@@ -156,6 +157,7 @@ LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t
   int32_t err = 0;
   sink_byte(s, '{');
   bool first_cont = true;
+  uint32_t n_listed = 0;   // members written (the host orders the members of a document that lists several, lm_pipeline.h)
   for (uint32_t cidx = 0; cidx < C && !err; cidx++) {
     const ContRow o = d.cont[m.cid0 + cidx];
     if ((o.kind_root & 0xff) != CK_TEXT) continue;
@@ -169,6 +171,7 @@ LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t
     if (!any_vis) continue;
     if (!first_cont) sink_byte(s, ',');
     first_cont = false;
+    n_listed++;
     if (o.kind_root & 0x100) {
       sink_lit(s, "\"cid:root-", 10);
       sink_escaped(s, d.data + o.name_off, o.name_len);
@@ -340,6 +343,7 @@ LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t
   sink_byte(s, '}');
   if (lane == 0) {
     rt_len[doc] = err ? 0u : (uint32_t)s.pos;
+    rt_cnt[doc] = n_listed;
     rt_status[doc] = err ? err : (int32_t)ST_OK;   // (s.pos > s.cap: the host sees the size and launches again with room for it)
   }
 }

@@ -1274,9 +1274,11 @@ struct Engine {
     rt_launches = 0;
     if (n_docs == 0) return;
     Dev d = last_d;
-    b_rt_len.ensure((size_t)n_docs * 8 + 8);
+    b_rt_len.ensure((size_t)n_docs * 12 + 8);
     uint32_t* len = b_rt_len.as<uint32_t>();
     int32_t* st = (int32_t*)(b_rt_len.as<uint32_t>() + n_docs);
+    uint32_t* cnt = b_rt_len.as<uint32_t>() + 2 * (size_t)n_docs;
+    std::vector<uint32_t> h_cnt(n_docs, 0);
     const char* slab_env = getenv("LM_RT_SLAB");
     for (uint32_t i = 0; i < n_docs; i++) {
       uint64_t cap = h_doc[i].status == ST_OK ? (slab_env ? (uint64_t)atoll(slab_env) : 2ull * h_doc[i].out_len + 64ull * h_doc[i].n_cont + 4096) : 0;
@@ -1286,9 +1288,10 @@ struct Engine {
       b_rt_out.ensure(h_rt_off[n_docs] + 64);
       b_rt_off.ensure((size_t)(n_docs + 1) * 8);
       lmbe::h2d(b_rt_off.p, h_rt_off.data(), (size_t)(n_docs + 1) * 8);
-      LM_LAUNCH(k_richtext, n_docs, 64, d, b_rt_out.as<uint8_t>(), (const uint64_t*)b_rt_off.as<uint64_t>(), len, st, 1);
+      LM_LAUNCH(k_richtext, n_docs, 64, d, b_rt_out.as<uint8_t>(), (const uint64_t*)b_rt_off.as<uint64_t>(), len, st, cnt, 1);
       rt_launches++;
       lmbe::d2h(h_rt_len.data(), len, (size_t)n_docs * 4);
+      lmbe::d2h(h_cnt.data(), cnt, (size_t)n_docs * 4);
       lmbe::d2h(h_rt_status.data(), st, (size_t)n_docs * 4);
       lmbe::sync();
       bool over = false;
@@ -1300,6 +1303,38 @@ struct Engine {
     h_rt.resize(h_rt_off[n_docs] + 1);
     if (h_rt_off[n_docs]) lmbe::d2h(h_rt.data(), b_rt_out.p, h_rt_off[n_docs]);
     lmbe::sync();
+    // canonical member order: a document that lists several Text containers has its members put into the bytewise order of their
+    // JSON-encoded keys (the kernel writes them in container-table order); bytes are moved, never changed
+    std::vector<uint8_t> tmp;
+    for (uint32_t i = 0; i < n_docs; i++) {
+      if (h_rt_status[i] != ST_OK || h_cnt[i] < 2 || h_rt_len[i] < 2) continue;
+      uint8_t* p = h_rt.data() + h_rt_off[i];
+      const size_t n = h_rt_len[i];
+      std::vector<std::pair<size_t, size_t>> mem;   // [begin, end) of every member inside the outer braces
+      size_t b = 1;
+      int depth = 0;
+      bool in_str = false;
+      for (size_t k = 1; k + 1 < n; k++) {
+        const uint8_t c = p[k];
+        if (in_str) { if (c == '\\') k++; else if (c == '"') in_str = false; continue; }
+        if (c == '"') in_str = true;
+        else if (c == '[' || c == '{') depth++;
+        else if (c == ']' || c == '}') depth--;
+        else if (c == ',' && depth == 0) { mem.emplace_back(b, k); b = k + 1; }
+      }
+      mem.emplace_back(b, n - 1);
+      if (mem.size() != h_cnt[i]) { h_rt_status[i] = ST_INTERNAL; continue; }
+      auto key_end = [&](const std::pair<size_t, size_t>& m) { size_t k = m.first + 1; while (k < m.second && p[k] != '"') k += p[k] == '\\' ? 2 : 1; return k; };
+      std::stable_sort(mem.begin(), mem.end(), [&](const std::pair<size_t, size_t>& x, const std::pair<size_t, size_t>& y) {
+        const size_t xe = key_end(x), ye = key_end(y), xl = xe - x.first, yl = ye - y.first;
+        const int c = memcmp(p + x.first, p + y.first, xl < yl ? xl : yl);
+        return c != 0 ? c < 0 : xl < yl;
+      });
+      tmp.assign(1, '{');
+      for (size_t m = 0; m < mem.size(); m++) { if (m) tmp.push_back(','); tmp.insert(tmp.end(), p + mem[m].first, p + mem[m].second); }
+      tmp.push_back('}');
+      if (tmp.size() == n) memcpy(p, tmp.data(), n); else h_rt_status[i] = ST_INTERNAL;
+    }
   }
 
   // ---- lm_export: the updates document `i` holds beyond `from_vv` (lm_export.h).  The blobs come back from the arena, the

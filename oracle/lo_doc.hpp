@@ -745,20 +745,23 @@ struct Doc {
     return c.root ? "cid:root-" + c.name + ":Text" : "cid:" + std::to_string(c.counter) + "@" + std::to_string(c.peer) + ":Text";
   }
   // every Text container in which something (a scalar, an anchor) is visible at the rendered version:
-  // {"<container id>": <richtext value>, …}, ids bytewise sorted
+  // {"<container id>": <richtext value>, …}, members in the bytewise order of their JSON-encoded keys
   std::string to_richtext() {
     materialize();
     std::map<std::string, uint32_t> texts;
     for (uint32_t i = 0; i < containers.size(); i++) {
       auto it = seqs.find(i);
-      if (containers[i].kind == CK_TEXT && it != seqs.end() && it->second->tr.active_len() > 0) texts[cid_string(containers[i])] = i;
+      if (!(containers[i].kind == CK_TEXT && it != seqs.end() && it->second->tr.active_len() > 0)) continue;
+      std::string esc;
+      json_escape(cid_string(containers[i]), esc);   // members in the bytewise order of their JSON-encoded keys (the quotes are not compared)
+      texts[esc.substr(1, esc.size() - 2)] = i;
     }
     std::string out = "{";
     bool first = true;
     for (auto& kv : texts) {
       if (!first) out.push_back(',');
       first = false;
-      json_escape(kv.first, out);
+      out.push_back('"'); out += kv.first; out.push_back('"');
       out.push_back(':');
       richtext_json(kv.second, out);
     }
