@@ -763,8 +763,29 @@ LM_KERNEL void k_elem_fill(Dev d) {
     if (valid) r = d.op[row];
     uint32_t kind = (r.cidx_kind >> 16) & 0xff;
     bool want = valid && (kind == OK_TEXT_INS || kind == OK_LIST_INS || kind == OK_STYLE_START || kind == OK_STYLE_END);
+    const bool cand_text = want && kind == OK_TEXT_INS;
     if (want && !d.chg_flag[r.chg]) want = false;
     if (want && r.ctr + r.len > ext) want = false;
+    // a Text insert of a change that is NOT applied (pending: a dependency is missing) fills no slot, but its string is decoded by the
+    // reference all the same when the block is read (String::from_utf8 in the value reader, value.rs:608-859): not UTF-8, or not as
+    // many scalars as the row's length, fails the import there whether or not the change is ever applied.  (Found on damaged rich-text
+    // documents whose flipped dependency made the damaged change pending: rendered here, DecodeDataCorruptionError there.)
+    if (cand_text && !want) {
+      const uint8_t* q = d.data + d.op_val[row];
+      Rd vq = rd_make(q, q < lim ? (uint64_t)(lim - q) : 0ull);
+      uint64_t nb = rd_uleb(vq);
+      if (vq.bad || nb > rd_left(vq)) bad = true;
+      else {
+        uint32_t n = 0;
+        for (uint64_t i = 0; i < nb && !bad;) {
+          uint32_t b0 = vq.p[i], extra = b0 < 0x80 ? 0u : (b0 & 0xE0) == 0xC0 ? 1u : (b0 & 0xF0) == 0xE0 ? 2u : (b0 & 0xF8) == 0xF0 ? 3u : 4u;
+          if (extra == 4 || i + extra >= nb + (extra ? 0 : 1)) { bad = true; break; }
+          for (uint32_t k = 1; k <= extra; k++) if ((vq.p[i + k] & 0xC0) != 0x80) bad = true;
+          n++; i += extra + 1;
+        }
+        if (n != r.len) bad = true;
+      }
+    }
     uint64_t e0 = ebase + r.ctr;
     // a style anchor: cp[] names its op row (CP_ANCHOR | row inside the document) — what k_richtext resolves the StyleOp from; the
     // renderers only look at the marker (tb[] == TB_ANCHOR, cp[] >= CP_ANCHOR)

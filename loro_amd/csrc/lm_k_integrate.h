@@ -776,7 +776,21 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
               // span-granular kernels do, and finish a damaged row by position: ts_del_positional); the cheap half of that comparison is
               // kept: the active length must drop by exactly the row's length — a row that names elements nobody inserted, elements of
               // another container, deleted or future ones is LM_DATA_CORRUPTION, never a value the reference would not have computed
-              // from it.  (A row re-pointed at OTHER active elements passes: DESIGN §7.)
+              // from it.  The other half (round 5, late): the targets must BE the elements at the row's positions — the reference deletes
+              // what stands there (crdt_rope.rs:256-335), so a row re-pointed at other active elements would render a value the reference
+              // does not compute (9 of 400 damaged rich-text documents did, tests/test_emu_richtext.py) — checked element by element before
+              // the delete is applied; a mismatch is LM_DATA_CORRUPTION here (this kernel has no positional path: the host's cue to fall
+              // back).  A move's delete half found its target by position already.
+              if (mv_to == NONE && !t.err) {
+                const int64_t start = r.a2 > 0 ? (int64_t)r.prop : (int64_t)r.prop + 1 - (int64_t)Ln;   // DeleteSpan::start (list_op.rs:303-309)
+                for (uint32_t j = a; j < b && !t.err; j++) {
+                  // offset j: positive span — the rest of the row stands at prop, prop + 1, … once offsets [0, a) are gone; negative span —
+                  // offset j deletes target + (L-1-j), which stands at start + (L-1-j) (the offsets in front of it stood above)
+                  const int64_t pos = r.a2 > 0 ? (int64_t)r.prop + (int64_t)(j - a) : start + (int64_t)(Ln - 1 - j);
+                  const uint32_t idj = r.a2 > 0 ? r.a1 + j : r.a1 + (Ln - 1 - j);
+                  if (pos < 0 || pos > 0x7fffffff || tr_active_id_at(t, (uint32_t)pos) != pid_make(r.a0, idj)) LM_SETERR(t.err, ST_DATA_CORRUPTION);
+                }
+              }
               const uint32_t act0 = t.tot_active;
               tr_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
               if ((act0 - t.tot_active) != (t1 - t0) || Ln != r.len) LM_SETERR(t.err, ST_DATA_CORRUPTION);

@@ -141,3 +141,40 @@ def same(got, want, what=""):
         assert g[0] == w[0], (what, i, g[0], w[0])
         if w[0] == 0:
             assert g[1] == w[1], (what, i, g[1][:400], w[1][:400])
+
+
+def damaged_docs(n=400, seed=5):
+    """rich-text sessions (marks of several keys, multi-byte scalars) with one blob damaged by byte flips and the envelope checksum re-fitted"""
+    import struct
+    rng = random.Random(seed)
+    base = [_fuzz.blobs_of(_fuzz.random_session(9000 + s, n_peers=3, n_steps=80, kinds=("text",), styles="rich")) for s in range(12)]
+
+    def refit(blob):
+        body = blob[20:]
+        return blob[:16] + struct.pack("<I", _oracle.xxh32(body)) + body
+    docs = []
+    for _ in range(n):
+        d = list(rng.choice(base)); j = rng.randrange(len(d)); b = bytearray(d[j])
+        for _ in range(rng.choice([1, 1, 2, 4])):
+            k = rng.randrange(22, len(b))
+            b[k] = rng.choice([b[k] ^ (1 << rng.randrange(8)), rng.randrange(256), 0xFF, 0x80, 0])
+        d[j] = refit(bytes(b))
+        docs.append(d)
+    return docs
+
+
+def check_damaged(run, docs):
+    """run(docs) -> (merge results, richtext results).  What both sides accept is rendered alike (JSON, version vector, richtext), and the
+    device never renders a document the oracle rejects.  Returns (both accept, only the oracle accepts)."""
+    want_j = _oracle.merge_batch(docs, threads=8)
+    want = _oracle.richtext_batch(docs)
+    got_j, got = run(docs)
+    n_both = n_oracle_only = 0
+    for i in range(len(docs)):
+        g, w = got_j[i], want_j[i]
+        assert not (g[0] == 0 and w[0] not in (0, 4)), (i, "the device rendered a document the oracle rejects", w[0])
+        if g[0] == 0 and w[0] == 0:
+            n_both += 1
+            assert g == w and got[i] == want[i], (i, g[1][:200], w[1][:200])
+        n_oracle_only += g[0] != 0 and w[0] == 0
+    return n_both, n_oracle_only

@@ -95,3 +95,14 @@ def test_a_slab_that_is_too_small_sends_the_batch_through_a_second_launch(monkey
     monkeypatch.delenv("LM_RT_SLAB")
     _, got = _harness(docs)
     _richtext.same(got, want, "default slab")
+
+
+@pytest.mark.parametrize("auto", ["0", "1"])
+def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected(monkeypatch, auto):
+    """byte flips in documents full of marks and multi-byte scalars, under the suites' kernel choice and under the product default
+    (LM_SPAN_AUTO=1: the element-granular kernel, whose deletes are now checked against the row's positions — 9 of these 400 documents
+    used to come back with a value the reference does not compute) — and a damaged string in a PENDING change is an error as in the
+    reference, which decodes every value of a block it reads."""
+    monkeypatch.setenv("LM_SPAN_AUTO", auto)
+    n_both, n_oracle_only = _richtext.check_damaged(_harness, _richtext.damaged_docs())
+    assert n_both >= 40 and n_oracle_only <= (8 if auto == "0" else 24), (n_both, n_oracle_only)

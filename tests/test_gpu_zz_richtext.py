@@ -78,3 +78,15 @@ def test_config5_shaped_documents_with_bold_marks(engine, monkeypatch):
     want = _oracle.richtext_batch(docs, frontiers=fronts)
     _richtext.same(got, want, "cfg5")
     assert all(st == 0 for st, _ in got) and max(js.count(b'"attributes"') for _, js in got) > 50
+
+
+@pytest.mark.parametrize("auto", ["0", "1"])
+def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected(engine, monkeypatch, auto):
+    """1,600 damaged rich-text documents (four seeds), suites' kernel choice and product default: what both sides accept is rendered
+    alike — JSON, version vector, richtext — and the device never renders a document the oracle rejects"""
+    monkeypatch.setenv("LM_SPAN_AUTO", auto)
+    n_both = 0
+    for seed in (5, 6, 7, 8):
+        nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_docs(400, seed=seed))
+        n_both += nb
+    assert n_both >= 160
