@@ -452,8 +452,9 @@ LM_DEV uint32_t kc_pack(uint32_t n_map, uint32_t n_style) { return (n_map & 0x7f
 // value walk that names corruption where it stands (an undefined value tag, a nested map key index beyond the block's key table, an
 // oversized collection are DecodeDataCorruptionError in the reference, value.rs:342-459 — the hot decoders only latch their reader
 // there and report the block as DecodeError at its end; a write to a flag inside their walker costs them ~20 %, see above).  Only the
-// verdict is taken from this pass, and only DataCorruption: the rows it writes belong to a block whose document has failed.
-static constexpr uint32_t DEC_RECLASS = 0xDEC0DE01u;   // BlockDesc.pad of a block a decoder left with ST_DECODE_ERROR
+// verdict (DecodeError / DataCorruption, whichever its sequential walk meets first) is taken from this pass: the rows it writes belong to
+// a block whose document has failed.
+static constexpr uint32_t DEC_RECLASS = 0xDEC0DE01u;   // BlockDesc.pad of a block a row decoder left with ST_DECODE_ERROR / ST_DATA_CORRUPTION
 template <bool EXACT> LM_DEV void lane_skip_value(Rd& r, uint32_t& vf, int cdepth, uint32_t n_keys) {
   uint32_t f_cnt[16];
   if (EXACT) skip_loro_value_fs<true>(r, vf, cdepth, f_cnt, n_keys);
@@ -463,7 +464,7 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
   uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
   if (bi >= d.n_blocks) return;
   BlockDesc bd = d.blk[bi];
-  if (EXACT ? (bd.status != ST_DECODE_ERROR || bd.pad != DEC_RECLASS) : (bd.status != ST_OK)) return;
+  if (EXACT ? ((bd.status != ST_DECODE_ERROR && bd.status != ST_DATA_CORRUPTION) || bd.pad != DEC_RECLASS) : (bd.status != ST_OK)) return;
   const uint32_t* off = d.boff + (uint64_t)bi * BCN;
   const uint32_t* cnt = d.bcnt + (uint64_t)bi * BCN;
   uint32_t N = bd.n_changes;
@@ -547,6 +548,12 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
     DodCur ld = dod_make(hr);
     for (uint32_t i = 0; i + 1 < N; i++) (void)dod_next(ld);
     dod_finish(ld, hr, N - 1);
+    {   // the last change's lamport = lamport_start + lamport_len - its length, in u32 with checked arithmetic (block_meta_encode.rs:215-221):
+        // the wire lamports are not used (recomputed from the dependencies on import), this verdict is
+      const uint64_t kn_ = known > bd.counter_len ? bd.counter_len : known;
+      const uint64_t lend = (uint64_t)bd.lamport_start + (uint64_t)bd.lamport_len, last_len = (uint64_t)bd.counter_len - kn_;
+      if (lend > 0xFFFFFFFFull || lend < last_len) st = st ? st : ST_DECODE_ERROR;
+    }
     if (h.bad || bc.r.bad || dc.r.bad || pc.r.bad || hr.bad) st = st ? st : ST_DECODE_ERROR;
     for (uint32_t i = 0; i < N; i++) d.chg[chg0 + i].op0 = 0;
   }
@@ -559,7 +566,11 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
     RleCur mc = rle_make(m);
     uint64_t tot = 0;
     for (uint32_t i = 0; i < N; i++) tot += rle_next_uvar(mc);
-    if (mc.r.bad || tot > rd_left(mc.r)) DEC_ST(ST_DATA_CORRUPTION);
+    // (the reference: a timestamp / message-length column that does not decode — too few values, a run that announces more than N —
+    // is DecodeError (block_encode.rs:563-571 through serde_columnar); lengths that exceed the message bytes are data corruption)
+    if (mc.rem != 0) mc.r.bad = true;
+    if (mc.r.bad) DEC_ST(ST_DECODE_ERROR);
+    else if (tot > rd_left(mc.r)) DEC_ST(ST_DATA_CORRUPTION);
   }
   // ---- keys
   {
@@ -704,6 +715,10 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
       }
       if (vfl & VF_UNSUPPORTED) unsupported = true;
       if (vfl & VF_CORRUPT) DEC_ST(ST_DATA_CORRUPTION);
+      // (EXACT: a value that runs out of input ends the reference's decode at THIS row with DecodeError; the hot decoders go on with
+      // a latched reader — which hands out zeros — and may note a data-corruption finding on a later row in front of their
+      // end-of-block DecodeError)
+      if (EXACT && v.bad) DEC_ST(ST_DECODE_ERROR);
       // decode_op mapping (outdated_encode_reordered.rs:215-476)
       bool take_del = false;
       if (ckind == CK_TEXT) {
@@ -762,10 +777,10 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
     if (c_cont.r.bad || c_prop.r.bad || c_vt.r.bad || c_len.r.bad || v.bad) st = st ? st : ST_DECODE_ERROR;
     if (counter != (uint64_t)bd.counter_start + bd.counter_len) DEC_ST(ST_DATA_CORRUPTION);
   }
-  if (EXACT) { if (st == ST_DATA_CORRUPTION) d.blk[bi].status = st; return; }
+  if (EXACT) { if (st == ST_DATA_CORRUPTION || st == ST_DECODE_ERROR) d.blk[bi].status = st; return; }
   if (st == ST_OK && unsupported) st = ST_UNSUPPORTED;
   d.blk[bi].status = st;
-  d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = st == ST_DECODE_ERROR ? DEC_RECLASS : kc_el;
+  d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = (st == ST_DECODE_ERROR || st == ST_DATA_CORRUPTION) ? DEC_RECLASS : kc_el;
 }
 LM_KERNEL void k_block_decode(Dev d) { block_decode_lane<false>(d); }
 LM_KERNEL void k_block_reclassify(Dev d) { block_decode_lane<true>(d); }

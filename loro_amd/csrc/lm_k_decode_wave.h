@@ -251,6 +251,12 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
       DodCur ld = dod_make(hr);
       for (uint32_t i = 0; i + 1 < N; i++) (void)dod_next(ld);
       dod_finish(ld, hr, N - 1);
+      {   // the last change's lamport = lamport_start + lamport_len - its length, in u32 with checked arithmetic (block_meta_encode.rs:215-221):
+          // the wire lamports are not used (recomputed from the dependencies on import), this verdict is
+        const uint64_t kn_ = known > bd.counter_len ? bd.counter_len : known;
+        const uint64_t lend = (uint64_t)bdp->lamport_start + (uint64_t)bdp->lamport_len, last_len = (uint64_t)bd.counter_len - kn_;
+        if (lend > 0xFFFFFFFFull || lend < last_len) st = st ? st : ST_DECODE_ERROR;
+      }
       if (h.bad || bc.r.bad || after_bool.bad || dc.r.bad || pc.r.bad || hr.bad) st = st ? st : ST_DECODE_ERROR;
     }
     {  // change_meta: timestamps + message lengths, shape only (block_encode.rs:563-571)
@@ -261,7 +267,9 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
       RleCur mc = rle_make(m);
       uint64_t tot = 0;
       for (uint32_t i = 0; i < N; i++) tot += rle_next_uvar(mc);
-      if (mc.r.bad || tot > rd_left(mc.r)) st = st ? st : ST_DATA_CORRUPTION;
+      if (mc.rem != 0) mc.r.bad = true;   // (a run that announces more than N values: DecodeError, like every column that does not decode — lm_k_decode.h)
+      if (mc.r.bad) st = st ? st : ST_DECODE_ERROR;
+      else if (tot > rd_left(mc.r)) st = st ? st : ST_DATA_CORRUPTION;
     }
     {  // keys
       Rd k = sec(SEC_KEYS);
@@ -771,7 +779,7 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
     if (st == ST_OK && (tail & 2)) st = ST_DATA_CORRUPTION;
     if (st == ST_OK && (tail & 4)) st = ST_UNSUPPORTED;
     d.blk[bi].status = st;
-    d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = st == ST_DECODE_ERROR ? DEC_RECLASS : kc_el;   // (k_block_reclassify looks at such a block once more)
+    d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = (st == ST_DECODE_ERROR || st == ST_DATA_CORRUPTION) ? DEC_RECLASS : kc_el;   // (k_block_reclassify looks at such a block once more)
   }
 #ifdef LM_PROF_DEC
   DEC_PH(7);

@@ -65,6 +65,7 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   uint32_t cache_leaf;            // leaf currently mirrored in `cr` (NONE = none): typing stays in one leaf for many ops
   LeafRegs cr;                    // write-through register copy of that leaf
   int32_t err;
+  uint32_t beyond;   // an insert row named a position beyond the end
 #ifdef LM_PROF
   uint64_t prof[PF_N];
 #endif
@@ -278,6 +279,7 @@ LM_DEV void tr_insert(Tr& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   PROF_T0();
   PROF_CNT(t, PF_NINS, 1);
   uint32_t p, ins, origin_left = NONE;
+  t.beyond |= pos > t.tot_active ? 1u : 0u;    // (lm_k_integrate_span.h ts_insert: the reference places such a row behind trailing tombstones too — LM_DATA_CORRUPTION when the document is closed)
   if (pos > t.tot_active) pos = t.tot_active;  // beyond the end: clamp (query "missing" case)
   if (pos == 0) { p = 0; ins = 0; }
   else {
@@ -685,7 +687,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
   t.dir_cap = dir_cap;
   t.leaf_cap = m.leaf_cap;
   t.n_leaf = 0;
-  t.err = 0;
+  t.err = 0; t.beyond = 0;
 #ifdef LM_PROF
   for (int i = 0; i < PF_N; i++) t.prof[i] = 0;
   uint64_t pf_begin = lmw::clock();
@@ -839,6 +841,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
     dir_used += t.n_dir;
     lmw::block_sync();
   }
+  if (!t.err && t.beyond) t.err = ST_DATA_CORRUPTION;
   if (t.err && lane == 0) {
     d.doc[doc].status = t.err;
     if (t.err == ST_RETRY) lmw::atomic_add(retry_count, 1u);

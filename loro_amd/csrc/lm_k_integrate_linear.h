@@ -141,6 +141,7 @@ LM_DEV void tl_prepare(Ts& t, Tl& c, uint32_t pos, uint32_t room) {
 // insert of run [pid0, pid0 + len) behind the pos-th element
 LM_DEV void tl_insert(Ts& t, Tl& c, uint32_t pos, uint32_t pid0, uint32_t len) {
   uint32_t lane = (uint32_t)lmw::lane();
+  t.beyond |= pos > t.tot_active ? 1u : 0u;   // (see ts_insert: the document is closed with LM_DATA_CORRUPTION)
   pos = pos > t.tot_active ? t.tot_active : pos;
   t.tot_active += len;
   {

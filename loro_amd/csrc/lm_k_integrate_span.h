@@ -45,6 +45,7 @@ struct Ts {   // wave-uniform context of one (document, sequence container) repl
   uint32_t loc_pend;              // per lane: the item of `cr` in this lane entered the leaf since the last flush, its loc[] entries are pending
                                   // (a lane flag, not a 64-bit mask: it shifts with the items on the vector unit — the kernel is scalar-issue bound)
   int32_t err;
+  uint32_t beyond;                // an insert row named a position beyond the end (sticky; LM_DATA_CORRUPTION when the document is closed)
 #ifdef LM_PROF
   mutable uint64_t prof[PF_N];
 #endif
@@ -532,6 +533,11 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   // (POS: the kernel that replays damaged documents rejects the row — see above; the others clamp it as they always did: the check
   // was measured at 2 % of the replay of healthy documents, an exit edge in front of the in-leaf path)
   if (POS && pos > t.tot_active) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+  // (an insert BEYOND the end is placed by the reference behind everything its tree holds — trailing tombstones and future items
+  // included (the B-tree query misses and returns the end of the tree, crdt_rope.rs:81-82), not behind the last ACTIVE element, where
+  // the clamp below puts it: one damaged document in 3,600 was rendered with two list items elsewhere.  No writer emits such a row;
+  // the row is noted — an OR into a register, no exit edge — and the document closed with LM_DATA_CORRUPTION)
+  t.beyond |= pos > t.tot_active ? 1u : 0u;
   if (pos > t.tot_active) pos = t.tot_active;
   t.n_alive += len;
   if (ts_insert_fast(t, pos, pid0, len)) { PROF_ADD(t, PF_PLACE); PROF_CNT(t, PF_LEAF, 1u << 20); return; }
@@ -1622,7 +1628,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   t.it = d.it + (uint64_t)m.leaf0 * SP_REC;
   t.loc = d.loc + elem0;
   t.ebase = s_ebase; t.cur = s_cur; t.end = s_end; t.da = s_da; t.db = s_db; t.ds = s_ds; t.ds_on = false;
-  t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0;
+  t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0; t.beyond = 0;
   t.n_alive = 0;
   if (lane == 0) {   // (resident trackers keep the by-id verdict — LM_DATA_CORRUPTION: their lists would have to outlive the run)
     uint64_t pl = (!POS || !d.posdel) ? 0ull : (uint64_t)(uintptr_t)(d.posdel + (uint64_t)doc * (3 * PD_CAP));
@@ -2087,6 +2093,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   }
   // a delete row that does not match its position: the document is replayed by k_integrate_span_pos (lm_pipeline.h) — unless this IS
   // that kernel, the document is resident (its list would have to outlive the run) or holds a MovableList: LM_DATA_CORRUPTION
+  if (!t.err && t.beyond) t.err = ST_DATA_CORRUPTION;   // an insert row beyond the end (ts_insert / tl_insert)
   if (t.err == ST_POSDEL && (POS || RES || ML || !d.posdel)) t.err = ST_DATA_CORRUPTION;
   if (t.err && lane == 0) {
     d.doc[doc].status = t.err;

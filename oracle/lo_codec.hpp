@@ -545,8 +545,10 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
   std::vector<int64_t> lamports = take_delta_of_delta(header, N - 1);
   {
     int64_t last_len = lengths.back();
-    int64_t ll = (int64_t)lamport_start + (int64_t)lamport_len - last_len;
-    if (ll < 0 || ll > (int64_t)UINT32_MAX) fail(ST_DECODE_ERROR, "invalid lamport");
+    // block_meta_encode.rs:215-221: lamport_start.checked_add(lamport_len) in u32, then checked_sub(last_len)
+    int64_t lend = (int64_t)lamport_start + (int64_t)lamport_len;
+    if (lend > (int64_t)UINT32_MAX || lend < last_len) fail(ST_DECODE_ERROR, "invalid lamport");
+    int64_t ll = lend - last_len;
     lamports.push_back(ll);
   }
   std::vector<int64_t> counters;
