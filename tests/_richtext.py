@@ -178,3 +178,40 @@ def check_damaged(run, docs):
             assert g == w and got[i] == want[i], (i, g[1][:200], w[1][:200])
         n_oracle_only += g[0] != 0 and w[0] == 0
     return n_both, n_oracle_only
+
+
+def damaged_mixed_docs(n=600, seed=1):
+    """rich-text + list + map sessions, nested containers and MovableLists, one blob damaged per document by byte flips, truncation, a
+    spliced range or a duplicated range, checksum re-fitted (the corpus that turned up the last-lamport rule, the surplus run in the
+    message-length column and the insert beyond the end)"""
+    import struct
+    rng = random.Random(seed)
+    base = [_fuzz.blobs_of(_fuzz.random_session(9100 + s, n_peers=3, n_steps=90, kinds=("text", "list", "map"), styles="rich")) for s in range(8)]
+    base += [_fuzz.blobs_of(_fuzz.nested_session(9200 + s, n_steps=100)) for s in range(6)]
+    base += [_fuzz.blobs_of(_fuzz.movable_session(9300 + s, n_peers=3, n_steps=90, nested=s % 2 == 0)) for s in range(6)]
+
+    def refit(blob):
+        body = blob[20:]
+        return blob[:16] + struct.pack("<I", _oracle.xxh32(body)) + body
+
+    def corrupt(blob):
+        b = bytearray(blob)
+        k = rng.random()
+        if k < 0.6:
+            for _ in range(rng.choice([1, 1, 2, 5])):
+                i = rng.randrange(22, len(b))
+                b[i] = rng.choice([b[i] ^ (1 << rng.randrange(8)), rng.randrange(256), 0xFF, 0x80, 0])
+        elif k < 0.75:
+            del b[rng.randrange(22, len(b)):]
+        elif k < 0.9:
+            i = rng.randrange(22, len(b)); j = min(len(b), i + rng.randrange(1, 40))
+            b[i:j] = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 50)))
+        else:
+            i = rng.randrange(22, len(b))
+            b[i:i] = b[rng.randrange(22, len(b)):][: rng.randrange(1, 64)]
+        return refit(bytes(b)) if len(b) > 22 else bytes(b)
+    docs = []
+    for _ in range(n):
+        d = list(rng.choice(base)); j = rng.randrange(len(d)); d[j] = corrupt(d[j])
+        docs.append(d)
+    return docs

@@ -106,3 +106,12 @@ def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected
     monkeypatch.setenv("LM_SPAN_AUTO", auto)
     n_both, n_oracle_only = _richtext.check_damaged(_harness, _richtext.damaged_docs())
     assert n_both >= 40 and n_oracle_only <= (8 if auto == "0" else 24), (n_both, n_oracle_only)
+
+
+@pytest.mark.parametrize("seed,auto", [(3, "1"), (5, "1"), (6, "0")])
+def test_damaged_mixed_documents(monkeypatch, seed, auto):
+    """the seeds on which the device used to give a verdict the reference does not give: two blocks whose last lamport does not fit
+    (seed 3), a message-length column with a surplus run (seed 5), an insert row beyond the end (seed 6)"""
+    monkeypatch.setenv("LM_SPAN_AUTO", auto)
+    n_both, _ = _richtext.check_damaged(_harness, _richtext.damaged_mixed_docs(600, seed=seed))
+    assert n_both >= 40

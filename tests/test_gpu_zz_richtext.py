@@ -90,3 +90,15 @@ def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected
         nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_docs(400, seed=seed))
         n_both += nb
     assert n_both >= 160
+
+
+@pytest.mark.parametrize("auto", ["0", "1"])
+def test_damaged_mixed_documents(engine, monkeypatch, auto):
+    """3,600 damaged documents over rich-text / list / map sessions, nested containers and MovableLists (six seeds): rendered like the
+    reference or rejected, never a document the oracle rejects"""
+    monkeypatch.setenv("LM_SPAN_AUTO", auto)
+    n_both = 0
+    for seed in (3, 5, 6, 16, 17, 18):
+        nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_mixed_docs(600, seed=seed))
+        n_both += nb
+    assert n_both >= 250
