@@ -84,7 +84,7 @@ def merge_batch(docs, threads=1, packed=None, frontiers=None):
     return out
 
 
-def richtext_batch(docs, frontiers=None):
+def richtext_batch(docs, frontiers=None, threads=8, with_merge=False):
     """Per document (status, richtext bytes): the richtext value (TextHandler::get_richtext_value) of every Text container in
     which something is visible at the rendered version, as one canonical JSON object {"<container id>": [spans…], …} — the checker of lm_richtext."""
     L = lib()
@@ -97,20 +97,27 @@ def richtext_batch(docs, frontiers=None):
             foff = np.zeros(n + 1, dtype=np.uint64)
             foff[1:] = np.cumsum([len(f) for f in fb], dtype=np.uint64)
             fdata = np.frombuffer(b"".join(fb) or b"\0", dtype=np.uint8).copy()
-            h = L.lo_batch_run_at(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, fdata.ctypes.data, foff.ctypes.data, 1)
+            h = L.lo_batch_run_at(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, fdata.ctypes.data, foff.ctypes.data, threads)
         else:
-            h = L.lo_batch_run(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, 1)
+            h = L.lo_batch_run(data.ctypes.data, off.ctypes.data, doc_blob.ctypes.data, n, threads)
     finally:
         L.lo_option_richtext(0)
-    out = []
+    out, merged = [], []
     try:
         ln = ctypes.c_uint64()
         for i in range(n):
+            st = L.lo_batch_status(h, i)
             p = L.lo_batch_richtext(h, i, ctypes.byref(ln))
-            out.append((L.lo_batch_status(h, i), ctypes.string_at(p, ln.value) if ln.value else b""))
+            out.append((st, ctypes.string_at(p, ln.value) if ln.value else b""))
+            if with_merge:   # the same run's merge results (what merge_batch returns)
+                p = L.lo_batch_json(h, i, ctypes.byref(ln))
+                js = ctypes.string_at(p, ln.value) if ln.value else b""
+                p = L.lo_batch_vv(h, i, ctypes.byref(ln))
+                vv = ctypes.string_at(p, ln.value) if ln.value else b""
+                merged.append((st, js, vv, L.lo_batch_pending(h, i)))
     finally:
         L.lo_batch_free(h)
-    return out
+    return (out, merged) if with_merge else out
 
 
 class Session:

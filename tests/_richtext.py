@@ -143,11 +143,27 @@ def same(got, want, what=""):
             assert g[1] == w[1], (what, i, g[1][:400], w[1][:400])
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def _base_rich():
+    return [_fuzz.blobs_of(_fuzz.random_session(9000 + s, n_peers=3, n_steps=80, kinds=("text",), styles="rich")) for s in range(12)]
+
+
+@functools.lru_cache(maxsize=None)
+def _base_mixed():
+    base = [_fuzz.blobs_of(_fuzz.random_session(9100 + s, n_peers=3, n_steps=90, kinds=("text", "list", "map"), styles="rich")) for s in range(8)]
+    base += [_fuzz.blobs_of(_fuzz.nested_session(9200 + s, n_steps=100)) for s in range(6)]
+    base += [_fuzz.blobs_of(_fuzz.movable_session(9300 + s, n_peers=3, n_steps=90, nested=s % 2 == 0)) for s in range(6)]
+    return base
+
+
 def damaged_docs(n=400, seed=5):
     """rich-text sessions (marks of several keys, multi-byte scalars) with one blob damaged by byte flips and the envelope checksum re-fitted"""
     import struct
     rng = random.Random(seed)
-    base = [_fuzz.blobs_of(_fuzz.random_session(9000 + s, n_peers=3, n_steps=80, kinds=("text",), styles="rich")) for s in range(12)]
+    base = _base_rich()
 
     def refit(blob):
         body = blob[20:]
@@ -166,8 +182,7 @@ def damaged_docs(n=400, seed=5):
 def check_damaged(run, docs):
     """run(docs) -> (merge results, richtext results).  What both sides accept is rendered alike (JSON, version vector, richtext), and the
     device never renders a document the oracle rejects.  Returns (both accept, only the oracle accepts)."""
-    want_j = _oracle.merge_batch(docs, threads=8)
-    want = _oracle.richtext_batch(docs)
+    want, want_j = _oracle.richtext_batch(docs, threads=16, with_merge=True)
     got_j, got = run(docs)
     n_both = n_oracle_only = 0
     for i in range(len(docs)):
@@ -186,9 +201,7 @@ def damaged_mixed_docs(n=600, seed=1):
     message-length column and the insert beyond the end)"""
     import struct
     rng = random.Random(seed)
-    base = [_fuzz.blobs_of(_fuzz.random_session(9100 + s, n_peers=3, n_steps=90, kinds=("text", "list", "map"), styles="rich")) for s in range(8)]
-    base += [_fuzz.blobs_of(_fuzz.nested_session(9200 + s, n_steps=100)) for s in range(6)]
-    base += [_fuzz.blobs_of(_fuzz.movable_session(9300 + s, n_peers=3, n_steps=90, nested=s % 2 == 0)) for s in range(6)]
+    base = _base_mixed()
 
     def refit(blob):
         body = blob[20:]

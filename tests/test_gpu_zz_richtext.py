@@ -82,23 +82,23 @@ def test_config5_shaped_documents_with_bold_marks(engine, monkeypatch):
 
 @pytest.mark.parametrize("auto", ["0", "1"])
 def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected(engine, monkeypatch, auto):
-    """1,600 damaged rich-text documents (four seeds), suites' kernel choice and product default: what both sides accept is rendered
+    """800 damaged rich-text documents (two seeds), suites' kernel choice and product default: what both sides accept is rendered
     alike — JSON, version vector, richtext — and the device never renders a document the oracle rejects"""
     monkeypatch.setenv("LM_SPAN_AUTO", auto)
     n_both = 0
-    for seed in (5, 6, 7, 8):
+    for seed in (5, 6):
         nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_docs(400, seed=seed))
         n_both += nb
-    assert n_both >= 160
+    assert n_both >= 80
 
 
 @pytest.mark.parametrize("auto", ["0", "1"])
 def test_damaged_mixed_documents(engine, monkeypatch, auto):
-    """3,600 damaged documents over rich-text / list / map sessions, nested containers and MovableLists (six seeds): rendered like the
+    """2,400 damaged documents over rich-text / list / map sessions, nested containers and MovableLists (four seeds): rendered like the
     reference or rejected, never a document the oracle rejects"""
     monkeypatch.setenv("LM_SPAN_AUTO", auto)
     n_both = 0
-    for seed in (3, 5, 6, 16, 17, 18):
+    for seed in (3, 5, 6, 16):
         nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_mixed_docs(600, seed=seed))
         n_both += nb
-    assert n_both >= 250
+    assert n_both >= 160
