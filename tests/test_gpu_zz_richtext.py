@@ -82,23 +82,18 @@ def test_config5_shaped_documents_with_bold_marks(engine, monkeypatch):
 
 @pytest.mark.parametrize("auto", ["0", "1"])
 def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected(engine, monkeypatch, auto):
-    """800 damaged rich-text documents (two seeds), suites' kernel choice and product default: what both sides accept is rendered
-    alike — JSON, version vector, richtext — and the device never renders a document the oracle rejects"""
+    """400 damaged rich-text documents, suites' kernel choice and product default: what both sides accept is rendered alike — JSON,
+    version vector, richtext — and the device never renders a document the oracle rejects (more seeds: the kernel-logic suite)"""
     monkeypatch.setenv("LM_SPAN_AUTO", auto)
-    n_both = 0
-    for seed in (5, 6):
-        nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_docs(400, seed=seed))
-        n_both += nb
-    assert n_both >= 80
+    nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_docs(400, seed=5))
+    assert nb >= 40
 
 
-@pytest.mark.parametrize("auto", ["0", "1"])
-def test_damaged_mixed_documents(engine, monkeypatch, auto):
-    """2,400 damaged documents over rich-text / list / map sessions, nested containers and MovableLists (four seeds): rendered like the
-    reference or rejected, never a document the oracle rejects"""
+@pytest.mark.parametrize("seed,auto", [(3, "1"), (5, "1"), (6, "1"), (16, "0")])
+def test_damaged_mixed_documents(engine, monkeypatch, seed, auto):
+    """damaged documents over rich-text / list / map sessions, nested containers and MovableLists (600 per seed; 3, 5, 6 are the seeds
+    that turned up the last-lamport rule, the surplus message-length run and the insert beyond the end): rendered like the reference
+    or rejected, never a document the oracle rejects"""
     monkeypatch.setenv("LM_SPAN_AUTO", auto)
-    n_both = 0
-    for seed in (3, 5, 6, 16):
-        nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_mixed_docs(600, seed=seed))
-        n_both += nb
-    assert n_both >= 160
+    nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_mixed_docs(600, seed=seed))
+    assert nb >= 30
