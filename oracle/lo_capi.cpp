@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <malloc.h>
 #include "lo_doc.hpp"
+#include "lo_state.hpp"
 
 using namespace lo;
 
@@ -105,6 +106,22 @@ int32_t lo_batch_status(void* h, uint32_t i) { return ((Batch*)h)->res[i].status
 uint64_t lo_batch_pending(void* h, uint32_t i) { return ((Batch*)h)->res[i].pending; }
 const char* lo_batch_json(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*)h)->res[i]; *len = r.json.size(); return r.json.data(); }
 const char* lo_batch_vv(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*)h)->res[i]; *len = r.vv.size(); return r.vv.data(); }
+// the deep value a FastSnapshot's STATE section holds, without replaying its history (lo_state.hpp; groundwork for SURVEY §8f N3)
+int32_t lo_snapshot_state_json(const uint8_t* blob, uint64_t len, int root_only, const char** out, uint64_t* out_len) {
+  static thread_local std::string res;
+  try {
+    bool u = false;
+    res = snapshot_state_json(blob, (size_t)len, u, root_only != 0);
+    *out = res.data(); *out_len = res.size();
+    return u ? ST_UNSUPPORTED : ST_OK;
+  } catch (const DecodeErr& e) {
+    res = e.what; *out = res.data(); *out_len = 0;
+    return e.st;
+  } catch (const std::exception& e) {
+    res = e.what(); *out = res.data(); *out_len = 0;
+    return ST_INTERNAL;
+  }
+}
 void lo_option_richtext(int on) { g_richtext.store(on); }
 const char* lo_batch_richtext(void* h, uint32_t i, uint64_t* len) { auto& r = ((Batch*)h)->res[i]; *len = r.richtext.size(); return r.richtext.data(); }
 const char* lo_batch_err(void* h, uint32_t i) { return ((Batch*)h)->res[i].err.c_str(); }

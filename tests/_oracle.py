@@ -120,6 +120,17 @@ def richtext_batch(docs, frontiers=None, threads=8, with_merge=False):
     return (out, merged) if with_merge else out
 
 
+def snapshot_state(blob, root_only=False):
+    """(status, json bytes): the deep value the STATE section of a FastSnapshot holds, rendered without replaying its history
+    (oracle/lo_state.hpp).  root_only: a shallow snapshot's state at its shallow root."""
+    L = lib()
+    L.lo_snapshot_state_json.restype = ctypes.c_int32
+    L.lo_snapshot_state_json.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+    p, n = ctypes.c_void_p(), ctypes.c_uint64()
+    st = L.lo_snapshot_state_json(blob, len(blob), 1 if root_only else 0, ctypes.byref(p), ctypes.byref(n))
+    return st, (ctypes.string_at(p.value, n.value) if n.value else b"")
+
+
 class Session:
     """One resident document rendered step by step: step(new_blobs, frontiers=None) imports more blobs into the same
     document and renders it — the checker of lm_import + lm_run.  Returns (status, json, vv, pending) like merge()."""

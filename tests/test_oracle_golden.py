@@ -302,3 +302,35 @@ def test_oracle_rejects_damaged_documents_without_crashing():
         res = _oracle.merge_batch(docs, threads=8)
         assert {r[0] for r in res} <= {0, 1, 2, 3, 4}
         assert any(r[0] == 0 for r in res) and any(r[0] != 0 for r in res)
+
+
+# ---- the STATE section of the snapshot fixtures, read for its values (oracle/lo_state.hpp; groundwork for SURVEY §8f N3)
+@pytest.mark.parametrize("name", ["snapshot.blob", "snapshot.ts.blob", "runtime-snapshot.ts.blob"])
+def test_snapshot_state_section_holds_the_value_its_history_gives(name):
+    """docs/encoding-container-states.md as read by lo_state.hpp (ContainerWrapper, postcard LoroValue / ContainerID, Map / List /
+    Text / MovableList visible values) against Rust- and TS-written snapshots: the value rendered from the state section ALONE is,
+    byte for byte, the value the checker gets by replaying the snapshot's history — and the value the reference expects"""
+    st, js = _oracle.snapshot_state(BLOB[name])
+    hist = _oracle.merge_batch([[BLOB[name]]])[0]
+    assert (st, js) == (hist[0], hist[1])
+    v = json.loads(js)
+    want = FX["json"]["snapshot.deep.json" if name.startswith("snapshot") else "runtime.expected.json"]
+    for k, x in want.items():
+        if k in ("tree", "counter"):          # out of the device scope: rendered null, status LM_UNSUPPORTED
+            assert v[k] is None and st == 4
+            continue
+        if isinstance(x, dict):
+            for kk, xx in x.items():
+                if kk in ("child_tree", "mergeable"):   # Tree child / mergeable-container markers (binary activation values)
+                    continue
+                assert v[k][kk] == xx, (k, kk)
+        else:
+            assert v[k] == x, k
+
+
+def test_shallow_snapshot_state_at_its_latest_version_and_at_its_root():
+    # crates/loro/tests/loro_js_interop.rs:129-147: get_deep_value() after the import, and after checkout(shallow_since_frontiers)
+    assert _oracle.snapshot_state(BLOB["shallow.ts.blob"]) == (0, b'{"text":"0123456789"}')
+    assert _oracle.snapshot_state(BLOB["shallow.ts.blob"], root_only=True) == (0, b'{"text":"01234"}')
+    # (the history path cannot render it: the ops below the shallow root are gone — LM_UNSUPPORTED there, oracle and device)
+    assert _oracle.merge_batch([[BLOB["shallow.ts.blob"]]])[0][0] == 4
