@@ -67,7 +67,9 @@ typedef struct lm_doc_in {
   /* Optional checkout (LoroDoc::checkout, crates/loro-internal/src/loro.rs:1625-1760): render the state at
    * these frontiers instead of the latest version.  Bytes = Frontiers::encode() (version/frontiers.rs:219-223:
    * postcard Vec<ID>, sorted).  NULL = latest.  The one-byte encoding 00 is the empty version.  With a checkout
-   * the vv output is the version of the rendered state (state_vv), not oplog_vv. */
+   * the vv output is the version of the rendered state (state_vv), not oplog_vv.  The batch entry replays the version's causal
+   * closure only (same bytes as import + checkout on every healthy document); LM_CHECKOUT_FULL=1 in the environment makes it import
+   * the whole history first, as the reference does — a document damaged OUTSIDE the rendered version then fails like there. */
   const uint8_t* checkout_frontiers;
   size_t checkout_len;
 } lm_doc_in;

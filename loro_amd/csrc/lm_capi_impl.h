@@ -117,12 +117,21 @@ struct lm_ctx_impl {
         for (size_t b = 0; b < docs_api[i].n; b++) { key.push_back((uint64_t)(uintptr_t)docs_api[i].blobs[b]); key.push_back((uint64_t)docs_api[i].lens[b]); }
         groups[key].push_back((uint32_t)i);
       }
+      // LM_CHECKOUT_FULL=1: EVERY entry with a checkout takes this path, alone in its group too — the whole history is imported (what
+      // LoroDoc::import does before LoroDoc::checkout, loro.rs:568-649,1625-1760) and the version is reached by moving the trackers,
+      // instead of the batch entry's replay of the version's causal closure only (DESIGN §7 "Checkout").  On healthy documents the two
+      // give the same bytes; on DAMAGED ones the closure replay never meets damage that lies outside the rendered version — it renders
+      // where the reference's import fails (≈1 % of a damaged corpus with checkouts) or, rarely, renders another value.  Off by default:
+      // it costs a full replay per checked-out document.
+      const char* cf = getenv("LM_CHECKOUT_FULL");
+      const bool full = cf && atoi(cf) != 0;
+      bool any_fold = false;
       if (want) {
         std::vector<uint8_t> fold(n_api, 0);
         for (auto& kv : groups) {
           bool any_front = false;
           for (uint32_t i : kv.second) any_front |= docs_api[i].front != nullptr;
-          if (kv.second.size() >= 2 && any_front && docs_api[kv.second[0]].n) for (uint32_t i : kv.second) fold[i] = 1;
+          if ((kv.second.size() >= 2 || full) && any_front && docs_api[kv.second[0]].n) for (uint32_t i : kv.second) { fold[i] = 1; any_fold = true; }
         }
         std::map<std::vector<uint64_t>, uint32_t> seen;
         for (size_t i = 0; i < n_api; i++) {   // staged documents in the order of their first entries
@@ -139,7 +148,7 @@ struct lm_ctx_impl {
           uniq_of[i] = u;
         }
       }
-      if (want && udocs.size() < n_api) {
+      if (want && (udocs.size() < n_api || (full && any_fold))) {
         for (size_t i = 0; i < n_api; i++)
           if (docs_api[i].front && docs_api[i].front_len == 0) throw std::runtime_error("checkout_frontiers with zero length (the empty version is the byte 00)");
         sh = Shared();

@@ -875,3 +875,58 @@ def test_value_level_corruption_in_a_rejected_block_is_named_like_the_reference(
     bad = bytes(blob[:16]) + struct.pack("<I", _oracle.xxh32(body)) + body
     monkeypatch.setenv("LM_RECLASS", "1")
     assert _oracle.merge_batch([[bad]])[0][0] == 3 == _emu.merge_batch([[bad]])[0][0]
+
+
+def _damaged_checkout_docs(n=300, seed=1):
+    """(docs, frontiers): rich sessions with one blob damaged by byte flips (checksum re-fitted), most rendered at a recorded version"""
+    import random, struct, _fuzz
+    rng = random.Random(seed)
+    base = []
+    for s in range(10):
+        snaps = []
+        reps = _fuzz.random_session(9500 + s, n_peers=3, n_steps=80, kinds=("text", "list", "map"), styles="rich", snapshots=snaps)
+        base.append((_fuzz.blobs_of(reps), [v for v, _ in snaps]))
+    docs, fronts = [], []
+    for _ in range(n):
+        blobs, vers = rng.choice(base)
+        d = list(blobs); j = rng.randrange(len(d)); b = bytearray(d[j])
+        for _ in range(rng.choice([0, 1, 1, 2])):
+            k = rng.randrange(22, len(b))
+            b[k] = rng.choice([b[k] ^ (1 << rng.randrange(8)), rng.randrange(256), 0xFF, 0])
+        body = bytes(b[20:])
+        d[j] = bytes(b[:16]) + struct.pack("<I", _oracle.xxh32(body)) + body
+        docs.append(d)
+        fronts.append(wire.encode_frontiers(rng.choice(vers)) if vers and rng.random() < 0.8 else None)
+    return docs, fronts
+
+
+def test_checkouts_through_the_full_import(monkeypatch):
+    """LM_CHECKOUT_FULL=1: a checked-out entry imports its whole history and reaches the version by moving the trackers (the
+    reference's import + checkout) instead of replaying the version's causal closure.  Healthy documents: the same bytes as ever
+    (the checkout known answers and every recorded version of random sessions).  Damaged documents: damage that lies OUTSIDE the
+    rendered version is met as the reference meets it — without the knob the closure replay renders a few documents the oracle
+    rejects (DESIGN §7 "Checkout"); with it none, and what both accept is rendered alike."""
+    from loro_amd._cabi import Context
+    docs, fronts = _damaged_checkout_docs()
+    want = _oracle.merge_batch(docs, threads=8, frontiers=fronts)
+
+    def dev_only(got):
+        return sum(1 for g, w in zip(got, want) if g[0] == 0 and w[0] not in (0, 4))
+    monkeypatch.setenv("LM_SHARE_REPLAY", "0")
+    assert dev_only(_emu.merge_batch(docs, fronts)) > 0          # the documented deviation of the closure replay
+    monkeypatch.delenv("LM_SHARE_REPLAY")
+    monkeypatch.setenv("LM_CHECKOUT_FULL", "1")
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs, fronts)
+        assert c.b.shared_documents(c.h) == len(docs)
+    assert dev_only(got) == 0
+    n_both = 0
+    for g, w in zip(got, want):
+        if g[0] == 0 and w[0] == 0:
+            assert g == w
+            n_both += 1
+    assert n_both > 100
+    cd, cf = _checkout_cases()
+    cw = _oracle.merge_batch(cd, frontiers=cf)
+    for i, (g, w) in enumerate(zip(_emu.merge_batch(cd, cf), cw)):
+        assert (g == w) if w[0] == 0 else (g[0] == w[0]), (i, g[:3], w[:3])
