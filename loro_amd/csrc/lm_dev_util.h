@@ -342,6 +342,8 @@ LM_DEV int64_t dod_next(DodCur& c) {
 }
 // after taking `n` values: validate the used-bits byte and advance the byte reader past the stream
 LM_DEV void dod_finish(DodCur& c, Rd& r, uint64_t n) {
+  if (c.bad) r.bad = true;   // (an option tag other than 0 / 1 in front of an EMPTY stream too: the early return below used to skip it — a
+                             // block with no foreign dependency and a damaged tag byte was accepted where the reference fails, found on damaged resident sessions)
   if (!c.has_first) { if (n != 0 || c.last_used != 0) r.bad = true; return; }
   if (n == 0) { r.bad = true; return; }
   if (n == 1) { if (c.last_used != 0) r.bad = true; }

@@ -533,3 +533,8 @@ def huge_run_column_docs():
     docs.append(build("enc_delta_rle", 2, lambda b: b + wire.zigzag(giant) + wire.zigzag((1 << 62)))); names.append("prop column: giant run of an overflowing delta")
     docs.append(build("enc_delta_rle", 5, lambda b: b + wire.zigzag(giant) + wire.zigzag(-(1 << 40)))); names.append("delete-start len column: giant run appended")
     return names, docs
+
+
+# a 129-byte blob (one change of a map / list / text session, no foreign dependency) whose EMPTY dependency-counter column carries the
+# option tag 3a instead of 00: DecodeError in the reference (test_a_damaged_option_tag_in_front_of_an_empty_delta_of_delta_column)
+DOD_TAG_BLOB_HEX = "6c6f726f0000000000000000000000006abb1f0600046a0f050f05011101f9456d4caa000000000101003a0000000501000001001003040102000004010000020401010006110474657874036d6170026b32046c6973740016010404010004020405000400040105040b04010304010010036a687807030301030205017a070101"

@@ -3,6 +3,7 @@ bit-for-bit with the oracle.  This exercises the same kernel source and host pip
 GPU parity tests proper are in test_gpu_parity.py (-m gpu)."""
 import pytest
 
+import os
 import _oracle, _emu, _cases
 from loro_amd import wire, workload
 
@@ -930,3 +931,17 @@ def test_checkouts_through_the_full_import(monkeypatch):
     cw = _oracle.merge_batch(cd, frontiers=cf)
     for i, (g, w) in enumerate(zip(_emu.merge_batch(cd, cf), cw)):
         assert (g == w) if w[0] == 0 else (g[0] == w[0]), (i, g[:3], w[:3])
+
+
+def test_a_damaged_option_tag_in_front_of_an_empty_delta_of_delta_column():
+    """a block without foreign dependencies (its dependency-counter column is the empty DeltaOfDelta: option tag 00, used bits 00) whose
+    tag byte was damaged (3a): DecodeError in the reference (`DeltaOfDeltaDecoder::new`, block_meta_encode.rs:190-214) — dod_finish used
+    to return before it looked at the tag of an empty stream.  Found on damaged resident sessions (one blob of 129 bytes)."""
+    bad = bytes.fromhex(_cases.DOD_TAG_BLOB_HEX)
+    assert _oracle.merge_batch([[bad]])[0][0] == 1
+    for dec in ("1", "0"):
+        os.environ["LM_DECODE"] = dec
+        try:
+            assert _emu.merge_batch([[bad]])[0][0] == 1
+        finally:
+            del os.environ["LM_DECODE"]

@@ -97,3 +97,11 @@ def test_damaged_mixed_documents(engine, monkeypatch, seed, auto):
     monkeypatch.setenv("LM_SPAN_AUTO", auto)
     nb, _ = _richtext.check_damaged(lambda docs: _run(engine, docs), _richtext.damaged_mixed_docs(600, seed=seed))
     assert nb >= 30
+
+
+def test_a_damaged_option_tag_in_front_of_an_empty_delta_of_delta_column(engine, monkeypatch):
+    import _cases
+    bad = bytes.fromhex(_cases.DOD_TAG_BLOB_HEX)
+    for dec in ("1", "0"):
+        monkeypatch.setenv("LM_DECODE", dec)
+        assert engine.merge_batch([[bad]])[0][0] == 1 == _oracle.merge_batch([[bad]])[0][0]
