@@ -97,7 +97,7 @@ def test_a_slab_that_is_too_small_sends_the_batch_through_a_second_launch(monkey
     _richtext.same(got, want, "default slab")
 
 
-@pytest.mark.parametrize("auto", ["0", "1"])
+@pytest.mark.parametrize("auto", ["1"])   # (the suites' kernel choice "0": the GPU suite runs both)
 def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected(monkeypatch, auto):
     """byte flips in documents full of marks and multi-byte scalars, under the suites' kernel choice and under the product default
     (LM_SPAN_AUTO=1: the element-granular kernel, whose deletes are now checked against the row's positions — 9 of these 400 documents
@@ -106,9 +106,10 @@ def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected
     monkeypatch.setenv("LM_SPAN_AUTO", auto)
     n_both, n_oracle_only = _richtext.check_damaged(_harness, _richtext.damaged_docs())
     assert n_both >= 40 and n_oracle_only <= (8 if auto == "0" else 24), (n_both, n_oracle_only)
+    # (the seed-3 finding of the mixed corpus — a last lamport that does not fit u32 — is run on the GPU: test_gpu_zz_richtext.py)
 
 
-@pytest.mark.parametrize("seed,auto", [(3, "1"), (5, "1"), (6, "0")])
+@pytest.mark.parametrize("seed,auto", [(3, "1"), (5, "1"), (6, "0")][1:])
 def test_damaged_mixed_documents(monkeypatch, seed, auto):
     """the seeds on which the device used to give a verdict the reference does not give: two blocks whose last lamport does not fit
     (seed 3), a message-length column with a surplus run (seed 5), an insert row beyond the end (seed 6)"""
