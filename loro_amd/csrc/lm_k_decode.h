@@ -566,11 +566,11 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
     RleCur mc = rle_make(m);
     uint64_t tot = 0;
     for (uint32_t i = 0; i < N; i++) tot += rle_next_uvar(mc);
-    // (the reference: a timestamp / message-length column that does not decode — too few values, a run that announces more than N —
-    // is DecodeError (block_encode.rs:563-571 through serde_columnar); lengths that exceed the message bytes are data corruption)
+    // (the reference maps EVERY failure of these two columns — a timestamp stream that does not decode, too few values, a run that
+    // announces more than N — to DecodeDataCorruptionError (block_encode.rs:563-571: `.map_err(|_| LoroError::DecodeDataCorruptionError)`
+    // on both decoders; only the HEADER columns of block_meta_encode.rs are DecodeError); lengths beyond the message bytes likewise)
     if (mc.rem != 0) mc.r.bad = true;
-    if (mc.r.bad) DEC_ST(ST_DECODE_ERROR);
-    else if (tot > rd_left(mc.r)) DEC_ST(ST_DATA_CORRUPTION);
+    if (mc.r.bad || tot > rd_left(mc.r)) DEC_ST(ST_DATA_CORRUPTION);
   }
   // ---- keys
   {

@@ -267,9 +267,8 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
       RleCur mc = rle_make(m);
       uint64_t tot = 0;
       for (uint32_t i = 0; i < N; i++) tot += rle_next_uvar(mc);
-      if (mc.rem != 0) mc.r.bad = true;   // (a run that announces more than N values: DecodeError, like every column that does not decode — lm_k_decode.h)
-      if (mc.r.bad) st = st ? st : ST_DECODE_ERROR;
-      else if (tot > rd_left(mc.r)) st = st ? st : ST_DATA_CORRUPTION;
+      if (mc.rem != 0) mc.r.bad = true;   // (a run that announces more than N values does not decode either)
+      if (mc.r.bad || tot > rd_left(mc.r)) st = st ? st : ST_DATA_CORRUPTION;   // (both change_meta columns: DecodeDataCorruptionError, block_encode.rs:563-571 — lm_k_decode.h)
     }
     {  // keys
       Rd k = sec(SEC_KEYS);

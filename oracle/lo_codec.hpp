@@ -587,8 +587,14 @@ inline void decode_block(Reader blk, std::vector<Change>& out, RawBlock* raw = n
   }
   // ---- change_meta (block_encode.rs:563-571): validated for shape, content not result-bearing
   {
-    std::vector<int64_t> ts = take_delta_of_delta(change_meta, N);
-    std::vector<uint64_t> msg_lens = take_any_rle_uvar(change_meta, N);
+    // (both decoders' failures are mapped to DecodeDataCorruptionError here — `.map_err(|_| LoroError::DecodeDataCorruptionError)`,
+    // block_encode.rs:563-571 — unlike the header columns of block_meta_encode.rs, which stay DecodeError)
+    std::vector<int64_t> ts;
+    std::vector<uint64_t> msg_lens;
+    try {
+      ts = take_delta_of_delta(change_meta, N);
+      msg_lens = take_any_rle_uvar(change_meta, N);
+    } catch (const DecodeErr&) { fail(ST_DATA_CORRUPTION, "change_meta column"); }
     uint64_t tot = 0;
     for (auto l : msg_lens) tot += l;
     if (tot > change_meta.remaining()) fail(ST_DATA_CORRUPTION, "commit message bytes");

@@ -535,6 +535,43 @@ def huge_run_column_docs():
     return names, docs
 
 
+def damaged_change_meta_docs():
+    """the two change_meta columns — timestamps (DeltaOfDelta) and commit-message lengths (AnyRle) — fail with
+    LoroError::DecodeDataCorruptionError whatever the decoder's complaint is (block_encode.rs:563-571: both `take_n_finalize` calls
+    and `DeltaOfDeltaDecoder::new` are `.map_err(|_| LoroError::DecodeDataCorruptionError)`), unlike the header columns of
+    block_meta_encode.rs (DecodeError).  (names, documents): a small valid history whose one block has one of the two columns
+    replaced — every one of them is LM_DATA_CORRUPTION (3)."""
+    from loro_amd import wire
+    names, docs = [], []
+
+    def build(patch_name, nth, make):
+        orig = getattr(wire, patch_name)
+        calls = {"n": 0}
+
+        def patched(vals):
+            calls["n"] += 1
+            out = orig(vals)
+            return make(out) if calls["n"] == nth else out
+        setattr(wire, patch_name, patched)
+        try:
+            r = wire.Replica(9)
+            r.text_insert("text", 0, "hello"); r.commit()
+            r.map_set("m", "k", 1); r.commit()
+            r.text_insert("text", 2, "xy"); r.commit()
+            return [r.export()]
+        finally:
+            setattr(wire, patch_name, orig)
+    # enc_any_rle_uvar calls per block: dep counts, dep peer idx, MESSAGE LENGTHS (3rd), the len column
+    docs.append(build("enc_any_rle_uvar", 3, lambda b: b"")); names.append("message lengths: no value at all")
+    docs.append(build("enc_any_rle_uvar", 3, lambda b: wire.zigzag(2) + wire.uleb(0))); names.append("message lengths: two values for three changes")
+    docs.append(build("enc_any_rle_uvar", 3, lambda b: wire.zigzag(7) + wire.uleb(0))); names.append("message lengths: a run that announces seven values")
+    docs.append(build("enc_any_rle_uvar", 3, lambda b: wire.zigzag(3) + wire.uleb(9))); names.append("message lengths beyond the message bytes")
+    # enc_delta_of_delta calls per block: dep counters, lamports, TIMESTAMPS (3rd)
+    docs.append(build("enc_delta_of_delta", 3, lambda b: b"\x07" + b[1:])); names.append("timestamps: an option tag that is neither 0 nor 1")
+    docs.append(build("enc_delta_of_delta", 3, lambda b: b[:-1] if len(b) > 10 else b"\x01")); names.append("timestamps: the stream is cut short")
+    return names, docs
+
+
 # a 129-byte blob (one change of a map / list / text session, no foreign dependency) whose EMPTY dependency-counter column carries the
 # option tag 3a instead of 00: DecodeError in the reference (test_a_damaged_option_tag_in_front_of_an_empty_delta_of_delta_column)
 DOD_TAG_BLOB_HEX = "6c6f726f0000000000000000000000006abb1f0600046a0f050f05011101f9456d4caa000000000101003a0000000501000001001003040102000004010000020401010006110474657874036d6170026b32046c6973740016010404010004020405000400040105040b04010304010010036a687807030301030205017a070101"

@@ -34,6 +34,19 @@ def known_answers():
     return out
 
 
+def reference_held():
+    """[(name, blobs, expected richtext value of root Text "text")] — answers the REFERENCE's own tests hold for blobs it ships
+    (unlike known_answers(), nothing here goes through this repo's writer): crates/loro/tests/loro_js_interop.rs:86-94 asserts
+    `doc.get_text("text").get_richtext_value()` of runtime-snapshot.ts.blob == [{"insert":"b","attributes":{"bold":true}}] and
+    (`to_delta()` equality, :86-89) the same spans for runtime-updates.ts.blob.  The blobs come from
+    tests/golden/reference_fixtures.json (make_reference_fixtures.py).  Both documents also hold Tree / Counter containers, so
+    their status is LM_UNSUPPORTED (4) with everything in scope rendered."""
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_fixtures.json")))["blobs"]
+    want = [{"insert": "b", "attributes": {"bold": True}}]
+    return [(n, [bytes.fromhex(fx[n])], want) for n in ("runtime-snapshot.ts.blob", "runtime-updates.ts.blob")]
+
+
 def hand_cases():
     """[(name, blobs)] — shapes the rule has to get right: two peers mark the same range concurrently (greater (lamport, peer)
     decides), overlapping marks of different keys, a mark whose End anchor was deleted / whose Start anchor was deleted,

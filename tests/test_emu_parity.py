@@ -945,3 +945,19 @@ def test_a_damaged_option_tag_in_front_of_an_empty_delta_of_delta_column():
             assert _emu.merge_batch([[bad]])[0][0] == 1
         finally:
             del os.environ["LM_DECODE"]
+
+
+def test_damaged_change_meta_columns_are_data_corruption_like_the_reference():
+    """ADVICE r5 (medium): every failure of the timestamp / message-length columns is LoroError::DecodeDataCorruptionError in the
+    reference (block_encode.rs:563-571 maps both decoders' errors) — the oracle and both device decoders said DecodeError for a
+    column that does not decode; the header columns (block_meta_encode.rs) keep DecodeError"""
+    names, docs = _cases.damaged_change_meta_docs()
+    want = _oracle.merge_batch(docs)
+    assert [w[0] for w in want] == [3] * len(docs), list(zip(names, [w[0] for w in want]))
+    for dec in ("1", "0"):
+        os.environ["LM_DECODE"] = dec
+        try:
+            got = _emu.merge_batch(docs)
+            assert [g[0] for g in got] == [3] * len(docs), (dec, list(zip(names, [g[0] for g in got])))
+        finally:
+            del os.environ["LM_DECODE"]

@@ -16,6 +16,25 @@ def test_oracle_gives_the_references_known_answers():
         assert json.loads(js) == {"cid:root-text:Text": want}, (name, js)
 
 
+def test_oracle_gives_the_answer_the_reference_asserts_for_its_runtime_fixtures():
+    """loro_js_interop.rs:86-94 — a reference-held richtext answer on reference-shipped blobs (updates and snapshot form)"""
+    for name, blobs, want in _richtext.reference_held():
+        st, js = _oracle.richtext_batch([blobs])[0]
+        assert st == 4, name     # (Tree / Counter containers beside the Text: LM_UNSUPPORTED, everything in scope rendered)
+        assert json.loads(js) == {"cid:root-text:Text": want}, (name, js)
+
+
+def test_harness_gives_the_answer_the_reference_asserts_for_its_runtime_fixtures():
+    ra = _richtext.reference_held()
+    with Context(_emu.binding()) as c:
+        c.merge_batch([b for _, b, _ in ra])
+        got = c.richtext()
+    for (name, _, want), (st, js) in zip(ra, got):
+        assert json.loads(js) == {"cid:root-text:Text": want}, (name, st, js)
+    # (the document's status is LM_UNSUPPORTED for its Tree / Counter containers; the richtext result has a status of its own)
+    assert [j for _, j in got] == [j for _, j in _oracle.richtext_batch([b for _, b, _ in ra])]
+
+
 def test_oracle_hand_cases_read_as_expected():
     got = {name: json.loads(_oracle.richtext_batch([blobs])[0][1]) for name, blobs in _richtext.hand_cases()}
     t = got["concurrent marks of one key"]["cid:root-text:Text"]

@@ -29,6 +29,17 @@ def test_known_answers(engine):
         assert st == 0 and json.loads(js) == {"cid:root-text:Text": want}, (name, js)
 
 
+def test_the_answer_the_reference_asserts_for_its_runtime_fixtures(engine):
+    """crates/loro/tests/loro_js_interop.rs:86-94: get_richtext_value of runtime-snapshot.ts.blob / runtime-updates.ts.blob
+    == [{"insert":"b","attributes":{"bold":true}}] — reference-held answer, reference-shipped blobs, through the HIP path"""
+    ra = _richtext.reference_held()
+    res, got = _run(engine, [b for _, b, _ in ra])
+    for (name, _, want), (st, js) in zip(ra, got):
+        assert json.loads(js) == {"cid:root-text:Text": want}, (name, st, js)
+    # (the document's status is LM_UNSUPPORTED for its Tree / Counter containers; the richtext result has a status of its own)
+    assert [j for _, j in got] == [j for _, j in _oracle.richtext_batch([b for _, b, _ in ra])]
+
+
 @pytest.mark.parametrize("span", ["1", "0"])
 def test_batch_documents_under_both_integrate_kernels(engine, monkeypatch, span):
     monkeypatch.setenv("LM_SPAN", span)
@@ -105,3 +116,14 @@ def test_a_damaged_option_tag_in_front_of_an_empty_delta_of_delta_column(engine,
     for dec in ("1", "0"):
         monkeypatch.setenv("LM_DECODE", dec)
         assert engine.merge_batch([[bad]])[0][0] == 1 == _oracle.merge_batch([[bad]])[0][0]
+
+
+def test_damaged_change_meta_columns_are_data_corruption_like_the_reference(engine, monkeypatch):
+    """block_encode.rs:563-571: both change_meta decoders' failures are DecodeDataCorruptionError"""
+    import _cases
+    names, docs = _cases.damaged_change_meta_docs()
+    assert [w[0] for w in _oracle.merge_batch(docs)] == [3] * len(docs)
+    for dec in ("1", "0"):
+        monkeypatch.setenv("LM_DECODE", dec)
+        got = engine.merge_batch(docs)
+        assert [g[0] for g in got] == [3] * len(docs), (dec, list(zip(names, [g[0] for g in got])))
