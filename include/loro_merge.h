@@ -110,10 +110,23 @@ int lm_wait(lm_ctx* ctx);
  * lm_stage uploads such a document once; every lm_run imports it once (decode, causal graph, replay from the empty version) and
  * renders each entry by moving the document's trackers to the entry's version, instead of replaying the history once per entry.
  * Results are per entry and are those of import_batch + checkout on a document of its own.  lm_import on such a batch unfolds it
- * first — every entry becomes a resident document of its own over the bytes already in HBM — and then behaves as always; not
- * available on it: lm_summary_layout.  LM_SHARE_REPLAY=0 in the environment switches the folding off.  lm_shared_documents: the
+ * first — every entry becomes a resident document of its own over the bytes already in HBM — and then behaves as always; so does
+ * lm_richtext (the trackers have to stand at every entry's version).  Since round 6 EVERY entry with checkout_frontiers takes this
+ * path, alone in its group too: the whole history is imported before the version is rendered, as LoroDoc::import + LoroDoc::checkout
+ * do — damage outside the rendered version fails the entry like the reference (LM_CHECKOUT_FULL=0: the closure replay of rounds
+ * 1-5).  LM_SHARE_REPLAY=0 in the environment switches the folding off.  lm_shared_documents: the
  * number of documents the batch staged last was folded into (0 = every entry is its own document, also after an lm_import). */
 int lm_shared_documents(lm_ctx* ctx);
+
+/* Diagnostics of the last lm_run (round 6).  lm_fused_documents: LWW Map documents whose blocks hold scalar writes only and were
+ * resolved WITHOUT op rows — op columns folded straight into the document's LWW table (diff_calc.rs:488-616 MapDiffCalculator over
+ * block_encode.rs:417-428 columns; loro_amd/csrc/lm_k_map_fused.h).  lm_redo_documents: documents (entries) the run's configuration
+ * had no path for and that were replayed once more, from the staged bytes, through the span-granular batch pipeline — a delete row
+ * that does not match its position under the element-granular or the resident kernels (applied by position like the reference,
+ * crdt_rope.rs:256-335), a Map document the fused kernel gave up on: the verdict of a document depends neither on its neighbours
+ * in the batch nor on whether the host reused blob pointers. */
+int lm_fused_documents(lm_ctx* ctx);
+int lm_redo_documents(lm_ctx* ctx);
 
 /* Resident documents: import MORE blobs into the documents the context already holds, and / or render them
  * at other versions — what a Rust host does with

@@ -68,11 +68,97 @@ struct lm_ctx_impl {
     n_docs = sh.n_entries;
     sh = Shared();
     mapped = true;
+    rd.on = false;   // (documents replayed in the side engine are the parts' resident documents again)
     if (was_run) {   // lm_stage; lm_run; lm_import: the staged blobs are the resident documents' first step, an import of its own (lm_pipeline.h import_more)
       for (uint32_t p = 0; p < np; p++) for (uint32_t i = 0; i < parts[p]->n_docs; i++) parts[p]->r_step[i] = (uint32_t)parts[p]->r_blobs[i].size();
       run_parts();
     }
     ran = false;
+  }
+
+  // ---- DF_REDO (lm_types.h): documents the configuration the batch ran under has no path for — a delete row that does not match its
+  // position met by the element-granular kernel (the batch's statistics picked it, LM_SPAN_AUTO) or by the resident kernels of a folded
+  // batch; a Map document the fused decode→LWW kernel bailed out of — are replayed ONCE MORE, in a side engine that stages them from
+  // the pinned staging buffer lm_stage filled (nothing is read from the caller again) and runs the span-granular batch pipeline,
+  // whose k_integrate_span_pos finishes such rows by position like the reference (crdt_rope.rs:256-335).  Results, rendered bytes,
+  // hashes, summary rows, richtext values and exports of those documents then come from the side engine: a document's verdict does
+  // not depend on its neighbours in the batch nor on whether the host reused blob pointers.
+  struct Redo {
+    bool on = false;
+    std::unique_ptr<lm::Engine> eng;
+    std::vector<int32_t> of;               // API document / entry -> document of the side engine, -1 = none
+    std::vector<lm::DocResult> res;        // per side-engine document (a folded document whose whole-history import fails fails for every entry)
+    std::vector<std::vector<uint8_t>> fr;  // frontiers the items point at
+    uint32_t n = 0;
+  } rd;
+  void redo_pass(const std::vector<std::vector<uint32_t>>& flagged) {   // flagged[p] = documents of part p to replay
+    rd.on = false; rd.n = 0;
+    size_t total = 0;
+    for (auto& v : flagged) total += v.size();
+    if (!total || mapped) return;
+    std::vector<lm::Engine::RedoItem> items;
+    std::vector<lm::Engine*> parents;
+    std::vector<int32_t> verdict_of;        // item -> the item that carries its document's whole-history verdict (folded batches), -1 = itself
+    rd.of.assign(api_docs(), -1);
+    rd.fr.clear();
+    // (frontier bytes are copied first: the items keep pointers into rd.fr, which must not grow afterwards)
+    struct Want { uint32_t p, doc; int32_t api; const std::vector<uint8_t>* fr; int32_t verdict; };
+    std::vector<Want> want;
+    for (uint32_t p = 0; p < n_parts() && p < flagged.size(); p++)
+      for (uint32_t i : flagged[p]) {
+        lm::Engine& e = *parts[p];
+        if (!sh.on) {
+          rd.fr.emplace_back();
+          if (e.h_front_off.size() > (size_t)i + 1 && e.h_front_off[i + 1] > e.h_front_off[i]) rd.fr.back().assign(e.h_front_bytes.begin() + e.h_front_off[i], e.h_front_bytes.begin() + e.h_front_off[i + 1]);
+          want.push_back(Want{p, i, (int32_t)(first[p] + i), &rd.fr.back(), -1});
+        } else {
+          // a folded document: the whole history once (its verdict is every entry's, as LoroDoc::import in front of LoroDoc::checkout), then every entry at its version
+          const int32_t v = (int32_t)want.size();
+          rd.fr.emplace_back();
+          want.push_back(Want{p, i, -1, &rd.fr.back(), -1});
+          for (uint32_t en = 0; en < sh.n_entries; en++) if (sh.uniq_of[en] == first[p] + i) {
+            if (sh.fronts[en].empty()) { rd.of[en] = v; continue; }
+            rd.fr.push_back(sh.fronts[en]);
+            want.push_back(Want{p, i, (int32_t)en, nullptr, v});
+          }
+        }
+      }
+    {   // rd.fr is complete: hand out the pointers (entries of folded documents took their frontiers in push order)
+      size_t k = 0;
+      for (auto& w : want) { w.fr = &rd.fr[k++]; }
+    }
+    for (auto& w : want) {
+      items.push_back(lm::Engine::RedoItem{w.doc, w.fr->empty() ? nullptr : w.fr->data(), w.fr->size()});
+      parents.push_back(parts[w.p].get());
+      verdict_of.push_back(w.verdict);
+    }
+    if (!rd.eng) rd.eng.reset(new lm::Engine(device));
+    lm::Engine& a = *rd.eng;
+    a.force_span = true;
+    a.profiling = profiling != 0;
+    a.stage_from(parents, items);
+    a.run();
+    rd.res = a.results;
+    for (size_t k = 0; k < want.size(); k++) {
+      if (verdict_of[k] >= 0) {
+        const int32_t vs = a.results[verdict_of[k]].status;
+        if (vs != lm::ST_OK && vs != lm::ST_UNSUPPORTED) rd.res[k] = lm::DocResult{vs, 0, 0, 0, 0, 0, 0};
+      }
+      if (want[k].api >= 0) rd.of[want[k].api] = (int32_t)k;
+    }
+    rd.on = true; rd.n = (uint32_t)want.size();
+    for (auto& t : a.times) times.push_back(lm::KernelTime{t.name + " (redo)", t.ms});
+    // the summary rows of the replayed documents (k_summary_rows wrote the first verdict): patched in place
+    if (sum_rows_padded && !sh.on) {
+      lmbe::bind(parts[0]->sc);
+      for (size_t k = 0; k < want.size(); k++) if (want[k].api >= 0) {
+        const lm::DocResult& r = rd.res[k];
+        const bool ok = r.status == lm::ST_OK || r.status == lm::ST_UNSUPPORTED;
+        long long w[6] = {sum_first + (long long)want[k].api * sum_stride, r.status, ok ? (long long)r.pending : 0, ok ? (long long)r.json_len : 0, ok ? (long long)r.vv_len : 0, ok ? (long long)r.json_xxh64 : 0};
+        lmbe::h2d(sum_buf.as<long long>() + (size_t)want[k].api * 6, w, sizeof w);
+      }
+      lmbe::sync();
+    }
   }
 
   int device = 0;                  // HIP device of this context: every engine (stream, buffers) is created on it
@@ -82,9 +168,25 @@ struct lm_ctx_impl {
   long long sum_first = 0, sum_stride = 1;
   void sum_bind() {                // every part writes its own documents' rows
     for (uint32_t p = 0; p < n_parts() && p < parts.size(); p++) {
-      parts[p]->sum_rows = sum_rows_padded ? sum_buf.as<long long>() + (size_t)first[p] * 6 : nullptr;
+      // (a folded batch — entries that share their blobs — or one unfolded by lm_import: the API's documents are not the parts' contiguous
+      // ranges; their rows are written from the host after the run, sum_host_rows)
+      parts[p]->sum_rows = sum_rows_padded && !sh.on && !mapped ? sum_buf.as<long long>() + (size_t)first[p] * 6 : nullptr;
       parts[p]->sum_id0 = sum_first + (long long)first[p] * sum_stride; parts[p]->sum_stride = sum_stride;
     }
+  }
+
+  void sum_host_rows() {
+    if (!sum_rows_padded || !(sh.on || mapped)) return;
+    std::vector<long long> rows((size_t)api_docs() * 6, -1);
+    for_docs([&](uint32_t i, lm::Engine&, const lm::DocResult& r) {
+      const bool ok = r.status == lm::ST_OK || r.status == lm::ST_UNSUPPORTED;
+      long long* w = rows.data() + (size_t)i * 6;
+      w[0] = sum_first + (long long)i * sum_stride; w[1] = r.status; w[2] = ok ? (long long)r.pending : 0;
+      w[3] = ok ? (long long)r.json_len : 0; w[4] = ok ? (long long)r.vv_len : 0; w[5] = ok ? (long long)r.json_xxh64 : 0;
+    });
+    lmbe::bind(parts[0]->sc);
+    if (!rows.empty()) lmbe::h2d(sum_buf.p, rows.data(), rows.size() * 8);
+    lmbe::sync();
   }
 
   explicit lm_ctx_impl(int dev) : device(dev) {
@@ -121,10 +223,10 @@ struct lm_ctx_impl {
       // LoroDoc::import does before LoroDoc::checkout, loro.rs:568-649,1625-1760) and the version is reached by moving the trackers,
       // instead of the batch entry's replay of the version's causal closure only (DESIGN §7 "Checkout").  On healthy documents the two
       // give the same bytes; on DAMAGED ones the closure replay never meets damage that lies outside the rendered version — it renders
-      // where the reference's import fails (≈1 % of a damaged corpus with checkouts) or, rarely, renders another value.  Off by default:
-      // it costs a full replay per checked-out document.
+      // where the reference's import fails (≈1 % of a damaged corpus with checkouts) or, rarely, renders another value.  The default since
+      // round 6: a checked-out entry costs the replay of its whole history, as in the reference.
       const char* cf = getenv("LM_CHECKOUT_FULL");
-      const bool full = cf && atoi(cf) != 0;
+      const bool full = !(cf && atoi(cf) == 0);   // (round 6: the default — LM_CHECKOUT_FULL=0 keeps the closure replay of rounds 1-5 for single checkouts)
       bool any_fold = false;
       if (want) {
         std::vector<uint8_t> fold(n_api, 0);
@@ -169,6 +271,7 @@ struct lm_ctx_impl {
     n_docs = (uint32_t)n;
     ran = false;
     mapped = false;
+    rd.on = false;
     sum_rows_padded = 0;             // (a new batch: lm_summary_layout is called again for it)
     for (auto& pt : parts) pt->sum_rows = nullptr;
     // split into contiguous ranges of about equal blob bytes; small batches stay in one part
@@ -214,6 +317,7 @@ struct lm_ctx_impl {
   void import_parts(const lm::Engine::DocIn* docs, size_t n) {
     if (n != n_docs) throw std::runtime_error("lm_import: the document count differs from the resident batch");
     ran = false;
+    if (!sh.on) rd.on = false;
     uint32_t np2 = n_parts();
     std::vector<std::string> errs(np2);
     std::vector<std::vector<lm::Engine::DocIn>> per;
@@ -234,9 +338,17 @@ struct lm_ctx_impl {
     for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
   }
   void run() {
-    if (!sh.on) { run_parts(); return; }
+    if (!sh.on) {
+      run_parts();
+      std::vector<std::vector<uint32_t>> fl(n_parts());
+      for (uint32_t p = 0; p < n_parts(); p++) if (!parts[p]->resident) fl[p] = parts[p]->redo_docs;
+      redo_pass(fl);
+      sum_host_rows();
+      return;
+    }
+    rd.on = false;
+    std::vector<std::vector<uint32_t>> redo_flagged(n_parts());
     // every lm_run is the whole job: the import (decode, DAG, replay from the empty version) and one rendering run per checkout slot
-    if (sum_rows_padded) throw std::runtime_error("lm_summary_layout is not available for a batch that renders shared documents at several versions");
     uint32_t np = n_parts();
     std::vector<lm::KernelTime> all_times;
     sh.res.assign(sh.n_entries, lm::DocResult{0, 0, 0, 0, 0, 0, 0});
@@ -281,6 +393,7 @@ struct lm_ctx_impl {
         for (uint32_t i = 0; i < e.n_docs; i++) {
           uint32_t u = first[p] + i;
           if (s == 0) import_status[u] = e.results[i].status;
+          if (s == 0 && i == 0) redo_flagged[p] = e.redo_docs;   // (delete rows the resident kernels cannot finish by position: replayed below)
           uint32_t en = sh.by_slot[s][u];
           if (en == lm::NONE) continue;
           lm::DocResult r = e.results[i];
@@ -298,6 +411,8 @@ struct lm_ctx_impl {
     for (uint32_t p = 0; p < np; p++) { parts[p]->r_blobs = blobs0[p]; parts[p]->shared_mode = 0; }
     times = all_times;
     ran = true;
+    redo_pass(redo_flagged);
+    sum_host_rows();
   }
   void run_parts() {
     uint32_t np = n_parts();
@@ -323,8 +438,14 @@ struct lm_ctx_impl {
     for (uint32_t p = 0; p < np; p++) for (auto& t : parts[p]->times) times.push_back(t);
     ran = true;
   }
+  bool redone(size_t i) const { return rd.on && i < rd.of.size() && rd.of[i] >= 0; }
   template <class F> void for_docs(F f) {
-    if (sh.on) { for (uint32_t i = 0; i < sh.n_entries; i++) f(i, *parts[sh.part_of[i]], sh.res[i]); return; }
+    if (sh.on) { for (uint32_t i = 0; i < sh.n_entries; i++) { if (redone(i)) f(i, *rd.eng, rd.res[rd.of[i]]); else f(i, *parts[sh.part_of[i]], sh.res[i]); } return; }
+    if (rd.on) {
+      for (uint32_t p = 0; p < n_parts(); p++)
+        for (uint32_t i = 0; i < parts[p]->n_docs; i++) { if (redone(first[p] + i)) f(first[p] + i, *rd.eng, rd.res[rd.of[first[p] + i]]); else f(first[p] + i, *parts[p], parts[p]->results[i]); }
+      return;
+    }
     if (mapped) { for (uint32_t i = 0; i < n_docs; i++) f(i, *parts[emap[i].first], parts[emap[i].first]->results[emap[i].second]); return; }
     for (uint32_t p = 0; p < n_parts(); p++)
       for (uint32_t i = 0; i < parts[p]->n_docs; i++) f(first[p] + i, *parts[p], parts[p]->results[i]);
@@ -411,6 +532,8 @@ int LM_API(resident_fresh)(void* c) {
 }
 // diagnostics of the shared replay: the number of documents the batch staged last was folded into (0: every entry is its own document)
 int LM_API(shared_documents)(void* c) { auto* x = (lm_ctx_impl*)c; return x->sh.on ? (int)x->n_docs : 0; }
+int LM_API(fused_documents)(void* c) { auto* x = (lm_ctx_impl*)c; int n = 0; for (uint32_t p = 0; p < x->n_parts(); p++) n += (int)x->parts[p]->n_fused; return n; }
+int LM_API(redo_documents)(void* c) { auto* x = (lm_ctx_impl*)c; return x->rd.on ? (int)x->rd.n : 0; }
 int LM_API(run)(void* c) {
   auto* x = (lm_ctx_impl*)c;
   try { x->run(); return 0; } catch (const std::exception& e) { x->err = e.what(); return -1; }
@@ -452,7 +575,16 @@ int LM_API(fetch)(void* c, lm_doc_out_c* outs) {
         if (x->sh.vv_top[p]) lmbe::d2h(x->sh.h_vv[p].data(), x->sh.d_vv[p].p, x->sh.vv_top[p]);
         lmbe::sync();
       }
+      if (x->rd.on) x->rd.eng->fetch();
       for (uint32_t i = 0; i < x->sh.n_entries; i++) {
+        if (x->redone(i)) {
+          const lm::DocResult& r = x->rd.res[x->rd.of[i]];
+          outs[i].status = r.status;
+          outs[i].json = x->rd.eng->h_out.data() + r.json_off; outs[i].json_len = (size_t)r.json_len;
+          outs[i].vv = x->rd.eng->h_vv.data() + r.vv_off; outs[i].vv_len = (size_t)r.vv_len;
+          outs[i].pending_ops = r.pending;
+          continue;
+        }
         const lm::DocResult& r = x->sh.res[i];
         uint32_t p = x->sh.part_of[i];
         outs[i].status = r.status;
@@ -463,6 +595,7 @@ int LM_API(fetch)(void* c, lm_doc_out_c* outs) {
       return 0;
     }
     for (uint32_t p = 0; p < x->n_parts(); p++) x->parts[p]->fetch();
+    if (x->rd.on) x->rd.eng->fetch();
     x->for_docs([&](uint32_t i, lm::Engine& e, const lm::DocResult& r) {
       outs[i].status = r.status;
       outs[i].json = e.h_out.data() + r.json_off; outs[i].json_len = (size_t)r.json_len;
@@ -529,6 +662,14 @@ int LM_API(export)(void* c, size_t doc, const uint8_t* from_vv, size_t from_len,
   auto* x = (lm_ctx_impl*)c;
   try {
     if (!x->ran) throw std::runtime_error("lm_export before lm_run");
+    if (x->redone(doc)) {
+      lmenc::Bytes b = x->rd.eng->export_doc((uint32_t)x->rd.of[doc], from_vv, from_len);
+      *out = (uint8_t*)malloc(b.size() ? b.size() : 1);
+      if (!*out) throw std::runtime_error("out of memory");
+      memcpy(*out, b.data(), b.size());
+      *out_len = b.size();
+      return 0;
+    }
     if (x->sh.on) { if (doc >= x->sh.n_entries) throw std::runtime_error("lm_export: no such document"); doc = x->sh.uniq_of[doc]; }
     if (x->mapped && doc >= x->n_docs) throw std::runtime_error("lm_export: no such document");
     for (uint32_t p = 0; p < x->n_parts(); p++) {
@@ -550,15 +691,34 @@ int LM_API(richtext)(void* c) {
   auto* x = (lm_ctx_impl*)c;
   try {
     if (!x->ran) throw std::runtime_error("lm_richtext before lm_run");
-    if (x->sh.on) throw std::runtime_error("lm_richtext: not available on a batch folded by shared replay (stage with LM_SHARE_REPLAY=0)");
+    if (x->sh.on) {
+      // a folded batch (entries that share their blobs, or any checked-out entry: one import, the trackers moved from version to
+      // version): k_richtext reads the trackers as a run left them, so every entry becomes a resident document of its own over the
+      // bytes already uploaded (Engine::expand) and is replayed and moved to ITS version — the price of asking for richtext values of
+      // checked-out entries; the results of lm_fetch / lm_result_meta are those of that run from here on (the same bytes)
+      x->unfold();
+      x->ran = true;
+      x->sum_host_rows();
+    }
     for (uint32_t p = 0; p < x->n_parts(); p++) x->parts[p]->richtext();
+    if (x->rd.on) x->rd.eng->richtext();
     return 0;
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
 int LM_API(richtext_result)(void* c, size_t doc, int32_t* status, const uint8_t** json, size_t* json_len) {
   auto* x = (lm_ctx_impl*)c;
   try {
-    if (x->sh.on || doc >= x->n_docs) throw std::runtime_error("lm_richtext_result: no such document");
+    if (x->sh.on || doc >= x->api_docs()) throw std::runtime_error("lm_richtext_result: no such document");
+    if (x->redone(doc)) {   // (replayed in the side engine, DF_REDO)
+      lm::Engine& e = *x->rd.eng;
+      if (!e.rt_ran) throw std::runtime_error("lm_richtext_result before lm_richtext");
+      const uint32_t i = (uint32_t)x->rd.of[doc];
+      const bool ok = e.h_rt_status[i] == lm::ST_OK;
+      if (status) *status = e.h_rt_status[i];
+      if (json) *json = e.h_rt.data() + e.h_rt_off[i];
+      if (json_len) *json_len = ok ? (size_t)e.h_rt_len[i] : 0;
+      return 0;
+    }
     for (uint32_t p = 0; p < x->n_parts(); p++) {
       if (x->mapped ? x->emap[doc].first != p : (doc < x->first[p] || doc >= x->first[p + 1])) continue;
       lm::Engine& e = *x->parts[p];
@@ -711,8 +871,7 @@ int LM_API(comm_init)(void* c, int rank, int world, const uint8_t* id128) {
 int LM_API(summary_layout)(void* c, int64_t first_id, int64_t stride, size_t rows_padded) {
   auto* x = (lm_ctx_impl*)c;
   try {
-    if (x->sh.on || x->mapped) throw std::runtime_error("lm_summary_layout is not available for a batch that renders shared documents at several versions");
-    if (rows_padded < x->n_docs) throw std::runtime_error("lm_summary_layout: fewer rows than staged documents");
+    if (rows_padded < x->api_docs()) throw std::runtime_error("lm_summary_layout: fewer rows than staged documents");
     if (x->in_flight) throw std::runtime_error("lm_summary_layout while a run is in flight");
     lm::Engine& e = *x->parts[0];
     lmbe::bind(e.sc);

@@ -42,6 +42,7 @@ LM_KERNEL void k_doc_ranges(Dev d) {
   m.chg0 = o0[BC_CHG]; m.n_chg = o1[BC_CHG] - o0[BC_CHG];
   m.dep0 = o0[BC_DEP]; m.n_dep = o1[BC_DEP] - o0[BC_DEP];
   m.op0 = o0[BC_OP]; m.n_op = o1[BC_OP] - o0[BC_OP];
+  if (d.doc_fused && d.doc_fused[doc]) { m.op0 = d.n_op_rows + o0[BC_MAPOP]; m.n_op = o1[BC_MAPOP] - o0[BC_MAPOP]; }   // (its record table: one slot per row at most, lm_k_map_fused.h)
   m.key0 = o0[BC_KEY]; m.n_key = o1[BC_KEY] - o0[BC_KEY];
   m.cid0 = o0[BC_CID]; m.n_cid = o1[BC_CID] - o0[BC_CID];
   m.praw0 = o0[BC_PEER]; m.n_praw = o1[BC_PEER] - o0[BC_PEER];
@@ -68,6 +69,7 @@ LM_KERNEL void k_doc_tables(Dev d) {
     st = lmw::reduce_max(st);
     if ((int32_t)st > m.status) m.status = (int32_t)st;
   }
+  if (m.status == ST_MF_BAIL) { if (lane == 0) { d.doc[doc].status = ST_DATA_CORRUPTION; d.doc[doc].flags = DF_REDO; } return; }   // (k_block_head: replayed through the row tables, lm_capi_impl.h redo)
   if (status_fatal(m.status)) { if (lane == 0) d.doc[doc].status = m.status; return; }
   // ---- peers: insertion into an LDS set, then rank sort
   uint32_t P = 0;

@@ -23,6 +23,10 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   const uint32_t* res_old_blobs;   // resident documents: per document the number of blobs earlier runs already held (nullptr otherwise)
   uint32_t loc_cleared;       // 1: loc[] was set to NONE by a memset in front of the integrate stage (the waves skip their own clear)
   uint32_t* posdel;           // per document 3 * PD_CAP words: the delete rows the span-granular batch kernels applied by position (lm_k_integrate_span.h ts_del_positional); nullptr = a mismatch is LM_DATA_CORRUPTION
+  const uint8_t* doc_fused;   // per document: 1 = an LWW Map document decoded without op rows (lm_k_map_fused.h; nullptr: none in this run)
+  uint32_t n_op_rows;         // op rows of the batch's row tables (the fused documents' record tables start behind them)
+  uint32_t* blk_kind;         // per block (k_block_kind): bit 31 = Map ops with scalar values only, low bits = its op rows
+  uint32_t posdel_redo;       // 1: a replay without a positional delete path (element-granular kernel, resident kernels of a folded batch) flags a document that needs one DF_REDO — the context replays it through the span-granular batch kernels (lm_capi_impl.h)
   uint32_t no_linear;         // 1 (LM_LINEAR=0): no linear prefix — every node of a plain document goes through the tracker (lm_k_integrate_linear.h; A/B runs)
   uint32_t res_vis;           // 1: resident documents — the trackers stand at the rendered version, an item shows iff it is active
   const uint8_t* front;       // optional checkout frontiers (postcard Vec<ID>), front_off[n_docs+1]; empty range = latest
@@ -277,6 +281,68 @@ LM_DEV Rd blk_sec(const Dev& d, const BlockDesc& bd, int s) {
   return rd_make(d.data + bd.base + bd.sec_rel[s], bd.sec_len[s]);
 }
 
+// K3a (round 6): is this a block of Map ops with scalar values only?  One lane per block: the container ids (all of kind Map), the
+// value_type column (every value 8 = delete or 11 = a tagged LoroValue — whether that value is a scalar is the fused kernel's
+// business), no delete-start ids.  blk_kind = bit 31 | op rows.
+static constexpr uint32_t BK_MAPSIMPLE = 0x80000000u;
+LM_KERNEL void k_block_kind(Dev d) {
+  uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (bi >= d.n_blocks) return;
+  const BlockDesc bd = d.blk[bi];
+  uint32_t out = 0;
+  if (bd.status == ST_OK && bd.sec_len[SEC_DEL] == 0) {
+    bool ok = true;
+    Rd k = blk_sec(d, bd, SEC_CIDS);
+    uint64_t ncid = k.p < k.end ? rd_uleb(k) : 0;
+    if (ncid == 0 || ncid > 32) ok = false;
+    for (uint64_t i = 0; i < ncid && ok; i++) {
+      uint64_t fields = rd_uleb(k);
+      (void)rd_u8(k);
+      uint32_t kind = rd_u8(k);
+      (void)rd_uleb(k); (void)rd_zigzag(k);
+      if (fields != 4 || kind != CK_MAP) ok = false;
+    }
+    if (k.bad || k.p != k.end) ok = false;
+    uint64_t nops = 0;
+    if (ok) {
+      Rd o = blk_sec(d, bd, SEC_OPS);
+      uint64_t outer = rd_uleb(o), ncols = rd_uleb(o);
+      if (outer != 1 || ncols != 4) ok = false;
+      (void)rd_bytes(o); (void)rd_bytes(o);
+      Rd c2 = rd_bytes(o);
+      if (o.bad) ok = false;
+      while (ok && c2.p < c2.end) {
+        int64_t kk = rd_zigzag(c2);
+        if (kk == 0 || c2.bad) { ok = false; break; }
+        uint64_t n = kk > 0 ? 1u : (uint64_t)(-kk);
+        if (n > rd_left(c2)) { ok = false; break; }
+        for (uint64_t j = 0; j < n; j++) { uint32_t vt = rd_u8(c2) & 0x7f; if (vt != 8 && vt != 11) ok = false; }
+        nops += kk > 0 ? (uint64_t)kk : n;
+        if (nops > (1u << 24)) ok = false;
+      }
+    }
+    if (ok && nops == bd.counter_len && nops > 0) out = BK_MAPSIMPLE | (uint32_t)nops;
+  }
+  d.blk_kind[bi] = out;
+}
+// … and is this a document of such blocks (one lane per document)?  Worth a workgroup of its own only with enough rows; a history of
+// one change per write is left to the row tables (the fused kernel walks a block's changes one after the other).
+LM_KERNEL void k_doc_kind(Dev d, uint8_t* doc_fused, uint32_t min_rows, uint32_t chg_ratio) {
+  uint32_t doc = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
+  if (doc >= d.n_docs) return;
+  uint32_t b0 = d.doc_blob[doc], b1 = d.doc_blob[doc + 1];
+  uint32_t k0 = d.blob_blk0[b0], k1 = d.blob_blk0[b1];
+  bool ok = k1 > k0;
+  uint64_t rows = 0, chg = 0;
+  for (uint32_t b = b0; b < b1 && ok; b++) ok = d.blob_status[b] == ST_OK;
+  for (uint32_t k = k0; k < k1 && ok; k++) {
+    uint32_t v = d.blk_kind[k];
+    if (!(v & BK_MAPSIMPLE)) ok = false;
+    rows += v & 0x7fffffffu; chg += d.blk[k].n_changes;
+  }
+  doc_fused[doc] = ok && rows >= min_rows && rows < (1u << 24) && chg * chg_ratio <= rows ? 1 : 0;
+}
+
 // K3: one lane per block — count the rows each table will receive.
 LM_KERNEL void k_block_count(Dev d) {
   uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
@@ -319,8 +385,9 @@ LM_KERNEL void k_block_count(Dev d) {
     // 2^28 in two bytes — cannot decode to a block: DecodeError here, before any table is sized by it
     if (!bad && nops > (uint64_t)bd.counter_len) bad = true;
   }
+  const bool fused = d.doc_fused && d.doc_fused[bd.doc];   // (lm_k_map_fused.h: no op rows, no key rows but the root containers' names)
   uint64_t nkeys = 0;
-  {
+  if (!fused) {
     Rd k = blk_sec(d, bd, SEC_KEYS);
     while (k.p < k.end && !k.bad) { uint64_t l = rd_uleb(k); rd_skip(k, l); nkeys++; }
     if (k.bad) bad = true;
@@ -330,10 +397,13 @@ LM_KERNEL void k_block_count(Dev d) {
     Rd k = blk_sec(d, bd, SEC_CIDS);
     if (k.p < k.end) ncid = rd_uleb(k);
     if (k.bad || ncid > (1u << 20)) bad = true;
+    if (fused && !bad) {   // one key row per ROOT container id (k_doc_tables reads the names through them)
+      for (uint64_t i = 0; i < ncid; i++) { (void)rd_uleb(k); uint32_t is_root = rd_u8(k); (void)rd_u8(k); (void)rd_uleb(k); (void)rd_zigzag(k); nkeys += is_root ? 1u : 0u; }
+    }
   }
   if (bad) { d.blk[bi].status = ST_DECODE_ERROR; return; }
   (void)nmap;
-  {   // heads beyond the decoder's default LDS slot (Map blocks with hundreds of keys, blocks of thousands of changes): the host
+  if (!fused) {   // heads beyond the decoder's default LDS slot (Map blocks with hundreds of keys, blocks of thousands of changes): the host
       // launches the decoder a second time, with larger slots, for the groups that hold one (lm_pipeline.h)
     uint32_t span = (uint32_t)(bd.base & 15) + bd.sec_rel[SEC_VALUES];
     if (d.dec_stat && span > d.dec_slot) {
@@ -343,11 +413,11 @@ LM_KERNEL void k_block_count(Dev d) {
   }
   c[BC_CHG] = N;
   c[BC_DEP] = (uint32_t)ndep;
-  c[BC_OP] = (uint32_t)nops;
+  c[BC_OP] = fused ? 0u : (uint32_t)nops;
   c[BC_KEY] = (uint32_t)nkeys;
   c[BC_CID] = (uint32_t)ncid;
   c[BC_PEER] = (uint32_t)np;
-  c[BC_MAPOP] = (uint32_t)nops;   // upper bound on map ops (refined per doc by the LWW kernel's table size)
+  c[BC_MAPOP] = fused ? (uint32_t)nops : 0u;   // rows of a fused Map document (lm_k_map_fused.h): the capacity of its record table, handed out behind the op rows (k_doc_ranges)
   c[BC_ATOMS] = bd.counter_len;
 }
 
@@ -460,11 +530,14 @@ template <bool EXACT> LM_DEV void lane_skip_value(Rd& r, uint32_t& vf, int cdept
   if (EXACT) skip_loro_value_fs<true>(r, vf, cdepth, f_cnt, n_keys);
   else skip_loro_value_fs(r, vf, cdepth, f_cnt);
 }
-template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
+// HEAD (k_block_head): the blocks of the documents lm_k_map_fused.h decodes — header, change meta, container ids, the names of the root
+// containers; no key rows, no op rows (the fused kernel reads the columns itself).  The other decoders leave those blocks alone.
+template <bool EXACT, bool HEAD = false> LM_DEV void block_decode_lane(Dev d) {
   uint32_t bi = (uint32_t)(lmw::bid() * lmw::bdim() + lmw::tid());
   if (bi >= d.n_blocks) return;
   BlockDesc bd = d.blk[bi];
   if (EXACT ? ((bd.status != ST_DECODE_ERROR && bd.status != ST_DATA_CORRUPTION) || bd.pad != DEC_RECLASS) : (bd.status != ST_OK)) return;
+  if (HEAD != (d.doc_fused && d.doc_fused[bd.doc])) return;
   const uint32_t* off = d.boff + (uint64_t)bi * BCN;
   const uint32_t* cnt = d.bcnt + (uint64_t)bi * BCN;
   uint32_t N = bd.n_changes;
@@ -573,7 +646,7 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
     if (mc.r.bad || tot > rd_left(mc.r)) DEC_ST(ST_DATA_CORRUPTION);
   }
   // ---- keys
-  {
+  if (!HEAD) {
     Rd k = blk_sec(d, bd, SEC_KEYS);
     for (uint32_t i = 0; i < n_keys; i++) {
       uint64_t l = rd_uleb(k);
@@ -583,6 +656,7 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
     }
     if (k.bad) st = st ? st : ST_DECODE_ERROR;
   }
+  uint32_t head_root = 0;   // HEAD: root container ids met so far = the block's next key row
   // ---- cids (arena.rs:39-105)
   {
     Rd k = blk_sec(d, bd, SEC_CIDS);
@@ -594,7 +668,19 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
       int64_t koc = rd_zigzag(k);
       if (fields != 4) st = st ? st : ST_DECODE_ERROR;
       uint32_t* w = d.cid_raw + (uint64_t)(cid0 + i) * 4;
-      if (is_root) { if (koc < 0 || (uint64_t)koc >= n_keys) { DEC_ST(ST_DATA_CORRUPTION); koc = 0; } }
+      if (HEAD && is_root) {
+        // the name: the koc-th key of the block, found by walking that far (a root's name is among the first keys); its key row is
+        // numbered by the root ids of the block
+        Rd kk = blk_sec(d, bd, SEC_KEYS);
+        bool found = koc >= 0;
+        uint64_t l = 0;
+        for (int64_t q = 0; found && q <= koc; q++) { if (kk.p >= kk.end) { found = false; break; } l = rd_uleb(kk); if (q < koc) rd_skip(kk, l); if (kk.bad) found = false; }
+        if (found && l > rd_left(kk)) found = false;
+        if (!found || head_root >= n_keys) { DEC_ST(ST_DATA_CORRUPTION); d.key_off[key0 + (head_root < n_keys ? head_root : 0)] = 0; d.key_len[key0 + (head_root < n_keys ? head_root : 0)] = 0; koc = 0; }
+        else { d.key_off[key0 + head_root] = (uint64_t)(kk.p - d.data); d.key_len[key0 + head_root] = (uint32_t)l; koc = head_root; }
+        head_root++;
+      }
+      else if (is_root) { if (koc < 0 || (uint64_t)koc >= n_keys) { DEC_ST(ST_DATA_CORRUPTION); koc = 0; } }
       else { if (pidx >= n_peers) { DEC_ST(ST_DATA_CORRUPTION); pidx = 0; } if (koc < 0 || koc >= (int64_t)MAX_COUNTER) { st = st ? st : ST_UNSUPPORTED; koc = 0; } }
       w[0] = kind | (is_root ? 0x100u : 0u);
       w[1] = (uint32_t)pidx;
@@ -603,6 +689,14 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
       // (a kind beyond Counter is ContainerType::Unknown(kind), loro-common/src/lib.rs:793-804 — try_from_u8 never fails: the container is outside the device scope like Tree / Counter)
     }
     if (k.bad) st = st ? st : ST_DECODE_ERROR;
+  }
+  if (HEAD) {
+    // the rows are the fused kernel's: every one competes in the LWW table, none inserts an element
+    // (any finding: no verdict from here — k_block_count skipped this block's key table, so the row decoders, which own every error
+    // code, may meet something else first: the document goes through them, DF_REDO)
+    d.blk[bi].status = (st != ST_OK || unsupported) ? (int32_t)ST_MF_BAIL : (int32_t)ST_OK;
+    d.blk[bi].flags = kc_pack(d.blk_kind[bi] & 0x7fffffffu, 0); d.blk[bi].pad = 0;
+    return;
   }
   // ---- op rows
   {
@@ -783,6 +877,7 @@ template <bool EXACT> LM_DEV void block_decode_lane(Dev d) {
   d.blk[bi].flags = kc_pack(kc_map, kc_style); d.blk[bi].pad = (st == ST_DECODE_ERROR || st == ST_DATA_CORRUPTION) ? DEC_RECLASS : kc_el;
 }
 LM_KERNEL void k_block_decode(Dev d) { block_decode_lane<false>(d); }
+LM_KERNEL void k_block_head(Dev d) { block_decode_lane<false, true>(d); }
 LM_KERNEL void k_block_reclassify(Dev d) { block_decode_lane<true>(d); }
 
 }  // namespace lm

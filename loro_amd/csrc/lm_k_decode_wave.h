@@ -76,7 +76,7 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
   // only the scalar fields of the descriptor stay in registers; section extents are read where a section is opened
   struct { uint64_t base; uint32_t counter_start, counter_len, n_changes; } bd = {0, 0, 0, 0};
   const BlockDesc* bdp = d.blk + (have ? bi : 0);
-  bool ok = have && bdp->status == ST_OK;
+  bool ok = have && bdp->status == ST_OK && !(d.doc_fused && d.doc_fused[bdp->doc]);   // (a fused Map document's blocks: k_block_head + k_map_fused)
   if (ok) { bd.base = bdp->base; bd.counter_start = bdp->counter_start; bd.counter_len = bdp->counter_len; bd.n_changes = bdp->n_changes; }
   // ---- stage the block up to its value payloads: header | change_meta | cids | keys | positions | ops | delete_start_ids.
   // The payload bytes (mostly text) are not needed here — the walker only reads each value's length prefix, straight from

@@ -66,6 +66,7 @@ struct Tr {  // wave-uniform context of one (document, sequence container) repla
   LeafRegs cr;                    // write-through register copy of that leaf
   int32_t err;
   uint32_t beyond;   // an insert row named a position beyond the end
+  uint32_t posmis;   // a delete row whose targets are not the elements at its position (DF_REDO: replayed by the span-granular kernels)
 #ifdef LM_PROF
   uint64_t prof[PF_N];
 #endif
@@ -687,7 +688,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
   t.dir_cap = dir_cap;
   t.leaf_cap = m.leaf_cap;
   t.n_leaf = 0;
-  t.err = 0; t.beyond = 0;
+  t.err = 0; t.beyond = 0; t.posmis = 0;
 #ifdef LM_PROF
   for (int i = 0; i < PF_N; i++) t.prof[i] = 0;
   uint64_t pf_begin = lmw::clock();
@@ -790,12 +791,12 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
                   // offset j deletes target + (L-1-j), which stands at start + (L-1-j) (the offsets in front of it stood above)
                   const int64_t pos = r.a2 > 0 ? (int64_t)r.prop + (int64_t)(j - a) : start + (int64_t)(Ln - 1 - j);
                   const uint32_t idj = r.a2 > 0 ? r.a1 + j : r.a1 + (Ln - 1 - j);
-                  if (pos < 0 || pos > 0x7fffffff || tr_active_id_at(t, (uint32_t)pos) != pid_make(r.a0, idj)) LM_SETERR(t.err, ST_DATA_CORRUPTION);
+                  if (pos < 0 || pos > 0x7fffffff || tr_active_id_at(t, (uint32_t)pos) != pid_make(r.a0, idj)) { LM_SETERR(t.err, ST_DATA_CORRUPTION); t.posmis = 1; }
                 }
               }
               const uint32_t act0 = t.tot_active;
               tr_update_range(t, r.a0, t0, t1, UPD_DEL_INC);
-              if ((act0 - t.tot_active) != (t1 - t0) || Ln != r.len) LM_SETERR(t.err, ST_DATA_CORRUPTION);
+              if ((act0 - t.tot_active) != (t1 - t0) || Ln != r.len) { LM_SETERR(t.err, ST_DATA_CORRUPTION); t.posmis |= Ln == r.len ? 1u : 0u; }
               PROF_ADD(t, PF_DELETE);
               PROF_CNT(t, PF_NDEL, 1);
               TR_CHECK("delete", row);
@@ -842,6 +843,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(6) void k_integrate(Dev d, DevDag g, uint32_t dir_ca
     lmw::block_sync();
   }
   if (!t.err && t.beyond) t.err = ST_DATA_CORRUPTION;
+  // a delete row whose targets are not the elements at its position is applied BY POSITION by the reference (crdt_rope.rs:256-335) and by
+  // the span-granular batch kernels (k_integrate_span_pos); this kernel has no such path: the context replays the document through
+  // those kernels (lm_capi_impl.h redo) — the verdict of a document must not depend on which kernel its batch's statistics picked
+  if (t.err == ST_DATA_CORRUPTION && t.posmis && d.posdel_redo && lane == 0) lmw::atomic_or(&d.doc[doc].flags, DF_REDO);
   if (t.err && lane == 0) {
     d.doc[doc].status = t.err;
     if (t.err == ST_RETRY) lmw::atomic_add(retry_count, 1u);

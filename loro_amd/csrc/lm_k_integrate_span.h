@@ -2094,6 +2094,8 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   // a delete row that does not match its position: the document is replayed by k_integrate_span_pos (lm_pipeline.h) — unless this IS
   // that kernel, the document is resident (its list would have to outlive the run) or holds a MovableList: LM_DATA_CORRUPTION
   if (!t.err && t.beyond) t.err = ST_DATA_CORRUPTION;   // an insert row beyond the end (ts_insert / tl_insert)
+  // (RES: the context replays such a document of a folded batch through the batch kernels, lm_capi_impl.h redo — DF_REDO)
+  if (t.err == ST_POSDEL && RES && !ML && d.posdel_redo && lane == 0) lmw::atomic_or(&d.doc[doc].flags, DF_REDO);
   if (t.err == ST_POSDEL && (POS || RES || ML || !d.posdel)) t.err = ST_DATA_CORRUPTION;
   if (t.err && lane == 0) {
     d.doc[doc].status = t.err;

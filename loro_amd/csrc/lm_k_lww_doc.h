@@ -32,6 +32,7 @@ LM_KERNEL LM_WAVES_PER_SIMD(8) void k_map_lww_doc(Dev d, uint32_t* retry_count) 
   const uint32_t tid = (uint32_t)lmw::tid();
   const DocMeta m = d.doc[doc];
   if (status_fatal(m.status) || m.n_mapop == 0) return;
+  if (d.doc_fused && d.doc_fused[doc]) return;                          // k_map_fused's document
   const uint32_t cap = d.ht_cap[doc];
   if (cap == 0 || cap > LWW_LDS_CAP || (m.flags & DF_MOVABLE)) return;   // k_map_lww's document
   LM_DYN_SHARED(unsigned long long, s_mem64);

@@ -18,6 +18,7 @@
 #include "lm_k_scan.h"
 #include "lm_k_emit.h"
 #include "lm_k_lww_doc.h"
+#include "lm_k_map_fused.h"
 #include "lm_k_fuse.h"
 #include "lm_k_lca.h"
 #include "lm_k_richtext.h"
@@ -71,7 +72,9 @@ struct Engine {
   DBuf b_data, b_blob_off, b_blob_len, b_doc_blob, b_blob_doc, b_front, b_front_off, b_froot, b_froot_off, b_blob_hash, b_big;
   // work buffers
   DBuf b_blob_status, b_blob_nblk, b_blob_blk0, b_tile, b_tot;
-  DBuf b_blk, b_bcnt, b_boff;
+  DBuf b_blk, b_bcnt, b_boff, b_blk_kind, b_doc_fused, b_mf_docs, b_mf_key0;
+  std::vector<uint8_t> h_fused;                   // per document: decoded by k_map_fused (lm_k_map_fused.h)
+  uint32_t n_fused = 0;
   DBuf b_chg, b_dep_peer, b_dep_ctr, b_dep_ci, b_op, b_op_val, b_op_blk, b_key_off, b_key_len, b_cid_raw, b_cid_map, b_peer_raw, b_peer_map;
   DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
   DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
@@ -152,7 +155,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -176,7 +179,49 @@ struct Engine {
     if (const char* e = getenv("LM_POSDEL")) k.posdel = atoi(e) != 0;                            // 0: a delete row whose target ids are not the elements at its position is LM_DATA_CORRUPTION (rounds 3-4) instead of being applied by position
     if (const char* e = getenv("LM_LINEAR")) k.linear = atoi(e) != 0;                            // 0: no linear prefix in the plain batch kernels (rounds 1-4: every node through the tracker)
     if (const char* e = getenv("LM_LWW_LDS")) k.lww_lds = atoi(e) != 0;                          // 0: every document's Map rows go through the HBM tables (k_map_lww), as in rounds 1-3
+    if (const char* e = getenv("LM_REDO")) k.redo = atoi(e) != 0;                                // 0: no second replay of the documents a kernel flags DF_REDO (round 5: their verdict is that kernel's LM_DATA_CORRUPTION)
+    // a side engine (lm_capi_impl.h redo) replays the documents another configuration flagged DF_REDO: span-granular batch kernels, whatever the batch's statistics say
+    if (const char* e = getenv("LM_MAP_FUSED")) k.map_fused = atoi(e) != 0;                      // 0: LWW Map documents go through the row tables like every other document (rounds 1-5)
+    if (const char* e = getenv("LM_MF_MIN_ROWS")) k.mf_min_rows = (uint32_t)atoi(e);             // rows from which a Map document gets a workgroup of k_map_fused (tests: 1)
+    if (const char* e = getenv("LM_MF_CHG_RATIO")) k.mf_chg_ratio = (uint32_t)atoi(e);           // … and rows per change it needs on average (tests: 0)
+    if (force_span) { k.span = true; k.span_auto = false; k.posdel = true; k.redo = false; k.map_fused = false; }
     kn = k;
+  }
+  bool force_span = false;
+  // ---- DF_REDO: what lm_stage left in the pinned staging buffer (the blobs as the device sees them: snapshots already reframed) —
+  // a side engine stages the documents to replay from there (stage_from); lm_import with new blobs reuses the buffer and ends that
+  bool st_valid = false;
+  std::vector<uint32_t> st_doc_blob, st_blob_len;
+  std::vector<uint64_t> st_blob_off, st_froot_off;
+  std::vector<uint8_t> st_froot;
+  std::vector<uint32_t> redo_docs;                // documents of the last run flagged DF_REDO (local indices)
+  struct RedoItem { uint32_t doc; const uint8_t* front; size_t front_len; };
+  void stage_from(const std::vector<Engine*>& parents, const std::vector<RedoItem>& items) {
+    for (Engine* pe : parents) if (!pe->st_valid) throw std::runtime_error("redo: the staged blobs are gone");
+    std::vector<std::vector<const uint8_t*>> bp(items.size());
+    std::vector<std::vector<size_t>> bl(items.size());
+    std::vector<DocIn> in(items.size());
+    for (size_t k = 0; k < items.size(); k++) {
+      const uint32_t i = items[k].doc;
+      Engine& parent = *parents[k];
+      for (uint32_t b = parent.st_doc_blob[i]; b < parent.st_doc_blob[i + 1]; b++) { bp[k].push_back(parent.h_stage + parent.st_blob_off[b]); bl[k].push_back(parent.st_blob_len[b]); }
+      in[k] = DocIn{bp[k].data(), bl[k].data(), bp[k].size(), items[k].front, items[k].front_len};
+    }
+    stage(in.data(), in.size());
+    // the state-section roots of the documents' snapshots (lm_stage read them from the mode-3 blobs, which the buffer no longer holds)
+    h_froot.clear();
+    h_froot_off.assign(items.size() + 1, 0);
+    for (size_t k = 0; k < items.size(); k++) {
+      h_froot_off[k] = h_froot.size();
+      const uint32_t i = items[k].doc;
+      Engine& parent = *parents[k];
+      if ((size_t)i + 1 < parent.st_froot_off.size()) h_froot.insert(h_froot.end(), parent.st_froot.begin() + parent.st_froot_off[i], parent.st_froot.begin() + parent.st_froot_off[i + 1]);
+    }
+    h_froot_off[items.size()] = h_froot.size();
+    lmbe::bind(sc);
+    b_froot.ensure(h_froot.size() + 16); if (!h_froot.empty()) lmbe::h2d(b_froot.p, h_froot.data(), h_froot.size());
+    b_froot_off.ensure((items.size() + 1) * 8); lmbe::h2d(b_froot_off.p, h_froot_off.data(), (items.size() + 1) * 8);
+    lmbe::sync();
   }
 
   explicit Engine(int device) { sc = lmbe::stream_create(device); }
@@ -187,7 +232,7 @@ struct Engine {
   ~Engine() { release_all(); if (h_stage) lmbe::hfree(h_stage); lmbe::stream_destroy(sc); }
   void release_all() {
     DBuf* all[] = {&b_front, &b_front_off, &b_froot, &b_froot_off, &b_blob_hash, &b_big, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
-                   &b_blk, &b_bcnt, &b_boff, &b_chg, &b_dep_peer, &b_dep_ctr, &b_dep_ci, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
+                   &b_blk, &b_bcnt, &b_boff, &b_blk_kind, &b_doc_fused, &b_mf_docs, &b_mf_key0, &b_chg, &b_dep_peer, &b_dep_ctr, &b_dep_ci, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
@@ -336,6 +381,8 @@ struct Engine {
     b_front.ensure(fr.size() + 16); if (!fr.empty()) lmbe::h2d(b_front.p, fr.data(), fr.size());
     b_front_off.ensure((nd + 1) * 8); lmbe::h2d(b_front_off.p, h_front_off.data(), (nd + 1) * 8);
     lmbe::sync();
+    st_valid = true; st_doc_blob = h_doc_blob; st_blob_len = h_blob_len; st_blob_off = h_blob_off; st_froot_off = h_froot_off; st_froot = h_froot;
+    redo_docs.clear();
     ran = fetched = false;
     resident = false; tables_valid = false;   // a new batch: whatever was resident is gone
     have_prev = false; h_lca.clear();         // (lm_import_modes / lm_import_lca: nothing is known about the new batch's imports)
@@ -507,6 +554,7 @@ struct Engine {
     }
     uint64_t add = top - arena_top;
     if (add) {
+      st_valid = false;
       if (add + 64 > h_stage_cap) {
         uint8_t* nh = (uint8_t*)lmbe::halloc(add + add / 4 + 4096);
         if (!nh) throw std::runtime_error("host staging allocation failed");
@@ -587,7 +635,7 @@ struct Engine {
       b_prev_uniq.ensure((size_t)(sv.NP + 1) * 8); lmbe::d2d(b_prev_uniq.p, b_peer_uniq.p, (size_t)(sv.NP + 1) * 8);
       b_prev_end.ensure((size_t)(sv.NP + 1) * 4); lmbe::d2d(b_prev_end.p, b_peer_end_all.p, (size_t)(sv.NP + 1) * 4);
     }
-    uint32_t NB = 0, NC = 0, NO = 0, NCID = 0, NP = 0;
+    uint32_t NB = 0, NC = 0, NO = 0, NCID = 0, NP = 0, sv_NK = 0;
     DevDag g;
     memset(&g, 0, sizeof g);
     bool span = kn.span;   // (a batch of small documents for the common kernel switches to the element-granular one below, once the documents' records are known)
@@ -652,11 +700,28 @@ struct Engine {
     b_tot.ensure(64 * 4);
     d.dec_stat = b_tot.as<uint32_t>() + 48; d.dec_slot = kn.dec_slot; d.cut_min_rows = kn.cut_min_rows; d.vs_row_cost = kn.vs_row_cost;
     lmbe::dmemset(d.dec_stat, 0, 12);
+    // LWW Map documents whose blocks hold scalar writes only are decoded WITHOUT op rows (lm_k_map_fused.h): found here, in front of
+    // the row counts (their blocks ask for no op rows and for key rows of their root containers' names only).  Batches only, and only
+    // while the side engine can take a document the fused kernel gives up on (DF_REDO)
+    n_fused = 0;
+    h_fused.assign(n_docs, 0);
+    const bool mf_on = kn.map_fused && kn.redo && kn.lww_lds && kn.ht_opt && kn.ht_opt <= LWW_LDS_CAP && !resident && st_valid && NB;
+    if (mf_on) {
+      b_blk_kind.ensure((size_t)(NB + 1) * 4); b_doc_fused.ensure((size_t)n_docs + 16);
+      d.blk_kind = b_blk_kind.as<uint32_t>();
+      LM_LAUNCH(k_block_kind, cdiv(NB, 64), 64, d);
+      LM_LAUNCH(k_doc_kind, cdiv(n_docs, 64), 64, d, b_doc_fused.as<uint8_t>(), kn.mf_min_rows, kn.mf_chg_ratio);
+      d.doc_fused = b_doc_fused.as<uint8_t>();
+    }
     if (NB) LM_LAUNCH(k_block_count, cdiv(NB, 64), 64, d);
     lmbe::toc("k_frame_fill+k_block_count", times, profiling);
     scan(d.bcnt, d.boff, NB, BCN);
     uint32_t tot[BCN];
     lmbe::d2h(tot, d.boff + (uint64_t)NB * BCN, sizeof tot);
+    if (mf_on) { lmbe::d2h(h_fused.data(), b_doc_fused.p, n_docs); for (uint32_t i = 0; i < n_docs; i++) n_fused += h_fused[i]; }
+    if (!n_fused) d.doc_fused = nullptr;
+    const uint32_t NF = n_fused ? tot[BC_MAPOP] : 0u;    // record rows of the fused documents, behind the op rows
+    const uint32_t KF = n_fused * LWW_LDS_CAP;           // their slot-numbered key rows, behind the key rows
     uint32_t dec_stat[3] = {0, 0, 0};
     lmbe::d2h(dec_stat, d.dec_stat, 12);
     uint32_t ND = tot[BC_DEP], NK = tot[BC_KEY];
@@ -664,8 +729,10 @@ struct Engine {
     // 3. row tables
     b_chg.ensure((size_t)(NC + 1) * sizeof(ChangeRow));
     b_dep_peer.ensure((size_t)(ND + 1) * 4); b_dep_ctr.ensure((size_t)(ND + 1) * 4); b_dep_ci.ensure((size_t)(ND + 1) * 4);
-    b_op.ensure((size_t)(NO + 1) * sizeof(OpRow)); b_op_val.ensure((size_t)(NO + 1) * 8); b_op_blk.ensure((size_t)(NO + 1) * 4);
-    b_key_off.ensure((size_t)(NK + 1) * 8); b_key_len.ensure((size_t)(NK + 1) * 4);
+    if ((uint64_t)NO + NF > 0xfffffff0ull || (uint64_t)NK + KF > 0xfffffff0ull) throw std::runtime_error("batch too large for 32-bit row indices");
+    b_op.ensure((size_t)(NO + NF + 1) * sizeof(OpRow)); b_op_val.ensure((size_t)(NO + NF + 1) * 8); b_op_blk.ensure((size_t)(NO + NF + 1) * 4);
+    b_key_off.ensure((size_t)(NK + KF + 1) * 8); b_key_len.ensure((size_t)(NK + KF + 1) * 4);
+    d.n_op_rows = NO; sv_NK = NK;
     b_cid_raw.ensure((size_t)(NCID + 1) * 16); b_cid_map.ensure((size_t)(NCID + 1) * 4);
     b_peer_raw.ensure((size_t)(NP + 1) * 8); b_peer_map.ensure((size_t)(NP + 1) * 4);
     b_doc.ensure((size_t)n_docs * sizeof(DocMeta));
@@ -704,7 +771,9 @@ struct Engine {
 #if defined(LM_PROF_DEC) || defined(LM_PROF_DAG)   // experiment builds: cycle accounting of the decoder's phases / of k_dag_a's passes (tests/tools/gpu_prof_dec.py, gpu_prof_dag.py)
       b_prof.ensure((size_t)n_docs * 16 * 8); d.prof = b_prof.as<unsigned long long>(); lmbe::dmemset(b_prof.p, 0, (size_t)n_docs * 16 * 8);
 #endif
-      if (!kn.decode_wave) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
+      if (n_fused) LM_LAUNCH(k_block_head, cdiv(NB, 64), 64, d);   // the fused documents' blocks: header, meta, container ids
+      if (n_fused == n_docs) {}                                    // (nothing left for the row decoders)
+      else if (!kn.decode_wave) LM_LAUNCH(k_block_decode, cdiv(NB, 64), 64, d);
       else {
         uint32_t slot_cap = kn.dec_slot;
         // heads beyond the default slot: those groups get a launch of their own.  LM_DEC_BIG_MODE=1 (default): slots sized for their
@@ -888,6 +957,7 @@ struct Engine {
     // placed was written by k_elem_fill
     d.loc_cleared = (!resident && span && kn.loc_memset) ? 1u : 0u;
     d.no_linear = kn.linear ? 0u : 1u;
+    d.posdel_redo = (kn.redo && kn.posdel && st_valid && (resident ? shared_mode != 0 : !span)) ? 1u : 0u;
     if (span && !resident && kn.posdel) { b_posdel.ensure((size_t)n_docs * 3 * PD_CAP * 4 + 16); d.posdel = b_posdel.as<uint32_t>(); }
     if (d.loc_cleared && elem) lmbe::dmemset(b_loc.p, 0xff, (size_t)elem * 4);
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
@@ -957,11 +1027,23 @@ struct Engine {
     b_tot.ensure(64 * 4);
     uint32_t* retry_cnt = b_tot.as<uint32_t>() + 32;
     lmbe::dmemset(retry_cnt, 0, 16);   // [0] documents to re-run with the worst-case directory, [1] resident documents replayed from the empty version, [2] documents whose optimistic LWW table filled up, [3] documents with a delete row that does not match its position (k_integrate_span_pos)
+    if (n_fused && ht && !reuse) {
+      // workgroup -> fused document, most rows first; every document's slot-numbered key rows
+      std::vector<uint32_t> mfd, mfk(n_docs, 0);
+      uint32_t rank = 0;
+      for (uint32_t i = 0; i < n_docs; i++) if (h_fused[i]) { mfk[i] = sv_NK + rank * LWW_LDS_CAP; rank++; if (h_doc[i].status == ST_OK && h_doc[i].n_mapop) mfd.push_back(i); }
+      std::stable_sort(mfd.begin(), mfd.end(), [&](uint32_t a, uint32_t b) { return h_doc[a].n_op > h_doc[b].n_op; });
+      b_mf_docs.ensure(mfd.size() * 4 + 4); b_mf_key0.ensure((size_t)n_docs * 4 + 4);
+      if (!mfd.empty()) lmbe::h2d(b_mf_docs.p, mfd.data(), mfd.size() * 4);
+      lmbe::h2d(b_mf_key0.p, mfk.data(), (size_t)n_docs * 4);
+      DevMf mf; mf.docs = b_mf_docs.as<uint32_t>(); mf.doc_fused = d.doc_fused; mf.key0 = b_mf_key0.as<uint32_t>();
+      if (!mfd.empty()) LM_LAUNCH_DYN(k_map_fused, (uint32_t)mfd.size(), MF_WG, (size_t)MF_LDS, d, mf, retry_cnt);
+    }
     if (NO && ht) {   // (ht == 0: no document holds a Map / MovableList-LWW / out-of-scope row, k_dag_a)
       // documents whose (optimistic) table fits LDS are resolved by a workgroup each (lm_k_lww_doc.h); the others — resident
       // documents, MovableLists, tables sized for every row — one row per lane in their HBM tables
       bool any_lds = false, any_hbm = false;
-      for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK && h_doc[i].n_mapop) {
+      for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK && h_doc[i].n_mapop && !h_fused[i]) {
         if (kn.lww_lds && !resident && h_ht_cap[i] <= LWW_LDS_CAP && !(h_doc[i].flags & DF_MOVABLE)) any_lds = true; else any_hbm = true;
       }
       if (any_lds) LM_LAUNCH_DYN(k_map_lww_doc, n_docs, LWW_WG, (size_t)LWW_LDS_CAP * 24 + (MAX_PEERS + MAX_CONTAINERS / 32 + 8) * 4, d, retry_cnt);
@@ -1232,6 +1314,8 @@ struct Engine {
       r.pending = ok ? (((uint64_t)h_doc[i].pending_hi << 32) | h_doc[i].pending_lo) : 0;
       r.json_xxh64 = ok ? h_hash[i] : 0;
     }
+    redo_docs.clear();
+    if (kn.redo && st_valid) for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].flags & DF_REDO) redo_docs.push_back(i);
     lmbe::flush_times(times);
     if (resident) {
       // a document whose run failed keeps what it held before: the blobs of this step are dropped again (reference import is

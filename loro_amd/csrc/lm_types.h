@@ -16,6 +16,7 @@ enum : int32_t {
   ST_INTERNAL = 5,
   ST_FRONTIERS_NOT_FOUND = 6,
   ST_RETRY = 100,   // internal: the optimistic LDS directory overflowed; the document is re-run with the worst-case size
+  ST_MF_BAIL = 102, // internal (a BLOCK's status): k_block_head met something in a fused Map document's block — the verdict is the row decoders': the document is flagged DF_REDO (k_doc_tables)
 };
 
 enum : uint32_t { SEC_HEADER = 0, SEC_META, SEC_CIDS, SEC_KEYS, SEC_POS, SEC_OPS, SEC_DEL, SEC_VALUES, SEC_N };
@@ -124,6 +125,10 @@ enum : uint32_t {
   DF_FUSED = 256u,           // a plain document whose changes hold few rows each (one change per keystroke): k_fuse_rows chained its rows into runs
                              // across change boundaries, k_integrate_span_plain_fuse replays the runs (lm_k_fuse.h)
   DF_CUT = 512u,             // k_dag_a: the document is large enough for the node cut + descending-peer replay order to pay (k_dag_a / k_dag_b)
+  DF_REDO = 1024u,           // the kernel that met this document has no path for it and another configuration of the pipeline has: an element-granular
+                             // / resident replay that met a delete row which does not match its position (the span-granular batch kernels finish such
+                             // rows by position, k_integrate_span_pos), a Map document the fused decode→LWW kernel (lm_k_map_fused.h) bailed out of.
+                             // The context replays such documents once more in a side engine with that configuration (lm_capi_impl.h redo)
   DF_PLAIN = 8u,             // no sliced change, no style anchor, no MovableList (k_dag_a); the host clears it for checked-out documents
                              // and under LM_PLAIN=0: such a document is replayed by k_integrate_span_plain_sweep (lm_pipeline.h)
 };

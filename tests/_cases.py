@@ -575,3 +575,79 @@ def damaged_change_meta_docs():
 # a 129-byte blob (one change of a map / list / text session, no foreign dependency) whose EMPTY dependency-counter column carries the
 # option tag 3a instead of 00: DecodeError in the reference (test_a_damaged_option_tag_in_front_of_an_empty_delta_of_delta_column)
 DOD_TAG_BLOB_HEX = "6c6f726f0000000000000000000000006abb1f0600046a0f050f05011101f9456d4caa000000000101003a0000000501000001001003040102000004010000020401010006110474657874036d6170026b32046c6973740016010404010004020405000400040105040b04010304010010036a687807030301030205017a070101"
+
+
+def map_sessions(n, base=61000, scalar_only=True):
+    """LWW Map documents for the fused decode -> LWW kernel (lm_k_map_fused.h): 1-4 peers writing / deleting keys of one or two root
+    Maps — integers of every width, strings (empty, long), floats, bools, null, binary; keys that are empty, non-ASCII, quoted, with a
+    tab, 20-43 bytes long (a key table the kernel's candidate test cannot take: the document is replayed through the row tables) —
+    commits of a few rows each, pairwise syncs, a duplicated blob, a missing peer (pending changes).  scalar_only=False adds nested
+    list / map values (the kernel leaves those documents to the row tables too)."""
+    import random
+    docs = []
+    for s in range(n):
+        seed = base + s
+        rng = random.Random(seed)
+        n_peers = rng.randint(1, 4)
+        reps = [wire.Replica(1000 + seed * 10 + i) for i in range(n_peers)]
+        keys = ["k%d" % i for i in range(rng.randint(1, 40))] + ["", "ключ", "a\"b", "long-key-%s" % ("x" * rng.choice([3, 20, 30, 40])), "tab\tkey"][: rng.randint(0, 5)]
+        names = ["map"] + (["m2"] if rng.random() < 0.3 else [])
+        for step in range(rng.randint(5, 400)):
+            r = rng.choice(reps)
+            nm = rng.choice(names); key = rng.choice(keys)
+            if rng.random() < 0.15:
+                r.map_delete(nm, key)
+            else:
+                vals = [None, True, False, rng.randint(-10**14, 10**14), rng.randint(-3, 3), "s%d" % rng.randint(0, 999), b"\x00\xff",
+                        rng.random() * 10 ** rng.randint(-5, 9), "x" * rng.randint(0, 200)]
+                if not scalar_only and s % 3 == 0:
+                    vals += [[1, 2, "z"], {"a": 1, "b": [2]}]
+                r.map_set(nm, key, rng.choice(vals))
+            if rng.random() < 0.3:
+                r.commit()
+            if rng.random() < 0.1 and n_peers > 1:
+                a, b = rng.sample(reps, 2); a.commit(); b.commit(); a.merge_from(b)
+        for r in reps:
+            r.commit()
+        blobs = _fuzz.blobs_of(reps, rng)
+        if rng.random() < 0.2 and blobs:
+            blobs.append(blobs[0])
+        if rng.random() < 0.15 and len(blobs) > 1:
+            blobs = blobs[1:]
+        if blobs:
+            docs.append(blobs)
+    return docs
+
+
+def damaged_map_docs(n, seed=1):
+    """map_sessions() documents with one blob damaged (byte flips, truncation, splices; envelope checksum re-fitted)"""
+    import random, struct
+    import _oracle
+    rng = random.Random(seed)
+
+    def refit(blob):
+        body = blob[20:]
+        return blob[:16] + struct.pack("<I", _oracle.xxh32(body)) + body
+
+    def corrupt(blob):
+        b = bytearray(blob)
+        k = rng.random()
+        if k < 0.6:
+            for _ in range(rng.choice([1, 1, 2, 5])):
+                i = rng.randrange(22, len(b))
+                b[i] = rng.choice([b[i] ^ (1 << rng.randrange(8)), rng.randrange(256), 0xFF, 0x80, 0])
+        elif k < 0.75:
+            del b[rng.randrange(22, len(b)):]
+        elif k < 0.9:
+            i = rng.randrange(22, len(b)); j = min(len(b), i + rng.randrange(1, 40))
+            b[i:j] = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 50)))
+        else:
+            i = rng.randrange(22, len(b))
+            b[i:i] = b[rng.randrange(22, len(b)):][: rng.randrange(1, 64)]
+        return refit(bytes(b)) if len(b) > 22 else bytes(b)
+    # (no duplicated blobs here: a damaged copy beside the intact one is a corner of the pending-change bookkeeping of its own, NEXT.md)
+    base = [d for d in map_sessions(24, base=62000 + seed * 100) if len(set(d)) == len(d)]
+    docs = []
+    for i in range(n):
+        d = list(rng.choice(base)); j = rng.randrange(len(d)); d[j] = corrupt(d[j]); docs.append(d)
+    return docs

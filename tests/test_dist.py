@@ -136,6 +136,36 @@ def test_summary_rows_written_on_the_device_match_the_host_summary():
         assert (lmdist.rows_tensor(ptr, rows).numpy()[:len(docs)] == want).all()
 
 
+def test_summary_rows_of_folded_batches_and_of_replayed_documents():
+    """round 6: lm_summary_layout works on a batch whose entries were folded (shared blobs / checked-out entries: the
+    rows are written from the host after the run) and the rows of documents the side engine replayed (DF_REDO) are the replay's"""
+    import _emu, _oracle
+    from loro_amd._cabi import Context
+    bad, _good = _cases.misnamed_delete_docs(6)
+    empty = b"\x00"
+    docs, fr = [], []
+    for d in bad:
+        docs += [d, d]; fr += [None, empty]
+    want = _oracle.merge_batch(docs, frontiers=fr)
+    for env in ({"LM_SPAN_AUTO": "1", "LM_SHARE_REPLAY": "0"}, {"LM_SPAN_AUTO": "0"}):
+        os.environ.update(env)
+        try:
+            with Context(_emu.binding()) as c:
+                c.stage(docs, fr)
+                c.summary_layout(7, 2, len(docs) + 3)
+                c.run()
+                assert c.fetch() == want
+                st, jl, vl, pe = c.result_meta()
+                exp = lmdist.summarize_device([7 + 2 * i for i in range(len(docs))], st, pe, jl, vl, c.result_hashes())
+                ptr, rows = c.summary_rows_ptr()
+                t = lmdist.rows_tensor(ptr, rows).numpy()
+                assert (t[:len(docs)] == exp).all() and (t[len(docs):] == -1).all(), env
+                assert list(st) == [w[0] for w in want]
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
 def _stub_rccl():
     """tests/emu/rccl_stub.c → a shared library with the four RCCL entry points the product resolves by dlsym, on host pointers"""
     import subprocess

@@ -5,6 +5,7 @@ import pytest
 
 import os
 import _oracle, _emu, _cases
+from loro_amd._cabi import Context
 from loro_amd import wire, workload
 
 
@@ -916,8 +917,7 @@ def test_checkouts_through_the_full_import(monkeypatch):
     monkeypatch.setenv("LM_SHARE_REPLAY", "0")
     assert dev_only(_emu.merge_batch(docs, fronts)) > 0          # the documented deviation of the closure replay
     monkeypatch.delenv("LM_SHARE_REPLAY")
-    monkeypatch.setenv("LM_CHECKOUT_FULL", "1")
-    with Context(_emu.binding()) as c:
+    with Context(_emu.binding()) as c:                           # (the default since round 6; LM_CHECKOUT_FULL=0 switches it off)
         got = c.merge_batch(docs, fronts)
         assert c.b.shared_documents(c.h) == len(docs)
     assert dev_only(got) == 0
@@ -961,3 +961,93 @@ def test_damaged_change_meta_columns_are_data_corruption_like_the_reference():
             assert [g[0] for g in got] == [3] * len(docs), (dec, list(zip(names, [g[0] for g in got])))
         finally:
             del os.environ["LM_DECODE"]
+
+
+# ---- round 6: LWW Map documents without op rows (lm_k_map_fused.h) and the side engine that replays what a configuration has no path for
+
+def _map_env(monkeypatch, on=True):
+    monkeypatch.setenv("LM_MF_MIN_ROWS", "1"); monkeypatch.setenv("LM_MF_CHG_RATIO", "0")   # (the product asks for 2,048 rows and 4 per change)
+    if not on:
+        monkeypatch.setenv("LM_MAP_FUSED", "0")
+
+
+def test_map_documents_are_resolved_without_op_rows(monkeypatch):
+    """configs[2]-shaped documents (both variants) and 160 random Map sessions: op columns folded straight into the LDS LWW table,
+    results equal to the oracle's and to the row-table path's; documents the kernel is not built for (nested values, long keys) are
+    replayed through the row tables by the side engine"""
+    from loro_amd import workload
+    _map_env(monkeypatch)
+    docs = [workload.cfg3_doc(d, n_peers=4, n_writes=700, n_keys=96, combined=d % 2 == 0, per_change=50) for d in range(4)]
+    docs += _cases.map_sessions(160, scalar_only=False)
+    want = _oracle.merge_batch(docs, threads=8)
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs)
+        n_fused, n_redo = c.b.fused_documents(c.h), c.b.redo_documents(c.h)
+    assert got == want
+    assert n_fused == len(docs) and 20 <= n_redo <= 110, (n_fused, n_redo)
+    monkeypatch.setenv("LM_MAP_FUSED", "0")
+    with Context(_emu.binding()) as c:
+        assert c.merge_batch(docs) == want and c.b.fused_documents(c.h) == 0
+
+
+def test_map_documents_without_op_rows_at_checked_out_versions(monkeypatch):
+    from loro_amd import workload
+    _map_env(monkeypatch)
+    monkeypatch.setenv("LM_SHARE_REPLAY", "0")   # (a checked-out entry of a folded batch is a resident document: the row tables)
+    docs, fr = [], []
+    for d in range(6):
+        blobs = workload.cfg3_doc(d, n_peers=3, n_writes=200, n_keys=30, combined=(d % 2 == 0), per_change=20)
+        for ctr in (0, 57, 199):
+            docs.append(blobs); fr.append(wire.encode_frontiers([(d * 1000 + 1, ctr)] + ([(d * 1000 + 2, 100)] if ctr == 57 else [])))
+        docs.append(blobs); fr.append(None)
+    with Context(_emu.binding()) as c:
+        got = c.merge_batch(docs, fr)
+        assert c.b.fused_documents(c.h) == len(docs)
+    assert got == _oracle.merge_batch(docs, frontiers=fr)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_damaged_map_documents_get_the_row_decoders_verdicts(monkeypatch, seed):
+    """the fused kernel gives no verdict on anything it is not built for — the side engine's row decoders do: status, bytes and
+    pending ops of every damaged document are those of the row-table path; nothing the oracle rejects is rendered"""
+    docs = _cases.damaged_map_docs(300, seed=seed)
+    want = _oracle.merge_batch(docs, threads=8)
+    _map_env(monkeypatch)
+    with Context(_emu.binding()) as c:
+        fused = c.merge_batch(docs)
+        assert c.b.fused_documents(c.h) > 100 and c.b.redo_documents(c.h) > 20
+    monkeypatch.setenv("LM_MAP_FUSED", "0")
+    with Context(_emu.binding()) as c:
+        rows = c.merge_batch(docs)
+    assert fused == rows
+    assert not [i for i in range(len(docs)) if want[i][0] != 0 and fused[i][0] == 0]
+    assert not [i for i in range(len(docs)) if want[i][0] == 0 and fused[i][0] == 0 and fused[i] != want[i]]
+
+
+def test_a_documents_verdict_depends_neither_on_its_neighbours_nor_on_shared_blobs(monkeypatch):
+    """ADVICE r5 (medium + low): delete rows that name other elements than the ones at their positions are applied by position by the
+    reference (crdt_rope.rs:256-335) and by the span-granular batch kernels.  The element-granular kernel (picked by the batch's
+    statistics, LM_SPAN_AUTO) and the resident kernels (every entry of a folded batch — entries that share their blobs, any
+    checked-out entry) have no such path: they flag the document DF_REDO and the context replays it through the batch pipeline, so
+    every configuration renders what the oracle renders; LM_REDO=0 shows the round-5 behaviour."""
+    bad, _good = _cases.misnamed_delete_docs(12)
+    empty = b"\x00"
+    want_latest = _oracle.merge_batch(bad)
+    want_empty = _oracle.merge_batch(bad, frontiers=[empty] * len(bad))
+    assert all(w[0] == 0 for w in want_latest)
+    docs, fr, want = [], [], []
+    for i, d in enumerate(bad):
+        docs += [d, d]; fr += [None, empty]; want += [want_latest[i], want_empty[i]]
+    for env in ({"LM_SPAN_AUTO": "1", "LM_SHARE_REPLAY": "0"}, {"LM_SPAN_AUTO": "0"}, {"LM_SPAN_AUTO": "1"}, {"LM_SPAN_AUTO": "1", "LM_CHECKOUT_FULL": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with Context(_emu.binding()) as c:
+            got = c.merge_batch(docs, fr)
+            n_redo = c.b.redo_documents(c.h)
+        assert got == want, env
+        assert n_redo > 0 or env.get("LM_SPAN_AUTO") == "0" and env.get("LM_SHARE_REPLAY") == "0", env
+        for k in env:
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("LM_SPAN_AUTO", "0"); monkeypatch.setenv("LM_REDO", "0")
+    with Context(_emu.binding()) as c:
+        assert [g[0] for g in c.merge_batch(docs, fr)] == [3] * len(docs)

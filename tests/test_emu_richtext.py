@@ -95,14 +95,21 @@ def test_resident_documents_step_by_step():
         _richtext.same([o for o, x in zip(ok, g) if x[0] == 0], [y for y, x in zip(w, g) if x[0] == 0], "step %d" % k)
 
 
-def test_a_folded_batch_refuses():
-    docs, fronts = _richtext.checkout_cases(n=1)
-    shared = [docs[0]] * 3
+def test_a_folded_batch_is_unfolded_for_its_richtext_values():
+    """entries that share their blobs (and, since round 6, every checked-out entry) are imported once and rendered by moving the
+    trackers; lm_richtext needs the trackers AT every entry's version: the batch is unfolded — every entry a resident document over
+    the bytes already uploaded — replayed, and gives the oracle's values (folding must not take API calls away)"""
+    docs, fronts = _richtext.checkout_cases(n=2)
+    shared = [docs[0]] * 3 + [docs[-1]] * 2
+    fr = fronts[:3] + [fronts[-1], fronts[-3]]
     with Context(_emu.binding()) as c:
-        c.merge_batch(shared, fronts[:3])
-        assert c.b.shared_documents(c.h) == 1
-        with pytest.raises(RuntimeError):
-            c.richtext()
+        res = c.merge_batch(shared, fr)
+        assert c.b.shared_documents(c.h) == 2
+        got = c.richtext()
+        assert c.b.shared_documents(c.h) == 0
+        assert c.fetch() == res      # (the same bytes after the unfolded run)
+    assert res == _oracle.merge_batch(shared, frontiers=fr)
+    _richtext.same(got, _oracle.richtext_batch(shared, fr), "folded")
 
 
 def test_a_slab_that_is_too_small_sends_the_batch_through_a_second_launch(monkeypatch):
