@@ -324,7 +324,8 @@ struct Engine {
       uint8_t* host = h_stage;
       const std::vector<const uint8_t*>& src = bsrc;
       std::vector<size_t> cut{0};           // chunk c = blobs [cut[c], cut[c+1])
-      const uint64_t CHUNK = 16ull << 20;
+      uint64_t CHUNK = 16ull << 20;
+      if (const char* e = getenv("LM_STAGE_CHUNK_MB")) { long v = atol(e); if (v >= 1 && v <= 1024) CHUNK = (uint64_t)v << 20; }   // (A/B of the staging pipeline)
       for (size_t j = 0; j < nb; j++) if (h_blob_off[j + 1] - h_blob_off[cut.back()] >= CHUNK && j + 1 < nb) cut.push_back(j + 1);
       cut.push_back(nb);
       size_t nc = cut.size() - 1;
@@ -344,6 +345,7 @@ struct Engine {
         }
       };
       size_t nt = nc < 2 ? 0 : (nc < 6 ? nc - 1 : 6);
+      if (const char* e = getenv("LM_STAGE_THREADS")) { long v = atol(e); if (v >= 1 && v <= 64 && nc >= 2) nt = (size_t)v < nc - 1 ? (size_t)v : nc - 1; }
       std::vector<std::thread> th;
       for (size_t t = 0; t < nt; t++) th.emplace_back(gather);
       if (!nt) gather();
@@ -1036,7 +1038,8 @@ struct Engine {
       b_mf_docs.ensure(mfd.size() * 4 + 4); b_mf_key0.ensure((size_t)n_docs * 4 + 4);
       if (!mfd.empty()) lmbe::h2d(b_mf_docs.p, mfd.data(), mfd.size() * 4);
       lmbe::h2d(b_mf_key0.p, mfk.data(), (size_t)n_docs * 4);
-      DevMf mf; mf.docs = b_mf_docs.as<uint32_t>(); mf.doc_fused = d.doc_fused; mf.key0 = b_mf_key0.as<uint32_t>();
+      DevMf mf; mf.docs = b_mf_docs.as<uint32_t>(); mf.doc_fused = d.doc_fused; mf.key0 = b_mf_key0.as<uint32_t>(); mf.stop_after = 0;
+      if (const char* e = getenv("LM_MF_STOP")) mf.stop_after = (uint32_t)atoi(e);   // (timing experiments: the results are not the documents')
       if (!mfd.empty()) LM_LAUNCH_DYN(k_map_fused, (uint32_t)mfd.size(), MF_WG, (size_t)MF_LDS, d, mf, retry_cnt);
     }
     if (NO && ht) {   // (ht == 0: no document holds a Map / MovableList-LWW / out-of-scope row, k_dag_a)
@@ -1297,7 +1300,7 @@ struct Engine {
     }
     payload_bytes = 0;
     for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].status == ST_OK) payload_bytes += (uint64_t)h_doc[i].out_len + h_doc[i].vv_len;
-#if defined(LM_PROF) || defined(LM_PROF_DEC) || defined(LM_PROF_EMIT) || defined(LM_PROF_DAG)
+#if defined(LM_PROF) || defined(LM_PROF_DEC) || defined(LM_PROF_EMIT) || defined(LM_PROF_DAG) || defined(LM_PROF_MF)
     h_prof.resize((size_t)n_docs * 16);
     lmbe::d2h(h_prof.data(), d.prof, (size_t)n_docs * 16 * 8);
 #endif

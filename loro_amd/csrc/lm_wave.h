@@ -280,8 +280,24 @@ LM_DEV uint32_t scan_incl_add(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
   return v;
 }
+// the same crossbar walk with max instead of add (unsigned; a lane without a source sees 0)
+LM_DEV uint32_t scan_incl_max(uint32_t v) {
+  uint32_t t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+  return v;
+}
 #else
 LM_DEV uint32_t scan_incl_add(uint32_t v) { return scan_incl_add_shfl(v); }
+LM_DEV uint32_t scan_incl_max(uint32_t v) {
+  int l = lane();
+  for (int d = 1; d < 64; d <<= 1) { uint32_t t = shfl_up(v, d); if (l >= d && t > v) v = t; }
+  return v;
+}
 #endif
 #ifndef LM_EMU
 // lane i receives lane i-d (d = 1 or 2) across the whole wave64 through the DPP crossbar (wave_shr:1, one or two VALU
