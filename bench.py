@@ -309,6 +309,38 @@ def _gen(args):
     raise ValueError(kind)
 
 
+# stage of lm_run (Engine::times) -> the kernels rocprofv3 sees for it
+_STAGE_KERNELS = {"k_block_decode": ("k_block_decode", "k_block_head", "k_block_reclassify"), "k_map_lww": ("k_map_lww", "k_map_fused"), "k_emit": ("k_emit",),
+                  "k_frame_fill+k_block_count": ("k_frame_fill", "k_block_desc", "k_block_count", "k_block_kind", "k_doc_kind"), "k_doc_tables+k_remap": ("k_doc_ranges", "k_doc_tables", "k_remap"),
+                  "k_frame_count": ("k_frame_count", "k_hash_big_blobs")}
+
+
+def _pmc_traffic_of(name, dom, n_docs):
+    """HBM traffic of the dominant STAGE of an other_configs entry from the newest committed rocprofv3 --pmc record of that entry
+    (profiles/<tag>_pmc_other.json, profiles/collect_other.sh: one process per entry, separate FETCH_SIZE / WRITE_SIZE passes):
+    sum over the stage's kernels of (2 x FETCH_SIZE + WRITE_SIZE) KiB x dispatches per pipeline run — the gfx950 FETCH correction of
+    /opt/skills/guides/MI355X_MICROARCH.md — scaled to this run's document count.  (None, None) when no record names the stage."""
+    pdir = os.path.join(ROOT, "profiles")
+    for tag in sorted({f.split("_pmc_other.json")[0] for f in os.listdir(pdir) if f.endswith("_pmc_other.json")}, reverse=True):
+        try:
+            rec = json.load(open(os.path.join(pdir, f"{tag}_pmc_other.json"))).get(name)
+        except Exception:
+            continue
+        if not rec:
+            continue
+        prefixes = _STAGE_KERNELS.get(dom, (dom,))
+        tot, used = 0.0, []
+        for kn, kk in rec.get("kernels", {}).items():
+            if kn.startswith(prefixes) and "FETCH_SIZE_KiB_per_launch" in kk and "WRITE_SIZE_KiB_per_launch" in kk:
+                tot += (2 * kk["FETCH_SIZE_KiB_per_launch"] + kk["WRITE_SIZE_KiB_per_launch"]) * 1024 * kk["calls"] / rec.get("runs_of_the_pipeline", 1)
+                used.append(kn)
+        if not used:
+            continue
+        return int(tot / rec["docs"] * n_docs), (f"profiles/{tag}_pmc_other.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{rec.get('command')}` (not this run), "
+                                                 f"(2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the dispatches of {', '.join(sorted(used))} in one pipeline run, per document x {n_docs} documents")
+    return None, None
+
+
 def other_configs(device, cores):
     """The other BASELINE.json configs on one GPU, each checked against the oracle on its distinct documents before it
     is timed (one context, runs strictly one after the other, inputs resident in HBM): docs/s and the algorithmic
@@ -317,7 +349,18 @@ def other_configs(device, cores):
     import loro_amd, _oracle, _cases
     from loro_amd import workload
     out = {}
-    with mp.get_context("fork").Pool(min(24, cores)) as pool:
+
+    class _Serial:   # LM_BENCH_NO_POOL=1 (profiles/collect_other.sh): rocprofv3 hangs on a process that forks a pool before it touches the GPU
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def map_async(self, f, xs):
+            only = os.environ.get("LM_BENCH_ONLY", "")
+            want = {"cfg3a": "configs[2]", "cfg3b": "configs[2]", "cfg5": "configs[4]", "tpl": "heterogeneous", "trace": "traces", "movable": "movable"}
+            class R:
+                def __init__(s, v): s.v = v
+                def get(s): return s.v
+            return R([f(x) if (not only or want.get(x[0], "") in only or (x[0] == "cfg5" and "richtext" in only)) else None for x in xs])
+    with (_Serial() if os.environ.get("LM_BENCH_NO_POOL") else mp.get_context("fork").Pool(min(24, cores))) as pool:
         g3 = pool.map_async(_gen, [("cfg3a", d) for d in range(8)] + [("cfg3b", d) for d in range(8)])
         g5 = pool.map_async(_gen, [("cfg5", d) for d in range(4)])
         # heterogeneous configs[1]: 2-peer concurrent text documents of seven sizes (4k .. 200k ops), fused and keystroke-per-change
@@ -336,7 +379,14 @@ def other_configs(device, cores):
             gm = ex
     note("other configs: documents generated")
 
+    only = os.environ.get("LM_BENCH_ONLY")   # profiles/collect_other.sh: ONE entry per process (its kernels are then that entry's in the rocprofv3 record)
+
+    def sel(name):
+        return not only or name == only
+
     def run(name, docs, fronts, distinct, desc, reps=3):
+        if not sel(name):
+            return
         # a leg that fails (its parity assert included) is REPORTED in its own entry — "error" instead of a rate — and leaves the
         # other entries and the headline value (which has its own parity assert) alone
         try:
@@ -379,22 +429,11 @@ def other_configs(device, cores):
         # HBM traffic of the dominant stage: only where a committed rocprofv3 --pmc record of this config names the same kernel
         # (profiles/collect_cfg3.sh: 2,048 documents; the counters scale with the documents)
         traffic, traffic_src = None, None
-        if name == "configs[2]" and dom:
-            for tag in sorted({f.split("_pmc_configs2.json")[0] for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_configs2.json")}, reverse=True):
-                try:
-                    pj = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_configs2.json")))
-                except Exception:
-                    continue
-                kk = pj.get("kernels", {}).get(pj.get("dominant_kernel", ""), {})
-                if not pj.get("dominant_kernel", "").startswith(dom) or "FETCH_SIZE_KiB_per_launch" not in kk:
-                    continue
-                per_doc = (2 * kk["FETCH_SIZE_KiB_per_launch"] + kk["WRITE_SIZE_KiB_per_launch"]) * 1024 * kk["calls"] / pj.get("runs_of_the_pipeline", 1) / pj["docs"]
-                traffic = int(per_doc * len(docs))
-                traffic_src = (f"profiles/{tag}_pmc_configs2.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{pj.get('command')}` (not this run), "
-                               f"(2 x FETCH_SIZE + WRITE_SIZE) KiB summed over {pj['dominant_kernel']}'s dispatches of one pipeline run, per document x {len(docs)} documents")
-                break
+        if dom:
+            traffic, traffic_src = _pmc_traffic_of(name, dom, len(docs))
         note(f"other configs: {name} done")
         out[name] = {"docs": len(docs), "distinct_docs": distinct, "docs_per_s": round(len(docs) / best, 1), "ms_per_batch": round(best * 1e3, 2),
+                     "pipeline_runs_in_this_process": 2 + reps,
                      "algorithmic_bytes": int(alg), "algorithmic_GBps": round(alg / best / 1e9, 2), "frac_of_hbm_peak": round(alg / best / 1e9 / HBM_PEAK_GBS, 5),
                      "stage_ms": stage_ms,
                      "roofline": None if not dom else {"bound": "hbm", "kernel": dom, "kernel_ms": stage_ms[dom], "achieved": round(alg / (stage_ms[dom] * 1e-3) / 1e9, 2),
@@ -408,27 +447,37 @@ def other_configs(device, cores):
                      "workload": desc}
 
     run("configs[0]", cfg1, None, 100, "100 docs x 2 peers x 1,000 sequential inserts, 2 blobs/doc")
-    d3 = [g[0] for g in g3]
+    d3 = [g[0] for g in g3] if sel("configs[2]") else [[]] * 16
     run("configs[2]", [d3[i % 16] for i in range(10000)], None, 16,
         "LWW Map, 16 peers x 10,000 writes on 1,024 keys per doc (160k ops/doc); the config's 10,000 docs (24 GB of blobs): 8 distinct "
         "histories x {one combined blob, 16 per-peer blobs}", reps=2)
     run("configs[3]", [cfg4_base[i % 96] for i in range(12500)], None, 96,
         "mixed List/Map/Text roots, 4 peers x ~1k ops with pairwise syncs; 12,500 docs = one GPU's share of the config's 100k over 8")
-    tpls = [g[0] for g in gh]
-    mix = [tpls[(d * 7919) % len(tpls)].stamp(d) for d in range(10000)]      # sizes interleaved pseudo-randomly: neighbouring waves differ
-    run("configs[1]-heterogeneous", mix, None, 64,
-        "10,000 two-peer concurrent text documents of seven shapes interleaved (4k, 20k, 50k, 100k, 200k ops with fused changes; 10k and "
-        f"40k ops with one change per keystroke): {sum(t.n_ops for t in tpls) // len(tpls)} ops/doc on average — per-wave load imbalance and divergent control flow")
-    ttr = [g[0] for g in gt]
-    run("configs[1]-128-traces", [ttr[(d * 7919) % len(ttr)].stamp(d) for d in range(10000)], None, 64,
+    if sel("configs[1]-heterogeneous"):
+        tpls = [g[0] for g in gh]
+        mix = [tpls[(d * 7919) % len(tpls)].stamp(d) for d in range(10000)]      # sizes interleaved pseudo-randomly: neighbouring waves differ
+        run("configs[1]-heterogeneous", mix, None, 64,
+            "10,000 two-peer concurrent text documents of seven shapes interleaved (4k, 20k, 50k, 100k, 200k ops with fused changes; 10k and "
+            f"40k ops with one change per keystroke): {sum(t.n_ops for t in tpls) // len(tpls)} ops/doc on average — per-wave load imbalance and divergent control flow")
+    ttr = [g[0] for g in gt] if sel("configs[1]-128-traces") else []
+    run("configs[1]-128-traces", [ttr[(d * 7919) % len(ttr)].stamp(d) for d in range(10000)] if ttr else [], None, 64,
         "configs[1] at its stated size (10,000 docs x 100k ops, 2 concurrent peers, 3 blobs) from 128 DIFFERENT synthetic traces interleaved "
         "pseudo-randomly, letters stamped per document: neighbouring waves replay different histories (the headline batch stamps one trace)")
     # configs[4]: 256 document INSTANCES (own copies of the blobs of 4 distinct histories) x 16 versions.  The 16 entries of an instance
     # name the same blobs: lm_stage folds them into one document, lm_run imports it once and renders the 16 versions by moving its
     # trackers (include/loro_merge.h "Shared replay"); LM_SHARE_REPLAY=0 replays the history once per entry (rounds 1-4: 1,148 renderings/s)
     n5 = 64
-    inst = [[bytes(bytearray(b)) for b in g5[d % 4][0]] for d in range(256)]
-    run("configs[4]", [inst[i // 16] for i in range(4096)], [g5[(i // 16) % 4][1][i % 16] for i in range(4096)], n5,
+    inst = [[bytes(bytearray(b)) for b in g5[d % 4][0]] for d in range(256)] if sel("configs[4]") or sel("configs[4]-one-replay-per-rendering") else [[]] * 256
+    if sel("configs[4]-one-replay-per-rendering"):
+        # (the round-4 formulation beside the shared one — every entry a document of its own, replayed up to its version's
+        # causal closure, LM_SHARE_REPLAY=0; 64 instances x 16 versions)
+        os.environ["LM_SHARE_REPLAY"] = "0"
+        try:
+            run("configs[4]-one-replay-per-rendering", [inst[i // 16] for i in range(1024)], [g5[(i // 16) % 4][1][i % 16] for i in range(1024)], n5,
+                "the configs[4] entry below with LM_SHARE_REPLAY=0: 1,024 renderings = 64 documents x 16 versions, every rendering a replay of its own (rounds 1-4)", reps=2)
+        finally:
+            del os.environ["LM_SHARE_REPLAY"]
+    run("configs[4]", [inst[i // 16] for i in range(4096)], [g5[(i // 16) % 4][1][i % 16] for i in range(4096)] if sel("configs[4]") else None, n5,
         "1M-op rich-text documents (2 peers alternating every 1k trace actions, ~1% marks), 16 checkouts each: 4,096 renderings = "
         "256 documents x 16 versions (of the config's 1,000 documents; 4 distinct histories); the 16 entries of a document share their "
         "blobs: imported once per lm_run, every version rendered by a move of the document's trackers", reps=2)
@@ -437,16 +486,18 @@ def other_configs(device, cores):
     try:
         if isinstance(gm, Exception):
             raise gm
-        dm = [g[0] for g in gm]
+        dm = [g[0] for g in gm] if sel("movable-lists (SURVEY 8f N4)") else [[]] * 16
         run("movable-lists (SURVEY 8f N4)", [dm[i % 16] for i in range(4096)], None, 16,
             "MovableList documents: a root and a child list of ~300-500 elements, 3 peers x ~500 concurrent insert / move / set / delete ops "
             "with pairwise syncs, nested child containers; 4,096 docs = 16 distinct histories")
     except Exception as ex:
         out["movable-lists (SURVEY 8f N4)"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     # the richtext row of SURVEY §8f N4 (lm_richtext, lm_k_richtext.h): the configs[4] histories (1M ops, ~1 % marks: ≈10k StyleOps per
-    # document) at the latest version, 256 document instances; timed = lm_richtext (two launches of k_richtext + the copy back), every
+    # document) at the latest version, 256 document instances; timed = lm_richtext (one launch of k_richtext + the copy back), every
     # result compared with the oracle's Doc::to_richtext of its history.  Guarded like the entry above.
     name = "richtext (SURVEY 8f N4)"
+    if not sel(name):
+        return out
     try:
         import json as _json
         rt_docs = [[bytes(bytearray(b)) for b in g5[d % 4][0]] for d in range(256)]
@@ -464,7 +515,7 @@ def other_configs(device, cores):
         rt_bytes = sum(len(g[1]) for g in got)
         out[name] = {"docs": len(rt_docs), "distinct_docs": 4, "docs_per_s": round(len(rt_docs) / best, 1), "ms_per_batch": round(best * 1e3, 2),
                      "richtext_bytes": rt_bytes, "spans_with_attributes_per_doc": got[0][1].count(b'"attributes"'),
-                     "timed": "lm_richtext after lm_run: k_richtext twice (sizes, bytes) + the copy back; the import itself is the configs[4] entry's",
+                     "timed": "lm_richtext after lm_run: ONE launch of k_richtext into optimistic slabs (a second, at exact sizes, only when a slab overflows) + the copy back; the import itself is the configs[4] entry's",
                      "cpu_baseline": {"value": round(4 / t_cpu, 2), "unit": "docs/s", "cores": 1, "kind": "port", "sample": "import + Doc::to_richtext of the 4 distinct histories, one thread (the replay dominates)"},
                      "parity": f"all {len(rt_docs)} results equal to the oracle's",
                      "workload": "1M-op rich-text documents (2 peers alternating every 1k trace actions, ~1% of the actions are bold marks), richtext value of the root Text at the latest version; 256 instances of 4 distinct histories"}

@@ -50,9 +50,12 @@ enum {
  *   - blobs: EncodeMode::FastUpdates (mode 4) and FastSnapshot (mode 3).  A snapshot is ingested on the host in front of
  *     the device path: its history from the ChangeStore section (replayed like updates, fast_snapshot.rs:326-344), the set
  *     of root containers from the keys of its state section (an empty document initialises its state store from that
- *     section, fast_snapshot.rs:168-258, so a root in which nothing is visible is still part of the value); the state
- *     VALUES are not read.  The first snapshot among a document's blobs plays that role (import_batch imports snapshots
- *     first).  Shallow snapshots (history trimmed below a shallow root) are LM_UNSUPPORTED;
+ *     section, fast_snapshot.rs:168-258, so a root in which nothing is visible is still part of the value).  The first
+ *     snapshot among a document's blobs plays that role (import_batch imports snapshots first).  A document that is ONE
+ *     snapshot rendered at its latest version is staged from the state section's VALUES instead (lm_state_documents below):
+ *     no history is uploaded, decoded or replayed.  Shallow snapshots (history trimmed below a shallow root) are rendered
+ *     that way at their latest version and at their shallow root; at any other version, next to other blobs, under
+ *     lm_import or lm_richtext they are LM_UNSUPPORTED;
  *   - per document: <= 255 peers, <= 256 containers of which <= 64 roots, container nesting <= 16, counters < 2^24 per
  *     peer (element ids are packed peer:8 | counter:24), < 2^24 Map / MovableList move+set op rows, <= 18,000 tracker leaves per sequence
  *     replay (~190k op runs; the 1M-op documents of BASELINE configs[4] use ~1,200), JSON < 4 GiB, a blob < 4 GiB;
@@ -127,6 +130,14 @@ int lm_shared_documents(lm_ctx* ctx);
  * in the batch nor on whether the host reused blob pointers. */
 int lm_fused_documents(lm_ctx* ctx);
 int lm_redo_documents(lm_ctx* ctx);
+/* lm_state_documents: documents of the batch staged last that were staged from their snapshot's STATE section instead of its history
+ * (encoding/fast_snapshot.rs:168-258: an empty document that imports a snapshot takes its state store from that
+ * section and replays nothing).  A document qualifies when it is ONE FastSnapshot blob rendered at its latest version — or ONE
+ * shallow snapshot rendered at exactly its shallow root (checkout_frontiers == shallow_since_frontiers, loro_js_interop.rs:141-147) —
+ * and every state value is of a kind this engine renders; the staged bytes are then proportional to the STATE, the history is
+ * neither uploaded nor decoded nor replayed, and `vv` is the snapshot's own.  A later lm_import into such a batch stages the
+ * snapshots once more through their ChangeStore (a history is what an import builds on).  LM_SNAPSHOT_STATE=0 switches it off. */
+int lm_state_documents(lm_ctx* ctx);
 
 /* Resident documents: import MORE blobs into the documents the context already holds, and / or render them
  * at other versions — what a Rust host does with

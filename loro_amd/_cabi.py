@@ -21,7 +21,7 @@ class RunStats(ctypes.Structure):
 
 SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
            "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca", "export", "comm_unique_id", "comm_init", "summary_allgather",
-           "summary_layout", "summary_rows_device", "summary_allgather_device", "shared_documents", "richtext", "richtext_result", "fused_documents", "redo_documents"]
+           "summary_layout", "summary_rows_device", "summary_allgather_device", "shared_documents", "richtext", "richtext_result", "fused_documents", "redo_documents", "state_documents"]
 
 
 class Binding:
@@ -69,6 +69,7 @@ class Binding:
         self.summary_allgather_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
         self.resident_fresh = g("resident_fresh"); self.resident_fresh.restype = ctypes.c_int; self.resident_fresh.argtypes = [ctypes.c_void_p]
         self.shared_documents = g("shared_documents"); self.shared_documents.restype = ctypes.c_int; self.shared_documents.argtypes = [ctypes.c_void_p]
+        self.state_documents = g("state_documents"); self.state_documents.restype = ctypes.c_int; self.state_documents.argtypes = [ctypes.c_void_p]
         self.fused_documents = g("fused_documents"); self.fused_documents.restype = ctypes.c_int; self.fused_documents.argtypes = [ctypes.c_void_p]
         self.redo_documents = g("redo_documents"); self.redo_documents.restype = ctypes.c_int; self.redo_documents.argtypes = [ctypes.c_void_p]
         self.run = g("run"); self.run.restype = ctypes.c_int; self.run.argtypes = [ctypes.c_void_p]

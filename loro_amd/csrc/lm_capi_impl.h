@@ -142,7 +142,7 @@ struct lm_ctx_impl {
     for (size_t k = 0; k < want.size(); k++) {
       if (verdict_of[k] >= 0) {
         const int32_t vs = a.results[verdict_of[k]].status;
-        if (vs != lm::ST_OK && vs != lm::ST_UNSUPPORTED) rd.res[k] = lm::DocResult{vs, 0, 0, 0, 0, 0, 0};
+        if ((vs != lm::ST_OK && vs != lm::ST_UNSUPPORTED) || (vs == lm::ST_UNSUPPORTED && a.results[verdict_of[k]].json_len == 0)) rd.res[k] = lm::DocResult{vs, 0, 0, 0, 0, 0, 0};
       }
       if (want[k].api >= 0) rd.of[want[k].api] = (int32_t)k;
     }
@@ -201,6 +201,24 @@ struct lm_ctx_impl {
   void stage(const lm::Engine::DocIn* docs_api, size_t n_api) {
     // entries that share their blobs: staged once (see Shared above).  LM_SHARE_REPLAY=0: every entry is its own document (rounds 1-4)
     std::vector<lm::Engine::DocIn> udocs;
+    // an entry that is ONE shallow snapshot checked out at exactly its shallow root (checkout_frontiers == the `fr` entry of the
+    // snapshot's third section; loro_js_interop.rs:141-147): that section IS the state at that version — staged from it, as a document
+    // of its own at "its latest version" (lm_snapshot.h snapshot_state_to_updates, root_only).  Any other version of a shallow
+    // snapshot needs ops replayed over a state base: LM_UNSUPPORTED as before
+    std::vector<lm::Engine::DocIn> pre;
+    {
+      const char* e = getenv("LM_SNAPSHOT_STATE");
+      std::vector<uint8_t> fr;
+      for (size_t i = 0; !(e && atoi(e) == 0) && i < n_api; i++) {
+        const lm::Engine::DocIn& d = docs_api[i];
+        if (d.n != 1 || !d.front || d.lens[0] < 22 || d.blobs[0][21] != 3 || memcmp(d.blobs[0], "loro", 4) != 0) continue;
+        fr.clear();
+        if (!lmsnap::snapshot_shallow_root_frontiers(d.blobs[0], d.lens[0], fr) || fr.size() != d.front_len || memcmp(fr.data(), d.front, fr.size()) != 0) continue;
+        if (pre.empty()) pre.assign(docs_api, docs_api + n_api);
+        pre[i].front = nullptr; pre[i].front_len = 0; pre[i].state_root = 1;
+      }
+      if (!pre.empty()) docs_api = pre.data();
+    }
     const lm::Engine::DocIn* docs = docs_api;
     size_t n = n_api;
     sh.on = false;
@@ -217,6 +235,7 @@ struct lm_ctx_impl {
         key.clear();
         key.push_back(docs_api[i].n);
         for (size_t b = 0; b < docs_api[i].n; b++) { key.push_back((uint64_t)(uintptr_t)docs_api[i].blobs[b]); key.push_back((uint64_t)docs_api[i].lens[b]); }
+        if (docs_api[i].state_root) { key.push_back(~0ull); key.push_back(i); }   // (a document of its own: never folded with the entries that share its bytes)
         groups[key].push_back((uint32_t)i);
       }
       // LM_CHECKOUT_FULL=1: EVERY entry with a checkout takes this path, alone in its group too — the whole history is imported (what
@@ -246,7 +265,7 @@ struct lm_ctx_impl {
             if (it != seen.end()) { uniq_of[i] = it->second; continue; }
             seen.emplace(key, u);
           }
-          udocs.push_back(lm::Engine::DocIn{docs_api[i].blobs, docs_api[i].lens, docs_api[i].n, nullptr, 0});
+          udocs.push_back(lm::Engine::DocIn{docs_api[i].blobs, docs_api[i].lens, docs_api[i].n, nullptr, 0, docs_api[i].state_root});
           uniq_of[i] = u;
         }
       }
@@ -290,6 +309,7 @@ struct lm_ctx_impl {
     // every part gathers and uploads its share on its own host thread and stream
     uint32_t np2 = n_parts();
     std::vector<std::string> errs(np2);
+    for (uint32_t p = 0; p < np2; p++) parts[p]->allow_state = !sh.on;   // (a folded batch's entries are checked out: the history is what they need)
     auto body = [&](uint32_t p) { try { parts[p]->stage(docs + first[p], first[p + 1] - first[p]); } catch (const std::exception& e) { errs[p] = e.what(); if (errs[p].empty()) errs[p] = "error"; } };
     std::vector<std::thread> th;
     for (uint32_t p = 1; p < np2; p++) th.emplace_back(body, p);
@@ -393,12 +413,15 @@ struct lm_ctx_impl {
         for (uint32_t i = 0; i < e.n_docs; i++) {
           uint32_t u = first[p] + i;
           if (s == 0) import_status[u] = e.results[i].status;
+          // (LM_UNSUPPORTED without a rendering — a limit of the engine, a shallow snapshot — is the document's verdict at every version;
+          // LM_UNSUPPORTED WITH one only says that out-of-scope containers ride along as null)
+          if (s == 0 && e.results[i].status == lm::ST_UNSUPPORTED && e.results[i].json_len == 0) import_status[u] = -(int32_t)lm::ST_UNSUPPORTED;
           if (s == 0 && i == 0) redo_flagged[p] = e.redo_docs;   // (delete rows the resident kernels cannot finish by position: replayed below)
           uint32_t en = sh.by_slot[s][u];
           if (en == lm::NONE) continue;
           lm::DocResult r = e.results[i];
           // a document whose import failed fails for every entry (its later runs would render the empty document it is left as)
-          if (s && import_status[u] != lm::ST_OK && import_status[u] != lm::ST_UNSUPPORTED) { r = lm::DocResult{import_status[u], 0, 0, 0, 0, 0, 0}; }
+          if (s && import_status[u] != lm::ST_OK && import_status[u] != lm::ST_UNSUPPORTED) { r = lm::DocResult{import_status[u] < 0 ? -import_status[u] : import_status[u], 0, 0, 0, 0, 0, 0}; }
           r.json_off += sh.out_top[p]; r.vv_off += sh.vv_top[p];
           sh.res[en] = r;
         }
@@ -534,6 +557,7 @@ int LM_API(resident_fresh)(void* c) {
 int LM_API(shared_documents)(void* c) { auto* x = (lm_ctx_impl*)c; return x->sh.on ? (int)x->n_docs : 0; }
 int LM_API(fused_documents)(void* c) { auto* x = (lm_ctx_impl*)c; int n = 0; for (uint32_t p = 0; p < x->n_parts(); p++) n += (int)x->parts[p]->n_fused; return n; }
 int LM_API(redo_documents)(void* c) { auto* x = (lm_ctx_impl*)c; return x->rd.on ? (int)x->rd.n : 0; }
+int LM_API(state_documents)(void* c) { auto* x = (lm_ctx_impl*)c; int n = 0; for (uint32_t p = 0; p < x->n_parts(); p++) n += (int)x->parts[p]->n_state_docs; return n; }
 int LM_API(run)(void* c) {
   auto* x = (lm_ctx_impl*)c;
   try { x->run(); return 0; } catch (const std::exception& e) { x->err = e.what(); return -1; }
@@ -691,6 +715,15 @@ int LM_API(richtext)(void* c) {
   auto* x = (lm_ctx_impl*)c;
   try {
     if (!x->ran) throw std::runtime_error("lm_richtext before lm_run");
+    {
+      // documents staged from their snapshots' STATE sections hold neither marks nor the real ids of their child containers (the keys of
+      // the richtext result): the batch is staged once more, every snapshot through its ChangeStore, and run again — the results of
+      // lm_fetch / lm_result_meta are that run's from here on (the same bytes; a shallow snapshot, which has no history to give, is
+      // LM_UNSUPPORTED in both from here on)
+      bool any = false;
+      for (uint32_t p = 0; p < x->n_parts(); p++) if (x->parts[p]->n_state_docs && !x->parts[p]->resident) { x->parts[p]->restage_history(); any = true; }
+      if (any) { x->run(); x->sum_host_rows(); }
+    }
     if (x->sh.on) {
       // a folded batch (entries that share their blobs, or any checked-out entry: one import, the trackers moved from version to
       // version): k_richtext reads the trackers as a run left them, so every entry becomes a resident document of its own over the

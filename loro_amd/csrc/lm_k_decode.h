@@ -23,6 +23,8 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   const uint32_t* res_old_blobs;   // resident documents: per document the number of blobs earlier runs already held (nullptr otherwise)
   uint32_t loc_cleared;       // 1: loc[] was set to NONE by a memset in front of the integrate stage (the waves skip their own clear)
   uint32_t* posdel;           // per document 3 * PD_CAP words: the delete rows the span-granular batch kernels applied by position (lm_k_integrate_span.h ts_del_positional); nullptr = a mismatch is LM_DATA_CORRUPTION
+  const uint8_t* vvo;         // per document: the version vector to write out instead of the decoded peers' (a document staged from a snapshot's STATE section, lm_snapshot.h); vvo_off[n_docs + 1], empty range = none; nullptr = no such document
+  const uint64_t* vvo_off;
   const uint8_t* doc_fused;   // per document: 1 = an LWW Map document decoded without op rows (lm_k_map_fused.h; nullptr: none in this run)
   uint32_t n_op_rows;         // op rows of the batch's row tables (the fused documents' record tables start behind them)
   uint32_t* blk_kind;         // per block (k_block_kind): bit 31 = Map ops with scalar values only, low bits = its op rows

@@ -1162,6 +1162,12 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
     uint32_t P = m.n_peers;
     uint8_t* vo = mode ? d.vv_out + d.vv_off[doc] : nullptr;
     const uint64_t vcap = d.vv_off[doc + 1] - d.vv_off[doc];   // 16 bytes per peer + 16: a true bound (10 + 5 bytes per entry)
+    const uint64_t ovn = d.vvo ? d.vvo_off[doc + 1] - d.vvo_off[doc] : 0;
+    if (ovn) {
+      // a document staged from a snapshot's STATE section (lm_snapshot.h): its oplog version is the snapshot's, not the synthetic peer's
+      for (uint64_t i = (uint64_t)lane; i < ovn && i < vcap; i += 64) if (vo) vo[i] = d.vvo[d.vvo_off[doc] + i];
+      vvn = (uint32_t)ovn;
+    } else {
     uint32_t cntp = 0;
     for (uint32_t p = 0; p < P; p++) if (d.peer_end[m.praw0 + p] > 0) cntp++;
     auto put_uleb = [&](uint64_t v) {
@@ -1173,6 +1179,7 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
       if (e == 0) continue;
       put_uleb(d.peer_uniq[m.praw0 + p]);
       put_uleb((uint64_t)e << 1);  // zigzag of a non-negative i32
+    }
     }
   }
 #ifdef LM_PROF_EMIT

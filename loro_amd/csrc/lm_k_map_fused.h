@@ -73,10 +73,16 @@ LM_DEV void mf_wave_lds_sync() {
 #endif
 }
 // four bytes of `data` at `pos` (any alignment), bytes at or beyond `end` read as `fill`
+// (`data` carries 64 bytes of slack behind the last blob — lm_pipeline.h stage / import_more — so a word that STARTS in front of `end`
+// may be read whole: one predicated load and a mask instead of a byte loop for the words that straddle the end)
 LM_DEV uint32_t mf_ld4(const uint8_t* data, uint64_t pos, uint64_t end, uint32_t fill) {
-  if (pos + 4 <= end) return ld32u(data + pos);
-  uint32_t x = 0;
-  for (uint32_t q = 0; q < 4; q++) x |= (pos + q < end ? (uint32_t)data[pos + q] : fill) << (8 * q);
+  const uint32_t f4 = fill * 0x01010101u;
+  uint32_t x = f4;
+  if (pos < end) {
+    x = ld32u(data + pos);
+    const uint64_t left = end - pos;
+    if (left < 4) { const uint32_t keep = (1u << (8 * (uint32_t)left)) - 1u; x = (x & keep) | (f4 & ~keep); }
+  }
   return x;
 }
 
@@ -276,39 +282,31 @@ LM_DEV bool mf_prop_all(const uint8_t* data, uint64_t p, uint64_t end, uint32_t 
     if (in_lds) {
       const uint32_t w0 = q;
       const uint32_t at = w0 + (uint32_t)lane;
-      uint32_t info = 0;               // adv (8) | rows (8) | kind (2: 0 none, 1 run, 2 literal) << 16
-      uint64_t vals = 0;               // run: the delta (i16) | literal: up to four deltas (i16 each)
-      if (at < L) {
-        const uint32_t* wp = (const uint32_t*)(cb + (at & ~3u));
-        const uint64_t lo = (((uint64_t)wp[1] << 32) | wp[0]) >> (8 * (at & 3u));          // bytes at .. at+4 (at least)
-        const uint64_t v = (at & 3u) ? (lo | ((uint64_t)wp[2] << (64 - 8 * (at & 3u)))) : lo;   // bytes at .. at+7
-        const uint32_t hb = (uint32_t)v & 0xffu;
-        if (!(hb & 0x80u) && hb) {
-          const int32_t k = (int32_t)(hb >> 1) ^ -(int32_t)(hb & 1u);
-          const uint64_t pay = v >> 8;                                   // seven payload bytes
-          const uint32_t term = (uint32_t)(((~pay) & 0x0080808080808080ull) != 0);   // (used below via the per-byte walk)
-          (void)term;
-          if (k > 0) {
-            // a run: count k, one delta of one or two bytes
-            const uint32_t b0 = (uint32_t)pay & 0xffu, b1 = (uint32_t)(pay >> 8) & 0xffu;
-            if (!(b0 & 0x80u)) { const uint32_t u = b0; vals = (uint64_t)(uint16_t)(int16_t)((int32_t)(u >> 1) ^ -(int32_t)(u & 1u)); info = 2u | ((uint32_t)k << 8) | (1u << 16); }
-            else if (!(b1 & 0x80u)) { const uint32_t u = (b0 & 0x7fu) | (b1 << 7); vals = (uint64_t)(uint16_t)(int16_t)((int32_t)(u >> 1) ^ -(int32_t)(u & 1u)); info = 3u | ((uint32_t)k << 8) | (1u << 16); }
-          } else if (k >= -4) {
-            // a literal of n <= 4 deltas of one or two bytes each, all inside the seven payload bytes
-            const uint32_t n = (uint32_t)(-k);
-            uint32_t o = 0;
-            bool okl = true;
-            for (uint32_t j = 0; j < 4; j++) {
-              if (j >= n) break;
-              if (o + 2 > 7) { okl = okl && o + 1 <= 7 && !((pay >> (8 * o)) & 0x80u); if (!okl) break; }
-              const uint32_t c0 = (uint32_t)(pay >> (8 * o)) & 0xffu, c1 = (uint32_t)(pay >> (8 * o + 8)) & 0xffu;
-              uint32_t u;
-              if (!(c0 & 0x80u)) { u = c0; o += 1; }
-              else if (!(c1 & 0x80u) && o + 2 <= 7) { u = (c0 & 0x7fu) | (c1 << 7); o += 2; }
-              else { okl = false; break; }
-              vals |= (uint64_t)(uint16_t)(int16_t)((int32_t)(u >> 1) ^ -(int32_t)(u & 1u)) << (16 * j);
-            }
-            if (okl) info = (1u + o) | (n << 8) | (2u << 16);
+      // T: the window's bytes without a continuation bit (bit l = byte w0 + l ends a varint) — one ballot; a segment that would start
+      // at a lane's byte is then a matter of bit counting: a run's delta ends at the first such byte behind the head, a literal of n
+      // values at the n-th
+      uint32_t info = 0;               // adv (8) | rows (8) | kind (1 run, 2 literal) << 16; 0 = not a head these lanes can take
+      uint32_t rdelta = 0;             // a run's delta (i16)
+      const uint32_t myb = at < L ? cb[at] : 0x80u;
+      const uint64_t T = lmw::ballot(at < L && !(myb & 0x80u));
+      if (at < L && !(myb & 0x80u) && myb) {
+        const int32_t k = (int32_t)(myb >> 1) ^ -(int32_t)(myb & 1u);
+        const uint64_t Tr = lane < 63 ? T >> (lane + 1) : 0ull;          // terminators behind the head byte
+        if (k > 0) {
+          const uint32_t e = Tr ? (uint32_t)__builtin_ctzll(Tr) : 64u;    // the delta's last byte, relative to the byte behind the head
+          if (e < 2) {
+            const uint32_t b0 = cb[at + 1], b1 = cb[at + 2];
+            const uint32_t u = e == 0 ? b0 : ((b0 & 0x7fu) | (b1 << 7));
+            rdelta = (uint32_t)(uint16_t)(int16_t)((int32_t)(u >> 1) ^ -(int32_t)(u & 1u));
+            info = (2u + e) | ((uint32_t)k << 8) | (1u << 16);
+          }
+        } else if (k >= -24) {
+          const uint32_t n = (uint32_t)(-k);
+          if ((uint32_t)lmw::popc64(Tr) >= n) {
+            uint64_t m = Tr;
+            for (uint32_t j = 1; j < n; j++) m &= m - 1;                  // (the n-th terminator: n - 1 lowest bits cleared)
+            const uint32_t e = (uint32_t)__builtin_ctzll(m);
+            info = (2u + e) | (n << 8) | (2u << 16);
           }
         }
         if ((info & 0xffu) + at > L) info = 0;                          // (the segment would run past the column)
@@ -348,10 +346,25 @@ LM_DEV bool mf_prop_all(const uint8_t* data, uint64_t p, uint64_t end, uint32_t 
           h = h > carry ? h : carry;
           carry = lmw::bcast(h, 63);
           const int hl = (int)((h - 1u) & 63u);
-          const uint32_t inf = lmw::shfl(info, hl), vlo = lmw::shfl((uint32_t)vals, hl), vhi = lmw::shfl((uint32_t)(vals >> 32), hl), rh = lmw::shfl(r_h, hl);
+          const uint32_t inf = lmw::shfl(info, hl), rd = lmw::shfl(rdelta, hl), rh = lmw::shfl(r_h, hl);
           if (rho < rows_w) {
-            const uint64_t vv = ((uint64_t)vhi << 32) | vlo;
-            a_prop[row + rho] = (inf >> 16) == 1u ? (uint16_t)vlo : (uint16_t)(vv >> (16 * ((rho - rh) & 3u)));
+            uint32_t dv = rd;
+            if ((inf >> 16) != 1u) {
+              // the (rho - rh)-th varint behind the head byte: between the terminator in front of it and its own
+              const uint32_t j = rho - rh;
+              uint64_t m = hl < 63 ? T >> (hl + 1) : 0ull;
+              uint32_t st = 0;
+              for (uint32_t i = 0; i < j; i++) { st = (uint32_t)__builtin_ctzll(m) + 1; m &= m - 1; }
+              const uint32_t en = (uint32_t)__builtin_ctzll(m);
+              const uint32_t p0 = w0 + (uint32_t)hl + 1 + st;
+              const uint32_t nb = en - st + 1;
+              const uint32_t c0 = cb[p0], c1 = cb[p0 + 1], c2 = cb[p0 + 2];
+              const uint32_t u = nb == 1 ? c0 : nb == 2 ? ((c0 & 0x7fu) | (c1 << 7)) : ((c0 & 0x7fu) | ((c1 & 0x7fu) << 7) | (c2 << 14));
+              const int32_t d = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+              if (nb > 3 || d > 32767 || d < -32768) bad = true;
+              dv = (uint32_t)(uint16_t)(int16_t)d;
+            }
+            a_prop[row + rho] = (uint16_t)dv;
           }
         }
         mf_wave_lds_sync();
@@ -556,10 +569,10 @@ LM_KERNEL LM_WAVES_PER_SIMD(4) void k_map_fused(Dev d, DevMf f, uint32_t* retry_
       for (uint32_t w0 = 0; w0 < klen_sec && fastk; w0 += 256) {   // candidates = bytes below 0x20, four bytes per lane and step
         const uint32_t o = w0 + 4u * (uint32_t)lane;
         const uint32_t x = mf_ld4(data, k0 + o, k0 + klen_sec, 0xffu);
-        uint32_t cand = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) cand |= (((x >> (8 * q)) & 0xffu) < 0x20u ? 1u : 0u) << q;
-        const uint32_t ncl = (uint32_t)__builtin_popcount(cand);
+        // bytes below 0x20: none of their bits 5-7 is set (folded onto bit 5 of each byte: the shifts stay inside the byte)
+        const uint32_t c5 = ~(x | (x >> 1) | (x >> 2)) & 0x20202020u;
+        const uint32_t cand = ((c5 >> 5) & 1u) | ((c5 >> 12) & 2u) | ((c5 >> 19) & 4u) | ((c5 >> 26) & 8u);
+        const uint32_t ncl = (uint32_t)__builtin_popcount(c5);
         const uint32_t incl = lmw::scan_incl_add(ncl);
         uint32_t rk = nk + incl - ncl;
         const uint32_t tot = lmw::bcast(incl, 63);
@@ -792,13 +805,12 @@ LM_KERNEL LM_WAVES_PER_SIMD(4) void k_map_fused(Dev d, DevMf f, uint32_t* retry_
 #endif
   lmw::block_sync();
   // ---- results (k_map_lww_doc's): containers, flags, the claimed slots slot for slot into the document's global table
-  if (s_misc[1]) {
+  if (s_misc[1] || s_misc[4]) {   // (an index beyond the tables' limits too: whatever is behind it, the row tables' verdict)
     if (tid == 0) { lmw::atomic_or(&d.doc[doc].flags, DF_REDO); LM_SETERR(d.doc[doc].status, ST_DATA_CORRUPTION); d.ht_cnt[doc] = 0; }
     return;
   }
   for (uint32_t c = tid; c < m.n_cont && c < MAX_CONTAINERS; c += MF_WG)
     if ((s_touch[c >> 5] >> (c & 31)) & 1) d.cont[m.cid0 + c].touched = 1;
-  if (tid == 0 && s_misc[4]) LM_SETERR(d.doc[doc].status, ST_INTERNAL);
   unsigned long long* keys = d.ht_key + d.ht0[doc];
   unsigned long long* best = d.ht_best + d.ht0[doc];
   uint32_t* list = d.ht_list + 2 * d.ht0[doc];

@@ -126,7 +126,7 @@ LM_DEV void rt_walk(const Dev& d, const DocMeta& m, uint32_t cidx, uint32_t vis_
   }
 }
 
-// mode 0: sizes only | 1: write into out + out_off[doc] (capacity out_off[doc + 1] - out_off[doc]; nothing is written beyond it).
+// mode 1 (the only one the host uses): write into out + out_off[doc] (capacity out_off[doc + 1] - out_off[doc]; nothing is written beyond it) and report the exact size — Engine::richtext launches once into optimistic slabs and a second time, at exact sizes, only when a document overflowed; mode 0 (sizes only) is kept for experiments.
 // rt_len[doc] = the exact size either way
 LM_KERNEL void k_richtext(Dev d, uint8_t* out, const uint64_t* out_off, uint32_t* rt_len, int32_t* rt_status, uint32_t* rt_cnt, int mode) {
   const uint32_t doc = (uint32_t)lmw::bid();

@@ -155,7 +155,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true, snapshot_state = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -183,11 +183,21 @@ struct Engine {
     // a side engine (lm_capi_impl.h redo) replays the documents another configuration flagged DF_REDO: span-granular batch kernels, whatever the batch's statistics say
     if (const char* e = getenv("LM_MAP_FUSED")) k.map_fused = atoi(e) != 0;                      // 0: LWW Map documents go through the row tables like every other document (rounds 1-5)
     if (const char* e = getenv("LM_MF_MIN_ROWS")) k.mf_min_rows = (uint32_t)atoi(e);             // rows from which a Map document gets a workgroup of k_map_fused (tests: 1)
+    if (const char* e = getenv("LM_SNAPSHOT_STATE")) k.snapshot_state = atoi(e) != 0;            // 0: a document given as one snapshot is replayed from its ChangeStore (rounds 2-5) instead of rendered from its state section
     if (const char* e = getenv("LM_MF_CHG_RATIO")) k.mf_chg_ratio = (uint32_t)atoi(e);           // … and rows per change it needs on average (tests: 0)
     if (force_span) { k.span = true; k.span_auto = false; k.posdel = true; k.redo = false; k.map_fused = false; }
     kn = k;
   }
   bool force_span = false;
+  // ---- documents staged from a snapshot's STATE section (lm_snapshot.h snapshot_state_to_updates): their version vector,
+  // and their ChangeStore in updates form — what they are staged from again when lm_import asks for the history after all
+  bool allow_state = true;                            // (the context switches it off for a folded batch: its entries are checked out)
+  std::vector<uint8_t> h_vvo;
+  std::vector<uint64_t> h_vvo_off;
+  std::vector<std::vector<uint8_t>> st_hist;          // per document: empty, or the history form of its snapshot
+  uint32_t n_state_docs = 0;
+  bool stage_history_only = false;                    // (restage_history: this stage call takes every snapshot through its ChangeStore)
+  DBuf b_vvo, b_vvo_off;
   // ---- DF_REDO: what lm_stage left in the pinned staging buffer (the blobs as the device sees them: snapshots already reframed) —
   // a side engine stages the documents to replay from there (stage_from); lm_import with new blobs reuses the buffer and ends that
   bool st_valid = false;
@@ -218,7 +228,23 @@ struct Engine {
       if ((size_t)i + 1 < parent.st_froot_off.size()) h_froot.insert(h_froot.end(), parent.st_froot.begin() + parent.st_froot_off[i], parent.st_froot.begin() + parent.st_froot_off[i + 1]);
     }
     h_froot_off[items.size()] = h_froot.size();
+    // … and the version vectors of documents staged from a snapshot's state section (their staged blob is the synthetic one)
+    h_vvo.clear(); h_vvo_off.assign(items.size() + 1, 0); n_state_docs = 0;
+    for (size_t k = 0; k < items.size(); k++) {
+      h_vvo_off[k] = h_vvo.size();
+      Engine& parent = *parents[k];
+      const uint32_t i = items[k].doc;
+      if (parent.n_state_docs && (size_t)i + 1 < parent.h_vvo_off.size() && parent.h_vvo_off[i + 1] > parent.h_vvo_off[i]) {
+        h_vvo.insert(h_vvo.end(), parent.h_vvo.begin() + parent.h_vvo_off[i], parent.h_vvo.begin() + parent.h_vvo_off[i + 1]);
+        n_state_docs++;
+      }
+    }
+    h_vvo_off[items.size()] = h_vvo.size();
     lmbe::bind(sc);
+    if (n_state_docs) {
+      b_vvo.ensure(h_vvo.size() + 16); lmbe::h2d(b_vvo.p, h_vvo.data(), h_vvo.size());
+      b_vvo_off.ensure((items.size() + 1) * 8); lmbe::h2d(b_vvo_off.p, h_vvo_off.data(), (items.size() + 1) * 8);
+    }
     b_froot.ensure(h_froot.size() + 16); if (!h_froot.empty()) lmbe::h2d(b_froot.p, h_froot.data(), h_froot.size());
     b_froot_off.ensure((items.size() + 1) * 8); lmbe::h2d(b_froot_off.p, h_froot_off.data(), (items.size() + 1) * 8);
     lmbe::sync();
@@ -232,7 +258,7 @@ struct Engine {
   ~Engine() { release_all(); if (h_stage) lmbe::hfree(h_stage); lmbe::stream_destroy(sc); }
   void release_all() {
     DBuf* all[] = {&b_front, &b_front_off, &b_froot, &b_froot_off, &b_blob_hash, &b_big, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
-                   &b_blk, &b_bcnt, &b_boff, &b_blk_kind, &b_doc_fused, &b_mf_docs, &b_mf_key0, &b_chg, &b_dep_peer, &b_dep_ctr, &b_dep_ci, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
+                   &b_vvo, &b_vvo_off, &b_blk, &b_bcnt, &b_boff, &b_blk_kind, &b_doc_fused, &b_mf_docs, &b_mf_key0, &b_chg, &b_dep_peer, &b_dep_ctr, &b_dep_ci, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
@@ -243,7 +269,7 @@ struct Engine {
   }
 
   // ---- stage: pack the blobs (16-byte aligned starts) and upload
-  struct DocIn { const uint8_t* const* blobs; const size_t* lens; size_t n; const uint8_t* front; size_t front_len; };
+  struct DocIn { const uint8_t* const* blobs; const size_t* lens; size_t n; const uint8_t* front; size_t front_len; uint8_t state_root = 0; };   // state_root: one shallow snapshot, shown at its shallow root (lm_capi_impl.h stage)
   void stage(const DocIn* docs, size_t nd) {
     lmbe::bind(sc);
     read_knobs();
@@ -272,6 +298,10 @@ struct Engine {
     h_froot_off.assign(nd + 1, 0);
     static const uint8_t stub_decode[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xff, 0xff};
     static const uint8_t stub_checksum[22] = {'l', 'o', 'r', 'o', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4};
+    std::vector<std::vector<uint8_t>> vvo_tmp(nd);
+    st_hist.assign(nd, {});
+    n_state_docs = 0;
+    const bool state_off = stage_history_only;
     for (size_t i = 0; i < nd; i++)
       for (size_t k = 0; k < docs[i].n; k++, b++) {
         const uint8_t* p = docs[i].blobs[k];
@@ -279,6 +309,23 @@ struct Engine {
         if (k == 0) h_froot_off[i] = froot.size();
         if (k == 0) { best_changes = 0; have_snapshot = false; }
         if (l >= 22 && memcmp(p, "loro", 4) == 0 && p[20] == 0 && p[21] == 3) {
+          // a document that IS one snapshot, rendered at its latest version: its state section is the value (fast_snapshot.rs:168-258)
+          // — staged as the state itself, never as the history (lm_snapshot.h snapshot_state_to_updates); a shallow snapshot has no
+          // other way to be rendered.  Declined (a state this reader cannot take): the ChangeStore, as for every other snapshot
+          if (docs[i].n == 1 && !docs[i].front && kn.snapshot_state && (allow_state || docs[i].state_root) && !state_off) {
+            std::vector<uint8_t> o2, vv2, roots2;
+            if (lmsnap::snapshot_state_to_updates(p, l, o2, vv2, &roots2, docs[i].state_root != 0)) {
+              std::vector<uint8_t> hist;
+              if (lmsnap::snapshot_to_updates(p, l, hist, nullptr, nullptr) == lmsnap::SN_OK) st_hist[i] = std::move(hist);
+              else st_hist[i].assign(p, p + l);             // (a shallow snapshot: lm_import restages it as it came — LM_UNSUPPORTED there, as before)
+              conv.push_back(std::move(o2)); p = conv.back().data(); l = conv.back().size();
+              froot.resize(h_froot_off[i]); froot.insert(froot.end(), roots2.begin(), roots2.end());
+              vvo_tmp[i] = std::move(vv2);
+              n_state_docs++;
+              bsrc[b] = p; blen[b] = l;
+              continue;
+            }
+          }
           // import_batch imports snapshots first, the one with the most changes first (loro.rs:1445-1449): THAT snapshot's state
           // section initialises the empty document's state store; the others arrive as updates
           std::vector<uint8_t> o, roots;
@@ -293,6 +340,13 @@ struct Engine {
         }
         bsrc[b] = p; blen[b] = l;
       }
+    h_vvo.clear(); h_vvo_off.assign(nd + 1, 0);
+    for (size_t i = 0; i < nd; i++) { h_vvo_off[i] = h_vvo.size(); h_vvo.insert(h_vvo.end(), vvo_tmp[i].begin(), vvo_tmp[i].end()); }
+    h_vvo_off[nd] = h_vvo.size();
+    if (n_state_docs) {
+      b_vvo.ensure(h_vvo.size() + 16); lmbe::h2d(b_vvo.p, h_vvo.data(), h_vvo.size());
+      b_vvo_off.ensure((nd + 1) * 8); lmbe::h2d(b_vvo_off.p, h_vvo_off.data(), (nd + 1) * 8);
+    }
     for (size_t i = 0; i < nd; i++) if (docs[i].n == 0) h_froot_off[i] = froot.size();
     h_froot_off[nd] = froot.size();
     for (size_t i = nd; i-- > 0;) if (h_froot_off[i] > h_froot_off[i + 1]) h_froot_off[i] = h_froot_off[i + 1];
@@ -404,6 +458,46 @@ struct Engine {
     }
     return p;
   }
+  void restage_history() {
+    if (!st_valid) throw std::runtime_error("lm_import: the staged blobs of a batch rendered from snapshot states are gone");
+    const size_t nd = n_docs;
+    std::vector<std::vector<const uint8_t*>> bp(nd);
+    std::vector<std::vector<size_t>> bl(nd);
+    std::vector<DocIn> in(nd);
+    std::vector<std::vector<uint8_t>> hist = std::move(st_hist);
+    std::vector<uint8_t> fronts = h_front_bytes;
+    std::vector<uint64_t> foff = h_front_off;
+    // (the other documents' blobs are read from the staging buffer while stage() gathers INTO it: copied out first)
+    std::vector<std::vector<uint8_t>> keep(n_blobs);
+    for (size_t i = 0; i < nd; i++) {
+      if (!hist[i].empty()) { bp[i].push_back(hist[i].data()); bl[i].push_back(hist[i].size()); }
+      else for (uint32_t b = st_doc_blob[i]; b < st_doc_blob[i + 1]; b++) { keep[b].assign(h_stage + st_blob_off[b], h_stage + st_blob_off[b] + st_blob_len[b]); bp[i].push_back(keep[b].data()); bl[i].push_back(keep[b].size()); }
+      const bool hf = foff.size() > i + 1 && foff[i + 1] > foff[i];
+      in[i] = DocIn{bp[i].data(), bl[i].data(), bp[i].size(), hf ? fronts.data() + foff[i] : nullptr, hf ? (size_t)(foff[i + 1] - foff[i]) : 0};
+    }
+    std::vector<uint8_t> froot_keep = st_froot;
+    std::vector<uint64_t> froot_off_keep = st_froot_off;
+    stage_history_only = true;
+    try { stage(in.data(), nd); } catch (...) { stage_history_only = false; throw; }
+    stage_history_only = false;
+    // (documents that were NOT snapshots any more in the buffer — already reframed — lost their state-section roots in this second pass: put back)
+    bool differs = false;
+    for (size_t i = 0; i < nd && !differs; i++) differs = hist[i].empty() && froot_off_keep.size() > i + 1 && froot_off_keep[i + 1] > froot_off_keep[i];
+    if (differs) {
+      std::vector<uint8_t> fr; std::vector<uint64_t> fo(nd + 1, 0);
+      for (size_t i = 0; i < nd; i++) {
+        fo[i] = fr.size();
+        if (hist[i].empty()) fr.insert(fr.end(), froot_keep.begin() + froot_off_keep[i], froot_keep.begin() + froot_off_keep[i + 1]);
+        else fr.insert(fr.end(), h_froot.begin() + h_froot_off[i], h_froot.begin() + h_froot_off[i + 1]);
+      }
+      fo[nd] = fr.size();
+      h_froot = fr; h_froot_off = fo; st_froot = fr; st_froot_off = fo;
+      lmbe::bind(sc);
+      b_froot.ensure(h_froot.size() + 16); if (!h_froot.empty()) lmbe::h2d(b_froot.p, h_froot.data(), h_froot.size());
+      b_froot_off.ensure((nd + 1) * 8); lmbe::h2d(b_froot_off.p, h_froot_off.data(), (nd + 1) * 8);
+      lmbe::sync();
+    }
+  }
   void adopt_resident() {   // the staged batch becomes the first generation of the resident documents
     r_blobs.assign(n_docs, {});
     for (uint32_t i = 0; i < n_docs; i++)
@@ -514,6 +608,14 @@ struct Engine {
     for (size_t i = 0; i < nd; i++)
       if (docs[i].front && docs[i].front_len == 0) throw std::runtime_error("checkout_frontiers with zero length (the empty version is the byte 00)");
     read_knobs();
+    if (!resident && n_state_docs) {
+      // documents staged from their snapshots' STATE sections hold no history a later import could build on (their ids are the
+      // synthetic peer's): the batch is staged once more, every snapshot through its ChangeStore this time (the blobs of the other
+      // documents are still in the pinned staging buffer)
+      const bool was_run = ran;
+      restage_history();
+      ran = was_run;
+    }
     if (!resident) {
       // The staged batch becomes the first generation of the resident documents — as ITS OWN import: `lm_stage; [lm_run;]
       // lm_import(b); lm_run` is import_batch(staged) followed by import(b), two diffs for the state store (a root whose text the
@@ -625,6 +727,7 @@ struct Engine {
     d.doc_blob = b_doc_blob.as<uint32_t>();
     d.n_blobs = n_blobs;
     d.n_docs = n_docs;
+    if (n_state_docs && !resident) { d.vvo = b_vvo.as<uint8_t>(); d.vvo_off = b_vvo_off.as<uint64_t>(); }
     results.assign(n_docs, DocResult{0, 0, 0, 0, 0, 0});
     if (n_docs == 0) { ran = true; return; }
     // resident documents whose blob lists did not change since the tables were built: only the rendered versions differ —
@@ -1228,6 +1331,7 @@ struct Engine {
         uint64_t cap = ok ? 2 * in_b + 64ull * h_doc[i].n_cont + 256 : 0;
         if (kn.slab_cap >= 0) cap = ok ? (uint64_t)kn.slab_cap : 0;
         uint64_t vcap = ok ? 16ull * h_doc[i].n_peers + 16 : 0;
+        if (ok && n_state_docs && !resident && h_vvo_off.size() > (size_t)i + 1) vcap += h_vvo_off[i + 1] - h_vvo_off[i];
         slab_off[i + 1] = slab_off[i] + ((cap + 15) & ~15ull);
         vslab_off[i + 1] = vslab_off[i] + ((vcap + 15) & ~15ull);
       }
@@ -1318,7 +1422,9 @@ struct Engine {
       r.json_xxh64 = ok ? h_hash[i] : 0;
     }
     redo_docs.clear();
-    if (kn.redo && st_valid) for (uint32_t i = 0; i < n_docs; i++) if (h_doc[i].flags & DF_REDO) redo_docs.push_back(i);
+    // (a fused Map document that FAILED anywhere: its op columns are validated late — behind the DAG stages — where the row tables'
+    // decoders speak first; the failure's code is theirs to give, so the document is replayed through them)
+    if (kn.redo && st_valid) for (uint32_t i = 0; i < n_docs; i++) if ((h_doc[i].flags & DF_REDO) || (i < h_fused.size() && h_fused[i] && h_doc[i].status != ST_OK)) redo_docs.push_back(i);
     lmbe::flush_times(times);
     if (resident) {
       // a document whose run failed keeps what it held before: the blobs of this step are dropped again (reference import is

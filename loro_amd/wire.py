@@ -600,13 +600,15 @@ def sstable(kvs, block_size: int = 4096, compress: bool = True) -> bytes:
 
 
 def encode_snapshot(blocks: List[List["Change"]], roots, vv: Dict[int, int], frontiers, block_size: int = 4096, compress: bool = True,
-                    shallow_root_state: bytes = b"") -> bytes:
+                    shallow_root_state: bytes = b"", state=None) -> bytes:
     """A FastSnapshot: ChangeStore SSTable (12-byte ID keys -> change blocks, `vv`, `fr`), state SSTable holding the root
-    containers `roots` = [(kind, name)] (values are placeholders: neither reader looks at them), empty shallow-root section."""
+    containers `roots` = [(kind, name)] with placeholder values (a reader of state VALUES declines them and takes the history), or —
+    `state` = [(key, value)] in key order, e.g. tests/_oracle.state_entries — the entries of a real state section; empty shallow-root section."""
     oplog = [(b"vv", encode_vv(vv)), (b"fr", encode_frontiers(frontiers))]
     for blk in blocks:
         oplog.append((struct.pack(">Qi", blk[0].peer, blk[0].counter), encode_block(blk)))
-    state = [(bytes([0x80 | kind]) + uleb(len(name.encode())) + name.encode(), b"\x00") for kind, name in roots]
+    if state is None:
+        state = [(bytes([0x80 | kind]) + uleb(len(name.encode())) + name.encode(), b"\x00") for kind, name in roots]
     o, st = sstable(oplog, block_size, compress), sstable(state, block_size, compress)
     body = struct.pack("<I", len(o)) + o + struct.pack("<I", len(st)) + st + struct.pack("<I", len(shallow_root_state)) + shallow_root_state
     return envelope(body, mode=3)
@@ -1003,7 +1005,7 @@ class Replica:
                 blocks += split_blocks(sel, max_block)
         return encode_updates(blocks)
 
-    def export_snapshot(self, roots=None, max_block: int = 4096, block_size: int = 4096, compress: bool = True) -> bytes:
+    def export_snapshot(self, roots=None, max_block: int = 4096, block_size: int = 4096, compress: bool = True, state=None) -> bytes:
         """ExportMode::Snapshot of everything this replica knows; `roots` = [(kind, name)] of the state section (default: every
         root container an op of the history addresses)."""
         assert not self.pending_ops
@@ -1018,7 +1020,7 @@ class Replica:
                         if o.cid.root and (o.cid.kind, o.cid.name) not in seen:
                             seen.append((o.cid.kind, o.cid.name))
             roots = seen
-        return encode_snapshot(blocks, roots, dict(self.vv), list(self.frontiers), block_size, compress)
+        return encode_snapshot(blocks, roots, dict(self.vv), list(self.frontiers), block_size, compress, state=state)
 
     def set_visible(self, name, kind: int, ids: List[Tuple[int, int]]):
         self.seq[self._cid(name, kind)] = list(ids)

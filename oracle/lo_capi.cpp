@@ -7,6 +7,7 @@
 #include <malloc.h>
 #include "lo_doc.hpp"
 #include "lo_state.hpp"
+#include "lo_state_write.hpp"
 
 using namespace lo;
 
@@ -114,6 +115,26 @@ int32_t lo_snapshot_state_json(const uint8_t* blob, uint64_t len, int root_only,
     res = snapshot_state_json(blob, (size_t)len, u, root_only != 0);
     *out = res.data(); *out_len = res.size();
     return u ? ST_UNSUPPORTED : ST_OK;
+  } catch (const DecodeErr& e) {
+    res = e.what; *out = res.data(); *out_len = 0;
+    return e.st;
+  } catch (const std::exception& e) {
+    res = e.what(); *out = res.data(); *out_len = 0;
+    return ST_INTERNAL;
+  }
+}
+// the state SSTable's entries of the document these blobs import to (lo_state_write.hpp; a generator for tests/): repeated
+// [u32le key length][key][u32le value length][value], keys ascending
+int32_t lo_state_entries(const uint8_t* data, const uint64_t* blob_off, uint32_t n_blobs, const char** out, uint64_t* out_len) {
+  static thread_local std::string res;
+  try {
+    Doc d;
+    for (uint32_t b = 0; b < n_blobs; b++) d.import(data + blob_off[b], (size_t)(blob_off[b + 1] - blob_off[b]));
+    res.clear();
+    auto put32 = [&](size_t v) { for (int k = 0; k < 4; k++) res.push_back((char)(uint8_t)(v >> (8 * k))); };
+    for (auto& kv : state_entries(d)) { put32(kv.first.size()); res += kv.first; put32(kv.second.size()); res += kv.second; }
+    *out = res.data(); *out_len = res.size();
+    return d.unsupported ? ST_UNSUPPORTED : ST_OK;
   } catch (const DecodeErr& e) {
     res = e.what; *out = res.data(); *out_len = 0;
     return e.st;

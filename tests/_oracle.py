@@ -131,6 +131,27 @@ def snapshot_state(blob, root_only=False):
     return st, (ctypes.string_at(p.value, n.value) if n.value else b"")
 
 
+def state_entries(blobs):
+    """(status, [(key, value)]): the state SSTable's entries of the document `blobs` (updates) import to, with their visible values
+    (oracle/lo_state_write.hpp) — what loro_amd.wire.encode_snapshot(state=...) writes as a snapshot's state section."""
+    import struct
+    L = lib()
+    L.lo_state_entries.restype = ctypes.c_int32
+    L.lo_state_entries.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+    data = b"".join(blobs)
+    off = np.zeros(len(blobs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(b) for b in blobs])
+    p, n = ctypes.c_void_p(), ctypes.c_uint64()
+    st = L.lo_state_entries(data, off.ctypes.data, len(blobs), ctypes.byref(p), ctypes.byref(n))
+    raw = ctypes.string_at(p.value, n.value) if n.value else b""
+    out, at = [], 0
+    while at < len(raw):
+        kl = struct.unpack_from("<I", raw, at)[0]; k = raw[at + 4:at + 4 + kl]; at += 4 + kl
+        vl = struct.unpack_from("<I", raw, at)[0]; v = raw[at + 4:at + 4 + vl]; at += 4 + vl
+        out.append((k, v))
+    return st, out
+
+
 class Session:
     """One resident document rendered step by step: step(new_blobs, frontiers=None) imports more blobs into the same
     document and renders it — the checker of lm_import + lm_run.  Returns (status, json, vv, pending) like merge()."""

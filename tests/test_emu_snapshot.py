@@ -119,3 +119,136 @@ def test_snapshots_and_resident_documents():
     for k, (g, w) in enumerate(zip(got, want)):
         for i, (x, y) in enumerate(zip(g, w)):
             assert x == y, (k, i, x[:2], y[:2])
+
+
+# ---- documents staged from their snapshot's STATE section (lm_snapshot.h snapshot_state_to_updates) ----
+def real_snapshot(rep, **kw):
+    """rep's snapshot with a REAL state section: the entries the checker's state writer (oracle/lo_state_write.hpp) gives for rep's history"""
+    st, ents = _oracle.state_entries([rep.export()])
+    assert st in (0, 4), st
+    return rep.export_snapshot(state=ents, **kw)
+
+
+def shallow_snapshot(early_blobs, all_blobs, vv, root_frontiers, **kw):
+    """a shallow snapshot as shallow_snapshot.rs:32-190 lays it out: third section = the state at the shallow root + `fr`, second section =
+    the latest state's entries that differ from the root's, first section = the oplog's `vv` / `fr` (the history above the root is left
+    out here: neither state reader needs it, and no reader could replay it without the ops below the root)"""
+    st0, root = _oracle.state_entries(early_blobs)
+    st1, latest = _oracle.state_entries(all_blobs)
+    assert st0 in (0, 4) and st1 in (0, 4)
+    same = set(root)
+    overlay = [kv for kv in latest if kv not in same]
+    root_sst = wire.sstable(root + [(b"fr", wire.encode_frontiers(root_frontiers))], kw.get("block_size", 4096), kw.get("compress", True))
+    return wire.encode_snapshot([], [], vv, [], state=overlay, shallow_root_state=root_sst, **kw)
+
+
+def state_docs(n=40, first=0, styles=False):
+    docs = []
+    for seed in range(first, first + n):
+        rng = random.Random(seed)
+        mode = seed % 4
+        if mode == 3:
+            reps = _fuzz.movable_session(seed, n_peers=3, n_steps=80, nested=seed % 8 == 3)
+        elif mode == 2:
+            reps = _fuzz.nested_session(seed, n_peers=3, n_steps=100)
+        else:
+            reps = _fuzz.random_session(seed, n_peers=rng.randint(2, 4), n_steps=rng.randint(40, 200), kinds=("text", "list", "map"), styles=styles, max_ins=20)
+        kw = [dict(), dict(block_size=200), dict(compress=False), dict(block_size=64, max_block=300), dict(block_size=1 << 16, max_block=1 << 15)][seed % 5]
+        docs += [[real_snapshot(reps[0], **kw)], [real_snapshot(reps[-1], **kw)]]
+    return docs
+
+
+def shallow_docs(n=12, first=300):
+    """(docs, frontiers, want): generated shallow snapshots at their latest version and at their shallow root"""
+    docs, fronts, want = [], [], []
+    for seed in range(first, first + n):
+        reps = _fuzz.random_session(seed, n_peers=2, n_steps=120, kinds=("text", "list", "map"), max_ins=12, sync_prob=0.0)
+        a = reps[0]
+        own = a.changes.get(a.peer, [])
+        k = max(1, len(own) // 2)
+        if not own or not all(all(d[0] == a.peer for d in c.deps) for c in own[:k]):
+            continue
+        early = wire.Replica(a.peer); early.changes = {a.peer: own[:k]}
+        root_fr = [(a.peer, own[k - 1].ctr_end - 1)]
+        full = _fuzz.blobs_of(reps)
+        vv = {}
+        for r in reps:
+            if r.changes.get(r.peer):
+                vv[r.peer] = r.changes[r.peer][-1].ctr_end
+        snap = shallow_snapshot([early.export()], full, vv, root_fr, **([dict(), dict(block_size=128)][seed % 2]))
+        w_latest, w_root = _oracle.merge(full), _oracle.merge([early.export()])
+        docs += [[snap], [snap]]; fronts += [None, wire.encode_frontiers(root_fr)]
+        want += [w_latest, (w_root[0], w_root[1], w_latest[2], 0)]      # (a checkout does not move the oplog's version vector)
+    return docs, fronts, want
+
+
+def _ref_blobs():
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_fixtures.json")))
+    return {k: bytes.fromhex(v) for k, v in fx["blobs"].items()}
+
+
+def check_state_path(ctx_factory, n=40):
+    """the state path against the history path and the checker: generated snapshots with real state sections, the reference-held
+    snapshots, generated and reference-held shallow snapshots (loro_js_interop.rs:129-147), the fall back when an import follows"""
+    import os
+    docs = state_docs(n)
+    want = _oracle.merge_batch(docs, threads=8)
+    assert all(w[0] == 0 for w in want)
+    with ctx_factory() as c:
+        got = c.merge_batch(docs)
+        assert c.b.state_documents(c.h) == len(docs)
+        assert got == want
+        for d, w in zip(docs, want):                              # the two state readers agree, byte for byte, with the history
+            assert _oracle.snapshot_state(d[0]) == (w[0], w[1])
+        # lm_richtext needs marks and the real ids of child containers — only the history has them: the batch is staged again through
+        # the ChangeStores and run again (same bytes)
+        styled = state_docs(8, first=500, styles="rich")
+        sw_ = _oracle.merge_batch(styled, threads=8)
+        assert c.merge_batch(styled) == sw_ and c.b.state_documents(c.h) == len(styled)
+        assert c.richtext() == _oracle.richtext_batch(styled) and c.b.state_documents(c.h) == 0 and c.fetch() == sw_
+        os.environ["LM_SNAPSHOT_STATE"] = "0"
+        try:
+            assert c.merge_batch(docs) == want and c.b.state_documents(c.h) == 0
+        finally:
+            del os.environ["LM_SNAPSHOT_STATE"]
+        # placeholder states (wire's default writer) are declined: the ChangeStore is what such a document is staged from
+        plain = [[_fuzz.random_session(7, n_peers=2, n_steps=60, kinds=("text", "map"))[0].export_snapshot()]]
+        assert c.merge_batch(plain) == _oracle.merge_batch(plain) and c.b.state_documents(c.h) == 0
+        # the reference-held snapshots: three with history (the state gives what the history gives), one shallow
+        B = _ref_blobs()
+        names = ["snapshot.blob", "snapshot.ts.blob", "runtime-snapshot.ts.blob", "shallow.ts.blob"]
+        ref = [[B[k]] for k in names]
+        got = c.merge_batch(ref)
+        assert c.b.state_documents(c.h) == 4
+        hist = _oracle.merge_batch(ref[:3])
+        assert got[:3] == hist
+        assert got[3] == (0, b'{"text":"0123456789"}', wire.encode_vv({77: 10}), 0)            # loro_js_interop.rs:129-139
+        root = c.merge_batch([[B["shallow.ts.blob"]]], [wire.encode_frontiers([(77, 4)])])     # loro_js_interop.rs:141-147 (shallow_since_vv[77] == 4 … frontiers 77@4)
+        assert root[0] == (0, b'{"text":"01234"}', wire.encode_vv({77: 10}), 0) and c.b.state_documents(c.h) == 1
+        # … any other version of a shallow snapshot needs ops replayed over a state base: reported, not guessed
+        other = c.merge_batch([[B["shallow.ts.blob"]]], [wire.encode_frontiers([(77, 6)])])
+        assert other[0][0] == 4 and not other[0][1]
+        # generated shallow snapshots, latest version and shallow root, next to ordinary documents
+        sd, sf, sw = shallow_docs()
+        assert len(sd) >= 8
+        mix_d, mix_f = sd + docs[:6], sf + [None] * 6
+        got = c.merge_batch(mix_d, mix_f)
+        assert got == sw + want[:6] and c.b.state_documents(c.h) == len(mix_d)
+        # an import into a batch staged from states: the snapshots are staged once more through their ChangeStore
+        reps = _fuzz.random_session(90, n_peers=2, n_steps=80, kinds=("text", "map"))
+        a, b = reps[0], reps[-1]
+        own_b = wire.Replica(b.peer); own_b.changes = {b.peer: b.changes.get(b.peer, [])}
+        snap = real_snapshot(a)
+        first = c.merge_batch([[snap], docs[0]])
+        assert c.b.state_documents(c.h) == 2 and first[0] == _oracle.merge([a.export()])
+        c.import_more([[own_b.export()], []])
+        c.run()
+        after = c.fetch()
+        sess = _oracle.Session()
+        sess.step([a.export()])
+        assert after[0] == sess.step([own_b.export()]) and after[1] == want[0]
+
+
+def test_documents_staged_from_their_snapshots_state_sections():
+    check_state_path(lambda: Context(_emu.binding()), n=24)

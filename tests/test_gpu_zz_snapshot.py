@@ -44,3 +44,9 @@ def test_snapshot_of_a_large_document_and_resident_documents():
         S.test_snapshots_and_resident_documents()
     finally:
         S._emu = S_emu
+
+
+def test_documents_staged_from_their_snapshots_state_sections():
+    """SURVEY §8f N3 (fast_snapshot.rs:168-258): one snapshot = its state section, no history uploaded / decoded / replayed; shallow
+    snapshots at their latest version and at their shallow root (loro_js_interop.rs:129-147)"""
+    S.check_state_path(_engine, n=60)

@@ -334,3 +334,23 @@ def test_shallow_snapshot_state_at_its_latest_version_and_at_its_root():
     assert _oracle.snapshot_state(BLOB["shallow.ts.blob"], root_only=True) == (0, b'{"text":"01234"}')
     # (the history path cannot render it: the ops below the shallow root are gone — LM_UNSUPPORTED there, oracle and device)
     assert _oracle.merge_batch([[BLOB["shallow.ts.blob"]]])[0][0] == 4
+
+
+def test_the_state_writer_of_the_test_generators_round_trips_through_the_pinned_reader():
+    """oracle/lo_state_write.hpp (the generator behind tests/test_emu_snapshot.py real_snapshot) against lo_state.hpp, the reader the
+    tests above pin on the Rust- and TS-written fixtures: write the state of a history, read it back, get the history's value —
+    on the fixtures' own histories and on generated sessions (nested children, MovableLists, styled text)"""
+    import _fuzz
+    from loro_amd import wire
+    for name in ("updates.blob", "runtime-updates.ts.blob"):
+        st, ents = _oracle.state_entries([BLOB[name]])
+        hist = _oracle.merge_batch([[BLOB[name]]])[0]
+        snap = wire.encode_snapshot([], [], {}, [], state=ents)
+        assert st == hist[0] and _oracle.snapshot_state(snap) == (hist[0], hist[1])
+    for seed in range(12):
+        reps = [_fuzz.movable_session(seed, n_peers=3, n_steps=60, nested=True), _fuzz.nested_session(seed, n_peers=3, n_steps=80),
+                _fuzz.random_session(seed, n_peers=3, n_steps=80, kinds=("text", "list", "map"), styles=True)][seed % 3]
+        blobs = _fuzz.blobs_of(reps)
+        st, ents = _oracle.state_entries(blobs)
+        hist = _oracle.merge(blobs)
+        assert st == hist[0] == 0 and _oracle.snapshot_state(wire.encode_snapshot([], [], {}, [], state=ents)) == (0, hist[1])

@@ -37,6 +37,8 @@ sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, 'tests')
 from loro_amd._cabi import Binding, Context
 from loro_amd import workload
 docs = [workload.Cfg2Template(50000, 25000, seed=0, commit_every=10, fuse=True).stamp(0)]
+if os.environ.get('ISA_DOC') == 'cfg3':   # one LWW Map document of configs[2]'s block shape (4 peers x 2,500 writes on 1,024 keys): ISA_DOC=cfg3 ... k_map_fused
+    docs = [workload.cfg3_doc(0, n_peers=4, n_writes=2500, n_keys=1024, combined=True)]
 if os.environ.get('ISA_DOC') == 'cfg4':   # one configs[3] document (mixed List / Map / Text, 4 peers, pairwise syncs): ISA_DOC=cfg4 ... k_integrate_span
     import _fuzz
     docs = [_fuzz.blobs_of(_fuzz.random_session(1000, n_peers=4, n_steps=1000, kinds=('text', 'list', 'map'), sync_prob=0.02, styles=True))]
