@@ -100,6 +100,20 @@ int lm_merge_batch(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs, lm_doc_out
  * (may be repeated), lm_fetch copies the rendered states back and fills outs[0..n_docs). */
 int lm_stage(lm_ctx* ctx, const lm_doc_in* docs, size_t n_docs);
 int lm_run(lm_ctx* ctx);
+
+/* Direct staging (round 6).  lm_stage copies the blobs host -> pinned staging buffer -> HBM; the first hop (a gather by a few host
+ * threads) is what bounds a server that feeds the engine from pageable memory (~38 GB/s on the development box).  A host that
+ * receives its blobs INTO memory obtained from lm_host_alloc (pinned; release with lm_host_free) skips it: when every blob of a
+ * batch lies inside one such region — each at a 16-byte aligned address, in the order they are staged (document by document, blob
+ * by blob), without overlap, and packed reasonably densely (the span from the first blob to the end of the last is copied whole:
+ * it must not exceed twice the blobs' bytes + 1 MiB) — lm_stage hands that span to the copy engine as it is and touches no byte
+ * of it.  The bytes between blobs are never interpreted.  The region must stay valid and unchanged until the NEXT lm_stage of the
+ * context (documents that are replayed — lm_redo_documents, lm_import after a state-staged batch — are read from it again).
+ * Anything else (a blob outside the region, unaligned, out of order; a snapshot, which is reframed on the host) takes the gather
+ * as before.  lm_staged_direct: 1 when the batch staged last took this path.  LM_STAGE_DIRECT=0 switches it off. */
+void* lm_host_alloc(size_t bytes);
+void lm_host_free(void* p);
+int lm_staged_direct(lm_ctx* ctx);
 int lm_fetch(lm_ctx* ctx, lm_doc_out* outs);
 /* Asynchronous lm_run: lm_run_async returns at once, lm_wait blocks until that run is finished (0 = ok).  Between the
  * two calls only other contexts may be used.  Two contexts in flight overlap one batch's decode stages with the other's

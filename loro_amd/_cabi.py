@@ -21,7 +21,7 @@ class RunStats(ctypes.Structure):
 
 SYMBOLS = ["create", "destroy", "last_error", "merge_batch", "stage", "run", "fetch", "get_stats", "set_profiling", "kernel_time", "selftest", "result_meta", "result_hashes", "n_streams", "run_async", "wait",
            "encode_block", "encode_updates", "free_bytes", "import", "resident_fresh", "import_modes", "import_lca", "export", "comm_unique_id", "comm_init", "summary_allgather",
-           "summary_layout", "summary_rows_device", "summary_allgather_device", "shared_documents", "richtext", "richtext_result", "fused_documents", "redo_documents", "state_documents"]
+           "summary_layout", "summary_rows_device", "summary_allgather_device", "shared_documents", "richtext", "richtext_result", "fused_documents", "redo_documents", "state_documents", "host_alloc", "host_free", "staged_direct"]
 
 
 class Binding:
@@ -69,6 +69,9 @@ class Binding:
         self.summary_allgather_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
         self.resident_fresh = g("resident_fresh"); self.resident_fresh.restype = ctypes.c_int; self.resident_fresh.argtypes = [ctypes.c_void_p]
         self.shared_documents = g("shared_documents"); self.shared_documents.restype = ctypes.c_int; self.shared_documents.argtypes = [ctypes.c_void_p]
+        self.host_alloc = g("host_alloc"); self.host_alloc.restype = ctypes.c_void_p; self.host_alloc.argtypes = [ctypes.c_size_t]
+        self.host_free = g("host_free"); self.host_free.restype = None; self.host_free.argtypes = [ctypes.c_void_p]
+        self.staged_direct = g("staged_direct"); self.staged_direct.restype = ctypes.c_int; self.staged_direct.argtypes = [ctypes.c_void_p]
         self.state_documents = g("state_documents"); self.state_documents.restype = ctypes.c_int; self.state_documents.argtypes = [ctypes.c_void_p]
         self.fused_documents = g("fused_documents"); self.fused_documents.restype = ctypes.c_int; self.fused_documents.argtypes = [ctypes.c_void_p]
         self.redo_documents = g("redo_documents"); self.redo_documents.restype = ctypes.c_int; self.redo_documents.argtypes = [ctypes.c_void_p]
@@ -111,6 +114,7 @@ class Context:
 
     def __init__(self, binding, device=0):
         self.b = binding
+        self.device = device
         self.h = binding.create(device)
         if not self.h:
             raise RuntimeError("lm_create failed: no usable HIP device (there is no CPU fallback)")
@@ -148,6 +152,43 @@ class Context:
                 arr[i].checkout_frontiers = f
                 arr[i].checkout_len = len(f)
         return arr, (n, keep)
+
+    def pack_pinned(self, docs, frontiers=None):
+        """_pack with the blobs copied ONCE into pinned memory of lm_host_alloc (16-byte aligned, in staging order, zero padded): what a
+        host that receives its blobs into such a region hands to lm_stage — the batch is then staged without the host-side gather
+        (include/loro_merge.h "Direct staging").  Returns (arr, keep) like _pack; release with free_pinned(packed)."""
+        n = len(docs)
+        total = sum(((len(x) + 15) & ~15) for blobs in docs for x in blobs) + 64
+        base = self.b.host_alloc(total)
+        if not base:
+            raise MemoryError("lm_host_alloc failed")
+        ctypes.memset(base, 0, total)
+        arr = (DocIn * max(n, 1))()
+        keep = [("pinned", base)]
+        at = 0
+        for i, blobs in enumerate(docs):
+            ptrs = (ctypes.c_void_p * max(len(blobs), 1))()
+            lens = (ctypes.c_size_t * max(len(blobs), 1))(*[len(x) for x in blobs])
+            for k, x in enumerate(blobs):
+                ctypes.memmove(base + at, bytes(x), len(x))
+                ptrs[k] = base + at
+                at += (len(x) + 15) & ~15
+            keep.append((ptrs, lens))
+            arr[i].blobs = ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_char_p))
+            arr[i].blob_lens = lens
+            arr[i].n_blobs = len(blobs)
+            f = frontiers[i] if frontiers is not None else None
+            if f is not None:
+                f = bytes(f)
+                keep.append(f)
+                arr[i].checkout_frontiers = f
+                arr[i].checkout_len = len(f)
+        return arr, (n, keep)
+
+    def free_pinned(self, packed):
+        tag, base = packed[1][1][0]
+        assert tag == "pinned"
+        self.b.host_free(base)
 
     def stage(self, docs, frontiers=None):
         """docs: list of lists of update blobs.  frontiers: optional list (one per document) of None or encoded

@@ -709,6 +709,15 @@ int LM_API(export)(void* c, size_t doc, const uint8_t* from_vv, size_t from_len,
   } catch (const std::exception& e) { x->err = e.what(); return -1; }
 }
 void LM_API(free_bytes)(uint8_t* p) { free(p); }
+// pinned host memory for the blobs a host hands to lm_stage (include/loro_merge.h "Direct staging")
+void* LM_API(host_alloc)(size_t bytes) {
+  if (!bytes) return nullptr;
+  void* p = lmbe::halloc(bytes);
+  if (p) lm::host_regions().add(p, bytes);
+  return p;
+}
+void LM_API(host_free)(void* p) { if (p && lm::host_regions().remove(p)) lmbe::hfree(p); }
+int LM_API(staged_direct)(void* c) { auto* x = (lm_ctx_impl*)c; int n = 0; for (uint32_t p = 0; p < x->n_parts(); p++) n += x->parts[p]->staged_direct ? 1 : 0; return n == (int)x->n_parts() ? 1 : 0; }
 // Richtext values of the documents of the last lm_run (lm_k_richtext.h): lm_richtext renders them on the device and copies them
 // back, lm_richtext_result hands out one document's bytes (valid until the next lm_richtext / lm_stage / lm_destroy).
 int LM_API(richtext)(void* c) {

@@ -123,6 +123,17 @@ LM_DEV uint64_t rle_next_uvar(RleCur& c) {
   c.rem--;
   return c.run ? (uint64_t)c.val : rd_uleb(c.r);
 }
+// the (wrapping) sum of the next n values of a uvar column: a run is k x its value
+LM_DEV uint64_t rle_sum_uvar(RleCur& c, uint64_t n) {
+  uint64_t tot = 0;
+  while (n) {
+    if (c.rem > 0 && c.run) {
+      const uint64_t k = (uint64_t)c.rem < n ? (uint64_t)c.rem : n;
+      tot += k * (uint64_t)c.val; c.rem -= (int64_t)k; n -= k;
+    } else { tot += rle_next_uvar(c); n--; }
+  }
+  return tot;
+}
 LM_DEV uint32_t rle_next_u8(RleCur& c) {
   if (c.rem == 0) { if (!rle_head(c)) return 0; if (c.run) c.val = (int64_t)rd_u8(c.r); }
   c.rem--;
@@ -302,6 +313,27 @@ LM_DEV bool bool_next(BoolCur& c) {
   return c.cur;
 }
 
+// n x bool_next with the values dropped: whole runs at a time
+LM_DEV void bool_skip(BoolCur& c, uint64_t n) {
+  while (n) {
+    if (c.rem == 0) { (void)bool_next(c); n--; continue; }
+    const uint64_t k = c.rem < n ? c.rem : n;
+    c.rem -= k; n -= k;
+  }
+}
+
+// n x bool_next: how many of the values are true
+LM_DEV uint64_t bool_count(BoolCur& c, uint64_t n) {
+  uint64_t t = 0;
+  while (n) {
+    if (c.rem == 0) { t += bool_next(c) ? 1u : 0u; n--; continue; }
+    const uint64_t k = c.rem < n ? c.rem : n;
+    if (c.cur) t += k;
+    c.rem -= k; n -= k;
+  }
+  return t;
+}
+
 // DeltaOfDelta cursor (docs/encoding.md:713-726)
 struct DodCur { const uint8_t* p; uint64_t nbits, pos; int64_t prev, delta; bool has_first, first_taken, bad; uint32_t last_used; };
 LM_DEV uint64_t dod_bits(DodCur& c, int n) {
@@ -339,6 +371,21 @@ LM_DEV int64_t dod_next(DodCur& c) {
   c.delta = (int64_t)((uint64_t)c.delta + (uint64_t)dd);      // wrapping, like the release-mode Rust reader (damaged input only)
   c.prev = (int64_t)((uint64_t)c.prev + (uint64_t)c.delta);
   return c.prev;
+}
+// n x dod_next with the values dropped (columns read for their shape only): a byte of zero bits is eight values with a
+// delta-of-delta of 0 — constant strides, the common case (lamports of one-op changes, equal timestamps) — taken in one step
+LM_DEV void dod_skip(DodCur& c, uint64_t n) {
+  if (n == 0) return;
+  if (!c.has_first) { c.bad = true; return; }
+  if (!c.first_taken) { c.first_taken = true; n--; }
+  while (n) {
+    if (n >= 8 && (c.pos & 7) == 0 && c.pos + 8 <= c.nbits && c.p[c.pos >> 3] == 0) {
+      c.pos += 8; n -= 8;
+      c.prev = (int64_t)((uint64_t)c.prev + 8ull * (uint64_t)c.delta);
+      continue;
+    }
+    (void)dod_next(c); n--;
+  }
 }
 // after taking `n` values: validate the used-bits byte and advance the byte reader past the stream
 LM_DEV void dod_finish(DodCur& c, Rd& r, uint64_t n) {

@@ -576,11 +576,13 @@ template <bool EXACT, bool HEAD = false> LM_DEV void block_decode_lane(Dev d) {
     // other dep counts AnyRle<usize>[N]
     RleCur dc = rle_make(bc.r);
     uint32_t dcur = dep0;
+    uint64_t others_total = 0;
     for (uint32_t i = 0; i < N; i++) {
       uint64_t others = rle_next_uvar(dc);
       ChangeRow c = d.chg[chg0 + i];
       uint32_t ds = c.op0;
       if (dcur + ds + others > dep0 + cnt[BC_DEP]) { st = ST_DECODE_ERROR; others = 0; ds = 0; }
+      others_total += others;
       c.dep0 = dcur;
       c.n_dep = ds + (uint32_t)others;
       if (ds) {
@@ -596,7 +598,7 @@ template <bool EXACT, bool HEAD = false> LM_DEV void block_decode_lane(Dev d) {
     // dep peer idx AnyRle<u32>[D]
     RleCur pc = rle_make(dc.r);
     uint64_t D = 0;
-    for (uint32_t i = 0; i < N; i++) {
+    for (uint32_t i = 0; i < N && others_total; i++) {   // (no dependency on another peer in the whole block: both columns are empty)
       ChangeRow c = d.chg[chg0 + i];
       for (uint32_t k = c.dep0 + c.op0; k < c.dep0 + c.n_dep; k++) {
         uint64_t pi = rle_next_uvar(pc);
@@ -621,7 +623,7 @@ template <bool EXACT, bool HEAD = false> LM_DEV void block_decode_lane(Dev d) {
     // wire lamports (DeltaOfDelta[N-1]) are validated for shape only: lamports are recomputed from deps on
     // import (outdated_encode_reordered.rs:61-62)
     DodCur ld = dod_make(hr);
-    for (uint32_t i = 0; i + 1 < N; i++) (void)dod_next(ld);
+    dod_skip(ld, N ? N - 1 : 0);
     dod_finish(ld, hr, N - 1);
     {   // the last change's lamport = lamport_start + lamport_len - its length, in u32 with checked arithmetic (block_meta_encode.rs:215-221):
         // the wire lamports are not used (recomputed from the dependencies on import), this verdict is
@@ -636,11 +638,10 @@ template <bool EXACT, bool HEAD = false> LM_DEV void block_decode_lane(Dev d) {
   {
     Rd m = blk_sec(d, bd, SEC_META);
     DodCur td = dod_make(m);
-    for (uint32_t i = 0; i < N; i++) (void)dod_next(td);
+    dod_skip(td, N);
     dod_finish(td, m, N);
     RleCur mc = rle_make(m);
-    uint64_t tot = 0;
-    for (uint32_t i = 0; i < N; i++) tot += rle_next_uvar(mc);
+    const uint64_t tot = rle_sum_uvar(mc, N);
     // (the reference maps EVERY failure of these two columns — a timestamp stream that does not decode, too few values, a run that
     // announces more than N — to DecodeDataCorruptionError (block_encode.rs:563-571: `.map_err(|_| LoroError::DecodeDataCorruptionError)`
     // on both decoders; only the HEADER columns of block_meta_encode.rs are DecodeError); lengths beyond the message bytes likewise)

@@ -130,6 +130,69 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
     n_peers = cnt[BC_PEER]; n_ops = cnt[BC_OP]; n_keys = cnt[BC_KEY]; n_cids = cnt[BC_CID];
   }
   int32_t st = ST_OK;          // errors of the sequential sections (role 0) — they precede every row error
+  // ---- a block of many changes (one change per keystroke: ≈200 per block): the change rows and the own-peer dependency rows are
+  // written by ALL EIGHT lanes of the block, an eighth of the changes each.  The three columns involved — change lengths (N-1
+  // varints), dep_on_self (BoolRle), other-dependency counts (AnyRle) — follow one another without length prefixes, so every lane
+  // walks them whole, but cheaply (sums and positions only: runs are taken in one step), and spends the full price — rows, stores —
+  // on its own changes only.  No lane talks to another: all eight compute the same totals and reach the same verdict.  ANY anomaly
+  // (a reader that runs out, lengths beyond the block's counters, dependency rows that do not add up, a first change that depends on
+  // "its peer's counter -1") leaves everything to role 0's sequential walk below, which owns the error codes.
+  // (Role 0 alone spent 57 % of the decoder's time on such blocks — profiles/r04_decoder_phases.log — with seven lanes idle.)
+  bool par = false;
+  Rd par_h = rd_make(blk_p, 0);           // role 0 continues from these when the shared walk stands
+  Rd par_after_bool = par_h, par_dc_end = par_h;
+  uint64_t par_known = 0, par_others = 0;
+  if (ok && N >= 16) {
+    Rd h = sec(SEC_HEADER);
+    (void)rd_uleb(h);
+    rd_skip(h, (uint64_t)n_peers * 8);
+    const uint32_t C = (N + 7) / 8;
+    const uint32_t i0 = r * C < N ? r * C : N, i1 = i0 + C < N ? i0 + C : N;
+    // change lengths: the counter my chunk starts at, the sum of all, where the column ends
+    Rd h_mine = h;
+    uint64_t pre = 0, known = 0;
+    bool empty_change = false;
+    for (uint32_t i = 0; i + 1 < N; i++) {
+      if (i == i0) { h_mine = h; pre = known; }
+      const uint64_t l = rd_uleb(h);
+      empty_change |= l == 0;
+      known += l;
+    }
+    if (i0 + 1 >= N) { h_mine = h; pre = known; }
+    bool fine = !h.bad && !empty_change && known < bd.counter_len;   // (every change holds an id: no counter is met twice, none is 0 behind the first)
+    // dep_on_self: values in front of my chunk, in the whole column; the column must end with its N-th value
+    BoolCur bcur = bool_make(h);
+    { BoolCur f = bcur; if (bool_next(f) && bd.counter_start == 0) fine = false; }
+    const uint64_t t_pre = bool_count(bcur, i0);
+    BoolCur b_mine = bcur;
+    const uint64_t t_all = t_pre + bool_count(bcur, N - i0);
+    if (bcur.rem != 0 || bcur.r.bad) fine = false;
+    // other-dependency counts: likewise
+    RleCur dcur_c = rle_make(bcur.r);
+    const uint64_t o_pre = rle_sum_uvar(dcur_c, i0);
+    RleCur d_mine = dcur_c;
+    const uint64_t o_all = o_pre + rle_sum_uvar(dcur_c, N - i0);
+    if (dcur_c.rem != 0 || dcur_c.r.bad || t_all + o_all != (uint64_t)cnt[BC_DEP] || o_all > (uint64_t)cnt[BC_DEP]) fine = false;
+    if (fine) {
+      par = true;
+      par_h = h; par_after_bool = bcur.r; par_dc_end = dcur_c.r; par_known = known; par_others = o_all;
+      uint32_t ctr = bd.counter_start + (uint32_t)pre;
+      uint32_t dc_at = dep0 + (uint32_t)(t_pre + o_pre);
+      uint64_t kn = pre;
+      for (uint32_t i = i0; i < i1; i++) {
+        uint64_t l;
+        if (i + 1 < N) { l = rd_uleb(h_mine); kn += l; } else l = bd.counter_len - known;
+        const uint32_t ds = bool_next(b_mine) ? 1u : 0u;
+        const uint32_t others = (uint32_t)rle_next_uvar(d_mine);
+        ChangeRow c;
+        c.peer = 0; c.ctr = ctr; c.len = (uint32_t)l; c.dep0 = dc_at; c.n_dep = ds + others; c.op0 = 0; c.n_op = 0; c.blk = bi;
+        d.chg[chg0 + i] = c;
+        if (ds && dc_at < dep0 + cnt[BC_DEP]) { d.dep_peer[dc_at] = 0; d.dep_ctr[dc_at] = ctr - 1; }   // (the bound: a sum that wrapped around must not become an address)
+        dc_at += ds + others;
+        ctr += (uint32_t)l;
+      }
+    }
+  }
   // ---- role 0: header, change meta, keys, container ids
   if (ok && r == 0) {
     Rd h = sec(SEC_HEADER);
@@ -146,9 +209,10 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
       // ONE lane per block — with one change per keystroke, ≈200 changes per block, that was most of the decoder's time on such
       // blocks: 52 ms of the heterogeneous batch's decode.)
       const Rd h_lens = h;              // the N-1 change lengths start here
-      uint64_t known = 0;
+      uint64_t known = par ? par_known : 0;
       uint32_t ctr = bd.counter_start;
-      for (uint32_t i = 0; i < N; i++) {
+      if (par) h = par_h;
+      for (uint32_t i = 0; i < N && !par; i++) {
         uint64_t l;
         if (i + 1 < N) { l = rd_uleb(h); known += l; if (known > bd.counter_len) { st = ST_DECODE_ERROR; l = 0; } }
         else l = bd.counter_len - (known > bd.counter_len ? bd.counter_len : known);
@@ -161,9 +225,10 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
       const BoolCur bc0 = bool_make(h);
       // the dep-count column starts where the BoolRle ends: run the bool cursor to its end first (N values)
       Rd after_bool = h;
-      {
+      if (par) after_bool = par_after_bool;
+      else {
         BoolCur t = bc0;
-        for (uint32_t i = 0; i < N; i++) (void)bool_next(t);
+        bool_skip(t, N);
         if (t.rem != 0) t.r.bad = true;
         after_bool = t.r;
       }
@@ -181,7 +246,9 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
       BoolCur bc = bc0;
       RleCur dc = dc0;
       uint32_t dcur = dep0;
-      {
+      uint64_t others_total = 0;      // dependencies on other peers in the whole block (0: the two columns that describe them are empty — no pass over the changes)
+      if (par) { others_total = par_others; dc.r = par_dc_end; dc.rem = 0; dcur = dep0 + cnt[BC_DEP]; }
+      else {
         Rd hl = h_lens;               // the changes' counters again, from their lengths
         uint64_t kn = 0;
         uint32_t cctr = bd.counter_start;
@@ -198,6 +265,7 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
             d.dep_ctr[dcur] = cctr ? cctr - 1 : 0;
           }
           dcur += ds + others;
+          others_total += others;
           uint64_t l = 0;
           if (i + 1 < N) { l = rd_uleb(hl); kn += l; if (kn > bd.counter_len) l = 0; }
           cctr += (uint32_t)l;
@@ -208,7 +276,7 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
       // dep peer idx AnyRle<u32>[D]
       RleCur pc = rle_make(dc.r);
       uint64_t D = 0;
-      {
+      if (others_total) {
         BoolCur b2 = bc0;
         RleCur d2 = dc0;
         uint32_t cur2 = dep0;
@@ -249,7 +317,7 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
       // wire lamports (DeltaOfDelta[N-1]): shape only — lamports are recomputed from deps on import
       // (outdated_encode_reordered.rs:61-62, loro_dag.rs:1179-1187)
       DodCur ld = dod_make(hr);
-      for (uint32_t i = 0; i + 1 < N; i++) (void)dod_next(ld);
+      dod_skip(ld, N ? N - 1 : 0);
       dod_finish(ld, hr, N - 1);
       {   // the last change's lamport = lamport_start + lamport_len - its length, in u32 with checked arithmetic (block_meta_encode.rs:215-221):
           // the wire lamports are not used (recomputed from the dependencies on import), this verdict is
@@ -262,11 +330,10 @@ LM_DEV void block_decode_wave_body(Dev d, uint32_t slot_cap, uint32_t head_lo, u
     {  // change_meta: timestamps + message lengths, shape only (block_encode.rs:563-571)
       Rd m = sec(SEC_META);
       DodCur td = dod_make(m);
-      for (uint32_t i = 0; i < N; i++) (void)dod_next(td);
+      dod_skip(td, N);
       dod_finish(td, m, N);
       RleCur mc = rle_make(m);
-      uint64_t tot = 0;
-      for (uint32_t i = 0; i < N; i++) tot += rle_next_uvar(mc);
+      const uint64_t tot = rle_sum_uvar(mc, N);
       if (mc.rem != 0) mc.r.bad = true;   // (a run that announces more than N values does not decode either)
       if (mc.r.bad || tot > rd_left(mc.r)) st = st ? st : ST_DATA_CORRUPTION;   // (both change_meta columns: DecodeDataCorruptionError, block_encode.rs:563-571 — lm_k_decode.h)
     }

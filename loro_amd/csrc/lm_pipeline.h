@@ -7,6 +7,8 @@
 //   LM_LAUNCH(kernel, grid, block, args...).
 #pragma once
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <atomic>
 #include <cstdint>
@@ -60,6 +62,26 @@ struct DocResult {
 };
 
 struct KernelTime { std::string name; double ms; };
+
+// ---- pinned host regions handed out by lm_host_alloc (include/loro_merge.h): blobs that already live in one of them are copied to
+// the device straight from where they are (Engine::stage "direct"), without the gather into the engine's own pinned staging buffer
+struct HostRegions {
+  std::mutex mu;
+  std::map<const uint8_t*, size_t> r;     // base -> bytes
+  void add(const void* p, size_t n) { std::lock_guard<std::mutex> g(mu); r[(const uint8_t*)p] = n; }
+  bool remove(const void* p) { std::lock_guard<std::mutex> g(mu); return r.erase((const uint8_t*)p) != 0; }
+  // the region that holds [p, p + n), or nullptr
+  const uint8_t* find(const uint8_t* p, size_t n, size_t* bytes) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = r.upper_bound(p);
+    if (it == r.begin()) return nullptr;
+    --it;
+    if (p < it->first || (size_t)(p - it->first) + n > it->second) return nullptr;
+    if (bytes) *bytes = it->second;
+    return it->first;
+  }
+};
+inline HostRegions& host_regions() { static HostRegions h; return h; }
 
 struct Engine {
   // staged input
@@ -155,7 +177,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true, snapshot_state = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true, snapshot_state = true, stage_direct = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -183,6 +205,7 @@ struct Engine {
     // a side engine (lm_capi_impl.h redo) replays the documents another configuration flagged DF_REDO: span-granular batch kernels, whatever the batch's statistics say
     if (const char* e = getenv("LM_MAP_FUSED")) k.map_fused = atoi(e) != 0;                      // 0: LWW Map documents go through the row tables like every other document (rounds 1-5)
     if (const char* e = getenv("LM_MF_MIN_ROWS")) k.mf_min_rows = (uint32_t)atoi(e);             // rows from which a Map document gets a workgroup of k_map_fused (tests: 1)
+    if (const char* e = getenv("LM_STAGE_DIRECT")) k.stage_direct = atoi(e) != 0;                // 0: blobs inside an lm_host_alloc region are gathered into the engine's staging buffer like any others
     if (const char* e = getenv("LM_SNAPSHOT_STATE")) k.snapshot_state = atoi(e) != 0;            // 0: a document given as one snapshot is replayed from its ChangeStore (rounds 2-5) instead of rendered from its state section
     if (const char* e = getenv("LM_MF_CHG_RATIO")) k.mf_chg_ratio = (uint32_t)atoi(e);           // … and rows per change it needs on average (tests: 0)
     if (force_span) { k.span = true; k.span_auto = false; k.posdel = true; k.redo = false; k.map_fused = false; }
@@ -214,7 +237,7 @@ struct Engine {
     for (size_t k = 0; k < items.size(); k++) {
       const uint32_t i = items[k].doc;
       Engine& parent = *parents[k];
-      for (uint32_t b = parent.st_doc_blob[i]; b < parent.st_doc_blob[i + 1]; b++) { bp[k].push_back(parent.h_stage + parent.st_blob_off[b]); bl[k].push_back(parent.st_blob_len[b]); }
+      for (uint32_t b = parent.st_doc_blob[i]; b < parent.st_doc_blob[i + 1]; b++) { bp[k].push_back(parent.st_base + parent.st_blob_off[b]); bl[k].push_back(parent.st_blob_len[b]); }
       in[k] = DocIn{bp[k].data(), bl[k].data(), bp[k].size(), items[k].front, items[k].front_len};
     }
     stage(in.data(), in.size());
@@ -254,6 +277,8 @@ struct Engine {
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
   uint8_t* h_stage = nullptr;      // pinned staging buffer of lm_stage (grow-only)
+  const uint8_t* st_base = nullptr;   // where the staged blobs are on the host: h_stage, or the caller's lm_host_alloc region (direct staging) — st_blob_off counts from here
+  bool staged_direct = false;
   size_t h_stage_cap = 0;
   ~Engine() { release_all(); if (h_stage) lmbe::hfree(h_stage); lmbe::stream_destroy(sc); }
   void release_all() {
@@ -352,10 +377,26 @@ struct Engine {
     for (size_t i = nd; i-- > 0;) if (h_froot_off[i] > h_froot_off[i + 1]) h_froot_off[i] = h_froot_off[i + 1];
     b_froot.ensure(froot.size() + 16); if (!froot.empty()) lmbe::h2d(b_froot.p, froot.data(), froot.size());
     b_froot_off.ensure((nd + 1) * 8); lmbe::h2d(b_froot_off.p, h_froot_off.data(), (nd + 1) * 8);
+    // Direct staging: every blob of this part lies — 16-byte aligned, in staging order, without overlap — inside ONE region of
+    // lm_host_alloc (pinned): the span [first blob, end of the last) is copied to the device as it is, chunk by chunk, and a blob's
+    // device offset is its distance from the first; no byte is touched by the host.  (A span much larger than its blobs — a caller
+    // that scattered them over the region — is not worth copying: gathered like pageable memory.)
+    bool direct = kn.stage_direct && nb > 0 && conv.empty();
+    if (direct) {
+      uint64_t sum = 0;
+      for (size_t j = 0; j < nb && direct; j++) {
+        sum += blen[j];
+        if (((uintptr_t)bsrc[j] & 15) || (j && bsrc[j] < bsrc[j - 1] + blen[j - 1])) direct = false;
+      }
+      const uint64_t span = direct ? (uint64_t)(bsrc[nb - 1] + blen[nb - 1] - bsrc[0]) : 0;
+      if (direct && (span > 2 * sum + (1u << 20) || !host_regions().find(bsrc[0], (size_t)span, nullptr))) direct = false;
+    }
+    staged_direct = direct;
     b = 0;
     for (size_t i = 0; i < nd; i++)
       for (size_t k = 0; k < docs[i].n; k++, b++) {
         if (blen[b] > 0xfffffff0ull) throw std::runtime_error("blob larger than 4 GiB");
+        if (direct) off = (uint64_t)(bsrc[b] - bsrc[0]);
         h_blob_off[b] = off;
         h_blob_len[b] = (uint32_t)blen[b];
         h_blob_doc[b] = (uint32_t)i;
@@ -367,14 +408,21 @@ struct Engine {
     // Pinned staging buffer, kept across batches (pinning a fresh gigabyte per batch cost more than the copy).  The
     // blobs are gathered into it by a few worker threads in ≈16 MB chunks of destination, and every chunk is handed
     // to the copy engine as soon as it is complete: the gather of chunk c+1 runs beside the DMA of chunk c.
-    if (data_bytes > h_stage_cap) {
+    if (!direct && data_bytes > h_stage_cap) {
       if (h_stage) lmbe::hfree(h_stage);
       h_stage_cap = data_bytes + data_bytes / 4 + 4096;
       h_stage = (uint8_t*)lmbe::halloc(h_stage_cap);
       if (!h_stage) { h_stage_cap = 0; throw std::runtime_error("host staging allocation failed"); }
     }
     b_data.ensure(data_bytes);
-    {
+    st_base = direct ? bsrc[0] : h_stage;
+    if (direct) {
+      // (the last blob's padding and the 64 bytes of slack behind it are the device's to clear: the caller's span ends with the blob)
+      const uint64_t span = (uint64_t)(bsrc[nb - 1] + blen[nb - 1] - bsrc[0]);
+      uint64_t CHUNK = 64ull << 20;
+      for (uint64_t o = 0; o < span; o += CHUNK) lmbe::h2d_async((uint8_t*)b_data.p + o, bsrc[0] + o, span - o < CHUNK ? span - o : CHUNK);
+      lmbe::dmemset((uint8_t*)b_data.p + span, 0, data_bytes - span);
+    } else {
       uint8_t* host = h_stage;
       const std::vector<const uint8_t*>& src = bsrc;
       std::vector<size_t> cut{0};           // chunk c = blobs [cut[c], cut[c+1])
@@ -471,7 +519,7 @@ struct Engine {
     std::vector<std::vector<uint8_t>> keep(n_blobs);
     for (size_t i = 0; i < nd; i++) {
       if (!hist[i].empty()) { bp[i].push_back(hist[i].data()); bl[i].push_back(hist[i].size()); }
-      else for (uint32_t b = st_doc_blob[i]; b < st_doc_blob[i + 1]; b++) { keep[b].assign(h_stage + st_blob_off[b], h_stage + st_blob_off[b] + st_blob_len[b]); bp[i].push_back(keep[b].data()); bl[i].push_back(keep[b].size()); }
+      else for (uint32_t b = st_doc_blob[i]; b < st_doc_blob[i + 1]; b++) { keep[b].assign(st_base + st_blob_off[b], st_base + st_blob_off[b] + st_blob_len[b]); bp[i].push_back(keep[b].data()); bl[i].push_back(keep[b].size()); }
       const bool hf = foff.size() > i + 1 && foff[i + 1] > foff[i];
       in[i] = DocIn{bp[i].data(), bl[i].data(), bp[i].size(), hf ? fronts.data() + foff[i] : nullptr, hf ? (size_t)(foff[i + 1] - foff[i]) : 0};
     }

@@ -130,3 +130,11 @@ def test_richtext_values_of_checked_out_entries_of_a_folded_batch(engine):
     got = engine.richtext()
     assert engine.fetch() == res == _oracle.merge_batch(docs, threads=8, frontiers=fronts)
     _richtext.same(got, _oracle.richtext_batch(docs, fronts), "folded")
+
+
+def test_direct_staging_from_pinned_host_memory():
+    """include/loro_merge.h "Direct staging": blobs inside an lm_host_alloc region reach the device without the host-side gather — same
+    results, the replay paths read the caller's region, whatever does not fit the contract is gathered"""
+    import loro_amd
+    import test_emu_stage_direct
+    test_emu_stage_direct.check_direct(lambda: loro_amd.MergeEngine(0))
