@@ -147,9 +147,12 @@ int lm_redo_documents(lm_ctx* ctx);
 /* lm_state_documents: documents of the batch staged last that were staged from their snapshot's STATE section instead of its history
  * (encoding/fast_snapshot.rs:168-258: an empty document that imports a snapshot takes its state store from that
  * section and replays nothing).  A document qualifies when it is ONE FastSnapshot blob rendered at its latest version — or ONE
- * shallow snapshot rendered at exactly its shallow root (checkout_frontiers == shallow_since_frontiers, loro_js_interop.rs:141-147) —
- * and every state value is of a kind this engine renders; the staged bytes are then proportional to the STATE, the history is
- * neither uploaded nor decoded nor replayed, and `vv` is the snapshot's own.  A later lm_import into such a batch stages the
+ * shallow snapshot rendered at exactly its shallow root (checkout_frontiers == shallow_since_frontiers, loro_js_interop.rs:141-147),
+ * or ONE snapshot + update blobs whose changes continue its history (every dependency below the snapshot's version is its
+ * frontiers; loro_amd/csrc/lm_snapshot_base.h) — and every state value is of a kind this engine renders; the staged bytes are then
+ * proportional to the STATE (+ the updates), the snapshot's history is neither uploaded nor decoded nor replayed, and `vv` is the
+ * snapshot's own merged with what the updates add.  Updates concurrent with part of the snapshot's history need that history: such
+ * a document is replayed from the snapshot's ChangeStore (same bytes out).  A later lm_import into such a batch stages the
  * snapshots once more through their ChangeStore (a history is what an import builds on).  LM_SNAPSHOT_STATE=0 switches it off. */
 int lm_state_documents(lm_ctx* ctx);
 

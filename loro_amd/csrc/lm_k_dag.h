@@ -223,6 +223,23 @@ LM_DEV uint32_t find_change(const Dev& d, const DocMeta& m, uint32_t peer, uint3
 #else
 #define DAG_PH(i) do {} while (0)
 #endif
+// A document staged on a snapshot's STATE (lm_snapshot.h / lm_snapshot_base.h) carries its BASE version in d.vvo: 8 bytes = the
+// synthetic peer that writes the state, then the snapshot's version vector (postcard map, ascending peers).  History below it is
+// known without being staged: a peer's changes may start at its base end, and the version the document reports includes the base.
+LM_DEV bool vvo_has(const Dev& d, uint32_t doc) { return d.vvo && d.vvo_off[doc + 1] - d.vvo_off[doc] > 8; }
+LM_DEV uint64_t vvo_synth_peer(const Dev& d, uint32_t doc) { uint64_t v = 0; const uint8_t* p = d.vvo + d.vvo_off[doc]; for (int k = 0; k < 8; k++) v |= (uint64_t)p[k] << (8 * k); return v; }
+LM_DEV uint32_t vvo_base_end(const Dev& d, uint32_t doc, uint64_t peer) {
+  if (!vvo_has(d, doc)) return 0;
+  Rd r = rd_make(d.vvo + d.vvo_off[doc] + 8, d.vvo_off[doc + 1] - d.vvo_off[doc] - 8);
+  const uint64_t n = rd_uleb(r);
+  for (uint64_t i = 0; i < n && !r.bad; i++) {
+    const uint64_t q = rd_uleb(r);
+    const uint64_t z = rd_uleb(r);
+    if (q == peer) return (uint32_t)(z >> 1);
+    if (q > peer) break;
+  }
+  return 0;
+}
 LM_KERNEL void k_dag_a(Dev d, DevDag g) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
@@ -247,7 +264,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     }
     g.blk_sorted[m.blk0 + rank] = bi;
   }
-  for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_ext[p] = 0; s_valid[p] = 0; d.peer_chg0[m.praw0 + p] = 0; d.peer_chg1[m.praw0 + p] = 0; }
+  for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_ext[p] = vvo_base_end(d, doc, d.peer_uniq[m.praw0 + p]); d.peer_base[m.praw0 + p] = s_ext[p]; s_valid[p] = 0; d.peer_chg0[m.praw0 + p] = 0; d.peer_chg1[m.praw0 + p] = 0; }   // (the base version: 0 unless the document is staged on a snapshot's state)
   lmw::block_sync();
   DAG_PH(0);
   // ---- 2. coverage walk: drop known changes, slice straddling ones, park blocks behind a counter gap
@@ -263,7 +280,7 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
     uint32_t peer = d.chg[c0].peer;
     if (peer != cur_peer) {
       if (cur_peer != NONE && lane == 0) { s_ext[cur_peer] = covered; d.peer_chg1[m.praw0 + cur_peer] = n_sorted; }
-      cur_peer = peer; covered = 0; gap = false;
+      cur_peer = peer; covered = s_ext[peer]; gap = false;
       if (lane == 0) d.peer_chg0[m.praw0 + peer] = n_sorted;
     }
     if (b.counter_start > covered) gap = true;
@@ -361,7 +378,10 @@ LM_KERNEL void k_dag_a(Dev d, DevDag g) {
       if (p < P) d.elem_base[m.praw0 + p] = run + inc - e;
       run += lmw::bcast(inc, 63);
     }
-    if (run > m.atoms && lane == 0) LM_SETERR(d.doc[doc].status, ST_INTERNAL);
+    // (a document staged on a snapshot's state: its peers' element slots begin at counter 0 like everyone's, so the base version's
+    // extent is part of the layout although none of its ops is staged — ids below it that delete rows name find empty slots there)
+    if (vvo_has(d, doc)) { if (run > m.atoms && lane == 0) d.doc[doc].atoms = run; }
+    else if (run > m.atoms && lane == 0) LM_SETERR(d.doc[doc].status, ST_INTERNAL);
   }
   // ---- 5. DAG nodes: maximal runs linked only by a dependency on the peer's previous op — cut behind every change another
   // peer's change depends on (AppDagNode::has_succ and the lazy node split of the reference, loro_dag.rs:302-367,995-1019):
@@ -562,7 +582,7 @@ LM_KERNEL void k_dag_b(Dev d, DevDag g, uint32_t res_mode) {
       uint32_t first = d.node_first[m.chg0 + n], last = d.node_last[m.chg0 + n];
       const ChangeRow& hc = d.chg[d.chg_sorted[m.chg0 + first]];
       uint32_t* vv = d.vvh + vvh0 + (uint64_t)n * P;
-      for (uint32_t p = (uint32_t)lane; p < P; p += 64) vv[p] = 0;
+      for (uint32_t p = (uint32_t)lane; p < P; p += 64) vv[p] = d.peer_base[m.praw0 + p];   // (the base version — zeros, ordinarily — is part of every version)
       uint32_t lam = 0;
       for (uint32_t k = hc.dep0; k < hc.dep0 + hc.n_dep; k++) {
         uint32_t q = d.dep_peer[k], c = d.dep_ctr[k];

@@ -66,6 +66,7 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   uint64_t* peer_uniq;   // [praw0 + i], i < n_peers, ascending
   uint32_t* peer_end;    // applied (exclusive) counter end == final VV; lowered to the checkout version by k_dag_b
   uint32_t* peer_ext;    // contiguous covered end
+  uint32_t* peer_base;   // the peer's end in the document's BASE version (k_dag_a: 0 unless the document is staged on a snapshot's state, Dev::vvo) — every version of the document holds at least this
   uint32_t* peer_end_all;// checked-out documents: the applied end at the LATEST version (peer_end before k_dag_b lowered it)
   uint32_t* elem_base;   // first element slot of the peer inside the doc's element range
   uint32_t* elem_cap;    // resident documents: element slots the peer's region holds (k_res_layout)

@@ -1162,17 +1162,37 @@ LM_DEV void emit_doc(Dev d, int mode, int pass) {
     uint32_t P = m.n_peers;
     uint8_t* vo = mode ? d.vv_out + d.vv_off[doc] : nullptr;
     const uint64_t vcap = d.vv_off[doc + 1] - d.vv_off[doc];   // 16 bytes per peer + 16: a true bound (10 + 5 bytes per entry)
-    const uint64_t ovn = d.vvo ? d.vvo_off[doc + 1] - d.vvo_off[doc] : 0;
-    if (ovn) {
-      // a document staged from a snapshot's STATE section (lm_snapshot.h): its oplog version is the snapshot's, not the synthetic peer's
-      for (uint64_t i = (uint64_t)lane; i < ovn && i < vcap; i += 64) if (vo) vo[i] = d.vvo[d.vvo_off[doc] + i];
-      vvn = (uint32_t)ovn;
-    } else {
-    uint32_t cntp = 0;
-    for (uint32_t p = 0; p < P; p++) if (d.peer_end[m.praw0 + p] > 0) cntp++;
     auto put_uleb = [&](uint64_t v) {
       do { uint8_t b = v & 0x7f; v >>= 7; if (v) b |= 0x80; if (vo && lane == 0 && vvn < vcap) vo[vvn] = b; vvn++; } while (v);
     };
+    if (vvo_has(d, doc)) {
+      // a document staged on a snapshot's STATE (lm_snapshot.h, lm_snapshot_base.h): its oplog version is the snapshot's version merged
+      // with what the staged updates added (k_dag_a started every peer at its base end) — without the synthetic peer that wrote the state
+      const uint64_t synth = vvo_synth_peer(d, doc);
+      const uint8_t* bp = d.vvo + d.vvo_off[doc] + 8;
+      const uint64_t bl = d.vvo_off[doc + 1] - d.vvo_off[doc] - 8;
+      for (int pass2 = 0; pass2 < 2; pass2++) {
+        Rd r = rd_make(bp, bl);
+        uint64_t nb = rd_uleb(r), j = 0, bq = 0, be = 0;
+        bool hb = false;
+        auto next_b = [&]() { hb = false; while (j < nb && !r.bad) { j++; bq = rd_uleb(r); be = rd_uleb(r) >> 1; if (be) { hb = true; break; } } };
+        next_b();
+        uint32_t i = 0, cnt = 0;
+        for (;;) {
+          while (i < P && (d.peer_end[m.praw0 + i] == 0 || d.peer_uniq[m.praw0 + i] == synth)) i++;
+          if (i >= P && !hb) break;
+          uint64_t q, e;
+          const uint64_t dq = i < P ? d.peer_uniq[m.praw0 + i] : 0;
+          if (i < P && (!hb || dq <= bq)) { q = dq; e = d.peer_end[m.praw0 + i]; if (hb && bq == dq) { if (be > e) e = be; next_b(); } i++; }
+          else { q = bq; e = be; next_b(); }
+          cnt++;
+          if (pass2) { put_uleb(q); put_uleb(e << 1); }
+        }
+        if (!pass2) put_uleb(cnt);
+      }
+    } else {
+    uint32_t cntp = 0;
+    for (uint32_t p = 0; p < P; p++) if (d.peer_end[m.praw0 + p] > 0) cntp++;
     put_uleb(cntp);
     for (uint32_t p = 0; p < P; p++) {
       uint32_t e = d.peer_end[m.praw0 + p];

@@ -26,6 +26,7 @@
 #include "lm_k_richtext.h"
 #include "lm_snapshot.h"
 #include "lm_export.h"
+#include "lm_snapshot_base.h"
 
 namespace lm {
 
@@ -98,7 +99,7 @@ struct Engine {
   std::vector<uint8_t> h_fused;                   // per document: decoded by k_map_fused (lm_k_map_fused.h)
   uint32_t n_fused = 0;
   DBuf b_chg, b_dep_peer, b_dep_ctr, b_dep_ci, b_op, b_op_val, b_op_blk, b_key_off, b_key_len, b_cid_raw, b_cid_map, b_peer_raw, b_peer_map;
-  DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
+  DBuf b_doc, b_peer_uniq, b_peer_end, b_peer_ext, b_peer_base, b_peer_end_all, b_elem_base, b_peer_chg0, b_peer_chg1, b_cont;
   DBuf b_chg_mask, b_chg_sorted, b_chg_lamport, b_chg_skip, b_chg_flag, b_node_first, b_node_last, b_node_order, b_vvh;
   DBuf b_blk_sorted, b_chg_node, b_node_done, b_node_lam;
   DBuf b_cp, b_loc, b_tb, b_fuse, b_dcnt, b_posdel;
@@ -217,7 +218,7 @@ struct Engine {
   bool allow_state = true;                            // (the context switches it off for a folded batch: its entries are checked out)
   std::vector<uint8_t> h_vvo;
   std::vector<uint64_t> h_vvo_off;
-  std::vector<std::vector<uint8_t>> st_hist;          // per document: empty, or the history form of its snapshot
+  std::vector<std::vector<std::vector<uint8_t>>> st_hist;   // per document: empty, or its blobs in history form (the snapshot through its ChangeStore, the updates as they came)
   uint32_t n_state_docs = 0;
   bool stage_history_only = false;                    // (restage_history: this stage call takes every snapshot through its ChangeStore)
   DBuf b_vvo, b_vvo_off;
@@ -284,7 +285,7 @@ struct Engine {
   void release_all() {
     DBuf* all[] = {&b_front, &b_front_off, &b_froot, &b_froot_off, &b_blob_hash, &b_big, &b_data, &b_blob_off, &b_blob_len, &b_doc_blob, &b_blob_doc, &b_blob_status, &b_blob_nblk, &b_blob_blk0, &b_tile, &b_tot,
                    &b_vvo, &b_vvo_off, &b_blk, &b_bcnt, &b_boff, &b_blk_kind, &b_doc_fused, &b_mf_docs, &b_mf_key0, &b_chg, &b_dep_peer, &b_dep_ctr, &b_dep_ci, &b_op, &b_op_val, &b_op_blk, &b_key_off, &b_key_len,
-                   &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base,
+                   &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_base, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
                    &b_dir_out, &b_lf_chunk, &b_fuse, &b_dcnt, &b_posdel,
@@ -327,7 +328,44 @@ struct Engine {
     st_hist.assign(nd, {});
     n_state_docs = 0;
     const bool state_off = stage_history_only;
-    for (size_t i = 0; i < nd; i++)
+    auto is_mode = [](const uint8_t* p, size_t l, uint8_t mode) { return l >= 22 && memcmp(p, "loro", 4) == 0 && p[20] == 0 && p[21] == mode; };
+    for (size_t i = 0; i < nd; i++) {
+      // ONE snapshot + updates that continue its history, rendered at the latest version: the snapshot is staged as its STATE and the
+      // updates are hung on it (lm_snapshot_base.h) — the snapshot's history is neither uploaded nor decoded nor replayed.  Declined
+      // (updates concurrent with part of the snapshot, …): every blob through the loop below, the snapshot through its ChangeStore
+      if (docs[i].n >= 2 && !docs[i].front && kn.snapshot_state && allow_state && !state_off) {
+        size_t ks = docs[i].n, n3 = 0, n4 = 0;
+        for (size_t k = 0; k < docs[i].n; k++) { if (is_mode(docs[i].blobs[k], docs[i].lens[k], 3)) { n3++; ks = k; } else if (is_mode(docs[i].blobs[k], docs[i].lens[k], 4)) n4++; }
+        std::vector<uint8_t> o2, vv2, roots2;
+        lmsnap::StateBase sb;
+        std::vector<std::pair<const uint8_t*, size_t>> U;
+        std::vector<std::vector<uint8_t>> outU;
+        if (n3 == 1 && n3 + n4 == docs[i].n) for (size_t k = 0; k < docs[i].n; k++) if (k != ks) U.emplace_back(docs[i].blobs[k], docs[i].lens[k]);
+        if (n3 == 1 && n3 + n4 == docs[i].n && lmsnap::snapshot_state_to_updates(docs[i].blobs[ks], docs[i].lens[ks], o2, vv2, &roots2, false, &sb) &&
+            lmsnap::rebase_updates_on_state(sb, U, outU)) {
+          h_froot_off[i] = froot.size();
+          froot.insert(froot.end(), roots2.begin(), roots2.end());
+          std::vector<uint8_t> hist;
+          if (lmsnap::snapshot_to_updates(docs[i].blobs[ks], docs[i].lens[ks], hist, nullptr, nullptr) != lmsnap::SN_OK) hist.assign(docs[i].blobs[ks], docs[i].blobs[ks] + docs[i].lens[ks]);
+          size_t u = 0;
+          for (size_t k = 0; k < docs[i].n; k++, b++) {
+            if (k == ks) { st_hist[i].push_back(hist); conv.push_back(std::move(o2)); }
+            else { st_hist[i].emplace_back(docs[i].blobs[k], docs[i].blobs[k] + docs[i].lens[k]); conv.push_back(std::move(outU[u++])); }
+            bsrc[b] = conv.back().data(); blen[b] = conv.back().size();
+          }
+          vvo_tmp[i].resize(8);
+          for (int x = 0; x < 8; x++) vvo_tmp[i][x] = (uint8_t)(sb.synth_peer >> (8 * x));
+          vvo_tmp[i].insert(vvo_tmp[i].end(), vv2.begin(), vv2.end());
+          n_state_docs++;
+          if (const char* dump = getenv("LM_DUMP_STATE_BASE")) {   // (debugging: the blobs as staged — <prefix><doc>_<blob>.bin)
+            for (size_t k = 0; k < docs[i].n; k++) {
+              std::string fn = std::string(dump) + std::to_string(i) + "_" + std::to_string(k) + ".bin";
+              if (FILE* f = fopen(fn.c_str(), "wb")) { fwrite(bsrc[b - docs[i].n + k], 1, blen[b - docs[i].n + k], f); fclose(f); }
+            }
+          }
+          continue;
+        }
+      }
       for (size_t k = 0; k < docs[i].n; k++, b++) {
         const uint8_t* p = docs[i].blobs[k];
         size_t l = docs[i].lens[k];
@@ -339,13 +377,16 @@ struct Engine {
           // other way to be rendered.  Declined (a state this reader cannot take): the ChangeStore, as for every other snapshot
           if (docs[i].n == 1 && !docs[i].front && kn.snapshot_state && (allow_state || docs[i].state_root) && !state_off) {
             std::vector<uint8_t> o2, vv2, roots2;
-            if (lmsnap::snapshot_state_to_updates(p, l, o2, vv2, &roots2, docs[i].state_root != 0)) {
+            lmsnap::StateBase sb;
+            if (lmsnap::snapshot_state_to_updates(p, l, o2, vv2, &roots2, docs[i].state_root != 0, &sb)) {
               std::vector<uint8_t> hist;
-              if (lmsnap::snapshot_to_updates(p, l, hist, nullptr, nullptr) == lmsnap::SN_OK) st_hist[i] = std::move(hist);
-              else st_hist[i].assign(p, p + l);             // (a shallow snapshot: lm_import restages it as it came — LM_UNSUPPORTED there, as before)
+              if (lmsnap::snapshot_to_updates(p, l, hist, nullptr, nullptr) == lmsnap::SN_OK) st_hist[i].push_back(std::move(hist));
+              else st_hist[i].emplace_back(p, p + l);       // (a shallow snapshot: lm_import restages it as it came — LM_UNSUPPORTED there, as before)
               conv.push_back(std::move(o2)); p = conv.back().data(); l = conv.back().size();
               froot.resize(h_froot_off[i]); froot.insert(froot.end(), roots2.begin(), roots2.end());
-              vvo_tmp[i] = std::move(vv2);
+              vvo_tmp[i].resize(8);                         // (Dev::vvo: the synthetic peer, then the snapshot's version vector)
+              for (int x = 0; x < 8; x++) vvo_tmp[i][x] = (uint8_t)(sb.synth_peer >> (8 * x));
+              vvo_tmp[i].insert(vvo_tmp[i].end(), vv2.begin(), vv2.end());
               n_state_docs++;
               bsrc[b] = p; blen[b] = l;
               continue;
@@ -365,6 +406,7 @@ struct Engine {
         }
         bsrc[b] = p; blen[b] = l;
       }
+    }
     h_vvo.clear(); h_vvo_off.assign(nd + 1, 0);
     for (size_t i = 0; i < nd; i++) { h_vvo_off[i] = h_vvo.size(); h_vvo.insert(h_vvo.end(), vvo_tmp[i].begin(), vvo_tmp[i].end()); }
     h_vvo_off[nd] = h_vvo.size();
@@ -512,13 +554,13 @@ struct Engine {
     std::vector<std::vector<const uint8_t*>> bp(nd);
     std::vector<std::vector<size_t>> bl(nd);
     std::vector<DocIn> in(nd);
-    std::vector<std::vector<uint8_t>> hist = std::move(st_hist);
+    std::vector<std::vector<std::vector<uint8_t>>> hist = std::move(st_hist);
     std::vector<uint8_t> fronts = h_front_bytes;
     std::vector<uint64_t> foff = h_front_off;
     // (the other documents' blobs are read from the staging buffer while stage() gathers INTO it: copied out first)
     std::vector<std::vector<uint8_t>> keep(n_blobs);
     for (size_t i = 0; i < nd; i++) {
-      if (!hist[i].empty()) { bp[i].push_back(hist[i].data()); bl[i].push_back(hist[i].size()); }
+      if (!hist[i].empty()) for (auto& hb : hist[i]) { bp[i].push_back(hb.data()); bl[i].push_back(hb.size()); }
       else for (uint32_t b = st_doc_blob[i]; b < st_doc_blob[i + 1]; b++) { keep[b].assign(st_base + st_blob_off[b], st_base + st_blob_off[b] + st_blob_len[b]); bp[i].push_back(keep[b].data()); bl[i].push_back(keep[b].size()); }
       const bool hf = foff.size() > i + 1 && foff[i + 1] > foff[i];
       in[i] = DocIn{bp[i].data(), bl[i].data(), bp[i].size(), hf ? fronts.data() + foff[i] : nullptr, hf ? (size_t)(foff[i + 1] - foff[i]) : 0};
@@ -530,12 +572,14 @@ struct Engine {
     stage_history_only = false;
     // (documents that were NOT snapshots any more in the buffer — already reframed — lost their state-section roots in this second pass: put back)
     bool differs = false;
-    for (size_t i = 0; i < nd && !differs; i++) differs = hist[i].empty() && froot_off_keep.size() > i + 1 && froot_off_keep[i + 1] > froot_off_keep[i];
+    // (… and so did the snapshots restaged in their history form: the root set of the state section is what the first pass read)
+    auto kept = [&](size_t i) { return froot_off_keep.size() > i + 1 && froot_off_keep[i + 1] > froot_off_keep[i]; };
+    for (size_t i = 0; i < nd && !differs; i++) differs = kept(i);
     if (differs) {
       std::vector<uint8_t> fr; std::vector<uint64_t> fo(nd + 1, 0);
       for (size_t i = 0; i < nd; i++) {
         fo[i] = fr.size();
-        if (hist[i].empty()) fr.insert(fr.end(), froot_keep.begin() + froot_off_keep[i], froot_keep.begin() + froot_off_keep[i + 1]);
+        if (kept(i)) fr.insert(fr.end(), froot_keep.begin() + froot_off_keep[i], froot_keep.begin() + froot_off_keep[i + 1]);
         else fr.insert(fr.end(), h_froot.begin() + h_froot_off[i], h_froot.begin() + h_froot_off[i + 1]);
       }
       fo[nd] = fr.size();
@@ -890,7 +934,7 @@ struct Engine {
     b_peer_raw.ensure((size_t)(NP + 1) * 8); b_peer_map.ensure((size_t)(NP + 1) * 4);
     b_doc.ensure((size_t)n_docs * sizeof(DocMeta));
     b_peer_uniq.ensure((size_t)(NP + 1) * 8);
-    for (DBuf* b : {&b_peer_end, &b_peer_ext, &b_peer_end_all, &b_elem_base, &b_peer_chg0, &b_peer_chg1}) b->ensure((size_t)(NP + 1) * 4);
+    for (DBuf* b : {&b_peer_end, &b_peer_ext, &b_peer_base, &b_peer_end_all, &b_elem_base, &b_peer_chg0, &b_peer_chg1}) b->ensure((size_t)(NP + 1) * 4);
     b_cont.ensure((size_t)(NCID + 1) * sizeof(ContRow));
     for (DBuf* b : {&b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first, &b_node_last, &b_node_order, &b_chg_node,
                     &b_node_done, &b_node_lam})
@@ -904,7 +948,7 @@ struct Engine {
     d.cid_raw = b_cid_raw.as<uint32_t>(); d.cid_map = b_cid_map.as<uint32_t>();
     d.peer_raw = b_peer_raw.as<uint64_t>(); d.peer_map = b_peer_map.as<uint32_t>();
     d.doc = b_doc.as<DocMeta>(); d.peer_uniq = b_peer_uniq.as<uint64_t>();
-    d.peer_end = b_peer_end.as<uint32_t>(); d.peer_ext = b_peer_ext.as<uint32_t>(); d.peer_end_all = b_peer_end_all.as<uint32_t>(); d.elem_base = b_elem_base.as<uint32_t>();
+    d.peer_end = b_peer_end.as<uint32_t>(); d.peer_ext = b_peer_ext.as<uint32_t>(); d.peer_base = b_peer_base.as<uint32_t>(); d.peer_end_all = b_peer_end_all.as<uint32_t>(); d.elem_base = b_elem_base.as<uint32_t>();
     d.peer_chg0 = b_peer_chg0.as<uint32_t>(); d.peer_chg1 = b_peer_chg1.as<uint32_t>();
     d.cont = b_cont.as<ContRow>();
     d.chg_sorted = b_chg_sorted.as<uint32_t>(); d.chg_lamport = b_chg_lamport.as<uint32_t>();

@@ -300,7 +300,16 @@ static inline bool pv_to_op(PRd& r, lmenc::Bytes& out, StateWriter& w, int depth
 // a mode-3 blob -> (a FastUpdates blob that replays to its state, its version vector as the C ABI writes it); false: declined
 // `root_only`: the state AT the shallow root (the third section alone) — what LoroDoc::checkout(shallow_since_frontiers) shows
 // (loro_js_interop.rs:141-147); the oplog's version vector stays the whole snapshot's
-inline bool snapshot_state_to_updates(const uint8_t* blob, size_t len, std::vector<uint8_t>& out, std::vector<uint8_t>& vv_out, std::vector<uint8_t>* roots, bool root_only = false) {
+// what a caller that stages UPDATES on top of the state needs to know about the base (lm_snapshot_base.h)
+struct StateBase {
+  uint64_t synth_peer = 0;                         // the peer of the synthetic change
+  uint32_t synth_len = 0;                          // its ops: counters [0, synth_len)
+  std::map<uint64_t, uint32_t> vv;                 // the snapshot's version vector (exclusive ends)
+  std::vector<std::pair<uint64_t, uint32_t>> frontiers;   // … and frontiers (ChangeStore `fr`)
+  std::map<lmenc::Bytes, uint32_t> child_ctr;      // real id of a child container (13-byte state key) -> counter of the synthetic op that creates it
+  bool has_movable = false;                        // a MovableList holds items (their element ids are synthetic: move / set rows cannot name them)
+};
+inline bool snapshot_state_to_updates(const uint8_t* blob, size_t len, std::vector<uint8_t>& out, std::vector<uint8_t>& vv_out, std::vector<uint8_t>* roots, bool root_only = false, StateBase* sb = nullptr) {
   if (len < 22 || memcmp(blob, "loro", 4) != 0 || blob[20] != 0 || blob[21] != 3) return false;
   if (lmenc::xxh32(blob + 20, len - 20, 0x4F524F4Cu) != rd32(blob + 16)) return false;
   const uint8_t* p = blob + 22;
@@ -310,15 +319,22 @@ inline bool snapshot_state_to_updates(const uint8_t* blob, size_t len, std::vect
   if (n != 0) return false;
   // the version vector of the oplog (ChangeStore key `vv`, VersionVector::encode: a postcard map) in the C ABI's order: ascending peer, no zero entry
   std::map<uint64_t, uint32_t> vv;
-  bool have_vv = false, ok = sstable_for_each(sec[0], sl[0], [&](const uint8_t* k, size_t kl, const uint8_t* v, size_t vl) {
+  std::vector<std::pair<uint64_t, uint32_t>> fr_ids;
+  bool have_vv = false, have_fr = false, ok = sstable_for_each(sec[0], sl[0], [&](const uint8_t* k, size_t kl, const uint8_t* v, size_t vl) {
     if (kl == 2 && memcmp(k, "vv", 2) == 0) {
       PRd r(v, vl);
       uint64_t cnt = r.uleb();
       for (uint64_t i = 0; i < cnt && !r.bad; i++) { uint64_t peer = r.uleb(); int64_t c = r.zz(); if (c > 0 && c <= 0x7fffffff) vv[peer] = (uint32_t)c; else if (c != 0) r.bad = true; }
       have_vv = !r.bad && r.p == r.end;
+    } else if (kl == 2 && memcmp(k, "fr", 2) == 0) {   // Frontiers::encode: postcard Vec<ID>
+      PRd r(v, vl);
+      uint64_t cnt = r.uleb();
+      for (uint64_t i = 0; i < cnt && !r.bad; i++) { uint64_t peer = r.uleb(); int64_t c = r.zz(); if (c >= 0 && c <= 0x7fffffff) fr_ids.emplace_back(peer, (uint32_t)c); else r.bad = true; }
+      have_fr = !r.bad && r.p == r.end;
     }
   });
   if (!ok || !have_vv) return false;
+  if (sb && !have_fr) return false;
   // the state: the shallow root's entries first, the (end-)state's over them (docs/encoding-container-states.md §1); `fr` is not a container
   std::map<lmenc::Bytes, lmenc::Bytes> st;
   auto load = [&](const uint8_t* sp, size_t sn) {
@@ -403,6 +419,7 @@ inline bool snapshot_state_to_updates(const uint8_t* blob, size_t len, std::vect
         }
         w.op_c.push_back(ci); w.op_prop.push_back(0); w.op_vt.push_back(11); w.op_len.push_back((uint32_t)cnt);
         w.ctr += (uint32_t)cnt;
+        if (c.kind == 4 && sb) sb->has_movable = true;
       }
     } else if (c.kind == 2) {     // Text: postcard(String) full_text (spans, ids and marks behind it are not needed for the value)
       uint64_t bl = r.uleb(); const uint8_t* tp = r.take((size_t)bl);
@@ -423,12 +440,18 @@ inline bool snapshot_state_to_updates(const uint8_t* blob, size_t len, std::vect
   lmenc::put_uleb(vv_out, vv.size());
   for (auto& e : vv) { lmenc::put_uleb(vv_out, e.first); lmenc::put_uleb(vv_out, (uint64_t)e.second << 1); }
   if (w.ctr == 0) {   // nothing visible anywhere: an empty update blob (the roots still come through `roots`)
+    if (sb) { sb->synth_len = 0; sb->vv = vv; sb->frontiers = fr_ids; }
     out = lmenc::encode_updates(nullptr, nullptr, 0);
     return true;
   }
   lm_block_tables t;
   memset(&t, 0, sizeof t);
-  const uint64_t peer = 1;
+  uint64_t peer = 1;
+  if (sb) {   // (updates follow: the synthetic peer must be nobody's)
+    peer = 0xFFFFFFFFFFFFFF00ull;
+    while (vv.count(peer)) peer--;
+    sb->synth_peer = peer; sb->synth_len = w.ctr; sb->vv = vv; sb->frontiers = fr_ids; sb->child_ctr = child_ctr;
+  }
   const uint32_t one_len = w.ctr, zero32 = 0; const uint8_t zero8 = 0; const int64_t zero64 = 0;
   std::vector<const uint8_t*> kp; std::vector<size_t> kl;
   for (auto& k2 : w.keys) { kp.push_back(k2.data()); kl.push_back(k2.size()); }

@@ -252,3 +252,84 @@ def check_state_path(ctx_factory, n=40):
 
 def test_documents_staged_from_their_snapshots_state_sections():
     check_state_path(lambda: Context(_emu.binding()), n=24)
+
+
+# ---- snapshot + updates on a state base (lm_snapshot_base.h): the updates continue the snapshot's history
+def state_base_docs(n=24, first=700, kinds=("text", "list", "map")):
+    """(docs, want): [snapshot of the history up to a critical version (real state section), the updates beyond it — one blob per peer]"""
+    docs, want = [], []
+    for seed in range(first, first + n):
+        rng = random.Random(seed)
+        reps = _fuzz.random_session(seed, n_peers=rng.randint(2, 3), n_steps=rng.randint(30, 120), kinds=kinds, solo_steps=rng.randint(10, 60), max_ins=10)
+        p0 = reps[0].peer
+        heads = [d[1] for r in reps[1:] for c in r.changes.get(r.peer, [])[:1] for d in c.deps if d[0] == p0]
+        if not heads:
+            continue
+        c_h = min(heads)
+        own = reps[0].changes.get(p0, [])
+        base = [c for c in own if c.ctr_end <= c_h + 1]
+        if not base or base[-1].ctr_end != c_h + 1:
+            continue
+        early = wire.Replica(p0); early.changes = {p0: base}; early.vv = {p0: c_h + 1}; early.frontiers = [(p0, c_h)]
+        snap = real_snapshot(early, **([dict(), dict(block_size=256)][seed % 2]))
+        upd = []
+        for r in reps:
+            o = wire.Replica(r.peer); o.changes = {r.peer: [c for c in r.changes.get(r.peer, []) if r.peer != p0 or c.counter > c_h]}
+            if o.changes[r.peer]:
+                upd.append(o.export())
+        rng.shuffle(upd)
+        at = rng.randint(0, len(upd))
+        docs.append(upd[:at] + [snap] + upd[at:])                      # (import_batch takes the snapshot first wherever it stands)
+        want.append(_oracle.merge(docs[-1]))                           # (the checker replays the snapshot's history)
+        full = _oracle.merge(_fuzz.blobs_of(reps))                     # … which is the whole session's, but for roots nothing is visible in
+        assert want[-1][2] == full[2] and (want[-1][1] == full[1] or b'""' in want[-1][1] or b"[]" in want[-1][1] or b"{}" in want[-1][1])
+    return docs, want
+
+
+def check_state_base(ctx_factory, n=24):
+    import os
+    docs, want = state_base_docs(n)
+    assert len(docs) >= n // 2 and all(w[0] == 0 for w in want)
+    with ctx_factory() as c:
+        got = c.merge_batch(docs)
+        assert c.b.state_documents(c.h) == len(docs), (c.b.state_documents(c.h), len(docs))
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g == w, (i, g[:3], w[:3])
+        os.environ["LM_SNAPSHOT_STATE"] = "0"
+        try:
+            assert c.merge_batch(docs) == want and c.b.state_documents(c.h) == 0
+        finally:
+            del os.environ["LM_SNAPSHOT_STATE"]
+        # child containers of the base, edited by the updates; base text deleted by id
+        a = wire.Replica(41)
+        a.text_insert("t", 0, "hello world"); cm = a.map_set_container("m", "child", wire.KIND_MAP); a.map_set(cm, "x", 1)
+        ct = a.map_set_container("m", "note", wire.KIND_TEXT); a.text_insert(ct, 0, "abc")
+        cl = a.list_insert_container("l", 0, wire.KIND_LIST); a.list_insert(cl, 0, [1, 2, 3]); a.commit()
+        base_vv = dict(a.vv)
+        snap = real_snapshot(a)
+        a.map_set(cm, "y", "new"); a.text_insert(ct, 3, "DEF"); a.list_insert(cl, 1, ["mid"]); a.text_delete("t", 0, 6); a.map_set("m", "top", True); a.commit()
+        b = wire.Replica(42); b.merge_from(a); b.seq = {k: list(v) for k, v in a.seq.items()}
+        b.text_insert(ct, 0, "<"); b.map_set(cm, "x", 2); b.commit()
+        a.text_insert(ct, 0, ">"); a.map_set(cm, "x", 3); a.commit()
+        ob = wire.Replica(42); ob.changes = {42: b.changes[42]}
+        doc = [snap, a.export(from_vv=base_vv), ob.export()]
+        full = wire.Replica(41); full.merge_from(a); full.merge_from(b)
+        w = _oracle.merge(doc)
+        assert w[1] == _oracle.merge([full.export()])[1]
+        g = c.merge_batch([doc])
+        assert g[0] == w and c.b.state_documents(c.h) == 1, (g[0][:2], w[:2])
+        # updates that are concurrent with part of the snapshot's history: declined, replayed from the ChangeStore — same bytes
+        reps = _fuzz.random_session(5, n_peers=3, n_steps=120, kinds=("text", "map"))
+        snap2 = real_snapshot(reps[0])
+        rest = _fuzz.blobs_of(reps[1:])
+        conc = [[snap2] + rest]
+        assert c.merge_batch(conc) == _oracle.merge_batch(conc) and c.b.state_documents(c.h) == 0
+        # an import after such a batch: staged again as history (the resident documents build on it)
+        c.merge_batch(docs[:4])
+        assert c.b.state_documents(c.h) == 4
+        c.import_more([[]] * 4); c.run()
+        assert c.fetch() == want[:4] and c.b.state_documents(c.h) == 0
+
+
+def test_updates_on_top_of_a_snapshots_state():
+    check_state_base(lambda: Context(_emu.binding()), n=24)

@@ -50,3 +50,9 @@ def test_documents_staged_from_their_snapshots_state_sections():
     """SURVEY §8f N3 (fast_snapshot.rs:168-258): one snapshot = its state section, no history uploaded / decoded / replayed; shallow
     snapshots at their latest version and at their shallow root (loro_js_interop.rs:129-147)"""
     S.check_state_path(_engine, n=60)
+
+
+def test_updates_on_top_of_a_snapshots_state():
+    """SURVEY §8f N3, second half (lm_snapshot_base.h): snapshot + updates that continue its history — the snapshot's history is
+    neither uploaded nor decoded nor replayed; updates concurrent with part of it fall back to the ChangeStore"""
+    S.check_state_base(_engine, n=60)
