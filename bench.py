@@ -319,6 +319,8 @@ def _gen(args):
         import random, _fuzz
         reps = _fuzz.movable_session(7000 + d, n_peers=3, n_steps=500, sync_prob=0.08, nested=True, bulk=300)
         return _fuzz.blobs_of(reps, random.Random(d)), None
+    if kind == "snap":         # a configs[1]-shaped history whose BASE (50k ops, one chain) arrives as a snapshot with a real state section
+        return workload.cfg2_snapshot_doc(d), None
     if kind == "trace":        # configs[1] at its stated size from ANOTHER synthetic trace (seed d)
         return workload.Cfg2Template(50000, 25000, seed=d, commit_every=10, fuse=True), None
     if kind == "tpl":          # a configs[1]-shaped template of another size / commit granularity
@@ -373,7 +375,7 @@ def other_configs(device, cores):
         def __exit__(self, *a): return False
         def map_async(self, f, xs):
             only = os.environ.get("LM_BENCH_ONLY", "")
-            want = {"cfg3a": "configs[2]", "cfg3b": "configs[2]", "cfg5": "configs[4]", "tpl": "heterogeneous", "trace": "traces", "movable": "movable"}
+            want = {"cfg3a": "configs[2]", "cfg3b": "configs[2]", "cfg5": "configs[4]", "tpl": "heterogeneous", "trace": "traces", "movable": "movable", "snap": "snapshot"}
             class R:
                 def __init__(s, v): s.v = v
                 def get(s): return s.v
@@ -388,9 +390,14 @@ def other_configs(device, cores):
         # configs[1] with 128 DIFFERENT traces (the headline batch stamps ONE trace 10,000 times: identical control flow in every wave)
         gt = pool.map_async(_gen, [("trace", sd) for sd in range(1, 129)])
         gm = pool.map_async(_gen, [("movable", d) for d in range(16)])
+        gs = pool.map_async(_gen, [("snap", d) for d in range(8)])
         cfg1 = [workload.cfg1_doc(d) for d in range(100)]
         cfg4_base = _cases.cfg4_docs(96)
         g3, g5, gh, gt = g3.get(), g5.get(), gh.get(), gt.get()
+        try:
+            gs = gs.get()
+        except Exception as ex:   # (not a BASELINE config either)
+            gs = ex
         try:
             gm = gm.get()
         except Exception as ex:   # (not a BASELINE config: its generator must not take the bench line down)
@@ -400,20 +407,20 @@ def other_configs(device, cores):
     only = os.environ.get("LM_BENCH_ONLY")   # profiles/collect_other.sh: ONE entry per process (its kernels are then that entry's in the rocprofv3 record)
 
     def sel(name):
-        return not only or name == only
+        return not only or name == only or name.startswith(only + ",")
 
-    def run(name, docs, fronts, distinct, desc, reps=3):
+    def run(name, docs, fronts, distinct, desc, reps=3, extra=None):
         if not sel(name):
             return
         # a leg that fails (its parity assert included) is REPORTED in its own entry — "error" instead of a rate — and leaves the
         # other entries and the headline value (which has its own parity assert) alone
         try:
-            _run(name, docs, fronts, distinct, desc, reps)
+            _run(name, docs, fronts, distinct, desc, reps, extra)
         except Exception as ex:
             out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300], "workload": desc}
             note(f"other configs: {name} FAILED: {type(ex).__name__}: {ex}"[:200])
 
-    def _run(name, docs, fronts, distinct, desc, reps):
+    def _run(name, docs, fronts, distinct, desc, reps, extra=None):
         t_cpu = time.perf_counter()
         want = _oracle.merge_batch(docs[:distinct], threads=min(32, cores), frontiers=None if fronts is None else fronts[:distinct])
         t_cpu = time.perf_counter() - t_cpu
@@ -435,6 +442,7 @@ def other_configs(device, cores):
             for _ in range(reps):
                 t = time.perf_counter(); e.run(); best = min(best, time.perf_counter() - t)
             st = e.stats()
+            more = extra(e) if extra else {}
             # every stage's own duration: one more pass with the context's streams run one after the other (HIP events per stage);
             # a stage's figure is the sum over the context's streams = the time the stage needs for the whole batch
             e.set_profiling(1); e.run()
@@ -463,6 +471,7 @@ def other_configs(device, cores):
                      "gpu_over_cpu": round(len(docs) / best / (distinct / t_cpu), 2),
                      "parity": (f"the first {n_checked} of {len(docs)} results equal to the oracle's (every document differs; as many as the CPU port replays in 25 s), all {len(docs)} succeeded" if name.endswith(("heterogeneous", "traces")) else f"all {len(docs)} results equal to the oracle's"),
                      "workload": desc}
+        out[name].update(more)
 
     run("configs[0]", cfg1, None, 100, "100 docs x 2 peers x 1,000 sequential inserts, 2 blobs/doc")
     d3 = [g[0] for g in g3] if sel("configs[2]") else [[]] * 16
@@ -481,6 +490,29 @@ def other_configs(device, cores):
     run("configs[1]-128-traces", [ttr[(d * 7919) % len(ttr)].stamp(d) for d in range(10000)] if ttr else [], None, 64,
         "configs[1] at its stated size (10,000 docs x 100k ops, 2 concurrent peers, 3 blobs) from 128 DIFFERENT synthetic traces interleaved "
         "pseudo-randomly, letters stamped per document: neighbouring waves replay different histories (the headline batch stamps one trace)")
+    # the configs[1] history with its base (50k ops, one peer's chain) delivered as a SNAPSHOT and the two concurrent
+    # branches (25k ops each) as updates on top of it — staged from the snapshot's state section (lm_snapshot.h / lm_snapshot_base.h):
+    # the base's history is neither uploaded nor decoded nor replayed; LM_SNAPSHOT_STATE=0 replays it from the ChangeStore
+    n3 = "snapshot + updates (SURVEY 8f N3)"
+    if sel(n3) or sel(n3 + ", history replayed"):
+        try:
+            if isinstance(gs, Exception):
+                raise gs
+            ds = [g[0] for g in gs]
+            sdocs = [ds[i % 8] for i in range(10000)]
+            run(n3, sdocs, None, 8,
+                "configs[1]-shaped documents (100k ops): the 50k-op base as ONE FastSnapshot blob (real state section, stored SSTable blocks), the two concurrent 25k-op "
+                "branches as update blobs; 10,000 docs = 8 distinct histories; staged from the state section — the next entry is the same batch with LM_SNAPSHOT_STATE=0",
+                extra=lambda eng: {"state_documents": int(eng.b.state_documents(eng.h))})
+            os.environ["LM_SNAPSHOT_STATE"] = "0"
+            try:
+                run(n3 + ", history replayed", sdocs, None, 8,
+                    "the batch above with LM_SNAPSHOT_STATE=0: the snapshot ingested through its ChangeStore (rounds 2-5), the whole history decoded and replayed", reps=2,
+                    extra=lambda eng: {"state_documents": int(eng.b.state_documents(eng.h))})
+            finally:
+                del os.environ["LM_SNAPSHOT_STATE"]
+        except Exception as ex:
+            out[n3] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     # configs[4]: 256 document INSTANCES (own copies of the blobs of 4 distinct histories) x 16 versions.  The 16 entries of an instance
     # name the same blobs: lm_stage folds them into one document, lm_run imports it once and renders the 16 versions by moving its
     # trackers (include/loro_merge.h "Shared replay"); LM_SHARE_REPLAY=0 replays the history once per entry (rounds 1-4: 1,148 renderings/s)

@@ -23,6 +23,8 @@ struct Dev {  // device pointers of one batch (passed by value to every kernel)
   const uint32_t* res_old_blobs;   // resident documents: per document the number of blobs earlier runs already held (nullptr otherwise)
   uint32_t loc_cleared;       // 1: loc[] was set to NONE by a memset in front of the integrate stage (the waves skip their own clear)
   uint32_t* posdel;           // per document 3 * PD_CAP words: the delete rows the span-granular batch kernels applied by position (lm_k_integrate_span.h ts_del_positional); nullptr = a mismatch is LM_DATA_CORRUPTION
+  const uint64_t* posdel_off; // per document (n_docs + 1): its slice of `posdel` in pieces; nullptr = PD_CAP pieces each
+  uint32_t* pd_row_idx;       // per op row of the batch: the first piece of a row applied by position in its document's list (documents whose slice exceeds PD_CAP: staged on a snapshot's state); nullptr = no such document
   const uint8_t* vvo;         // per document: the version vector to write out instead of the decoded peers' (a document staged from a snapshot's STATE section, lm_snapshot.h); vvo_off[n_docs + 1], empty range = none; nullptr = no such document
   const uint64_t* vvo_off;
   const uint8_t* doc_fused;   // per document: 1 = an LWW Map document decoded without op rows (lm_k_map_fused.h; nullptr: none in this run)

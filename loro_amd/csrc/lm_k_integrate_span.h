@@ -58,7 +58,10 @@ static constexpr uint32_t PD_CAP = 63;   // pieces per document (3 words each; o
 // document's list in HBM — NOT in the wave-uniform context: the kernel sits at its SGPR limit, seven more live scalars cost the
 // replay of every healthy document 3 % (profiles/r05_posdel_ab.log).  [0] position where the row stopped matching  [1] ids left
 // [2] first id of the row  [3] ids that matched  [4] pieces in the list  [5,6] the list (pointer; 0 = positional deletes are off)
-static constexpr uint32_t PD_LDS = 8;
+// [7] the list's capacity in pieces  [8,9] row index (pointer; 0 = none): per op row of the batch the first piece of that row in its
+// document's list — a document staged on a snapshot's state (lm_snapshot_base.h) deletes base content by position as a matter of
+// course, thousands of rows, where a damaged document has a handful (PD_CAP pieces, found by one lane per piece)
+static constexpr uint32_t PD_LDS = 12;
 LM_DEV uint32_t* pd_w(const Ts& t) { return const_cast<uint32_t*>(t.ebase) - PD_LDS; }
 template <bool POS>
 LM_DEV void pd_stop(Ts& t, uint32_t k, uint32_t left, uint32_t first, uint32_t matched) {   // (cold: a delete row that does not match its position)
@@ -947,8 +950,11 @@ LM_DEV void ts_del_positional(Ts& t, uint32_t row) {
   uint32_t n = lmw::first(w[1]), n_pos = lmw::first(w[4]);
   uint32_t* pos_list = (uint32_t*)(uintptr_t)(((uint64_t)lmw::first(w[6]) << 32) | lmw::first(w[5]));
   if (!pos_list) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+  const uint32_t pd_cap = lmw::first(w[7]);
+  uint32_t* row_idx = (uint32_t*)(uintptr_t)(((uint64_t)lmw::first(w[9]) << 32) | lmw::first(w[8]));
+  if (row_idx && lane == 0 && (n_match || n > 0)) row_idx[row] = n_pos;   // (the row's pieces follow one another from here)
   if (n_match) {
-    if (n_pos >= PD_CAP) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+    if (n_pos >= pd_cap) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
     if (lane == 0) { pos_list[3 * n_pos] = row; pos_list[3 * n_pos + 1] = first; pos_list[3 * n_pos + 2] = n_match; }
     n_pos++;
   }
@@ -969,7 +975,7 @@ LM_DEV void ts_del_positional(Ts& t, uint32_t row) {
     uint32_t id0 = lmw::bcast(R.id, slot), ln = lmw::bcast(R.len, slot);
     uint32_t piece = ln - off < n ? ln - off : n;
     uint32_t x = id0 + off;
-    if (n_pos >= PD_CAP) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+    if (n_pos >= pd_cap) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
     if (lane == 0) { pos_list[3 * n_pos] = row; pos_list[3 * n_pos + 1] = x; pos_list[3 * n_pos + 2] = piece; w[4] = n_pos + 1; }
     n_pos++;
 #ifdef LM_EMU_TRACE
@@ -992,6 +998,17 @@ LM_DEV bool ts_move_positional(Ts& t, uint32_t row, bool whole, int mode) {
   if (!n_pos) return false;
   const uint32_t* pos_list = (const uint32_t*)(uintptr_t)(((uint64_t)lmw::first(w[6]) << 32) | lmw::first(w[5]));
   uint32_t lane = (uint32_t)lmw::lane();
+  const uint32_t* row_idx = (const uint32_t*)(uintptr_t)(((uint64_t)lmw::first(w[9]) << 32) | lmw::first(w[8]));
+  if (row_idx) {   // (a long list: the row's pieces are found through the row index and follow one another)
+    uint32_t j = lmw::first(row_idx[row]);
+    if (j == NONE || j >= n_pos || lmw::first(pos_list[3 * j]) != row) return false;
+    if (!whole) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return true; }
+    for (; j < n_pos && !t.err && lmw::first(pos_list[3 * j]) == row; j++) {
+      uint32_t x = lmw::first(pos_list[3 * j + 1]), ln = lmw::first(pos_list[3 * j + 2]);
+      ts_update_range(t, pid_peer(x), pid_ctr(x), pid_ctr(x) + ln, mode);
+    }
+    return true;
+  }
   uint64_t pm = lmw::ballot(lane < n_pos && pos_list[3 * lane] == row);
   if (!pm) return false;
   // (a version that ends inside such a row would need the op-offset → piece mapping of tracker.rs:193-252; not reproduced)
@@ -1631,9 +1648,16 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   t.dir_cap = dir_cap; t.leaf_cap = m.leaf_cap; t.n_leaf = 0; t.err = 0; t.beyond = 0;
   t.n_alive = 0;
   if (lane == 0) {   // (resident trackers keep the by-id verdict — LM_DATA_CORRUPTION: their lists would have to outlive the run)
-    uint64_t pl = (!POS || !d.posdel) ? 0ull : (uint64_t)(uintptr_t)(d.posdel + (uint64_t)doc * (3 * PD_CAP));
+    uint64_t pl = 0, ri = 0, pcap = PD_CAP;
+    if (POS && d.posdel) {
+      const uint64_t p0 = d.posdel_off ? d.posdel_off[doc] : (uint64_t)doc * PD_CAP;
+      if (d.posdel_off) pcap = d.posdel_off[doc + 1] - p0;
+      pl = (uint64_t)(uintptr_t)(d.posdel + p0 * 3);
+      if (d.pd_row_idx && pcap > PD_CAP) ri = (uint64_t)(uintptr_t)d.pd_row_idx;
+    }
     uint32_t* w = s_ebase - PD_LDS;
     w[0] = w[1] = w[2] = w[3] = w[4] = 0; w[5] = (uint32_t)pl; w[6] = (uint32_t)(pl >> 32);
+    w[7] = (uint32_t)(pcap > 0xffffffffull ? 0xffffffffull : pcap); w[8] = (uint32_t)ri; w[9] = (uint32_t)(ri >> 32); w[10] = w[11] = 0;
   }
 #ifdef LM_PROF
   for (int i = 0; i < PF_N; i++) t.prof[i] = 0;

@@ -178,7 +178,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true, snapshot_state = true, stage_direct = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true, snapshot_state = true, stage_direct = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4, pd_state_pieces = 2; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -207,6 +207,7 @@ struct Engine {
     if (const char* e = getenv("LM_MAP_FUSED")) k.map_fused = atoi(e) != 0;                      // 0: LWW Map documents go through the row tables like every other document (rounds 1-5)
     if (const char* e = getenv("LM_MF_MIN_ROWS")) k.mf_min_rows = (uint32_t)atoi(e);             // rows from which a Map document gets a workgroup of k_map_fused (tests: 1)
     if (const char* e = getenv("LM_STAGE_DIRECT")) k.stage_direct = atoi(e) != 0;                // 0: blobs inside an lm_host_alloc region are gathered into the engine's staging buffer like any others
+    if (const char* e = getenv("LM_PD_STATE_PIECES")) k.pd_state_pieces = (uint32_t)atoi(e);          // by-position list of a document staged on a snapshot's state: pieces per op row (2; tests: 0 = overflow -> replayed from the snapshot's history)
     if (const char* e = getenv("LM_SNAPSHOT_STATE")) k.snapshot_state = atoi(e) != 0;            // 0: a document given as one snapshot is replayed from its ChangeStore (rounds 2-5) instead of rendered from its state section
     if (const char* e = getenv("LM_MF_CHG_RATIO")) k.mf_chg_ratio = (uint32_t)atoi(e);           // … and rows per change it needs on average (tests: 0)
     if (force_span) { k.span = true; k.span_auto = false; k.posdel = true; k.redo = false; k.map_fused = false; }
@@ -221,7 +222,8 @@ struct Engine {
   std::vector<std::vector<std::vector<uint8_t>>> st_hist;   // per document: empty, or its blobs in history form (the snapshot through its ChangeStore, the updates as they came)
   uint32_t n_state_docs = 0;
   bool stage_history_only = false;                    // (restage_history: this stage call takes every snapshot through its ChangeStore)
-  DBuf b_vvo, b_vvo_off;
+  DBuf b_vvo, b_vvo_off, b_pd_off, b_pd_row;
+  std::vector<uint8_t> redo_hist;                 // documents of redo_docs that are replayed from their snapshot's HISTORY (st_hist), not from the staged state
   // ---- DF_REDO: what lm_stage left in the pinned staging buffer (the blobs as the device sees them: snapshots already reframed) —
   // a side engine stages the documents to replay from there (stage_from); lm_import with new blobs reuses the buffer and ends that
   bool st_valid = false;
@@ -230,6 +232,10 @@ struct Engine {
   std::vector<uint8_t> st_froot;
   std::vector<uint32_t> redo_docs;                // documents of the last run flagged DF_REDO (local indices)
   struct RedoItem { uint32_t doc; const uint8_t* front; size_t front_len; };
+  bool redo_by_history(uint32_t doc) const {
+    for (size_t k = 0; k < redo_docs.size(); k++) if (redo_docs[k] == doc) return k < redo_hist.size() && redo_hist[k] != 0;
+    return false;
+  }
   void stage_from(const std::vector<Engine*>& parents, const std::vector<RedoItem>& items) {
     for (Engine* pe : parents) if (!pe->st_valid) throw std::runtime_error("redo: the staged blobs are gone");
     std::vector<std::vector<const uint8_t*>> bp(items.size());
@@ -238,6 +244,8 @@ struct Engine {
     for (size_t k = 0; k < items.size(); k++) {
       const uint32_t i = items[k].doc;
       Engine& parent = *parents[k];
+      if (parent.redo_by_history(i)) for (auto& hb : parent.st_hist[i]) { bp[k].push_back(hb.data()); bl[k].push_back(hb.size()); }
+      else
       for (uint32_t b = parent.st_doc_blob[i]; b < parent.st_doc_blob[i + 1]; b++) { bp[k].push_back(parent.st_base + parent.st_blob_off[b]); bl[k].push_back(parent.st_blob_len[b]); }
       in[k] = DocIn{bp[k].data(), bl[k].data(), bp[k].size(), items[k].front, items[k].front_len};
     }
@@ -258,7 +266,7 @@ struct Engine {
       h_vvo_off[k] = h_vvo.size();
       Engine& parent = *parents[k];
       const uint32_t i = items[k].doc;
-      if (parent.n_state_docs && (size_t)i + 1 < parent.h_vvo_off.size() && parent.h_vvo_off[i + 1] > parent.h_vvo_off[i]) {
+      if (parent.n_state_docs && (size_t)i + 1 < parent.h_vvo_off.size() && parent.h_vvo_off[i + 1] > parent.h_vvo_off[i] && !parent.redo_by_history(i)) {
         h_vvo.insert(h_vvo.end(), parent.h_vvo.begin() + parent.h_vvo_off[i], parent.h_vvo.begin() + parent.h_vvo_off[i + 1]);
         n_state_docs++;
       }
@@ -288,7 +296,7 @@ struct Engine {
                    &b_cid_raw, &b_cid_map, &b_peer_raw, &b_peer_map, &b_doc, &b_peer_uniq, &b_peer_end, &b_peer_ext, &b_peer_base, &b_peer_end_all, &b_elem_base,
                    &b_peer_chg0, &b_peer_chg1, &b_cont, &b_chg_mask, &b_chg_sorted, &b_chg_lamport, &b_chg_skip, &b_chg_flag, &b_node_first,
                    &b_node_last, &b_node_order, &b_vvh, &b_blk_sorted, &b_chg_node, &b_node_done, &b_node_lam, &b_cp, &b_loc, &b_tb, &b_it,
-                   &b_dir_out, &b_lf_chunk, &b_fuse, &b_dcnt, &b_posdel,
+                   &b_dir_out, &b_lf_chunk, &b_fuse, &b_dcnt, &b_posdel, &b_pd_off, &b_pd_row,
                    &b_cont_root0, &b_cont_nroot, &b_prof, &b_hash, &b_order, &b_ht_key, &b_ht_pfx, &b_ht_best, &b_ht0, &b_ht_cap, &b_ht_list, &b_ht_cnt, &b_slab, &b_vslab, &b_slab_off, &b_vslab_off, &b_slab2, &b_slab2_off, &b_out, &b_out_off,
                    &b_vv_out, &b_vv_off, &b_tk, &b_res, &b_dir_out2, &b_dir_b, &b_dir_b2, &b_doc_saved, &b_elem_cap, &b_old_blobs, &b_prev_doc, &b_prev_uniq, &b_prev_end, &b_lca_out, &b_lca_scratch, &b_lca_off};
     for (DBuf* b : all) b->release();
@@ -1155,7 +1163,29 @@ struct Engine {
     d.loc_cleared = (!resident && span && kn.loc_memset) ? 1u : 0u;
     d.no_linear = kn.linear ? 0u : 1u;
     d.posdel_redo = (kn.redo && kn.posdel && st_valid && (resident ? shared_mode != 0 : !span)) ? 1u : 0u;
-    if (span && !resident && kn.posdel) { b_posdel.ensure((size_t)n_docs * 3 * PD_CAP * 4 + 16); d.posdel = b_posdel.as<uint32_t>(); }
+    d.posdel_off = nullptr; d.pd_row_idx = nullptr;
+    if (span && !resident && kn.posdel) {
+      // a document staged on a snapshot's state (lm_snapshot_base.h) deletes base content by position as a matter of course — every
+      // delete row of its updates that names an element of the base: its list holds two pieces per op row (+ a row index, so a
+      // version move finds a row's pieces without a scan); everybody else: PD_CAP pieces, damaged rows only.  A list that overflows
+      // fails the document, and a state document that fails is replayed from its history (redo_hist below)
+      uint64_t pieces = 0;
+      bool big = false;
+      std::vector<uint64_t> h_pd_off(n_docs + 1);
+      for (uint32_t i = 0; i < n_docs; i++) {
+        h_pd_off[i] = pieces;
+        const bool on_state = n_state_docs && h_vvo_off.size() > (size_t)i + 1 && h_vvo_off[i + 1] > h_vvo_off[i] && h_doc[i].n_op > PD_CAP / 2;
+        pieces += on_state ? (uint64_t)kn.pd_state_pieces * h_doc[i].n_op + PD_CAP + 1 : (uint64_t)PD_CAP;
+        big |= on_state;
+      }
+      h_pd_off[n_docs] = pieces;
+      b_posdel.ensure((size_t)pieces * 3 * 4 + 16); d.posdel = b_posdel.as<uint32_t>();
+      if (big) {
+        b_pd_off.ensure(((size_t)n_docs + 1) * 8); lmbe::h2d(b_pd_off.p, h_pd_off.data(), ((size_t)n_docs + 1) * 8);
+        b_pd_row.ensure(((size_t)NO + 1) * 4); lmbe::dmemset(b_pd_row.p, 0xff, ((size_t)NO + 1) * 4);
+        d.posdel_off = b_pd_off.as<uint64_t>(); d.pd_row_idx = b_pd_row.as<uint32_t>();
+      }
+    }
     if (d.loc_cleared && elem) lmbe::dmemset(b_loc.p, 0xff, (size_t)elem * 4);
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
       if (resident) {
@@ -1516,7 +1546,14 @@ struct Engine {
     redo_docs.clear();
     // (a fused Map document that FAILED anywhere: its op columns are validated late — behind the DAG stages — where the row tables'
     // decoders speak first; the failure's code is theirs to give, so the document is replayed through them)
-    if (kn.redo && st_valid) for (uint32_t i = 0; i < n_docs; i++) if ((h_doc[i].flags & DF_REDO) || (i < h_fused.size() && h_fused[i] && h_doc[i].status != ST_OK)) redo_docs.push_back(i);
+    // (… and a document staged on a snapshot's STATE that failed in any way — an engine limit of the by-position path, a damaged update:
+    // replayed from the snapshot's history, where every verdict is the row decoders' / the tracker's on real ids)
+    redo_hist.clear();
+    if (kn.redo && st_valid) for (uint32_t i = 0; i < n_docs; i++) {
+      const bool on_state = !resident && n_state_docs && h_vvo_off.size() > (size_t)i + 1 && h_vvo_off[i + 1] > h_vvo_off[i] && i < st_hist.size() && !st_hist[i].empty() &&
+                            !(h_doc[i].status == ST_OK) && !force_span;
+      if ((h_doc[i].flags & DF_REDO) || (i < h_fused.size() && h_fused[i] && h_doc[i].status != ST_OK) || on_state) { redo_docs.push_back(i); redo_hist.push_back(on_state ? 1 : 0); }
+    }
     lmbe::flush_times(times);
     if (resident) {
       // a document whose run failed keeps what it held before: the blobs of this step are dropped again (reference import is

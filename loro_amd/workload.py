@@ -268,3 +268,27 @@ def cfg5_doc(d: int, n_ops=20000, turn=1000, mark_prob=0.01, n_checkouts=16, com
         p = rng.choice([q for q in last.vv if last.vv[q] > 0])
         fronts.append(wire.encode_frontiers([(p, rng.randrange(last.vv[p]))]))
     return [blob], fronts
+
+
+def cfg2_snapshot_doc(seed: int, n_base=50000, n_branch=25000, commit_every=10):
+    """a configs[1]-shaped history (base by peer A; A and B continue concurrently) delivered as
+    [snapshot of the base (real state section: tests/_oracle.state_entries — the checker's state writer), A's branch, B's branch]."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import _oracle
+    acts = synthetic_trace(n_base + n_branch, 1000 + seed)
+    pa, pb = 0x3111111111111 + 2 * seed, 0x3111111111112 + 2 * seed
+    a = wire.Replica(pa)
+    _apply(a, acts[:n_base], commit_every)
+    base_vv = dict(a.vv)
+    st, ents = _oracle.state_entries([a.export()])
+    assert st == 0
+    snap = a.export_snapshot(state=ents, compress=False)
+    b = wire.Replica(pb)
+    b.merge_from(a)
+    b.seq = {k: list(v) for k, v in a.seq.items()}
+    branch = acts[n_base:]
+    _apply(a, branch, commit_every)
+    _apply(b, [(p, dl, ("Z" if ch else "")) for (p, dl, ch) in branch], commit_every)
+    ob = wire.Replica(pb); ob.changes = {pb: b.changes[pb]}
+    return [snap, a.export(from_vv=base_vv), ob.export()]

@@ -9,7 +9,9 @@ allrec = json.load(open(path)) if os.path.exists(path) else {}
 line = {}
 for l in open(log, errors="replace"):
     if l.startswith('{"name"'):
-        line = json.loads(l)
+        cand = json.loads(l)
+        if not line or cand.get("name") == name:
+            line = cand
 # (other_configs._run runs the pipeline 1 + reps + 1 times — parity, timed repetitions, the stage-timing pass: `pipeline_runs` of the tool's line)
 rec = {"command": f'python tests/tools/gpu_one_config.py "{name}"', "docs": line.get("docs"), "runs_of_the_pipeline": line.get("pipeline_runs") or 5, "stage_ms": line.get("stage_ms"),
        "docs_per_s": line.get("docs_per_s"), "kernels": {}}

@@ -333,3 +333,27 @@ def check_state_base(ctx_factory, n=24):
 
 def test_updates_on_top_of_a_snapshots_state():
     check_state_base(lambda: Context(_emu.binding()), n=24)
+
+
+def check_state_base_large(ctx_factory, n_base=3000, n_branch=1500, n=3):
+    """configs[1]-shaped documents whose 50 %-base arrives as a snapshot: thousands of delete rows of the two concurrent branches name base
+    content — applied by position, remembered in a per-document list sized by the op rows (Dev::posdel_off / pd_row_idx); a list that
+    overflows (LM_PD_STATE_PIECES=0 forces it) sends the document to the side engine, which replays the snapshot's HISTORY"""
+    import os
+    from loro_amd import workload
+    docs = [workload.cfg2_snapshot_doc(s, n_base=n_base, n_branch=n_branch) for s in range(n)]
+    want = _oracle.merge_batch(docs)
+    assert all(w[0] == 0 for w in want)
+    with ctx_factory() as c:
+        assert c.merge_batch(docs) == want
+        assert c.b.state_documents(c.h) == n and c.b.redo_documents(c.h) == 0
+        os.environ["LM_PD_STATE_PIECES"] = "0"
+        try:
+            assert c.merge_batch(docs) == want
+            assert c.b.state_documents(c.h) == n and c.b.redo_documents(c.h) == n
+        finally:
+            del os.environ["LM_PD_STATE_PIECES"]
+
+
+def test_many_base_deletes_on_top_of_a_snapshots_state():
+    check_state_base_large(lambda: Context(_emu.binding()))

@@ -56,3 +56,9 @@ def test_updates_on_top_of_a_snapshots_state():
     """SURVEY §8f N3, second half (lm_snapshot_base.h): snapshot + updates that continue its history — the snapshot's history is
     neither uploaded nor decoded nor replayed; updates concurrent with part of it fall back to the ChangeStore"""
     S.check_state_base(_engine, n=60)
+
+
+def test_many_base_deletes_on_top_of_a_snapshots_state():
+    """a configs[1]-shaped history with its base as a snapshot: thousands of by-position deletes per document (crdt_rope.rs:256-335),
+    and the fall-back to the snapshot's history when the by-position list overflows"""
+    S.check_state_base_large(_engine, n_base=20000, n_branch=10000, n=4)

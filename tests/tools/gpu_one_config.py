@@ -7,5 +7,5 @@ os.environ["LM_BENCH_ONLY"] = sys.argv[1]
 os.environ["LM_BENCH_NO_POOL"] = "1"
 import bench
 out = bench.other_configs(0, os.cpu_count() or 8)
-e = out.get(sys.argv[1], {})
-print(json.dumps({"name": sys.argv[1], "docs": e.get("docs"), "docs_per_s": e.get("docs_per_s"), "ms_per_batch": e.get("ms_per_batch"), "stage_ms": e.get("stage_ms"), "error": e.get("error"), "pipeline_runs": e.get("pipeline_runs_in_this_process")}))
+for name, e in out.items():
+  print(json.dumps({"name": name, "docs": e.get("docs"), "docs_per_s": e.get("docs_per_s"), "ms_per_batch": e.get("ms_per_batch"), "stage_ms": e.get("stage_ms"), "error": e.get("error"), "pipeline_runs": e.get("pipeline_runs_in_this_process"), "state_documents": e.get("state_documents"), "gpu_over_cpu": e.get("gpu_over_cpu")}))
