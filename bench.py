@@ -490,27 +490,33 @@ def other_configs(device, cores):
     run("configs[1]-128-traces", [ttr[(d * 7919) % len(ttr)].stamp(d) for d in range(10000)] if ttr else [], None, 64,
         "configs[1] at its stated size (10,000 docs x 100k ops, 2 concurrent peers, 3 blobs) from 128 DIFFERENT synthetic traces interleaved "
         "pseudo-randomly, letters stamped per document: neighbouring waves replay different histories (the headline batch stamps one trace)")
-    # the configs[1] history with its base (50k ops, one peer's chain) delivered as a SNAPSHOT and the two concurrent
-    # branches (25k ops each) as updates on top of it — staged from the snapshot's state section (lm_snapshot.h / lm_snapshot_base.h):
-    # the base's history is neither uploaded nor decoded nor replayed; LM_SNAPSHOT_STATE=0 replays it from the ChangeStore
+    # a configs[1]-shaped history whose base (50k ops, one peer's chain) arrives as a SNAPSHOT and what follows as updates
+    # on top of it — staged from the snapshot's state section (lm_snapshot.h / lm_snapshot_base.h): the base's history is neither uploaded
+    # nor decoded nor replayed.  Three entries: (1) the updates are one branch that continues the snapshot (the whole document is one
+    # chain: replayed by the linear prefix, by position); (2) the same batch with LM_SNAPSHOT_STATE=0 — the snapshot through its
+    # ChangeStore, as in rounds 2-5; (3) two concurrent 25k-op branches: the cost rule (lm_snapshot_base.h `pays`) sends such a document
+    # through its history — on the state every delete of base content goes through the tracker's by-position path, measured 3.5 x slower
+    # (tests/tools/gpu_snapbase.py) — `state_documents` says which path the batch took
     n3 = "snapshot + updates (SURVEY 8f N3)"
-    if sel(n3) or sel(n3 + ", history replayed"):
+    if sel(n3):
         try:
             if isinstance(gs, Exception):
                 raise gs
             ds = [g[0] for g in gs]
-            sdocs = [ds[i % 8] for i in range(10000)]
-            run(n3, sdocs, None, 8,
-                "configs[1]-shaped documents (100k ops): the 50k-op base as ONE FastSnapshot blob (real state section, stored SSTable blocks), the two concurrent 25k-op "
-                "branches as update blobs; 10,000 docs = 8 distinct histories; staged from the state section — the next entry is the same batch with LM_SNAPSHOT_STATE=0",
-                extra=lambda eng: {"state_documents": int(eng.b.state_documents(eng.h))})
+            sd_ = lambda eng: {"state_documents": int(eng.b.state_documents(eng.h))}
+            chain = [[ds[i % 8][0], ds[i % 8][1]] for i in range(10000)]
+            run(n3, chain, None, 8,
+                "configs[1]-shaped documents: the 50k-op base as ONE FastSnapshot blob (real state section, stored SSTable blocks), one 25k-op branch that continues it as an "
+                "update blob (75k ops per document); 10,000 docs = 8 distinct histories; staged from the state section", extra=sd_)
             os.environ["LM_SNAPSHOT_STATE"] = "0"
             try:
-                run(n3 + ", history replayed", sdocs, None, 8,
-                    "the batch above with LM_SNAPSHOT_STATE=0: the snapshot ingested through its ChangeStore (rounds 2-5), the whole history decoded and replayed", reps=2,
-                    extra=lambda eng: {"state_documents": int(eng.b.state_documents(eng.h))})
+                run(n3 + ", history replayed", chain, None, 8,
+                    "the batch above with LM_SNAPSHOT_STATE=0: the snapshot ingested through its ChangeStore (rounds 2-5), the whole history decoded and replayed", reps=2, extra=sd_)
             finally:
                 del os.environ["LM_SNAPSHOT_STATE"]
+            run(n3 + ", two concurrent branches", [ds[i % 8] for i in range(10000)], None, 8,
+                "the 50k-op base as a snapshot + TWO concurrent 25k-op branches as update blobs (100k ops per document): the cost rule declines the state path "
+                "(state_documents 0) and the snapshot's history is replayed", reps=2, extra=sd_)
         except Exception as ex:
             out[n3] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     # configs[4]: 256 document INSTANCES (own copies of the blobs of 4 distinct histories) x 16 versions.  The 16 entries of an instance

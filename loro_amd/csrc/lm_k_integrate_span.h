@@ -65,7 +65,12 @@ static constexpr uint32_t PD_LDS = 12;
 LM_DEV uint32_t* pd_w(const Ts& t) { return const_cast<uint32_t*>(t.ebase) - PD_LDS; }
 template <bool POS>
 LM_DEV void pd_stop(Ts& t, uint32_t k, uint32_t left, uint32_t first, uint32_t matched) {   // (cold: a delete row that does not match its position)
-  t.err = ST_POSDEL;   // (every kernel but k_integrate_span_pos: the document leaves with this verdict and is replayed by that kernel)
+  // (every kernel but k_integrate_span_pos: the document leaves with this verdict and is replayed by that kernel; POS with the optimistic
+  // directory, retry_pass 3: a directory overflow met on the way here stays the verdict — the document is replayed with the worst-case one)
+#ifdef LM_EMU_TRACE
+  if (getenv("LM_EMU_BASE") && lmw::lane() == 0 && t.err) fprintf(stderr, "pd_stop<%d> with err %d\n", (int)POS, (int)t.err);
+#endif
+  if (!POS || t.err != ST_RETRY) t.err = ST_POSDEL;
   if (POS && lmw::lane() == 0) { uint32_t* w = pd_w(t); w[0] = k; w[1] = left; w[2] = first; w[3] = matched; }
 }
 
@@ -224,7 +229,7 @@ LM_DEV void sd_set(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
 }
 LM_DEV void sd_insert_after(Ts& t, uint32_t p, uint32_t a, uint32_t b) {
   int lane = lmw::lane();
-  if (t.n_dir >= t.dir_cap) { t.err = ST_RETRY; return; }
+  if (t.n_dir >= t.dir_cap) { LM_SETERR(t.err, ST_RETRY); return; }
   lmw::wave_sync();
   uint32_t q = p + 1;
   for (uint32_t hi = t.n_dir; hi > q;) {
@@ -533,9 +538,12 @@ LM_DEV void ts_insert(Ts& t, uint32_t pos, uint32_t pid0, uint32_t len) {
   int lane = lmw::lane();
   PROF_T0();
   PROF_CNT(t, PF_NINS, 1);
+#ifdef LM_EMU_TRACE
+  if (getenv("LM_EMU_INS") && lane == 0) fprintf(stderr, "INS pos %u id %u:%u len %u\n", pos, pid0 >> 24, pid0 & 0xffffff, len);
+#endif
   // (POS: the kernel that replays damaged documents rejects the row — see above; the others clamp it as they always did: the check
   // was measured at 2 % of the replay of healthy documents, an exit edge in front of the in-leaf path)
-  if (POS && pos > t.tot_active) { LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }
+  if (POS && pos > t.tot_active) { if (!t.err) LM_SETERR(t.err, ST_DATA_CORRUPTION); return; }   // (an earlier verdict — a directory overflow during the move in front of the row — stays)
   // (an insert BEYOND the end is placed by the reference behind everything its tree holds — trailing tombstones and future items
   // included (the B-tree query misses and returns the end of the tree, crdt_rope.rs:81-82), not behind the last ACTIVE element, where
   // the clamp below puts it: one damaged document in 3,600 was rendered with two list items elsewhere.  No writer emits such a row;
@@ -830,6 +838,9 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
   // items only hold applied elements, so the in-leaf path needs neither the peer's element base nor its end (two LDS round trips)
   // (one attempt outside any loop: a row's range mostly lies in one run of the cached leaf, and a loop around the attempt carried
   // the whole cached leaf through its phi nodes — 70 instructions per row, most of them register moves)
+#ifdef LM_EMU_TRACE
+  if (getenv("LM_EMU_INS") && lane == 0) fprintf(stderr, "UPD mode %d hint %u peer %u [%u, %u) POS %d\n", mode, hint_k, peer, c0, c1, (int)POS);
+#endif
   if (c >= c1) return;
   bool tried = true;   // the in-leaf path has just declined this very element
   if (ts_update_fast<POS>(t, peer, c, c1, mode, hint_k)) {
@@ -943,6 +954,9 @@ LM_DEV void ts_update_range(Ts& t, uint32_t peer, uint32_t c0, uint32_t c1, int 
 // ts_move_ops consults instead of the row's own target span.  Cold: the row loop comes here only on ST_POSDEL.
 LM_DEV void ts_del_positional(Ts& t, uint32_t row) {
   int lane = lmw::lane();
+#ifdef LM_EMU_TRACE
+  if (getenv("LM_EMU_BASE") && lane == 0 && t.err != ST_POSDEL) fprintf(stderr, "ts_del_positional with err %d\n", (int)t.err);
+#endif
   t.err = 0;
   lmw::wave_sync();
   uint32_t* w = pd_w(t);
@@ -1562,8 +1576,9 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   {
     uint32_t fl = m.flags;
     if (RES && (fl & DF_PLAIN) && d.front_off[doc + 1] > d.front_off[doc]) fl &= ~DF_PLAIN;   // resident, rendered at a checked-out version: the general instantiation's
-    if (POS ? (fl & DF_MOVABLE) != 0 : (fl & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
-    if (PLAIN && !RES && ((fl & DF_FUSED) != 0 && d.fuse != nullptr) != FUSE) return;                      // (k_integrate_span_plain_fuse's / the plain kernel's)
+    // (POS: plain documents — fused ones too, row by row — are k_integrate_span_pos_plain's, the others k_integrate_span_pos's)
+    if (POS ? ((fl & DF_MOVABLE) != 0 || ((fl & DF_PLAIN) != 0) != PLAIN) : (fl & (DF_MOVABLE | DF_PLAIN)) != ((ML ? DF_MOVABLE : 0u) | (PLAIN ? DF_PLAIN : 0u))) return;   // another kernel's document
+    if (PLAIN && !RES && !POS && ((fl & DF_FUSED) != 0 && d.fuse != nullptr) != FUSE) return;                      // (k_integrate_span_plain_fuse's / the plain kernel's)
   }
   (void)SWEEP;
   if (retry_pass && m.status != (POS ? ST_POSDEL : ST_RETRY)) return;
@@ -1592,6 +1607,9 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   if (status_fatal(m.status)) return;
   uint32_t P = m.n_peers;
   for (uint32_t p = (uint32_t)lane; p < P; p += 64) { s_ebase[p] = d.elem_base[m.praw0 + p]; s_end[p] = d.peer_end[m.praw0 + p]; }
+  // (POS: the peers' ends in the document's BASE version — a document staged on a snapshot's state; ids below it are content the tracker
+  // holds only under the synthetic peer's ids: a delete row that names them is applied by position straight away, see the row loop)
+  if (POS && !RES) for (uint32_t p = (uint32_t)lane; p < P; p += 64) s_app[p] = d.peer_base[m.praw0 + p];
   // RES: the stored tracker of this document, if it can be used
   uint32_t* tk = nullptr;
   uint32_t tk_pcap = 0, P0 = 0, C0 = 0;
@@ -1664,7 +1682,7 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   uint64_t pf_begin = lmw::clock();
 #endif
   uint32_t dir_used = 0;
-  if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
+  if (m.leaf_cap > MAX_LEAVES_PER_DOC || (retry_pass && retry_pass != 3u && m.leaf_cap > dir_cap) || P > pmax) { if (lane == 0) LM_SETERR(d.doc[doc].status, ST_UNSUPPORTED); return; }
   if (RES && !fresh) {
     // the stored leaves: renumbered when the peer order changed, and loc[] (cleared above) written again for every item —
     // unless the layout did not move (keep_loc: then nothing was cleared and nothing is renumbered)
@@ -2041,6 +2059,14 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
               uint32_t hint = 0;
               if (a == 0 && b == r.len) hint = r.a2 > 0 ? (uint32_t)r.prop + 1 : (uint32_t)r.prop + 2 - Ln;
               if (not_del | bad_bits) { if (!not_del) LM_SETERR(t.err, ST_DATA_CORRUPTION); t1 = t0; hint = 0; }
+              if (POS && !RES && hint && !t.err && t1 > t0 && t1 <= lmw::first(s_app[r.a0])) {
+                // every target lies below the base version (lm_snapshot_base.h): no item carries these ids — the row is applied by position,
+                // as ts_update_range would find out by failing to match it (crdt_rope.rs:256-335; tracker.rs:40-60: content the tracker
+                // knows as a placeholder) — without the mismatch, the unwinding and the restart of the row loop
+                lmw::wave_sync();
+                if (lane == 0) { uint32_t* w = pd_w(t); w[0] = hint; w[1] = t1 - t0; w[2] = pid_make(r.a0, t0); w[3] = 0; }
+                ts_del_positional(t, row);
+              } else
               ts_update_range<POS>(t, r.a0, t0, t1, UPD_DEL_INC, hint);
               PROF_ADD(t, PF_DELETE);
               PROF_CNT(t, PF_NDEL, 1);
@@ -2121,6 +2147,10 @@ LM_DEV void integrate_span_body(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax
   // (RES: the context replays such a document of a folded batch through the batch kernels, lm_capi_impl.h redo — DF_REDO)
   if (t.err == ST_POSDEL && RES && !ML && d.posdel_redo && lane == 0) lmw::atomic_or(&d.doc[doc].flags, DF_REDO);
   if (t.err == ST_POSDEL && (POS || RES || ML || !d.posdel)) t.err = ST_DATA_CORRUPTION;
+  // (retry_pass 3: the by-position kernel launched with the OPTIMISTIC directory — a batch whose documents all take this path, staged on
+  // snapshot states, would otherwise run at the occupancy the worst-case directory leaves; a document that overflows it is replayed once
+  // more by the same kernel with the worst-case directory, retry_pass 2)
+  if (POS && retry_pass == 3u && t.err == ST_RETRY) t.err = ST_POSDEL;
   if (t.err && lane == 0) {
     d.doc[doc].status = t.err;
     if (t.err == ST_RETRY) lmw::atomic_add(retry_count, 1u);
@@ -2187,6 +2217,16 @@ LM_KERNEL LM_WAVES_PER_SIMD(4) LM_ONE_WAVE_GROUPS void k_integrate_span_pos(Dev 
                                 const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
                                 uint32_t* retry_count) {
   integrate_span_body<false, false, false, false, false, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
+}
+// … and the PLAIN ones among them (Text / List inserts and deletes only, rendered at the latest version): the plain body + POS — linear prefix,
+// lazy loc[], no style / checkout paths.  A batch staged on snapshot states (lm_snapshot_base.h) sends EVERY document here: the common body
+// replays such a document six times slower than the plain one (tests/tools/gpu_snapbase.py).  Rows are read through the 8-row window (no
+// V64 / R64: the row loop is entered again behind a row finished by position)
+LM_KERNEL LM_WAVES_PER_SIMD(4) LM_ONE_WAVE_GROUPS void k_integrate_span_pos_plain(Dev d, DevDag g, uint32_t dir_cap, uint32_t pmax, const OpRow* __restrict__ op_ro,
+                                const ChangeRow* __restrict__ chg_ro, const uint32_t* __restrict__ sorted_ro,
+                                const uint32_t* __restrict__ skip_ro, const uint32_t* __restrict__ vvh_ro, uint32_t retry_pass,
+                                uint32_t* retry_count) {
+  integrate_span_body<false, true, true, false, false, true>(d, g, dir_cap, pmax, op_ro, chg_ro, sorted_ro, skip_ro, vvh_ro, retry_pass, retry_count);
 }
 // Resident documents (DevRes above): the common body with PLAIN = false (sliced rows: the applied prefix), SWEEP, RES.
 // (128 VGPRs: the prologue / epilogue state of a resident document does not fit the 96 of five waves per SIMD without scratch)

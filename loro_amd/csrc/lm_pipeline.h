@@ -178,7 +178,7 @@ struct Engine {
   } sv;
 
   // environment knobs (A/B measurements and tests): read once per staged batch / import, not inside the run
-  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true, snapshot_state = true, stage_direct = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4, pd_state_pieces = 2; } kn;
+  struct Knobs { bool span = true, decode_wave = true, no_opt_dir = false, loc_memset = true; int plain = 2; uint32_t dec_slot = 1264, dec_slot_big = 4096, dec_big_mode = 1, dir_opt_max = 0; size_t lds_pad = 0; long long slab_cap = -1; uint32_t ht_opt = 2048, cut_min_rows = 2048, vs_row_cost = 300; bool lww_lds = true, fuse_rows = true, version_sweep = true, span_auto = true, linear = true, posdel = true, reclass = true, redo = true, map_fused = true, snapshot_state = true, snapshot_state_force = false, stage_direct = true; uint32_t mf_min_rows = 2048, mf_chg_ratio = 4, pd_state_pieces = 2; } kn;
   void read_knobs() {
     Knobs k;
     if (const char* e = getenv("LM_SPAN")) k.span = atoi(e) != 0;
@@ -208,7 +208,8 @@ struct Engine {
     if (const char* e = getenv("LM_MF_MIN_ROWS")) k.mf_min_rows = (uint32_t)atoi(e);             // rows from which a Map document gets a workgroup of k_map_fused (tests: 1)
     if (const char* e = getenv("LM_STAGE_DIRECT")) k.stage_direct = atoi(e) != 0;                // 0: blobs inside an lm_host_alloc region are gathered into the engine's staging buffer like any others
     if (const char* e = getenv("LM_PD_STATE_PIECES")) k.pd_state_pieces = (uint32_t)atoi(e);          // by-position list of a document staged on a snapshot's state: pieces per op row (2; tests: 0 = overflow -> replayed from the snapshot's history)
-    if (const char* e = getenv("LM_SNAPSHOT_STATE")) k.snapshot_state = atoi(e) != 0;            // 0: a document given as one snapshot is replayed from its ChangeStore (rounds 2-5) instead of rendered from its state section
+    if (const char* e = getenv("LM_SNAPSHOT_STATE")) { k.snapshot_state = atoi(e) != 0; k.snapshot_state_force = atoi(e) == 2; }   // (2: snapshot + updates on the state even where the history is expected to be cheaper, lm_snapshot_base.h `pays`)
+               // 0: a document given as one snapshot is replayed from its ChangeStore (rounds 2-5) instead of rendered from its state section
     if (const char* e = getenv("LM_MF_CHG_RATIO")) k.mf_chg_ratio = (uint32_t)atoi(e);           // … and rows per change it needs on average (tests: 0)
     if (force_span) { k.span = true; k.span_auto = false; k.posdel = true; k.redo = false; k.map_fused = false; }
     kn = k;
@@ -249,7 +250,9 @@ struct Engine {
       for (uint32_t b = parent.st_doc_blob[i]; b < parent.st_doc_blob[i + 1]; b++) { bp[k].push_back(parent.st_base + parent.st_blob_off[b]); bl[k].push_back(parent.st_blob_len[b]); }
       in[k] = DocIn{bp[k].data(), bl[k].data(), bp[k].size(), items[k].front, items[k].front_len};
     }
-    stage(in.data(), in.size());
+    stage_history_only = true;   // (a document replayed from its snapshot's history arrives as the snapshot itself: through its ChangeStore this time)
+    try { stage(in.data(), in.size()); } catch (...) { stage_history_only = false; throw; }
+    stage_history_only = false;
     // the state-section roots of the documents' snapshots (lm_stage read them from the mode-3 blobs, which the buffer no longer holds)
     h_froot.clear();
     h_froot_off.assign(items.size() + 1, 0);
@@ -348,16 +351,17 @@ struct Engine {
         lmsnap::StateBase sb;
         std::vector<std::pair<const uint8_t*, size_t>> U;
         std::vector<std::vector<uint8_t>> outU;
+        bool pays = true;
         if (n3 == 1 && n3 + n4 == docs[i].n) for (size_t k = 0; k < docs[i].n; k++) if (k != ks) U.emplace_back(docs[i].blobs[k], docs[i].lens[k]);
         if (n3 == 1 && n3 + n4 == docs[i].n && lmsnap::snapshot_state_to_updates(docs[i].blobs[ks], docs[i].lens[ks], o2, vv2, &roots2, false, &sb) &&
-            lmsnap::rebase_updates_on_state(sb, U, outU)) {
+            lmsnap::rebase_updates_on_state(sb, U, outU, &pays) && (pays || kn.snapshot_state_force)) {
           h_froot_off[i] = froot.size();
           froot.insert(froot.end(), roots2.begin(), roots2.end());
-          std::vector<uint8_t> hist;
-          if (lmsnap::snapshot_to_updates(docs[i].blobs[ks], docs[i].lens[ks], hist, nullptr, nullptr) != lmsnap::SN_OK) hist.assign(docs[i].blobs[ks], docs[i].blobs[ks] + docs[i].lens[ks]);
+          // (the history form is kept as the snapshot came: a copy — the caller's buffers need not outlive lm_stage — that is taken through
+          // its ChangeStore only if the document is ever staged as history: restage_history, a failed state replay)
           size_t u = 0;
           for (size_t k = 0; k < docs[i].n; k++, b++) {
-            if (k == ks) { st_hist[i].push_back(hist); conv.push_back(std::move(o2)); }
+            if (k == ks) { st_hist[i].emplace_back(docs[i].blobs[ks], docs[i].blobs[ks] + docs[i].lens[ks]); conv.push_back(std::move(o2)); }
             else { st_hist[i].emplace_back(docs[i].blobs[k], docs[i].blobs[k] + docs[i].lens[k]); conv.push_back(std::move(outU[u++])); }
             bsrc[b] = conv.back().data(); blen[b] = conv.back().size();
           }
@@ -387,9 +391,7 @@ struct Engine {
             std::vector<uint8_t> o2, vv2, roots2;
             lmsnap::StateBase sb;
             if (lmsnap::snapshot_state_to_updates(p, l, o2, vv2, &roots2, docs[i].state_root != 0, &sb)) {
-              std::vector<uint8_t> hist;
-              if (lmsnap::snapshot_to_updates(p, l, hist, nullptr, nullptr) == lmsnap::SN_OK) st_hist[i].push_back(std::move(hist));
-              else st_hist[i].emplace_back(p, p + l);       // (a shallow snapshot: lm_import restages it as it came — LM_UNSUPPORTED there, as before)
+              st_hist[i].emplace_back(p, p + l);            // (as it came: through its ChangeStore only when the batch is staged as history — a shallow snapshot is LM_UNSUPPORTED there, as before)
               conv.push_back(std::move(o2)); p = conv.back().data(); l = conv.back().size();
               froot.resize(h_froot_off[i]); froot.insert(froot.end(), roots2.begin(), roots2.end());
               vvo_tmp[i].resize(8);                         // (Dev::vvo: the synthetic peer, then the snapshot's version vector)
@@ -1397,8 +1399,30 @@ struct Engine {
       // Documents with a delete row whose target ids are not the elements at its position — damaged input; the reference applies
       // every delete by position (crdt_rope.rs:256-335) — left the launches above with ST_POSDEL: replayed once more by the kernel
       // that finishes such rows by position and remembers what they deleted (ts_del_positional), with the worst-case directory
-      LM_LAUNCH_DYN(k_integrate_span_pos, n_docs, 64, (size_t)(2 * dir_cap + (dir_cap >> SD_BSH) + 2 + PD_LDS + 4 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+      // Many such documents (a batch staged on snapshot states: every delete of base content goes this way): first with the optimistic
+      // directory — the worst-case one leaves a few waves per CU — and once more, worst case, for the documents that overflow it
+      uint32_t n_left = n_posdel;
+#ifdef LM_EMU_TRACE
+      if (getenv("LM_EMU_BASE")) fprintf(stderr, "POS documents %u, directory %u optimistic / %u worst case\n", n_posdel, dir_opt, dir_cap);
+#endif
+      if (n_posdel >= 64 && dir_opt < dir_cap) {
+        lmbe::dmemset(retry_cnt + 3, 0, 4);
+        LM_LAUNCH_DYN(k_integrate_span_pos, n_docs, 64, (size_t)(2 * dir_opt + (dir_opt >> SD_BSH) + 2 + PD_LDS + 5 * pmax + 1) * 4, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                      (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 3u, retry_cnt);
+        LM_LAUNCH_DYN(k_integrate_span_pos_plain, n_docs, 64, (size_t)(2 * dir_opt + (dir_opt >> SD_BSH) + 2 + PD_LDS + 5 * pmax + 1) * 4, d, g, dir_opt, pmax, (const OpRow*)d.op,
+                      (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 3u, retry_cnt);
+        lmbe::d2h(&n_left, retry_cnt + 3, 4);
+#ifdef LM_EMU_TRACE
+        if (getenv("LM_EMU_BASE")) fprintf(stderr, "POS pass with the optimistic directory (%u of %u): %u documents, %u left for the worst-case pass\n", dir_opt, dir_cap, n_posdel, n_left);
+#endif
+      }
+      if (n_left)
+      {
+      LM_LAUNCH_DYN(k_integrate_span_pos, n_docs, 64, (size_t)(2 * dir_cap + (dir_cap >> SD_BSH) + 2 + PD_LDS + 5 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
                     (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 2u, retry_cnt);
+      LM_LAUNCH_DYN(k_integrate_span_pos_plain, n_docs, 64, (size_t)(2 * dir_cap + (dir_cap >> SD_BSH) + 2 + PD_LDS + 5 * pmax + 1) * 4, d, g, dir_cap, pmax, (const OpRow*)d.op,
+                    (const ChangeRow*)d.chg, (const uint32_t*)d.chg_sorted, (const uint32_t*)d.chg_skip, (const uint32_t*)d.vvh, 2u, retry_cnt);
+      }
     }
     last_posdel = n_posdel;
     if (!resident && h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only (a resident tracker knows both versions)

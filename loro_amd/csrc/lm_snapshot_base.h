@@ -24,7 +24,12 @@
 
 namespace lmsnap {
 
-inline bool rebase_updates_on_state(const StateBase& sb, const std::vector<std::pair<const uint8_t*, size_t>>& U, std::vector<std::vector<uint8_t>>& out) {
+// `pays` (optional): false when the replay on the state is expected to cost MORE than the replay of the snapshot's history — measured on
+// configs[1]-shaped documents (tests/tools/gpu_snapbase.py): updates that are ONE chain behind the frontiers are replayed by
+// the linear prefix, by position, at twice the speed of the history path; updates with concurrent branches go through the tracker, where
+// every delete of base content takes the by-position path (ts_del_positional) and rows are not fused — about 1.1 ms per 1,000 update ops
+// and 2,000 documents against 0.2 ms per 1,000 ops of history: the state pays while the updates hold less than a fifth of the history's ops
+inline bool rebase_updates_on_state(const StateBase& sb, const std::vector<std::pair<const uint8_t*, size_t>>& U, std::vector<std::vector<uint8_t>>& out, bool* pays = nullptr) {
   if (sb.synth_len == 0) return false;
   struct Ch { uint64_t peer; uint32_t ctr, len, lamport; size_t blob, blk, idx; std::vector<std::pair<uint64_t, uint32_t>> deps; bool covers = false, done = false; };
   std::vector<std::vector<lmexp::Block>> blocks(U.size());
@@ -81,8 +86,15 @@ inline bool rebase_updates_on_state(const StateBase& sb, const std::vector<std::
   std::vector<size_t> order(chs.size());
   for (size_t i = 0; i < order.size(); i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return chs[a].lamport < chs[b].lamport; });   // (a dependency has the smaller lamport)
+  bool one_chain = true;
+  long prev = -1;
+  uint64_t update_ops = 0;
   for (size_t oi : order) {
     Ch& c = chs[oi];
+    update_ops += c.len;
+    if (prev < 0) { if (c.deps.size() != fr.size()) one_chain = false; }   // (all of them below the base, or the walk below declines the document)
+    else if (c.deps.size() != 1 || c.deps[0].first != chs[(size_t)prev].peer || c.deps[0].second != chs[(size_t)prev].ctr + chs[(size_t)prev].len - 1) one_chain = false;
+    prev = (long)oi;
     std::set<std::pair<uint64_t, uint32_t>> below;
     bool via = false;
     for (auto& dp : c.deps) {
@@ -95,6 +107,11 @@ inline bool rebase_updates_on_state(const StateBase& sb, const std::vector<std::
     else c.covers = via;
     if (!c.covers) return false;                               // concurrent with (part of) the base
     c.done = true;
+  }
+  if (pays) {
+    uint64_t base_ops = 0;
+    for (auto& kv : sb.vv) base_ops += kv.second;
+    *pays = one_chain || update_ops <= 4096 || update_ops * 5 <= base_ops;
   }
   // ---- the blocks again, hung on the synthetic change
   out.clear();

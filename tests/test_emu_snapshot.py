@@ -345,15 +345,50 @@ def check_state_base_large(ctx_factory, n_base=3000, n_branch=1500, n=3):
     want = _oracle.merge_batch(docs)
     assert all(w[0] == 0 for w in want)
     with ctx_factory() as c:
+        # the cost rule (lm_snapshot_base.h `pays`): updates that are ONE chain behind the snapshot are always replayed on its state (the
+        # linear prefix, by position); concurrent branches only while they are small beside the history
         assert c.merge_batch(docs) == want
-        assert c.b.state_documents(c.h) == n and c.b.redo_documents(c.h) == 0
-        os.environ["LM_PD_STATE_PIECES"] = "0"
+        concurrent_taken = 2 * n_branch <= 4096 or 2 * n_branch * 5 <= n_base
+        assert c.b.state_documents(c.h) == (n if concurrent_taken else 0) and c.b.redo_documents(c.h) == 0
+        chain = [[d[0], d[1]] for d in docs]
+        assert c.merge_batch(chain) == _oracle.merge_batch(chain) and c.b.state_documents(c.h) == n
+        os.environ["LM_SNAPSHOT_STATE"] = "2"      # (the by-position machinery at size, whatever the rule says)
         try:
             assert c.merge_batch(docs) == want
-            assert c.b.state_documents(c.h) == n and c.b.redo_documents(c.h) == n
+            assert c.b.state_documents(c.h) == n and c.b.redo_documents(c.h) == 0
+            os.environ["LM_PD_STATE_PIECES"] = "0"
+            try:
+                assert c.merge_batch(docs) == want
+                assert c.b.state_documents(c.h) == n and c.b.redo_documents(c.h) == n
+            finally:
+                del os.environ["LM_PD_STATE_PIECES"]
         finally:
-            del os.environ["LM_PD_STATE_PIECES"]
+            del os.environ["LM_SNAPSHOT_STATE"]
+
+
+def check_state_base_many_documents(ctx_factory, n_base=1200, n_branch=600, n_docs=66, dir_opt_max=4):
+    """a batch whose documents ALL delete base content by position: k_integrate_span_pos is launched with the optimistic directory first
+    (the worst-case one leaves a few waves per CU); LM_DIR_OPT_MAX makes the documents overflow it — replayed by the worst-case pass"""
+    import os
+    from loro_amd import workload
+    base = [workload.cfg2_snapshot_doc(s, n_base=n_base, n_branch=n_branch) for s in range(3)]
+    want = _oracle.merge_batch(base)
+    docs = [base[i % 3] for i in range(n_docs)]
+    os.environ["LM_SNAPSHOT_STATE"] = "2"
+    try:
+        with ctx_factory() as c:
+            got = c.merge_batch(docs)
+            assert all(g == want[i % 3] for i, g in enumerate(got)) and c.b.state_documents(c.h) == n_docs and c.b.redo_documents(c.h) == 0
+            os.environ["LM_DIR_OPT_MAX"] = str(dir_opt_max)
+            try:
+                got = c.merge_batch(docs)
+                assert all(g == want[i % 3] for i, g in enumerate(got)) and c.b.state_documents(c.h) == n_docs and c.b.redo_documents(c.h) == 0
+            finally:
+                del os.environ["LM_DIR_OPT_MAX"]
+    finally:
+        del os.environ["LM_SNAPSHOT_STATE"]
 
 
 def test_many_base_deletes_on_top_of_a_snapshots_state():
     check_state_base_large(lambda: Context(_emu.binding()))
+    check_state_base_many_documents(lambda: Context(_emu.binding()))

@@ -62,3 +62,4 @@ def test_many_base_deletes_on_top_of_a_snapshots_state():
     """a configs[1]-shaped history with its base as a snapshot: thousands of by-position deletes per document (crdt_rope.rs:256-335),
     and the fall-back to the snapshot's history when the by-position list overflows"""
     S.check_state_base_large(_engine, n_base=20000, n_branch=10000, n=4)
+    S.check_state_base_many_documents(_engine, n_base=20000, n_branch=10000, n_docs=300, dir_opt_max=16)
