@@ -408,6 +408,8 @@ def other_configs(device, cores):
     only = os.environ.get("LM_BENCH_ONLY")   # profiles/collect_other.sh: ONE entry per process (its kernels are then that entry's in the rocprofv3 record)
 
     def sel(name):
+        if os.environ.get("LM_BENCH_ONLY_EXACT"):   # (profiles/collect_other.sh: the rocprofv3 record must hold ONE entry's kernels)
+            return name == only
         return not only or name == only or name.startswith(only + ",")
 
     def run(name, docs, fronts, distinct, desc, reps=3, extra=None):
@@ -499,7 +501,7 @@ def other_configs(device, cores):
     # through its history — on the state every delete of base content goes through the tracker's by-position path, measured 3.5 x slower
     # (tests/tools/gpu_snapbase.py) — `state_documents` says which path the batch took
     n3 = "snapshot + updates (SURVEY 8f N3)"
-    if sel(n3):
+    if sel(n3) or (only or "").startswith(n3):
         try:
             if isinstance(gs, Exception):
                 raise gs

@@ -7,6 +7,7 @@ shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ $# -eq 0 ]; then set -- "configs[0]" "configs[2]" "configs[3]" "configs[1]-heterogeneous" "configs[1]-128-traces" "configs[4]" "movable-lists (SURVEY 8f N4)"; fi
 cd /tmp && export TMPDIR=/tmp
+export LM_BENCH_ONLY_EXACT=1
 i=0
 for NAME in "$@"; do
   i=$((i+1))
