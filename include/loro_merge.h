@@ -153,7 +153,12 @@ int lm_redo_documents(lm_ctx* ctx);
  * proportional to the STATE (+ the updates), the snapshot's history is neither uploaded nor decoded nor replayed, and `vv` is the
  * snapshot's own merged with what the updates add.  Updates concurrent with part of the snapshot's history need that history: such
  * a document is replayed from the snapshot's ChangeStore (same bytes out).  A later lm_import into such a batch stages the
- * snapshots once more through their ChangeStore (a history is what an import builds on).  LM_SNAPSHOT_STATE=0 switches it off. */
+ * snapshots once more through their ChangeStore (a history is what an import builds on).  Snapshot + updates is taken where it is the
+ * cheaper replay (lm_snapshot_base.h `pays`): always when the updates are ONE chain behind the snapshot's frontiers (replayed by the
+ * linear prefix: 2.2 x the rate of the history path on configs[1]-shaped documents), with concurrent branches only while the updates
+ * hold at most 4,096 ops or a fifth of the history's (their deletes of base content go through the tracker's by-position path).  A
+ * document staged on a state that fails in ANY way is replayed from its snapshot's history (lm_redo_documents counts it): the verdict
+ * is always the history's.  LM_SNAPSHOT_STATE=0 switches the state path off, =2 takes it wherever it is possible. */
 int lm_state_documents(lm_ctx* ctx);
 
 /* Resident documents: import MORE blobs into the documents the context already holds, and / or render them
