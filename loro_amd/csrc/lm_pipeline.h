@@ -224,7 +224,7 @@ struct Engine {
   uint32_t n_state_docs = 0;
   bool stage_history_only = false;                    // (restage_history: this stage call takes every snapshot through its ChangeStore)
   DBuf b_vvo, b_vvo_off, b_pd_off, b_pd_row;
-  std::vector<uint8_t> redo_hist;                 // documents of redo_docs that are replayed from their snapshot's HISTORY (st_hist), not from the staged state
+  std::vector<uint8_t> redo_hist;                 // per document: 1 = flagged in redo_docs AND replayed from its snapshot's HISTORY (st_hist), not from the staged state
   // ---- DF_REDO: what lm_stage left in the pinned staging buffer (the blobs as the device sees them: snapshots already reframed) —
   // a side engine stages the documents to replay from there (stage_from); lm_import with new blobs reuses the buffer and ends that
   bool st_valid = false;
@@ -233,10 +233,7 @@ struct Engine {
   std::vector<uint8_t> st_froot;
   std::vector<uint32_t> redo_docs;                // documents of the last run flagged DF_REDO (local indices)
   struct RedoItem { uint32_t doc; const uint8_t* front; size_t front_len; };
-  bool redo_by_history(uint32_t doc) const {
-    for (size_t k = 0; k < redo_docs.size(); k++) if (redo_docs[k] == doc) return k < redo_hist.size() && redo_hist[k] != 0;
-    return false;
-  }
+  bool redo_by_history(uint32_t doc) const { return doc < redo_hist.size() && redo_hist[doc] != 0; }
   void stage_from(const std::vector<Engine*>& parents, const std::vector<RedoItem>& items) {
     for (Engine* pe : parents) if (!pe->st_valid) throw std::runtime_error("redo: the staged blobs are gone");
     std::vector<std::vector<const uint8_t*>> bp(items.size());
@@ -536,7 +533,7 @@ struct Engine {
     h_front_off[nd] = fr.size();
     b_front.ensure(fr.size() + 16); if (!fr.empty()) lmbe::h2d(b_front.p, fr.data(), fr.size());
     b_front_off.ensure((nd + 1) * 8); lmbe::h2d(b_front_off.p, h_front_off.data(), (nd + 1) * 8);
-    lmbe::sync();
+    lmbe::sync();   // (leaving the copies of a directly staged batch in flight and returning at once was measured: 335k against 356k docs/s end to end, tests/tools/gpu_e2e.py — the host thread is not what bounds the rotation)
     st_valid = true; st_doc_blob = h_doc_blob; st_blob_len = h_blob_len; st_blob_off = h_blob_off; st_froot_off = h_froot_off; st_froot = h_froot;
     redo_docs.clear();
     ran = fetched = false;
@@ -1572,11 +1569,11 @@ struct Engine {
     // decoders speak first; the failure's code is theirs to give, so the document is replayed through them)
     // (… and a document staged on a snapshot's STATE that failed in any way — an engine limit of the by-position path, a damaged update:
     // replayed from the snapshot's history, where every verdict is the row decoders' / the tracker's on real ids)
-    redo_hist.clear();
+    redo_hist.assign(n_docs, 0);
     if (kn.redo && st_valid) for (uint32_t i = 0; i < n_docs; i++) {
       const bool on_state = !resident && n_state_docs && h_vvo_off.size() > (size_t)i + 1 && h_vvo_off[i + 1] > h_vvo_off[i] && i < st_hist.size() && !st_hist[i].empty() &&
                             !(h_doc[i].status == ST_OK) && !force_span;
-      if ((h_doc[i].flags & DF_REDO) || (i < h_fused.size() && h_fused[i] && h_doc[i].status != ST_OK) || on_state) { redo_docs.push_back(i); redo_hist.push_back(on_state ? 1 : 0); }
+      if ((h_doc[i].flags & DF_REDO) || (i < h_fused.size() && h_fused[i] && h_doc[i].status != ST_OK) || on_state) { redo_docs.push_back(i); redo_hist[i] = on_state ? 1 : 0; }
     }
     lmbe::flush_times(times);
     if (resident) {

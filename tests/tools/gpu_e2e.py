@@ -38,7 +38,7 @@ def leg(engs, packs, n_docs_each, steps, helpers):
     return n_docs_each * steps / dt, dt / steps * 1e3, t_stage / steps * 1e3, sorted((i, w, round((t - t0) * 1e3, 1)) for i, w, t in ev)
 
 
-for n_ctx, helpers, split in ((3, 1, 1), (4, 1, 1), (4, 2, 1), (4, 1, 2), (6, 2, 2), (6, 3, 2)):
+for n_ctx, helpers, split in ((3, 1, 1), (4, 1, 1), (4, 2, 1), (5, 2, 1)):
     per = N // split
     engs = [loro_amd.MergeEngine(0) for _ in range(n_ctx)]
     try:
