@@ -252,7 +252,7 @@ LM_DEV uint32_t ml_resolve(const Dev& d, const DocMeta& m, uint32_t cidx, uint32
 // then): loc[item] := the element the item positions, the per-element maxima of the move / set rows inside the rendered
 // version, and the state-store rule — a MovableList exists once an element was inserted, even if nothing is visible any
 // more (its diff lists every element the version knows: delta/movable_list.rs:32-34, diff_calc.rs:1880-1924).
-LM_KERNEL void k_mlist_post(Dev d) {
+LM_KERNEL void k_mlist_post(Dev d, DevDag g) {
   uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
   const DocMeta m = d.doc[doc];
@@ -282,6 +282,18 @@ LM_KERNEL void k_mlist_post(Dev d) {
         // the element must exist ("moved element should have a visible source position", diff_calc.rs:1927-1931)
         uint32_t pid_e = ml_resolve(d, m, cidx, r.a0, r.a1);
         if (pid_e == NONE) { err = ST_DATA_CORRUPTION; continue; }
+        {
+          // … and its insert must lie in the causal PAST of the row (the version at the head of the row's node, or the row's own peer's
+          // earlier ops).  A writer can only name an element it has seen; a damaged dependency can leave the insert concurrent with the
+          // row — the reference then fails or not depending on which of the two its iteration happens to replay first (the element is
+          // looked up when the row is replayed, diff_calc.rs:1927-1931): no value that is independent of the replay order, LM_DATA_CORRUPTION
+          // (found by tests/_richtext.py damaged_mixed_docs(600, seed=901), document 427: rendered where the oracle fails)
+          const uint32_t q = pid_peer(pid_e), c = pid_ctr(pid_e);
+          const uint64_t vvh0 = ((uint64_t)m.vvh0_hi << 32) | m.vvh0_lo;
+          const uint32_t node = g.chg_node[m.chg0 + ci];
+          const bool past = c < d.vvh[vvh0 + (uint64_t)node * m.n_peers + q] || (q == ch.peer && c < r.ctr);
+          if (!past) { err = ST_DATA_CORRUPTION; continue; }
+        }
         if (r.ctr >= pe) continue;   // past the version being rendered: does not compete (last_pos / last_value take the version)
         if (kind == OK_LIST_MOVE) loc[eb + r.ctr] = pid_e;
         uint32_t rel = ch.op0 + ri - m.op0;

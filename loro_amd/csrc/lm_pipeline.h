@@ -1425,7 +1425,7 @@ struct Engine {
     if (!resident && h_front_off.size() > n_docs && h_front_off[n_docs] > 0) LM_LAUNCH(k_seq_alive_latest, n_docs, 64, d);   // checked-out documents only (a resident tracker knows both versions)
     if (h_froot_off.size() > n_docs && h_froot_off[n_docs] > 0) LM_LAUNCH(k_state_roots, n_docs, 64, d);        // documents initialised from a snapshot only
     // documents holding a MovableList only: element → item maxima and the items' elements (loc[] is free from here on)
-    if (any_ml) LM_LAUNCH(k_mlist_post, n_docs, 64, d);
+    if (any_ml) LM_LAUNCH(k_mlist_post, n_docs, 64, d, g);
     if (resident) LM_LAUNCH(k_res_exists, n_docs, 64, d, rs, shared_mode);   // the state store keeps what it once held: OR over the document's runs
 #ifdef LM_EMU_TRACE
     if (getenv("LM_EMU_DUMP")) {  // kernel-logic harness only: leaves of document 0 in document order

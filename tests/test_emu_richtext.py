@@ -135,7 +135,7 @@ def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected
     # (the seed-3 finding of the mixed corpus — a last lamport that does not fit u32 — is run on the GPU: test_gpu_zz_richtext.py)
 
 
-@pytest.mark.parametrize("seed,auto", [(3, "1"), (5, "1"), (6, "0")][1:])
+@pytest.mark.parametrize("seed,auto", [(3, "1"), (5, "1"), (6, "0"), (901, "1")][1:])   # (901: a MovableList set row whose element's insert is not in its causal past, k_mlist_post)
 def test_damaged_mixed_documents(monkeypatch, seed, auto):
     """the seeds on which the device used to give a verdict the reference does not give: two blocks whose last lamport does not fit
     (seed 3), a message-length column with a surplus run (seed 5), an insert row beyond the end (seed 6)"""

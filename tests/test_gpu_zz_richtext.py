@@ -100,7 +100,7 @@ def test_damaged_rich_text_documents_are_rendered_like_the_reference_or_rejected
     assert nb >= 40
 
 
-@pytest.mark.parametrize("seed,auto", [(3, "1"), (5, "1"), (6, "1"), (16, "0")])
+@pytest.mark.parametrize("seed,auto", [(3, "1"), (5, "1"), (6, "1"), (16, "0"), (901, "1")])
 def test_damaged_mixed_documents(engine, monkeypatch, seed, auto):
     """damaged documents over rich-text / list / map sessions, nested containers and MovableLists (600 per seed; 3, 5, 6 are the seeds
     that turned up the last-lamport rule, the surplus message-length run and the insert beyond the end): rendered like the reference
