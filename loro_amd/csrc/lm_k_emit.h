@@ -1254,28 +1254,35 @@ LM_KERNEL void k_compact(Dev d, const uint64_t* src_addr, const uint64_t* vv_sla
   }
 }
 
-// K12: xxh64 (seed 0) of every document's rendered JSON, one wave per document — the content word of the merged-state
-// summary a sharded deployment all-gathers, so ranks can compare states without moving the JSON.
-// The four accumulators of the 32-byte stripe loop live in lanes 0..3 (each reads its own 8 bytes of a stripe).
+// K12: xxh64 (seed 0) of every document's rendered JSON — the content word of the merged-state summary a sharded deployment
+// all-gathers, so ranks can compare states without moving the JSON.
+// SIXTEEN documents per wave: the 32-byte stripe loop is a serial chain of 64-bit multiplies per accumulator, and a multiply
+// occupies the SIMD for the whole wave whatever its exec mask — with one document per wave (rounds 1-5: accumulators in lanes
+// 0..3, sixty lanes idle) the kernel was VALU-issue bound at 1/16 of the lanes (0.36 ms per 5,000 configs[1] documents).
+// Lanes 4g..4g+3 hold the four accumulators of document 16 * block + g (each reads its own 8 bytes of a stripe); the tail and
+// the avalanche are computed by all four lanes of the group, lane 4g stores.  Launch: ceil(n_docs / HASH_DOCS) waves.
+static constexpr uint32_t HASH_DOCS = 16;
 LM_DEV uint64_t xx_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 LM_KERNEL void k_hash_json(Dev d, uint64_t* out_hash) {
   static constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull,
                             P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
-  uint32_t doc = (uint32_t)lmw::bid();
   int lane = lmw::lane();
-  const DocMeta& m = d.doc[doc];
-  if (status_fatal(m.status)) { if (lane == 0) out_hash[doc] = 0; return; }
-  const uint8_t* p = d.out + d.out_off[doc];   // 16-byte aligned
-  uint64_t len = m.out_len, h;
-  uint64_t n_str = len / 32;
-  if (n_str) {
-    uint64_t v = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0ull : 0ull - P1;
-    if (lane < 4) {
-      const uint64_t* q = (const uint64_t*)p + lane;
+  const int g4 = lane & ~3, j = lane & 3;
+  uint32_t doc = (uint32_t)lmw::bid() * HASH_DOCS + (uint32_t)(lane >> 2);
+  const bool in = doc < d.n_docs;
+  const bool live = in && !status_fatal(d.doc[in ? doc : 0].status);
+  const uint8_t* p = live ? d.out + d.out_off[doc] : d.out;   // 16-byte aligned
+  const uint64_t len = live ? d.doc[doc].out_len : 0;
+  const uint64_t n_str = len / 32;
+  uint64_t v = j == 0 ? P1 + P2 : j == 1 ? P2 : j == 2 ? 0ull : 0ull - P1;
+  {
+    const uint64_t* q = (const uint64_t*)p + j;
 #pragma unroll 8
-      for (uint64_t s = 0; s < n_str; s++) v = xx_rotl(v + q[s * 4] * P2, 31) * P1;
-    }
-    uint64_t v1 = lmw::shfl64(v, 0), v2 = lmw::shfl64(v, 1), v3 = lmw::shfl64(v, 2), v4 = lmw::shfl64(v, 3);
+    for (uint64_t s = 0; s < n_str; s++) v = xx_rotl(v + q[s * 4] * P2, 31) * P1;
+  }
+  uint64_t v1 = lmw::shfl64(v, g4), v2 = lmw::shfl64(v, g4 + 1), v3 = lmw::shfl64(v, g4 + 2), v4 = lmw::shfl64(v, g4 + 3);
+  uint64_t h;
+  if (n_str) {
     h = xx_rotl(v1, 1) + xx_rotl(v2, 7) + xx_rotl(v3, 12) + xx_rotl(v4, 18);
     h = (h ^ (xx_rotl(v1 * P2, 31) * P1)) * P1 + P4;
     h = (h ^ (xx_rotl(v2 * P2, 31) * P1)) * P1 + P4;
@@ -1288,7 +1295,7 @@ LM_KERNEL void k_hash_json(Dev d, uint64_t* out_hash) {
   if (i + 4 <= len) { h ^= (uint64_t)(*(const uint32_t*)(p + i)) * P1; h = xx_rotl(h, 23) * P2 + P3; i += 4; }
   for (; i < len; i++) { h ^= (uint64_t)p[i] * P5; h = xx_rotl(h, 11) * P1; }
   h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
-  if (lane == 0) out_hash[doc] = h;
+  if (in && j == 0) out_hash[doc] = live ? h : 0;
 }
 
 // The per-document row of the merged-state summary a sharded deployment exchanges (layout = loro_amd/dist.py

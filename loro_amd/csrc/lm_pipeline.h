@@ -1540,7 +1540,7 @@ struct Engine {
       LM_LAUNCH(k_compact, n_docs, 64, d, (const uint64_t*)b_slab_off.as<uint64_t>(), vo, vs);
       lmbe::toc("k_compact", times, profiling);
       b_hash.ensure((size_t)n_docs * 8 + 8);
-      LM_LAUNCH(k_hash_json, n_docs, 64, d, b_hash.as<uint64_t>());
+      LM_LAUNCH(k_hash_json, cdiv(n_docs, HASH_DOCS), 64, d, b_hash.as<uint64_t>());
       if (sum_rows) LM_LAUNCH(k_summary_rows, cdiv(n_docs, 256), 256, d, (const uint64_t*)b_hash.as<uint64_t>(), sum_rows, sum_id0, sum_stride);
       h_hash.resize(n_docs);
       lmbe::d2h(h_hash.data(), b_hash.p, (size_t)n_docs * 8);
