@@ -72,4 +72,14 @@ LM_KERNEL void k_selftest(uint32_t* out, uint32_t rounds) {
   if (lane == 0) out[lmw::bid()] = bad;
 }
 
+// loc[] := NONE in front of the integrate stage (lm_pipeline.h): 16 bytes per lane and store, grid-stride.  hipMemsetAsync's fill
+// kernel wrote these 2 GB per 5,000 configs[1] documents at ≈2 TB/s (profiles/r06_kernel_stats.md: __amd_rocclr_fillBufferAligned,
+// ≈1 ms per launch of the pipeline); HBM takes stores faster than that.
+LM_KERNEL void k_fill_words(uint32_t* p, uint64_t n4, uint32_t v, uint32_t n_threads) {
+  struct alignas(16) U4 { uint32_t x, y, z, w; };
+  U4* q = (U4*)p;
+  const U4 w4 = {v, v, v, v};
+  for (uint64_t i = (uint64_t)lmw::bid() * (uint64_t)lmw::bdim() + (uint64_t)lmw::tid(); i < n4; i += n_threads) q[i] = w4;
+}
+
 }  // namespace lm

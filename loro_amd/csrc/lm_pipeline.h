@@ -1126,11 +1126,11 @@ struct Engine {
     if (resident) {
       // arenas that outlive the run: element payloads (a MovableList move keeps the id of the item it deleted in its own slot),
       // the leaf pool and the two generations of the leaf directories
-      b_cp.ensure_keep((elem_top + 1) * 4, b_cp.cap); b_loc.ensure_keep((elem_top + 1) * 4, b_loc.cap); b_dcnt.ensure((elem_top + 1) * 4); b_tb.ensure_keep(elem_top + 16, b_tb.cap);
+      b_cp.ensure_keep((elem_top + 1) * 4, b_cp.cap); b_loc.ensure_keep((elem_top + 4) * 4, b_loc.cap); b_dcnt.ensure((elem_top + 1) * 4); b_tb.ensure_keep(elem_top + 16, b_tb.cap);
       b_it.ensure_keep(((size_t)leaf_top + 1) * SP_REC * 4, b_it.cap);
       for (DBuf* b : {&b_dir_out, &b_dir_out2, &b_dir_b, &b_dir_b2}) b->ensure_keep(((size_t)leaf_top + 1) * 4, b->cap);
     } else {
-      b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 1) * 4); b_tb.ensure(elem + 16);
+      b_cp.ensure((elem + 1) * 4); b_loc.ensure((elem + 4) * 4); b_tb.ensure(elem + 16);
       if (LM_BATCH_VSWEEP && want_dcnt && span && kn.version_sweep) b_dcnt.ensure((elem + 1) * 4);   // (the batch kernels' only reader is ts_goto's version pass, compiled out by default: ADVICE r4)
       b_it.ensure((leaves + 1) * (span ? (size_t)SP_REC : 256) * 4);
       b_dir_out.ensure((leaves + 1) * 4);
@@ -1185,7 +1185,14 @@ struct Engine {
         d.posdel_off = b_pd_off.as<uint64_t>(); d.pd_row_idx = b_pd_row.as<uint32_t>();
       }
     }
-    if (d.loc_cleared && elem) lmbe::dmemset(b_loc.p, 0xff, (size_t)elem * 4);
+    if (d.loc_cleared && elem) {
+      // (k_fill_words, not hipMemsetAsync: its fill kernel writes at half of what HBM takes; the buffers are padded to 16 bytes.  Clearing
+      // speculatively on a second stream beside the decode stage — as many words as the last run needed, joined here — was built and
+      // measured: the step got SLOWER, 23.0 against 22.7 ms (k_frame_count 0.30 -> 0.72 ms under the 2 GB of stores; profiles/r06_side_fill_ab.log))
+      const uint64_t n4 = ((uint64_t)elem + 3) / 4;
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((n4 + 255) / 256, 4096);
+      LM_LAUNCH(k_fill_words, blocks, 256, b_loc.as<uint32_t>(), n4, NONE, blocks * 256u);
+    }
     if (ht) { lmbe::dmemset(b_ht_key.p, 0xff, ht * 8); lmbe::dmemset(b_ht_best.p, 0, ht * 8); }
       if (resident) {
         sv.d = d; sv.g = g; sv.NB = NB; sv.NC = NC; sv.NO = NO; sv.NCID = NCID; sv.NP = NP; sv.ht = ht;
